@@ -1,0 +1,268 @@
+/*
+ * rfn.h -- C ABI of librfn_hip.so: the MI355X (gfx950) implementation of the recurrent-fusion
+ * caption-decoder hot path of cswhjiang/Recurrent_Fusion_Network.
+ *
+ * The reference has no FFI for this path: its seam is the Python duck type returned by
+ * models.setup(opt) (reference models.py:14-38) whose forward()/sample() call nothing but ATen.
+ * Each entry point below names the reference code it replaces (paths relative to the reference
+ * checkout).  INTEGRATION.md shows the ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions (all entry points):
+ *   - plain C types only; every pointer is a DEVICE pointer unless its name ends in _host;
+ *   - all floating-point data is IEEE fp32, row-major; token / target ids are int64;
+ *   - the caller owns every buffer, including workspaces (sizes from the *_ws_bytes queries);
+ *   - `stream` is a hipStream_t passed as void*; calls are asynchronous on it, never allocate,
+ *     never synchronise, and are re-entrant (no global mutable state);
+ *   - return RFN_OK (0) or a negative RFN_ERR_* code; nothing is launched on a shape error.
+ */
+#ifndef RFN_H_
+#define RFN_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RFN_OK 0
+#define RFN_ERR_SHAPE (-1)       /* unsupported or inconsistent dimensions */
+#define RFN_ERR_UNSUPPORTED (-2) /* configuration the path does not implement (e.g. maxout) */
+#define RFN_ERR_LAUNCH (-3)      /* HIP launch failure */
+#define RFN_ERR_WORKSPACE (-4)   /* workspace too small */
+#define RFN_ERR_ARG (-5)         /* null / misaligned pointer */
+
+#define RFN_MAX_ENC 8
+#define RFN_ABI_VERSION 1
+
+/* Model dimensions: the fields RecurrentFusionModel.__init__ reads from `opt`
+ * (misc/RecurrentFusionModel.py:118-151). */
+typedef struct rfn_dims {
+    int32_t M;                 /* number of encoders, len(opt.feat_array_info)            */
+    int32_t R;                 /* opt.rnn_size                                            */
+    int32_t A;                 /* opt.att_hid_size                                        */
+    int32_t E;                 /* opt.input_encoding_size                                 */
+    int32_t T1;                /* opt.num_review_steps_0 (fusion stage I steps)           */
+    int32_t T2;                /* opt.num_review_steps   (fusion stage II steps)          */
+    int32_t K;                 /* opt.top_words_count                                     */
+    int32_t V1;                /* opt.vocab_size + 1                                      */
+    int32_t L[RFN_MAX_ENC];    /* feat_array_info[i]['att_num']                           */
+    int32_t D[RFN_MAX_ENC];    /* feat_array_info[i]['att_feat_size']                     */
+    int32_t F[RFN_MAX_ENC];    /* feat_array_info[i]['fc_feat_size']                      */
+    int32_t review_maxout;     /* opt.review_maxout: must be 0 (RFN_ERR_UNSUPPORTED)      */
+    int32_t decoder_maxout;    /* opt.maxout:        must be 0 (RFN_ERR_UNSUPPORTED)      */
+    float drop_fusion;         /* opt.drop_prob_fusion (stage I)                          */
+    float drop_reason;         /* opt.drop_prob_reason (stage II)                         */
+    float drop_lm;             /* opt.drop_prob_lm     (decoder)                          */
+} rfn_dims;
+
+int rfn_abi_version(void);
+const char* rfn_error_string(int code);
+
+/* ---- parameter table ------------------------------------------------------------------------
+ * Parameters and their gradients are passed as arrays of device pointers in ONE canonical order.
+ * rfn_param_name() returns the reference state_dict key of slot `idx` (e.g.
+ * "review_steps_individual.3.lstm.1.att_model.att_2_att_h.weight"), so a host binds the table by
+ * name and never hard-codes the order.  nn.Linear layout (out, in). */
+int rfn_param_count(const rfn_dims* d);
+int rfn_param_name(const rfn_dims* d, int idx, char* buf, size_t buflen);
+/* rows/cols of slot idx (cols = 1 for a bias) */
+int rfn_param_shape(const rfn_dims* d, int idx, int64_t* rows, int64_t* cols);
+
+/* ---- primitive operators (exported for unit parity tests and for other hosts) ---------------- */
+
+/* C[M,N] (+)= sum_s op(A_s)[M,K_s] * op(B_s)[N,K_s]^T + sum_s bias_s[N]; exact-fp32 MFMA
+ * (v_mfma_f32_32x32x2_f32: each output is a k-ordered fp32 fma chain).  Replaces every nn.Linear
+ * / mm / addmm / bmm on the path and their backward
+ * matmuls.  *_kfast = 1: the reduction index is the contiguous one (A is [M,K] with row stride
+ * lda; B is [N,K] = an nn.Linear weight).  *_kfast = 0: the output index is contiguous (A is
+ * [K,M] with row stride lda; B is [K,N]).  Up to RFN_GEMM_MAXSEG K-segments accumulate into one C
+ * (gate sums such as H2h(H) + z2h(z), misc/RecurrentFusionModel.py:53); up to RFN_GEMM_MAXGROUP
+ * same-shape problems run in one launch (the per-step weights of one encoder). */
+#define RFN_GEMM_MAXSEG 8
+#define RFN_GEMM_MAXGROUP 8
+typedef struct rfn_gemm_seg {
+    const float* A;
+    const float* B;
+    const float* bias; /* may be NULL */
+    int64_t lda, ldb;
+    int32_t K;
+    int32_t a_kfast, b_kfast;
+    int32_t pad_;
+} rfn_gemm_seg;
+typedef struct rfn_gemm_problem {
+    float* C;
+    int64_t ldc;
+    int32_t nseg;
+    int32_t pad_;
+    rfn_gemm_seg seg[RFN_GEMM_MAXSEG];
+} rfn_gemm_problem;
+int rfn_gemm_f32(int M, int N, int ngroups, const rfn_gemm_problem* problems_host, int accumulate,
+                 void* stream);
+
+/* out[n] (+)= sum_r X[r*ldx + n]   (bias gradients) */
+int rfn_colsum_f32(const float* X, int64_t ldx, int rows, int cols, float* out, int accumulate,
+                   void* stream);
+
+/* Additive soft attention, AttentionModelCore.forward (misc/AttentionModelCore.py:31-48; inlined
+ * copy misc/LSTMSoftAttentionCore.py:64-79), split at the GEMM boundary:
+ *   proj[b,l,:] = att_2_att_h(att_seq[b,l,:])  (hoisted GEMM, :32-34)
+ *   hproj[b,:]  = h_2_att_h(pre_h[b,:])        (GEMM, :36)
+ * scores:  alpha[b,:] = softmax_l( w . tanh(proj[b,l,:] + hproj[b,:]) + b_o )      (:39-44)
+ * context: z[b,:]     = sum_l alpha[b,l] * att_seq[b,l,:]                          (:45-47)
+ * Element (b,l,x) of proj / att_seq lives at base + b*stride_b + l*stride_l + x. */
+int rfn_attn_scores_fwd(const float* proj, int64_t proj_sb, int64_t proj_sl, const float* hproj,
+                        const float* w_out, const float* b_out, int B, int L, int A, float* alpha,
+                        void* stream);
+int rfn_attn_context_fwd(const float* att_seq, int64_t sb, int64_t sl, const float* alpha, int B,
+                         int L, int D, float* z, int64_t ldz, void* stream);
+/* dalpha[b,l] = <dz[b,:], att_seq[b,l,:]> */
+int rfn_attn_context_bwd_dalpha(const float* att_seq, int64_t sb, int64_t sl, const float* dz,
+                                int64_t lddz, int B, int L, int D, float* dalpha, void* stream);
+/* datt_seq[b,l,:] += alpha[b,l] * dz[b,:]   (only for differentiable att_seq: stages II, decoder) */
+int rfn_attn_context_bwd_dseq(const float* alpha, const float* dz, int64_t lddz, int B, int L,
+                              int D, float* datt_seq, int64_t sb, int64_t sl, void* stream);
+/* softmax + tanh backward.  ds = alpha*(dalpha - <alpha,dalpha>); dproj[b,l,a] (=|+=)
+ * ds[b,l]*w[a]*(1-e^2), e = tanh(proj+hproj); dhproj[b,a] = sum_l dproj[b,l,a];
+ * dw_part[b,a] = sum_l ds[b,l]*e[b,l,a]  (caller column-sums dw_part over b).
+ * dproj may alias proj (in-place).  */
+int rfn_attn_scores_bwd(const float* proj, int64_t proj_sb, int64_t proj_sl, const float* hproj,
+                        const float* w_out, const float* alpha, const float* dalpha, int B, int L,
+                        int A, float* dproj, int64_t dproj_sb, int64_t dproj_sl,
+                        int accumulate_dproj, float* dhproj, float* dw_part, void* stream);
+
+/* LSTM gate epilogue shared by the three cells (misc/RecurrentFusionModel.py:55-73,
+ * misc/LSTMSoftMultiAttentionFeatArrayNoInputCore.py:54-72, misc/LSTMSoftAttentionCore.py:83-101):
+ * gates[b, 0:4R] = [in | forget | out | g] pre-activations on entry, activations on exit;
+ * c_next = f*c_prev + i*g; h_next = dropout(o*tanh(c_next)).  drop_p > 0 draws a Philox mask from
+ * (seed, offset) that rfn_lstm_bwd regenerates. */
+int rfn_lstm_fwd(float* gates, int64_t ldg, const float* c_prev, int64_t ldcp, float* c_next,
+                 int64_t ldcn, float* h_next, int64_t ldh, int B, int R, float drop_p,
+                 uint64_t seed, uint64_t offset, void* stream);
+/* dgates (in place over the activations), dc_prev = dc_next_total * f.
+ * dh / dc_next are the TOTAL incoming gradients of h_next / c_next (dc_next may be NULL). */
+int rfn_lstm_bwd(float* gates, int64_t ldg, const float* c_prev, int64_t ldcp, const float* c_next,
+                 int64_t ldcn, const float* dh, int64_t lddh, const float* dc_next, int64_t lddcn,
+                 float* dc_prev, int64_t lddcp, int B, int R, float drop_p, uint64_t seed,
+                 uint64_t offset, void* stream);
+
+/* nn.Embedding gather (misc/RecurrentFusionModel.py:276): out[r,:] = W[id(r), :] with
+ * id(r) = ids[(r % inner)*ids_s_inner + (r / inner)*ids_s_outer]  (row r = (step, batch) reads
+ * ids[batch, step] with inner = B, ids_s_inner = ld_ids, ids_s_outer = 1). */
+int rfn_embed_fwd(const float* W, int E, int64_t V1, const int64_t* ids, int inner,
+                  int64_t ids_s_inner, int64_t ids_s_outer, int rows, float* out, int64_t ldo,
+                  void* stream);
+/* dW[v,:] = sum_{r: id(r)==v} dout[r,:]  (fixed order, overwrites all of dW) */
+int rfn_embed_bwd(const float* dout, int64_t ldo, const int64_t* ids, int inner,
+                  int64_t ids_s_inner, int64_t ids_s_outer, int rows, int E, int64_t V1, float* dW,
+                  void* stream);
+
+/* F.log_softmax over the vocabulary (misc/RecurrentFusionModel.py:278).  Row r of `logits`
+ * (ld = ldl) is written to out + (r % inner)*out_s_inner + (r / inner)*out_s_outer, which turns
+ * the path's time-major (step, batch) rows into the reference's (batch, step, V+1) layout. */
+int rfn_log_softmax_fwd(const float* logits, int64_t ldl, int rows, int V1, int inner,
+                        int64_t out_s_inner, int64_t out_s_outer, float* out, void* stream);
+/* dlogits[r,:] = g[r',:] - exp(logp[r',:]) * sum_v g[r',v]   (r' = the same row mapping) */
+int rfn_log_softmax_bwd(const float* g, const float* logp, int rows, int V1, int inner,
+                        int64_t s_inner, int64_t s_outer, float* dlogits, int64_t ldd, void* stream);
+
+/* max over steps of the reason heads (misc/RecurrentFusionModel.py:229,253):
+ * out[b,k] = max_t X[t,b,k]; arg[b,k] = first t attaining it. */
+int rfn_max_over_steps_fwd(const float* X, int T, int B, int K, float* out, int32_t* arg,
+                           void* stream);
+/* dX[t,b,k] = (arg[b,k]==t) ? dout[b,k] : 0 */
+int rfn_max_over_steps_bwd(const float* dout, const int32_t* arg, int T, int B, int K, float* dX,
+                           void* stream);
+
+/* y[r,c] = alpha*x[r,c] + beta*y[r,c]  (state mean misc/RecurrentFusionModel.py:233-235,
+ * gradient fan-in) */
+int rfn_axpby_2d(float alpha, const float* x, int64_t ldx, float beta, float* y, int64_t ldy,
+                 int rows, int cols, void* stream);
+
+/* y[r,c] = y[r,c] / divisor (IEEE division, as `sum / num_feat_array` in the reference) */
+int rfn_div_2d(float* y, int64_t ldy, int rows, int cols, float divisor, void* stream);
+
+/* ---- criteria (misc/utils.py) --------------------------------------------------------------- */
+/* ReviewNetEnsembleCriterion language term (misc/utils.py:163-184): loss_out[0] (+)=
+ * -sum_{b,t} mask[b,t]*q[b,t,:].logp[b,t,:] / B with q one-hot (eps = 0) or label-smoothed, and
+ * dlogp (same layout as logp, overwritten) = d loss / d logp * gscale.  Either output may be NULL. */
+int rfn_xe_loss(const float* logp, int B, int T, int V1, const int64_t* target, int64_t ld_target,
+                const float* mask, int64_t ld_mask, float eps, float gscale,
+                float* scratch /* B*T floats, needed when loss_out != NULL */, float* loss_out,
+                int accumulate_loss, float* dlogp, void* stream);
+/* nn.MultiLabelMarginLoss, mean reduction (misc/utils.py:186-190), scaled by `scale`:
+ * loss_out[0] (+)= scale * MLM(pred, target); dpred (overwritten) = scale * gscale * dMLM/dpred. */
+int rfn_multilabel_margin(const float* pred, int B, int K, const int64_t* target, float scale,
+                          float gscale, float* scratch /* B floats when loss_out != NULL */,
+                          float* loss_out, int accumulate_loss, float* dpred, void* stream);
+
+/* clip_gradient + Adam with L2 weight decay (misc/utils.py:292-296, train.py:69-71,162-163),
+ * one pass: g = clamp(g, +-clip) + wd*p; m,v update; p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps).
+ * grad_scale multiplies g first (1/world_size after a sum all-reduce). */
+int rfn_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, float grad_clip, float grad_scale,
+                  int step, void* stream);
+
+/* greedy pick of sample() (misc/RecurrentFusionModel.py:619-649) for one step t >= 1:
+ * it = argmax_v logp[b,:] (first maximum), sample_lp[b] = that value,
+ * unfinished[b] = (t==1 ? 1 : unfinished[b]) & (it>0), seq_out[b] = it*unfinished,
+ * next_ids[b] = it (UNMASKED: the reference embeds the raw argmax, :637). */
+int rfn_greedy_pick(const float* logp, int64_t ldl, int B, int V1, int t, int64_t* next_ids,
+                    int64_t* seq_out, int64_t ld_seq, float* lp_out, int64_t ld_lp,
+                    int32_t* unfinished, void* stream);
+
+/* ---- whole-path entry points ---------------------------------------------------------------- */
+/* Phase 1 = get_init_state + get_thought_vectors (misc/RecurrentFusionModel.py:333-343, 283-331;
+ * the same code is inlined in forward :199-255 and sample :557-612): fc2h, T1 fusion-stage-I steps
+ * over M encoders, reason heads, state mean, T2 stage-II steps.
+ * Inputs : params (rfn_param_count pointers), fc_feats[i] (B,F_i), att_feats[i] (B,L_i,D_i).
+ * Outputs: comb (T2,B,R) time-major thought_vectors_comb; h_out,c_out (B,R) = state_review;
+ *          reason_pred (M+1,B,K).
+ * `ws` keeps every activation rfn_prefix_bwd needs (size rfn_prefix_ws_bytes; with train = 0 a
+ * smaller inference workspace suffices and rfn_prefix_bwd must not be called). */
+size_t rfn_prefix_ws_bytes(const rfn_dims* d, int B, int train);
+int rfn_prefix_fwd(const rfn_dims* d, int B, const float* const* params,
+                   const float* const* fc_feats, const float* const* att_feats, float* comb,
+                   float* h_out, float* c_out, float* reason_pred, void* ws, size_t ws_bytes,
+                   int train, uint64_t seed, void* stream);
+/* Gradients of phase 1.  d_comb (T2,B,R), d_h, d_c (B,R), d_reason_pred (M+1,B,K) are the incoming
+ * gradients (any may be NULL = zero).  Every slot of grads[] (same table as params) that belongs
+ * to phase 1 is OVERWRITTEN exactly once (no zero-fill needed); phase-2 slots are not touched. */
+int rfn_prefix_bwd(const rfn_dims* d, int B, const float* const* params,
+                   const float* const* fc_feats, const float* const* att_feats,
+                   const float* d_comb, const float* d_h, const float* d_c,
+                   const float* d_reason_pred, float* const* grads, void* ws, size_t ws_bytes,
+                   uint64_t seed, void* stream);
+
+/* Phase 2 = the teacher-forced decoder loop of forward() (misc/RecurrentFusionModel.py:257-281):
+ * for s < S: xt = embed(ids[b,s]); decoder cell (misc/LSTMSoftAttentionCore.py:60-102);
+ * log_prob[b,s,:] = log_softmax(logit(h)).  `ids` is (B, ld_ids) int64, column s feeds step s.
+ * The caller derives S from the reference's break rule (:274). */
+size_t rfn_decoder_ws_bytes(const rfn_dims* d, int B, int S, int train);
+int rfn_decoder_fwd(const rfn_dims* d, int B, int S, const float* const* params, const float* comb,
+                    const float* h0, const float* c0, const int64_t* ids, int64_t ld_ids,
+                    float* log_prob /* (B,S,V1) */, void* ws, size_t ws_bytes, int train,
+                    uint64_t seed, void* stream);
+/* d_log_prob (B,S,V1) in; d_comb (T2,B,R), d_h0, d_c0 (B,R) out (overwritten); the phase-2 slots of
+ * grads[] (embed, logit, decoder.*) are overwritten. */
+int rfn_decoder_bwd(const rfn_dims* d, int B, int S, const float* const* params, const float* comb,
+                    const float* h0, const float* c0, const int64_t* ids, int64_t ld_ids,
+                    const float* log_prob, const float* d_log_prob, float* d_comb, float* d_h0,
+                    float* d_c0, float* const* grads, void* ws, size_t ws_bytes, uint64_t seed,
+                    void* stream);
+
+/* One free-running decoder step for sample()/sample_beam()/one_time_step
+ * (misc/RecurrentFusionModel.py:345-350, 616-653, 526-527): state (h,c) is updated in place,
+ * logits (B,V1) pre-softmax and/or logp (B,V1) are written when non-NULL.
+ * cproj = att_2_att_h(comb) (T2*B, A) must have been filled by rfn_decoder_prepare. */
+size_t rfn_decoder_step_ws_bytes(const rfn_dims* d, int B);
+int rfn_decoder_prepare(const rfn_dims* d, int B, const float* const* params, const float* comb,
+                        float* cproj, void* stream);
+int rfn_decoder_step(const rfn_dims* d, int B, const float* const* params, const float* comb,
+                     const float* cproj, const int64_t* ids, float* h, float* c, float* logits,
+                     float* logp, void* ws, size_t ws_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RFN_H_ */

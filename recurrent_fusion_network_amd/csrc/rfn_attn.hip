@@ -1,0 +1,328 @@
+// Additive soft attention of the recurrent-fusion path, split at the GEMM boundary.
+//
+// Reference: AttentionModelCore.forward (misc/AttentionModelCore.py:31-48) and its inlined copy in
+// the decoder cell (misc/LSTMSoftAttentionCore.py:64-79).  The two projections (att_2_att_h, hoisted
+// over all steps; h_2_att_h) are MFMA GEMMs (rfn_gemm.hip); everything between them and the gate
+// GEMM lives here and is HBM-bound streaming work:
+//   scores  : s[b,l] = w . tanh(proj[b,l,:] + hproj[b,:]) + b_o ; alpha = softmax_l(s)
+//             reads the (B,L,A) projection slice ONCE, the (B,L,A) tanh tensor never exists
+//             (the reference materialises it three times).
+//   context : z[b,:] = sum_l alpha[b,l] att_seq[b,l,:]   -- one coalesced pass over the features.
+// Layout: lanes run along the contiguous feature/hidden index with 16-B loads, a wave owns whole
+// (b,l) rows, softmax reductions are 64-lane shuffles (L <= a few hundred: SURVEY.md section 5).
+#include "rfn_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define ATT_THREADS 256
+#define ATT_WAVES 4
+
+template <bool VEC>
+__device__ __forceinline__ float row_tanh_dot(const float* __restrict__ p, const float* __restrict__ hp_s,
+                                              const float* __restrict__ w_s, int A, int lane) {
+    float part = 0.f;
+    if constexpr (VEC) {
+        for (int a = lane * 4; a < A; a += 256) {
+            const f32x4 x = *reinterpret_cast<const f32x4*>(p + a);
+            const f32x4 hh = *reinterpret_cast<const f32x4*>(hp_s + a);
+            const f32x4 ww = *reinterpret_cast<const f32x4*>(w_s + a);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) part += tanhf(x[e] + hh[e]) * ww[e];
+        }
+    } else {
+        for (int a = lane; a < A; a += 64) part += tanhf(p[a] + hp_s[a]) * w_s[a];
+    }
+    return rfn_wave_sum(part);
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(ATT_THREADS) void attn_scores_fwd_k(const float* __restrict__ proj, long sb, long sl,
+                                                                const float* __restrict__ hproj,
+                                                                const float* __restrict__ w_out,
+                                                                const float* __restrict__ b_out, int L, int A,
+                                                                float* __restrict__ alpha) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int Ap = (A + 3) & ~3;
+    float* hp_s = sm;
+    float* w_s = sm + Ap;
+    float* s_s = sm + 2 * Ap;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int a = tid; a < A; a += ATT_THREADS) {
+        hp_s[a] = hproj[(long)b * A + a];
+        w_s[a] = w_out[a];
+    }
+    __syncthreads();
+    const float bo = b_out ? b_out[0] : 0.f;
+    for (int l = wave; l < L; l += ATT_WAVES) {
+        const float s = row_tanh_dot<VEC>(proj + b * sb + l * sl, hp_s, w_s, A, lane) + bo;
+        if (lane == 0) s_s[l] = s;
+    }
+    __syncthreads();
+    // softmax over L: every wave reduces redundantly (L is small), then all threads write
+    float m = -INFINITY;
+    for (int l = lane; l < L; l += 64) m = fmaxf(m, s_s[l]);
+    m = rfn_wave_max(m);
+    float sum = 0.f;
+    for (int l = lane; l < L; l += 64) sum += expf(s_s[l] - m);
+    sum = rfn_wave_sum(sum);
+    const float inv = 1.0f / sum;
+    for (int l = tid; l < L; l += ATT_THREADS) alpha[(long)b * L + l] = expf(s_s[l] - m) * inv;
+}
+
+extern "C" int rfn_attn_scores_fwd(const float* proj, int64_t proj_sb, int64_t proj_sl, const float* hproj,
+                                   const float* w_out, const float* b_out, int B, int L, int A, float* alpha,
+                                   void* stream) {
+    if (B <= 0 || L <= 0 || A <= 0) return RFN_ERR_SHAPE;
+    if (!proj || !hproj || !w_out || !alpha) return RFN_ERR_ARG;
+    const size_t lds = (2 * ((A + 3) & ~3) + L) * sizeof(float);
+    if (lds > 64 * 1024) return RFN_ERR_SHAPE;
+    const bool vec = (A % 4 == 0) && rfn_aligned16(proj) && (proj_sb % 4 == 0) && (proj_sl % 4 == 0);
+    hipStream_t st = (hipStream_t)stream;
+    if (vec)
+        hipLaunchKernelGGL(attn_scores_fwd_k<true>, dim3(B), dim3(ATT_THREADS), lds, st, proj, (long)proj_sb,
+                           (long)proj_sl, hproj, w_out, b_out, L, A, alpha);
+    else
+        hipLaunchKernelGGL(attn_scores_fwd_k<false>, dim3(B), dim3(ATT_THREADS), lds, st, proj, (long)proj_sb,
+                           (long)proj_sl, hproj, w_out, b_out, L, A, alpha);
+    RFN_CHECK_LAUNCH();
+    return RFN_OK;
+}
+
+// ---- context: z[b,d] = sum_l alpha[b,l] x[b,l,d] ------------------------------------------------
+template <bool VEC>
+__global__ __launch_bounds__(ATT_THREADS) void attn_context_fwd_k(const float* __restrict__ x, long sb, long sl,
+                                                                 const float* __restrict__ alpha, int L, int D,
+                                                                 float* __restrict__ z, long ldz) {
+    extern __shared__ __attribute__((aligned(16))) float al_s[];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    for (int l = tid; l < L; l += ATT_THREADS) al_s[l] = alpha[(long)b * L + l];
+    __syncthreads();
+    const float* xb = x + b * sb;
+    if constexpr (VEC) {
+        const int d = (blockIdx.x * ATT_THREADS + tid) * 4;
+        if (d >= D) return;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        int l = 0;
+        for (; l + 4 <= L; l += 4) {  // 4 independent 16-B loads in flight per lane
+            const f32x4 x0 = *reinterpret_cast<const f32x4*>(xb + (l + 0) * sl + d);
+            const f32x4 x1 = *reinterpret_cast<const f32x4*>(xb + (l + 1) * sl + d);
+            const f32x4 x2 = *reinterpret_cast<const f32x4*>(xb + (l + 2) * sl + d);
+            const f32x4 x3 = *reinterpret_cast<const f32x4*>(xb + (l + 3) * sl + d);
+            acc += al_s[l] * x0;
+            acc += al_s[l + 1] * x1;
+            acc += al_s[l + 2] * x2;
+            acc += al_s[l + 3] * x3;
+        }
+        for (; l < L; ++l) acc += al_s[l] * *reinterpret_cast<const f32x4*>(xb + l * sl + d);
+        *reinterpret_cast<f32x4*>(z + b * ldz + d) = acc;
+    } else {
+        const int d = blockIdx.x * ATT_THREADS + tid;
+        if (d >= D) return;
+        float acc = 0.f;
+        for (int l = 0; l < L; ++l) acc += al_s[l] * xb[l * sl + d];
+        z[b * ldz + d] = acc;
+    }
+}
+
+extern "C" int rfn_attn_context_fwd(const float* att_seq, int64_t sb, int64_t sl, const float* alpha, int B, int L,
+                                    int D, float* z, int64_t ldz, void* stream) {
+    if (B <= 0 || L <= 0 || D <= 0) return RFN_ERR_SHAPE;
+    if (!att_seq || !alpha || !z) return RFN_ERR_ARG;
+    if ((size_t)L * sizeof(float) > 64 * 1024) return RFN_ERR_SHAPE;
+    const bool vec = (D % 4 == 0) && rfn_aligned16(att_seq) && rfn_aligned16(z) && (sb % 4 == 0) && (sl % 4 == 0) &&
+                     (ldz % 4 == 0);
+    hipStream_t st = (hipStream_t)stream;
+    if (vec)
+        hipLaunchKernelGGL(attn_context_fwd_k<true>, dim3(rfn_cdiv(D, 4 * ATT_THREADS), B), dim3(ATT_THREADS),
+                           L * sizeof(float), st, att_seq, (long)sb, (long)sl, alpha, L, D, z, (long)ldz);
+    else
+        hipLaunchKernelGGL(attn_context_fwd_k<false>, dim3(rfn_cdiv(D, ATT_THREADS), B), dim3(ATT_THREADS),
+                           L * sizeof(float), st, att_seq, (long)sb, (long)sl, alpha, L, D, z, (long)ldz);
+    RFN_CHECK_LAUNCH();
+    return RFN_OK;
+}
+
+// ---- backward of the context: dalpha[b,l] = <dz[b,:], x[b,l,:]> ---------------------------------
+#define DAL_ROWS 16 /* rows of L per block: B * ceil(L/16) blocks keep every CU streaming */
+template <bool VEC>
+__global__ __launch_bounds__(ATT_THREADS) void attn_dalpha_k(const float* __restrict__ x, long sb, long sl,
+                                                            const float* __restrict__ dz, long lddz, int L, int D,
+                                                            float* __restrict__ dalpha) {
+    extern __shared__ __attribute__((aligned(16))) float dz_s[];
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int d = tid; d < D; d += ATT_THREADS) dz_s[d] = dz[b * lddz + d];
+    __syncthreads();
+    const int l0 = blockIdx.x * DAL_ROWS;
+    for (int r = wave; r < DAL_ROWS; r += ATT_WAVES) {
+        const int l = l0 + r;
+        if (l >= L) break;
+        const float* p = x + b * sb + l * sl;
+        float part = 0.f;
+        if constexpr (VEC) {
+            for (int d = lane * 4; d < D; d += 256) {
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(p + d);
+                const f32x4 gv = *reinterpret_cast<const f32x4*>(dz_s + d);
+                part += xv[0] * gv[0] + xv[1] * gv[1] + xv[2] * gv[2] + xv[3] * gv[3];
+            }
+        } else {
+            for (int d = lane; d < D; d += 64) part += p[d] * dz_s[d];
+        }
+        part = rfn_wave_sum(part);
+        if (lane == 0) dalpha[(long)b * L + l] = part;
+    }
+}
+
+extern "C" int rfn_attn_context_bwd_dalpha(const float* att_seq, int64_t sb, int64_t sl, const float* dz,
+                                           int64_t lddz, int B, int L, int D, float* dalpha, void* stream) {
+    if (B <= 0 || L <= 0 || D <= 0) return RFN_ERR_SHAPE;
+    if (!att_seq || !dz || !dalpha) return RFN_ERR_ARG;
+    const size_t lds = (size_t)((D + 3) & ~3) * sizeof(float);
+    if (lds > 64 * 1024) return RFN_ERR_SHAPE;
+    const bool vec = (D % 4 == 0) && rfn_aligned16(att_seq) && (sb % 4 == 0) && (sl % 4 == 0);
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(rfn_cdiv(L, DAL_ROWS), B);
+    if (vec)
+        hipLaunchKernelGGL(attn_dalpha_k<true>, grid, dim3(ATT_THREADS), lds, st, att_seq, (long)sb, (long)sl, dz,
+                           (long)lddz, L, D, dalpha);
+    else
+        hipLaunchKernelGGL(attn_dalpha_k<false>, grid, dim3(ATT_THREADS), lds, st, att_seq, (long)sb, (long)sl, dz,
+                           (long)lddz, L, D, dalpha);
+    RFN_CHECK_LAUNCH();
+    return RFN_OK;
+}
+
+// ---- datt_seq[b,l,:] += alpha[b,l] * dz[b,:]  (stage II / decoder: att_seq is differentiable) ----
+__global__ __launch_bounds__(ATT_THREADS) void attn_dseq_k(const float* __restrict__ alpha,
+                                                          const float* __restrict__ dz, long lddz, int L, int D,
+                                                          float* __restrict__ dx, long sb, long sl) {
+    const int l = blockIdx.x, b = blockIdx.y;
+    const float a = alpha[(long)b * L + l];
+    float* o = dx + b * sb + l * sl;
+    const float* g = dz + b * lddz;
+    for (int d = threadIdx.x; d < D; d += ATT_THREADS) o[d] += a * g[d];
+}
+
+extern "C" int rfn_attn_context_bwd_dseq(const float* alpha, const float* dz, int64_t lddz, int B, int L, int D,
+                                         float* datt_seq, int64_t sb, int64_t sl, void* stream) {
+    if (B <= 0 || L <= 0 || D <= 0) return RFN_ERR_SHAPE;
+    if (!alpha || !dz || !datt_seq) return RFN_ERR_ARG;
+    hipLaunchKernelGGL(attn_dseq_k, dim3(L, B), dim3(ATT_THREADS), 0, (hipStream_t)stream, alpha, dz, (long)lddz, L,
+                       D, datt_seq, (long)sb, (long)sl);
+    RFN_CHECK_LAUNCH();
+    return RFN_OK;
+}
+
+// ---- backward of scores: softmax bwd + tanh bwd, writes dproj (may alias proj) -------------------
+// One block per batch row.  For each 64*W-wide chunk of A (W = 4 with 16-B accesses) every wave
+// sweeps its rows l = wave, wave+4, ... keeping the chunk's column sums (dhproj, dw) in registers;
+// the four waves' sums are combined through LDS in a fixed order (deterministic).
+template <bool VEC>
+__global__ __launch_bounds__(ATT_THREADS) void attn_scores_bwd_k(
+    const float* proj /* may alias dproj */, long sb, long sl, const float* __restrict__ hproj,
+    const float* __restrict__ w_out, const float* __restrict__ alpha, const float* __restrict__ dalpha, int L, int A,
+    float* dproj, long dsb, long dsl, int accumulate, float* __restrict__ dhproj, float* __restrict__ dw_part) {
+    constexpr int W = VEC ? 4 : 1;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int Ap = (A + 3) & ~3;
+    float* hp_s = sm;             // [Ap]
+    float* w_s = sm + Ap;         // [Ap]
+    float* red_h = sm + 2 * Ap;   // [4][Ap]
+    float* red_w = sm + 6 * Ap;   // [4][Ap]
+    float* dot_s = sm + 10 * Ap;  // [4]
+    float* ds_s = sm + 10 * Ap + 4;  // [L]
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int a = tid; a < A; a += ATT_THREADS) {
+        hp_s[a] = hproj[(long)b * A + a];
+        w_s[a] = w_out[a];
+    }
+    // softmax backward: ds = alpha * (dalpha - <alpha, dalpha>)
+    float part = 0.f;
+    for (int l = tid; l < L; l += ATT_THREADS) part += alpha[(long)b * L + l] * dalpha[(long)b * L + l];
+    part = rfn_wave_sum(part);
+    if (lane == 0) dot_s[wave] = part;
+    __syncthreads();
+    const float dot = (dot_s[0] + dot_s[1]) + (dot_s[2] + dot_s[3]);
+    for (int l = tid; l < L; l += ATT_THREADS)
+        ds_s[l] = alpha[(long)b * L + l] * (dalpha[(long)b * L + l] - dot);
+    __syncthreads();
+
+    for (int a0 = 0; a0 < A; a0 += 64 * W) {
+        const int a = a0 + lane * W;
+        float ah[W], aw[W];
+#pragma unroll
+        for (int e = 0; e < W; ++e) ah[e] = aw[e] = 0.f;
+        if (a < A) {
+            float hh[W], ww[W];
+#pragma unroll
+            for (int e = 0; e < W; ++e) {
+                hh[e] = hp_s[a + e];
+                ww[e] = w_s[a + e];
+            }
+            for (int l = wave; l < L; l += ATT_WAVES) {
+                const float dsl_v = ds_s[l];
+                const float* p = proj + b * sb + l * sl + a;
+                float* o = dproj + b * dsb + l * dsl + a;
+                float xv[W], ov[W];
+                if constexpr (VEC) {
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(p);
+                    xv[0] = t[0]; xv[1] = t[1]; xv[2] = t[2]; xv[3] = t[3];
+                } else {
+                    xv[0] = p[0];
+                }
+#pragma unroll
+                for (int e = 0; e < W; ++e) {
+                    const float t = tanhf(xv[e] + hh[e]);
+                    const float dpre = dsl_v * ww[e] * (1.0f - t * t);
+                    ov[e] = dpre;
+                    ah[e] += dpre;
+                    aw[e] += dsl_v * t;
+                }
+                if constexpr (VEC) {
+                    f32x4 t = {ov[0], ov[1], ov[2], ov[3]};
+                    if (accumulate) t += *reinterpret_cast<const f32x4*>(o);
+                    *reinterpret_cast<f32x4*>(o) = t;
+                } else {
+                    o[0] = accumulate ? o[0] + ov[0] : ov[0];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < W; ++e) {
+                red_h[wave * Ap + a + e] = ah[e];
+                red_w[wave * Ap + a + e] = aw[e];
+            }
+        }
+    }
+    __syncthreads();
+    for (int a = tid; a < A; a += ATT_THREADS) {
+        dhproj[(long)b * A + a] = (red_h[a] + red_h[Ap + a]) + (red_h[2 * Ap + a] + red_h[3 * Ap + a]);
+        dw_part[(long)b * A + a] = (red_w[a] + red_w[Ap + a]) + (red_w[2 * Ap + a] + red_w[3 * Ap + a]);
+    }
+}
+
+extern "C" int rfn_attn_scores_bwd(const float* proj, int64_t proj_sb, int64_t proj_sl, const float* hproj,
+                                   const float* w_out, const float* alpha, const float* dalpha, int B, int L, int A,
+                                   float* dproj, int64_t dproj_sb, int64_t dproj_sl, int accumulate_dproj,
+                                   float* dhproj, float* dw_part, void* stream) {
+    if (B <= 0 || L <= 0 || A <= 0) return RFN_ERR_SHAPE;
+    if (!proj || !hproj || !w_out || !alpha || !dalpha || !dproj || !dhproj || !dw_part) return RFN_ERR_ARG;
+    const size_t lds = (size_t)(10 * ((A + 3) & ~3) + 4 + L) * sizeof(float);
+    if (lds > 96 * 1024) return RFN_ERR_SHAPE;
+    const bool vec = (A % 4 == 0) && rfn_aligned16(proj) && rfn_aligned16(dproj) && (proj_sb % 4 == 0) &&
+                     (proj_sl % 4 == 0) && (dproj_sb % 4 == 0) && (dproj_sl % 4 == 0);
+    hipStream_t st = (hipStream_t)stream;
+    if (vec) {
+        auto k = attn_scores_bwd_k<true>;
+        if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k, dim3(B), dim3(ATT_THREADS), lds, st, proj, (long)proj_sb, (long)proj_sl, hproj, w_out,
+                           alpha, dalpha, L, A, dproj, (long)dproj_sb, (long)dproj_sl, accumulate_dproj, dhproj,
+                           dw_part);
+    } else {
+        auto k = attn_scores_bwd_k<false>;
+        if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k, dim3(B), dim3(ATT_THREADS), lds, st, proj, (long)proj_sb, (long)proj_sl, hproj, w_out,
+                           alpha, dalpha, L, A, dproj, (long)dproj_sb, (long)dproj_sl, accumulate_dproj, dhproj,
+                           dw_part);
+    }
+    RFN_CHECK_LAUNCH();
+    return RFN_OK;
+}

@@ -1,0 +1,107 @@
+// LSTM gate epilogue shared by the three cells of the recurrent-fusion path.
+//
+// Reference: misc/RecurrentFusionModel.py:55-73 (stage I), misc/LSTMSoftMultiAttentionFeatArrayNoInputCore.py
+// :54-72 (stage II), misc/LSTMSoftAttentionCore.py:83-101 (decoder).  Gate chunk order in the 4R
+// vector is [in | forget | out | g] (NOT cuDNN's i,f,g,o); the recurrent h is the POST-dropout
+// value, c is never dropped.
+// Element-wise and tiny (B*R elements): one thread per (b, j), coalesced along j.
+#include "rfn_common.h"
+
+// Philox4x32-10 keyed by `seed`; counter = (element index, call-site offset).  One 32-bit draw per
+// element; forward and backward regenerate the same mask from (seed, offset) instead of storing it.
+__device__ __forceinline__ uint32_t mulhi32(uint32_t a, uint32_t b) { return __umulhi(a, b); }
+__device__ __forceinline__ float rfn_philox_uniform(uint64_t seed, uint64_t offset, uint64_t idx) {
+    uint32_t c0 = (uint32_t)idx, c1 = (uint32_t)(idx >> 32), c2 = (uint32_t)offset, c3 = (uint32_t)(offset >> 32);
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = mulhi32(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = mulhi32(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return (float)(c0 >> 8) * (1.0f / 16777216.0f);  // [0, 1)
+}
+
+__global__ __launch_bounds__(256) void lstm_fwd_k(float* __restrict__ gates, long ldg, const float* c_prev /* may alias c_next */,
+                                                  long ldcp, float* c_next, long ldcn,
+                                                  float* __restrict__ h_next, long ldh, int B, int R, float drop_p,
+                                                  uint64_t seed, uint64_t offset) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)B * R) return;
+    const int b = (int)(idx / R), j = (int)(idx - (long)b * R);
+    float* g = gates + b * ldg;
+    const float ig = rfn_sigmoid(g[j]);
+    const float fg = rfn_sigmoid(g[R + j]);
+    const float og = rfn_sigmoid(g[2 * R + j]);
+    const float gg = tanhf(g[3 * R + j]);
+    g[j] = ig;
+    g[R + j] = fg;
+    g[2 * R + j] = og;
+    g[3 * R + j] = gg;
+    const float c = fg * c_prev[b * ldcp + j] + ig * gg;
+    c_next[b * ldcn + j] = c;
+    float hv = og * tanhf(c);
+    if (drop_p > 0.f) {
+        const float u = rfn_philox_uniform(seed, offset, (uint64_t)idx);
+        hv = (u >= drop_p) ? hv * (1.0f / (1.0f - drop_p)) : 0.f;
+    }
+    h_next[b * ldh + j] = hv;
+}
+
+extern "C" int rfn_lstm_fwd(float* gates, int64_t ldg, const float* c_prev, int64_t ldcp, float* c_next,
+                            int64_t ldcn, float* h_next, int64_t ldh, int B, int R, float drop_p, uint64_t seed,
+                            uint64_t offset, void* stream) {
+    if (B <= 0 || R <= 0 || drop_p < 0.f || drop_p >= 1.f) return RFN_ERR_SHAPE;
+    if (!gates || !c_prev || !c_next || !h_next) return RFN_ERR_ARG;
+    hipLaunchKernelGGL(lstm_fwd_k, dim3(rfn_cdiv((long)B * R, 256)), dim3(256), 0, (hipStream_t)stream, gates,
+                       (long)ldg, c_prev, (long)ldcp, c_next, (long)ldcn, h_next, (long)ldh, B, R, drop_p, seed,
+                       offset);
+    RFN_CHECK_LAUNCH();
+    return RFN_OK;
+}
+
+__global__ __launch_bounds__(256) void lstm_bwd_k(float* __restrict__ gates, long ldg, const float* __restrict__ c_prev,
+                                                  long ldcp, const float* __restrict__ c_next, long ldcn,
+                                                  const float* __restrict__ dh, long lddh,
+                                                  const float* dc_next /* may alias dc_prev */, long lddcn,
+                                                  float* dc_prev, long lddcp, int B, int R, float drop_p,
+                                                  uint64_t seed, uint64_t offset) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)B * R) return;
+    const int b = (int)(idx / R), j = (int)(idx - (long)b * R);
+    float* g = gates + b * ldg;
+    const float ig = g[j], fg = g[R + j], og = g[2 * R + j], gg = g[3 * R + j];
+    float dhv = dh[b * lddh + j];
+    if (drop_p > 0.f) {
+        const float u = rfn_philox_uniform(seed, offset, (uint64_t)idx);
+        dhv = (u >= drop_p) ? dhv * (1.0f / (1.0f - drop_p)) : 0.f;
+    }
+    const float tc = tanhf(c_next[b * ldcn + j]);
+    float dc = dhv * og * (1.0f - tc * tc);
+    if (dc_next) dc += dc_next[b * lddcn + j];
+    const float d_o = dhv * tc;
+    const float d_i = dc * gg;
+    const float d_f = dc * c_prev[b * ldcp + j];
+    const float d_g = dc * ig;
+    g[j] = d_i * ig * (1.0f - ig);
+    g[R + j] = d_f * fg * (1.0f - fg);
+    g[2 * R + j] = d_o * og * (1.0f - og);
+    g[3 * R + j] = d_g * (1.0f - gg * gg);
+    dc_prev[b * lddcp + j] = dc * fg;
+}
+
+extern "C" int rfn_lstm_bwd(float* gates, int64_t ldg, const float* c_prev, int64_t ldcp, const float* c_next,
+                            int64_t ldcn, const float* dh, int64_t lddh, const float* dc_next, int64_t lddcn,
+                            float* dc_prev, int64_t lddcp, int B, int R, float drop_p, uint64_t seed, uint64_t offset,
+                            void* stream) {
+    if (B <= 0 || R <= 0 || drop_p < 0.f || drop_p >= 1.f) return RFN_ERR_SHAPE;
+    if (!gates || !c_prev || !c_next || !dh || !dc_prev) return RFN_ERR_ARG;
+    hipLaunchKernelGGL(lstm_bwd_k, dim3(rfn_cdiv((long)B * R, 256)), dim3(256), 0, (hipStream_t)stream, gates,
+                       (long)ldg, c_prev, (long)ldcp, c_next, (long)ldcn, dh, (long)lddh, dc_next, (long)lddcn,
+                       dc_prev, (long)lddcp, B, R, drop_p, seed, offset);
+    RFN_CHECK_LAUNCH();
+    return RFN_OK;
+}

@@ -1,0 +1,41 @@
+// Shared declarations for the gfx950 kernels of the recurrent-fusion decoder path.
+// Written for MI355X (CDNA4) only: 64-lane waves, fp32 MFMA, 160 KiB LDS per CU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rfn.h"
+
+#define RFN_WAVE 64
+
+// Launch-error check used by every host launcher: kernels are asynchronous, the only error a
+// launcher can see is a bad configuration.
+#define RFN_CHECK_LAUNCH()                                   \
+    do {                                                     \
+        hipError_t e_ = hipGetLastError();                   \
+        if (e_ != hipSuccess) return RFN_ERR_LAUNCH;         \
+    } while (0)
+
+#define RFN_TRY(expr)                 \
+    do {                              \
+        int rc_ = (expr);             \
+        if (rc_ != RFN_OK) return rc_; \
+    } while (0)
+
+static inline int rfn_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+static inline bool rfn_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
+
+#ifdef __HIPCC__
+__device__ __forceinline__ float rfn_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float rfn_wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float rfn_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+#endif

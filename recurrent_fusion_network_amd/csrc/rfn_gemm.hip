@@ -1,0 +1,334 @@
+// Exact-fp32 grouped / K-segmented GEMM on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32).
+//
+// Replaces every nn.Linear / mm / addmm on the recurrent-fusion path (SURVEY.md 2.2 K0-K2, K5, K6,
+// K8, K9, K11) and their backward matmuls.  The dominant instance is the hoisted attention feature
+// projection att_2_att_h (misc/AttentionModelCore.py:32-34): (B*L x D) . (D x T1*A) per encoder,
+// 91.5 % of the path's FLOPs, plus its weight gradient in backward.
+//
+// Numerics: every output element is a chain of fp32 fma's (MFMA f32 is bit-for-bit an fmaf chain,
+// one rounding per product), i.e. true fp32 -- required for bit-exact greedy token ids.
+//
+// Structure (MI355X-first, not a CUDA tiling):
+//   * 256 threads = 4 waves (2x2); block tile BMxBNx32, wave tile (BM/2)x(BN/2) built from 32x32
+//     MFMA tiles, accumulators stay in the unified VGPR/AGPR file.
+//   * operands whose reduction index is contiguous are staged [row][k] with a 36-float row
+//     (conflict-free ds_read_b128 for the 16-lane b128 groups); operands whose OUTPUT index is
+//     contiguous (the transposed operands of the backward GEMMs) are staged [k][row] and read with
+//     conflict-free ds_read_b32 -- no transposition pass anywhere.
+//   * global -> register prefetch of tile i+1 overlaps the MFMAs of tile i; LDS is double buffered,
+//     one barrier per K step; 2 blocks/CU co-reside so the partner's MFMAs cover staging.
+//   * 1-D grid with a bijective XCD remap + 8-row bands so the blocks sharing an A row-panel and a
+//     B column-panel run on one XCD's L2 at the same time.
+#include "rfn_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define GEMM_BK 32
+#define GEMM_LDK 36 /* [row][k] row length in floats: 32 + 4 pad */
+#define GEMM_THREADS 256
+
+struct GemmArgs {
+    int M, N, ngroups, accumulate;
+    int tiles_m, tiles_n;
+    rfn_gemm_problem g[RFN_GEMM_MAXGROUP];
+};
+
+// ---- staging of one ROWS x 32 operand tile ---------------------------------------------------
+template <int ROWS, bool KFAST, bool VEC>
+struct Stage {
+    static constexpr int NV = ROWS / 32;  // float4 per thread (ROWS*32 floats / 256 threads / 4)
+    static constexpr int LDR = ROWS + 4;  // [k][row] row length
+    static constexpr int LDS_FLOATS = KFAST ? ROWS * GEMM_LDK : GEMM_BK * LDR;
+    f32x4 v[NV];
+
+    // rows [row0, row0+ROWS) x k [k0, k0+32) of an operand with `nrows` valid rows and K valid k.
+    __device__ __forceinline__ void load(const float* __restrict__ base, long ld, int row0,
+                                         int nrows, int k0, int K, int tid) {
+        if constexpr (VEC && KFAST) {
+            const int c4 = tid & 7;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const int r = row0 + (tid >> 3) + 32 * j;
+                const int k = k0 + 4 * c4;
+                f32x4 x = {0.f, 0.f, 0.f, 0.f};
+                if (r < nrows && k < K) x = *reinterpret_cast<const f32x4*>(base + (long)r * ld + k);
+                v[j] = x;
+            }
+        } else if constexpr (VEC && !KFAST) {
+            constexpr int RQ = ROWS / 4;            // float4 per k row
+            constexpr int KSTEP = GEMM_THREADS / RQ;  // k rows covered per pass
+            const int r = row0 + 4 * (tid % RQ);
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const int k = k0 + tid / RQ + KSTEP * j;
+                f32x4 x = {0.f, 0.f, 0.f, 0.f};
+                if (r < nrows && k < K) x = *reinterpret_cast<const f32x4*>(base + (long)k * ld + r);
+                v[j] = x;
+            }
+        } else if constexpr (KFAST) {
+            const int kk = tid & 31;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = row0 + (tid >> 5) + 8 * (4 * j + e);
+                    const int k = k0 + kk;
+                    v[j][e] = (r < nrows && k < K) ? base[(long)r * ld + k] : 0.f;
+                }
+            }
+        } else {
+            constexpr int KSTEP = GEMM_THREADS / ROWS;  // 2 (ROWS=128) or 4 (ROWS=64)
+            const int r = row0 + tid % ROWS;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int k = k0 + tid / ROWS + KSTEP * (4 * j + e);
+                    v[j][e] = (r < nrows && k < K) ? base[(long)k * ld + r] : 0.f;
+                }
+            }
+        }
+    }
+
+    __device__ __forceinline__ void store(float* __restrict__ lds, int tid) const {
+        if constexpr (VEC && KFAST) {
+            const int c4 = tid & 7;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const int r = (tid >> 3) + 32 * j;
+                *reinterpret_cast<f32x4*>(lds + r * GEMM_LDK + 4 * c4) = v[j];
+            }
+        } else if constexpr (VEC && !KFAST) {
+            constexpr int RQ = ROWS / 4;
+            constexpr int KSTEP = GEMM_THREADS / RQ;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const int k = tid / RQ + KSTEP * j;
+                *reinterpret_cast<f32x4*>(lds + k * LDR + 4 * (tid % RQ)) = v[j];
+            }
+        } else if constexpr (KFAST) {
+            const int kk = tid & 31;
+#pragma unroll
+            for (int j = 0; j < NV; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) lds[((tid >> 5) + 8 * (4 * j + e)) * GEMM_LDK + kk] = v[j][e];
+        } else {
+            constexpr int KSTEP = GEMM_THREADS / ROWS;
+#pragma unroll
+            for (int j = 0; j < NV; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    lds[(tid / ROWS + KSTEP * (4 * j + e)) * LDR + tid % ROWS] = v[j][e];
+        }
+    }
+
+    // the 4 k-values (k = 8q + 4h + c, c = 0..3) of tile row `row` for this lane's k-half h
+    __device__ __forceinline__ static f32x4 frag(const float* __restrict__ lds, int row, int q, int h) {
+        if constexpr (KFAST) {
+            return *reinterpret_cast<const f32x4*>(lds + row * GEMM_LDK + 8 * q + 4 * h);
+        } else {
+            f32x4 x;
+            const float* p = lds + (8 * q + 4 * h) * LDR + row;
+            x[0] = p[0];
+            x[1] = p[LDR];
+            x[2] = p[2 * LDR];
+            x[3] = p[3 * LDR];
+            return x;
+        }
+    }
+};
+
+template <int BM, int BN, bool AK, bool BKF, bool VEC>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void rfn_gemm_kernel(const GemmArgs args) {
+    constexpr int MT = BM / 64;  // 32x32 MFMA tiles per wave along M
+    constexpr int NT = BN / 64;
+    using StA = Stage<BM, AK, VEC>;
+    using StB = Stage<BN, BKF, VEC>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    // LDS: [A buf0 | A buf1 | B buf0 | B buf1]; pointers are computed, not tabulated
+    float* const sA0 = smem;
+    float* const sB0 = smem + 2 * StA::LDS_FLOATS;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, h = lane >> 5;
+
+    // ---- block -> (group, tile_m, tile_n): bijective XCD remap, then 8-row bands ------------
+    const int NC = args.ngroups * args.tiles_n;
+    const int nblk = NC * args.tiles_m;
+    int lid;
+    {
+        const int bid = blockIdx.x;
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+        lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int per_band = 8 * NC;
+    const int band = lid / per_band;
+    const int rem = lid - band * per_band;
+    const int band_rows = min(8, args.tiles_m - band * 8);
+    const int vcol = rem / band_rows;
+    const int tm = band * 8 + (rem - vcol * band_rows);
+    const int grp = vcol / args.tiles_n;
+    const int tn = vcol - grp * args.tiles_n;
+
+    const rfn_gemm_problem& P = args.g[grp];
+    const int row0 = tm * BM, col0 = tn * BN;
+    const int M = args.M, N = args.N;
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    StA stA;
+    StB stB;
+
+    // flattened (segment, k0) iteration space so the prefetch runs across segment boundaries
+    int total_iters = 0;
+    for (int s = 0; s < P.nseg; ++s) total_iters += (P.seg[s].K + GEMM_BK - 1) / GEMM_BK;
+
+    int seg = 0, k0 = 0;
+    auto issue_load = [&]() {
+        const rfn_gemm_seg& S = P.seg[seg];
+        stA.load(S.A, S.lda, row0, M, k0, S.K, tid);
+        stB.load(S.B, S.ldb, col0, N, k0, S.K, tid);
+        k0 += GEMM_BK;
+        if (k0 >= S.K) {
+            k0 = 0;
+            ++seg;
+        }
+    };
+
+    if (total_iters > 0) {
+        issue_load();
+        stA.store(sA0, tid);
+        stB.store(sB0, tid);
+    }
+    __syncthreads();
+
+    for (int it = 0; it < total_iters; ++it) {
+        const int cur = it & 1;
+        const bool more = (it + 1 < total_iters);
+        if (more) issue_load();  // global loads in flight during the MFMAs below
+
+        const float* a_l = sA0 + cur * StA::LDS_FLOATS;
+        const float* b_l = sB0 + cur * StB::LDS_FLOATS;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 af[MT], bf[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) af[i] = StA::frag(a_l, wm * (BM / 2) + i * 32 + l31, q, h);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bf[j] = StB::frag(b_l, wn * (BN / 2) + j * 32 + l31, q, h);
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][c], bf[j][c], acc[i][j], 0, 0, 0);
+        }
+
+        if (more) {
+            stA.store(sA0 + (cur ^ 1) * StA::LDS_FLOATS, tid);
+            stB.store(sB0 + (cur ^ 1) * StB::LDS_FLOATS, tid);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: bias, optional accumulate, bounds-checked store --------------------------
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int col = col0 + wn * (BN / 2) + j * 32 + l31;
+        if (col >= N) continue;
+        float bsum = 0.f;
+        for (int s = 0; s < P.nseg; ++s)
+            if (P.seg[s].bias) bsum += P.seg[s].bias[col];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row < M) {
+                    float* c = P.C + (long)row * P.ldc + col;
+                    float val = acc[i][j][r] + bsum;
+                    if (args.accumulate) val += *c;
+                    *c = val;
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, bool AK, bool BKF, bool VEC>
+static int launch_cfg(const GemmArgs& a, hipStream_t st) {
+    using StA = Stage<BM, AK, VEC>;
+    using StB = Stage<BN, BKF, VEC>;
+    const size_t lds = 2 * (StA::LDS_FLOATS + StB::LDS_FLOATS) * sizeof(float);
+    const int nblk = a.ngroups * a.tiles_m * a.tiles_n;
+    auto k = rfn_gemm_kernel<BM, BN, AK, BKF, VEC>;
+    static bool attr_set = false;  // idempotent; a race only repeats the same call
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k, dim3(nblk), dim3(GEMM_THREADS), lds, st, a);
+    RFN_CHECK_LAUNCH();
+    return RFN_OK;
+}
+
+template <bool AK, bool BKF, bool VEC>
+static int launch_tile(GemmArgs& a, hipStream_t st) {
+    // big tile when it still fills the chip (>= 2 blocks per CU), else 64x64 for the skinny
+    // per-step GEMMs (M = batch) so that more CUs get a tile.
+    const long big = (long)rfn_cdiv(a.M, 128) * rfn_cdiv(a.N, 128) * a.ngroups;
+    if (big >= 384) {
+        a.tiles_m = rfn_cdiv(a.M, 128);
+        a.tiles_n = rfn_cdiv(a.N, 128);
+        return launch_cfg<128, 128, AK, BKF, VEC>(a, st);
+    }
+    a.tiles_m = rfn_cdiv(a.M, 64);
+    a.tiles_n = rfn_cdiv(a.N, 64);
+    return launch_cfg<64, 64, AK, BKF, VEC>(a, st);
+}
+
+extern "C" int rfn_gemm_f32(int M, int N, int ngroups, const rfn_gemm_problem* problems, int accumulate,
+                            void* stream) {
+    if (M <= 0 || N <= 0) return RFN_OK;
+    if (ngroups < 1 || ngroups > RFN_GEMM_MAXGROUP || !problems) return RFN_ERR_SHAPE;
+    GemmArgs a;
+    a.M = M;
+    a.N = N;
+    a.ngroups = ngroups;
+    a.accumulate = accumulate;
+    const int ak = problems[0].seg[0].a_kfast, bk = problems[0].seg[0].b_kfast;
+    bool vec = true;
+    for (int g = 0; g < ngroups; ++g) {
+        const rfn_gemm_problem& p = problems[g];
+        if (p.nseg < 1 || p.nseg > RFN_GEMM_MAXSEG || !p.C) return RFN_ERR_SHAPE;
+        for (int s = 0; s < p.nseg; ++s) {
+            const rfn_gemm_seg& sg = p.seg[s];
+            if (!sg.A || !sg.B || sg.K < 0) return RFN_ERR_ARG;
+            if ((sg.a_kfast != 0) != (ak != 0) || (sg.b_kfast != 0) != (bk != 0)) return RFN_ERR_SHAPE;
+            // float4 staging needs 16-B aligned rows and whole float4s along the contiguous index
+            const bool a_ok = rfn_aligned16(sg.A) && (sg.lda % 4 == 0) && (ak ? sg.K % 4 == 0 : M % 4 == 0);
+            const bool b_ok = rfn_aligned16(sg.B) && (sg.ldb % 4 == 0) && (bk ? sg.K % 4 == 0 : N % 4 == 0);
+            vec = vec && a_ok && b_ok;
+        }
+        a.g[g] = p;
+    }
+    hipStream_t st = (hipStream_t)stream;
+#define RFN_DISPATCH(AKV, BKV)                                              \
+    return vec ? launch_tile<AKV, BKV, true>(a, st) : launch_tile<AKV, BKV, false>(a, st)
+    if (ak && bk) { RFN_DISPATCH(true, true); }
+    if (ak && !bk) { RFN_DISPATCH(true, false); }
+    if (!ak && bk) { RFN_DISPATCH(false, true); }
+    RFN_DISPATCH(false, false);
+#undef RFN_DISPATCH
+}

@@ -1,0 +1,450 @@
+// Small streaming kernels of the recurrent-fusion path: bias-gradient column sums, embedding
+// gather / deterministic scatter, vocabulary log-softmax, reason-head max over steps, the two
+// criteria of misc/utils.py, the clamp+Adam update and the greedy pick of sample().
+// All are HBM/L2-bound byte movers: coalesced 16-B accesses where alignment allows, wave shuffles for
+// reductions, fixed summation orders (no float atomics) so results are bitwise reproducible.
+#include "rfn_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float block_sum_256(float v, float* red /* [4] LDS */) {
+    v = rfn_wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+__device__ __forceinline__ float block_max_256(float v, float* red) {
+    v = rfn_wave_max(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+// ---- out[n] (+)= sum_r X[r, n] ----------------------------------------------------------------
+// block = 64 columns x 4 row lanes; each wave reads 256 contiguous bytes per row.
+__global__ __launch_bounds__(256) void colsum_k(const float* __restrict__ X, long ldx, int rows, int cols,
+                                                float* __restrict__ out, int accumulate) {
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+    float acc = 0.f;
+    if (c < cols)
+        for (int r = rl; r < rows; r += 4) acc += X[r * ldx + c];
+    red[rl][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (rl == 0 && c < cols) {
+        const int l = threadIdx.x & 63;
+        const float s = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+        out[c] = accumulate ? out[c] + s : s;
+    }
+}
+extern "C" int rfn_colsum_f32(const float* X, int64_t ldx, int rows, int cols, float* out, int accumulate,
+                              void* stream) {
+    if (rows < 0 || cols <= 0) return RFN_ERR_SHAPE;
+    if (!X || !out) return RFN_ERR_ARG;
+    hipLaunchKernelGGL(colsum_k, dim3(rfn_cdiv(cols, 64)), dim3(256), 0, (hipStream_t)stream, X, (long)ldx, rows,
+                       cols, out, accumulate);
+    RFN_CHECK_LAUNCH();
+    return RFN_OK;
+}
+
+// ---- embedding ----------------------------------------------------------------------------------
+__global__ __launch_bounds__(128) void embed_fwd_k(const float* __restrict__ W, int E, long V1,
+                                                   const int64_t* __restrict__ ids, int inner, long si, long so,
+                                                   float* __restrict__ out, long ldo) {
+    const int r = blockIdx.x;
+    long id = ids[(long)(r % inner) * si + (long)(r / inner) * so];
+    if (id < 0 || id >= V1) id = 0;  // the reference would raise; never fault the GPU
+    for (int e = threadIdx.x; e < E; e += 128) out[r * ldo + e] = W[id * E + e];
+}
+extern "C" int rfn_embed_fwd(const float* W, int E, int64_t V1, const int64_t* ids, int inner, int64_t ids_s_inner,
+                             int64_t ids_s_outer, int rows, float* out, int64_t ldo, void* stream) {
+    if (rows <= 0 || E <= 0 || V1 <= 0 || inner <= 0) return RFN_ERR_SHAPE;
+    if (!W || !ids || !out) return RFN_ERR_ARG;
+    hipLaunchKernelGGL(embed_fwd_k, dim3(rows), dim3(128), 0, (hipStream_t)stream, W, E, (long)V1, ids, inner,
+                       (long)ids_s_inner, (long)ids_s_outer, out, (long)ldo);
+    RFN_CHECK_LAUNCH();
+    return RFN_OK;
+}
+// one block per vocabulary row scans the token list in order: deterministic, no atomics.
+__global__ __launch_bounds__(128) void embed_bwd_k(const float* __restrict__ dout, long ldo,
+                                                   const int64_t* __restrict__ ids, int inner, long si, long so,
+                                                   int rows, int E, float* __restrict__ dW) {
+    const long v = blockIdx.x;
+    for (int e0 = 0; e0 < E; e0 += 128) {
+        const int e = e0 + threadIdx.x;
+        float acc = 0.f;
+        for (int r = 0; r < rows; ++r) {
+            const long id = ids[(long)(r % inner) * si + (long)(r / inner) * so];
+            if (id == v && e < E) acc += dout[r * ldo + e];
+        }
+        if (e < E) dW[v * E + e] = acc;
+    }
+}
+extern "C" int rfn_embed_bwd(const float* dout, int64_t ldo, const int64_t* ids, int inner, int64_t ids_s_inner,
+                             int64_t ids_s_outer, int rows, int E, int64_t V1, float* dW, void* stream) {
+    if (rows < 0 || E <= 0 || V1 <= 0 || inner <= 0) return RFN_ERR_SHAPE;
+    if (!dout || !ids || !dW) return RFN_ERR_ARG;
+    hipLaunchKernelGGL(embed_bwd_k, dim3((unsigned)V1), dim3(128), 0, (hipStream_t)stream, dout, (long)ldo, ids,
+                       inner, (long)ids_s_inner, (long)ids_s_outer, rows, E, dW);
+    RFN_CHECK_LAUNCH();
+    return RFN_OK;
+}
+
+// ---- log-softmax over the vocabulary --------------------------------------------------------------
+__global__ __launch_bounds__(256) void log_softmax_fwd_k(const float* __restrict__ logits, long ldl, int V1,
+                                                         int inner, long s_inner, long s_outer,
+                                                         float* __restrict__ out) {
+    __shared__ float red[4];
+    const int r = blockIdx.x;
+    const float* x = logits + r * ldl;
+    float* o = out + (long)(r % inner) * s_inner + (long)(r / inner) * s_outer;
+    float m = -INFINITY;
+    for (int v = threadIdx.x; v < V1; v += 256) m = fmaxf(m, x[v]);
+    m = block_max_256(m, red);
+    float s = 0.f;
+    for (int v = threadIdx.x; v < V1; v += 256) s += expf(x[v] - m);
+    s = block_sum_256(s, red);
+    const float lse = m + logf(s);
+    for (int v = threadIdx.x; v < V1; v += 256) o[v] = x[v] - lse;
+}
+extern "C" int rfn_log_softmax_fwd(const float* logits, int64_t ldl, int rows, int V1, int inner,
+                                   int64_t out_s_inner, int64_t out_s_outer, float* out, void* stream) {
+    if (rows <= 0 || V1 <= 0 || inner <= 0) return RFN_ERR_SHAPE;
+    if (!logits || !out) return RFN_ERR_ARG;
+    hipLaunchKernelGGL(log_softmax_fwd_k, dim3(rows), dim3(256), 0, (hipStream_t)stream, logits, (long)ldl, V1,
+                       inner, (long)out_s_inner, (long)out_s_outer, out);
+    RFN_CHECK_LAUNCH();
+    return RFN_OK;
+}
+__global__ __launch_bounds__(256) void log_softmax_bwd_k(const float* __restrict__ g, const float* __restrict__ logp,
+                                                         int V1, int inner, long s_inner, long s_outer,
+                                                         float* __restrict__ dlogits, long ldd) {
+    __shared__ float red[4];
+    const int r = blockIdx.x;
+    const long off = (long)(r % inner) * s_inner + (long)(r / inner) * s_outer;
+    const float* gr = g + off;
+    const float* lp = logp + off;
+    float s = 0.f;
+    for (int v = threadIdx.x; v < V1; v += 256) s += gr[v];
+    s = block_sum_256(s, red);
+    float* d = dlogits + r * ldd;
+    for (int v = threadIdx.x; v < V1; v += 256) d[v] = gr[v] - expf(lp[v]) * s;
+}
+extern "C" int rfn_log_softmax_bwd(const float* g, const float* logp, int rows, int V1, int inner, int64_t s_inner,
+                                   int64_t s_outer, float* dlogits, int64_t ldd, void* stream) {
+    if (rows <= 0 || V1 <= 0 || inner <= 0) return RFN_ERR_SHAPE;
+    if (!g || !logp || !dlogits) return RFN_ERR_ARG;
+    hipLaunchKernelGGL(log_softmax_bwd_k, dim3(rows), dim3(256), 0, (hipStream_t)stream, g, logp, V1, inner,
+                       (long)s_inner, (long)s_outer, dlogits, (long)ldd);
+    RFN_CHECK_LAUNCH();
+    return RFN_OK;
+}
+
+// ---- reason heads: max over steps ------------------------------------------------------------------
+__global__ __launch_bounds__(256) void max_steps_fwd_k(const float* __restrict__ X, int T, long BK,
+                                                       float* __restrict__ out, int32_t* __restrict__ arg) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= BK) return;
+    float m = X[i];
+    int a = 0;
+    for (int t = 1; t < T; ++t) {
+        const float v = X[t * BK + i];
+        if (v > m) {
+            m = v;
+            a = t;
+        }
+    }
+    out[i] = m;
+    if (arg) arg[i] = a;
+}
+extern "C" int rfn_max_over_steps_fwd(const float* X, int T, int B, int K, float* out, int32_t* arg, void* stream) {
+    if (T <= 0 || B <= 0 || K <= 0) return RFN_ERR_SHAPE;
+    if (!X || !out) return RFN_ERR_ARG;
+    const long BK = (long)B * K;
+    hipLaunchKernelGGL(max_steps_fwd_k, dim3(rfn_cdiv(BK, 256)), dim3(256), 0, (hipStream_t)stream, X, T, BK, out,
+                       arg);
+    RFN_CHECK_LAUNCH();
+    return RFN_OK;
+}
+__global__ __launch_bounds__(256) void max_steps_bwd_k(const float* __restrict__ dout, const int32_t* __restrict__ arg,
+                                                       int T, long BK, float* __restrict__ dX) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= BK) return;
+    const float g = dout ? dout[i] : 0.f;
+    const int a = arg[i];
+    for (int t = 0; t < T; ++t) dX[t * BK + i] = (t == a) ? g : 0.f;
+}
+extern "C" int rfn_max_over_steps_bwd(const float* dout, const int32_t* arg, int T, int B, int K, float* dX,
+                                      void* stream) {
+    if (T <= 0 || B <= 0 || K <= 0) return RFN_ERR_SHAPE;
+    if (!arg || !dX) return RFN_ERR_ARG;
+    const long BK = (long)B * K;
+    hipLaunchKernelGGL(max_steps_bwd_k, dim3(rfn_cdiv(BK, 256)), dim3(256), 0, (hipStream_t)stream, dout, arg, T, BK,
+                       dX);
+    RFN_CHECK_LAUNCH();
+    return RFN_OK;
+}
+
+// ---- y = alpha*x + beta*y on a strided 2-D view ------------------------------------------------------
+__global__ __launch_bounds__(256) void axpby_2d_k(float alpha, const float* __restrict__ x, long ldx, float beta,
+                                                  float* __restrict__ y, long ldy, int rows, int cols) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)rows * cols) return;
+    const int r = (int)(i / cols), c = (int)(i - (long)r * cols);
+    const float xv = x ? alpha * x[r * ldx + c] : 0.f;
+    float* p = y + r * ldy + c;
+    *p = (beta == 0.f) ? xv : xv + beta * *p;
+}
+extern "C" int rfn_axpby_2d(float alpha, const float* x, int64_t ldx, float beta, float* y, int64_t ldy, int rows,
+                            int cols, void* stream) {
+    if (rows <= 0 || cols <= 0) return RFN_ERR_SHAPE;
+    if (!y) return RFN_ERR_ARG;
+    hipLaunchKernelGGL(axpby_2d_k, dim3(rfn_cdiv((long)rows * cols, 256)), dim3(256), 0, (hipStream_t)stream, alpha,
+                       x, (long)ldx, beta, y, (long)ldy, rows, cols);
+    RFN_CHECK_LAUNCH();
+    return RFN_OK;
+}
+
+// ---- y[r,c] /= divisor (true division: the state mean sum/M of misc/RecurrentFusionModel.py:234-235) ----
+__global__ __launch_bounds__(256) void div_2d_k(float* __restrict__ y, long ldy, int rows, int cols, float divisor) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)rows * cols) return;
+    const int r = (int)(i / cols), c = (int)(i - (long)r * cols);
+    y[r * ldy + c] = y[r * ldy + c] / divisor;
+}
+extern "C" int rfn_div_2d(float* y, int64_t ldy, int rows, int cols, float divisor, void* stream) {
+    if (rows <= 0 || cols <= 0 || divisor == 0.f) return RFN_ERR_SHAPE;
+    if (!y) return RFN_ERR_ARG;
+    hipLaunchKernelGGL(div_2d_k, dim3(rfn_cdiv((long)rows * cols, 256)), dim3(256), 0, (hipStream_t)stream, y,
+                       (long)ldy, rows, cols, divisor);
+    RFN_CHECK_LAUNCH();
+    return RFN_OK;
+}
+
+// ---- fixed-order sum of n floats -> out[0] ---------------------------------------------------------
+__global__ __launch_bounds__(256) void sum_k(const float* __restrict__ x, int n, float scale, float* __restrict__ out,
+                                             int accumulate) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += x[i];
+    s = block_sum_256(s, red);
+    if (threadIdx.x == 0) out[0] = accumulate ? out[0] + s * scale : s * scale;
+}
+
+// ---- XE language loss (misc/utils.py:163-184) -------------------------------------------------------
+__global__ __launch_bounds__(256) void xe_loss_k(const float* __restrict__ logp, int T, int V1,
+                                                 const int64_t* __restrict__ target, long ld_t,
+                                                 const float* __restrict__ mask, long ld_m, float eps, float gcoef,
+                                                 float* __restrict__ row_loss, float* __restrict__ dlogp) {
+    __shared__ float red[4];
+    const int r = blockIdx.x, b = r / T, t = r - b * T;
+    const float* lp = logp + (long)r * V1;
+    long tg = target[b * ld_t + t];
+    if (tg < 0 || tg >= V1) tg = 0;
+    const float mk = mask[b * ld_m + t];
+    const float uni = eps / (float)V1;
+    float term = 0.f;
+    if (row_loss) {
+        if (eps > 0.f) {
+            float s = 0.f;
+            for (int v = threadIdx.x; v < V1; v += 256) s += lp[v];
+            s = block_sum_256(s, red);
+            term = (1.0f - eps) * lp[tg] + uni * s;
+        } else {
+            term = lp[tg];
+        }
+        if (threadIdx.x == 0) row_loss[r] = -mk * term;
+    }
+    if (dlogp) {
+        float* d = dlogp + (long)r * V1;
+        const float base = -mk * gcoef * uni;           // 0 when eps == 0
+        const float hot = -mk * gcoef * (1.0f - eps);
+        for (int v = threadIdx.x; v < V1; v += 256) d[v] = (v == tg) ? base + hot : base;
+    }
+}
+extern "C" int rfn_xe_loss(const float* logp, int B, int T, int V1, const int64_t* target, int64_t ld_target,
+                           const float* mask, int64_t ld_mask, float eps, float gscale, float* scratch,
+                           float* loss_out, int accumulate_loss, float* dlogp, void* stream) {
+    if (B <= 0 || T <= 0 || V1 <= 0) return RFN_ERR_SHAPE;
+    if (!logp || !target || !mask || (loss_out && !scratch)) return RFN_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(xe_loss_k, dim3(B * T), dim3(256), 0, st, logp, T, V1, target, (long)ld_target, mask,
+                       (long)ld_mask, eps, gscale / (float)B, loss_out ? scratch : nullptr, dlogp);
+    RFN_CHECK_LAUNCH();
+    if (loss_out) {
+        hipLaunchKernelGGL(sum_k, dim3(1), dim3(256), 0, st, scratch, B * T, 1.0f / (float)B, loss_out,
+                           accumulate_loss);
+        RFN_CHECK_LAUNCH();
+    }
+    return RFN_OK;
+}
+
+// ---- nn.MultiLabelMarginLoss (mean) -----------------------------------------------------------------
+// Row b: targets = ids before the first -1; loss_b = sum_{j in targets} sum_{i not target}
+// max(0, 1 - x[j] + x[i]) / K.  One block per row; hit counts per target through LDS integer atomics.
+__global__ __launch_bounds__(256) void mlm_k(const float* __restrict__ pred, int K, const int64_t* __restrict__ target,
+                                             float scale_over_B, float gcoef, float* __restrict__ row_loss,
+                                             float* __restrict__ dpred) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* x = sm;                                   // [K]
+    int* tg = reinterpret_cast<int*>(sm + K);        // [K] target list
+    int* cnt = tg + K;                               // [K] hits per target slot
+    unsigned char* is_t = reinterpret_cast<unsigned char*>(cnt + K);  // [K]
+    __shared__ int nt_s;
+    __shared__ float red[4];
+    const int b = blockIdx.x;
+    for (int i = threadIdx.x; i < K; i += 256) {
+        x[i] = pred[(long)b * K + i];
+        is_t[i] = 0;
+        cnt[i] = 0;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int n = 0;
+        for (; n < K; ++n) {
+            const long t = target[(long)b * K + n];
+            if (t < 0 || t >= K) break;
+            tg[n] = (int)t;
+            is_t[t] = 1;
+        }
+        nt_s = n;
+    }
+    __syncthreads();
+    const int nt = nt_s;
+    const float invK = 1.0f / (float)K;
+    float loss = 0.f;
+    for (int i = threadIdx.x; i < K; i += 256) {
+        float gi = 0.f;
+        if (!is_t[i]) {
+            for (int n = 0; n < nt; ++n) {
+                const float z = 1.0f - x[tg[n]] + x[i];
+                if (z > 0.f) {
+                    loss += z;
+                    gi += 1.0f;
+                    atomicAdd(&cnt[n], 1);
+                }
+            }
+        }
+        if (dpred) dpred[(long)b * K + i] = gi * invK * gcoef;  // targets fixed up below
+    }
+    loss = block_sum_256(loss, red);  // also orders the dpred writes above before the fix-up
+    if (row_loss && threadIdx.x == 0) row_loss[b] = loss * invK;
+    if (dpred && threadIdx.x == 0) {
+        // a duplicated target id receives the hits of every slot that names it
+        for (int n = 0; n < nt; ++n) dpred[(long)b * K + tg[n]] = 0.f;
+        for (int n = 0; n < nt; ++n) dpred[(long)b * K + tg[n]] -= (float)cnt[n] * invK * gcoef;
+    }
+    (void)scale_over_B;
+}
+extern "C" int rfn_multilabel_margin(const float* pred, int B, int K, const int64_t* target, float scale, float gscale,
+                                     float* scratch, float* loss_out, int accumulate_loss, float* dpred,
+                                     void* stream) {
+    if (B <= 0 || K <= 0) return RFN_ERR_SHAPE;
+    if (!pred || !target || (loss_out && !scratch)) return RFN_ERR_ARG;
+    const size_t lds = (size_t)K * (sizeof(float) + 2 * sizeof(int) + 1) + 16;
+    if (lds > 60 * 1024) return RFN_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(mlm_k, dim3(B), dim3(256), lds, st, pred, K, target, scale / (float)B,
+                       scale * gscale / (float)B, loss_out ? scratch : nullptr, dpred);
+    RFN_CHECK_LAUNCH();
+    if (loss_out) {
+        hipLaunchKernelGGL(sum_k, dim3(1), dim3(256), 0, st, scratch, B, scale / (float)B, loss_out,
+                           accumulate_loss);
+        RFN_CHECK_LAUNCH();
+    }
+    return RFN_OK;
+}
+
+// ---- clip_gradient + Adam (misc/utils.py:292-296, train.py:69-71) -----------------------------------
+__global__ __launch_bounds__(256) void adam_k(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                              float* __restrict__ v, long n, float lr_over_bc1, float beta1,
+                                              float beta2, float eps, float inv_sqrt_bc2, float wd, float clip,
+                                              float gscale) {
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        float gv = g[i] * gscale;
+        gv = fminf(fmaxf(gv, -clip), clip);
+        const float pv = p[i];
+        gv += wd * pv;
+        const float mv = beta1 * m[i] + (1.0f - beta1) * gv;
+        const float vv = beta2 * v[i] + (1.0f - beta2) * gv * gv;
+        m[i] = mv;
+        v[i] = vv;
+        p[i] = pv - lr_over_bc1 * mv / (sqrtf(vv) * inv_sqrt_bc2 + eps);
+    }
+}
+extern "C" int rfn_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                             float beta2, float eps, float weight_decay, float grad_clip, float grad_scale, int step,
+                             void* stream) {
+    if (n <= 0 || step < 1) return RFN_ERR_SHAPE;
+    if (!p || !g || !m || !v) return RFN_ERR_ARG;
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    const int blocks = (int)(n / 256 + 1 < 4096 ? n / 256 + 1 : 4096);
+    hipLaunchKernelGGL(adam_k, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n,
+                       (float)(lr / bc1), beta1, beta2, eps, (float)(1.0 / sqrt(bc2)), weight_decay, grad_clip,
+                       grad_scale);
+    RFN_CHECK_LAUNCH();
+    return RFN_OK;
+}
+
+// ---- greedy pick of sample() (misc/RecurrentFusionModel.py:619-649) -----------------------------------
+__global__ __launch_bounds__(256) void greedy_pick_k(const float* __restrict__ logp, long ldl, int V1, int t,
+                                                     int64_t* __restrict__ next_ids, int64_t* __restrict__ seq_out,
+                                                     long ld_seq, float* __restrict__ lp_out, long ld_lp,
+                                                     int32_t* __restrict__ unfinished) {
+    __shared__ float vs[4];
+    __shared__ int is[4];
+    const int b = blockIdx.x;
+    const float* x = logp + b * ldl;
+    float m = -INFINITY;
+    int mi = 0x7fffffff;
+    for (int v = threadIdx.x; v < V1; v += 256) {
+        const float xv = x[v];
+        if (xv > m) {  // strided ascending scan keeps the first maximum per thread
+            m = xv;
+            mi = v;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float om = __shfl_xor(m, o, 64);
+        const int oi = __shfl_xor(mi, o, 64);
+        if (om > m || (om == m && oi < mi)) {
+            m = om;
+            mi = oi;
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        vs[wave] = m;
+        is[wave] = mi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (vs[w] > m || (vs[w] == m && is[w] < mi)) {
+                m = vs[w];
+                mi = is[w];
+            }
+        int unf = (t == 1) ? 1 : unfinished[b];
+        unf = unf && (mi > 0);
+        unfinished[b] = unf;
+        next_ids[b] = mi;
+        seq_out[b * ld_seq] = unf ? mi : 0;
+        lp_out[b * ld_lp] = m;
+    }
+}
+extern "C" int rfn_greedy_pick(const float* logp, int64_t ldl, int B, int V1, int t, int64_t* next_ids,
+                               int64_t* seq_out, int64_t ld_seq, float* lp_out, int64_t ld_lp, int32_t* unfinished,
+                               void* stream) {
+    if (B <= 0 || V1 <= 0 || t < 1) return RFN_ERR_SHAPE;
+    if (!logp || !next_ids || !seq_out || !lp_out || !unfinished) return RFN_ERR_ARG;
+    hipLaunchKernelGGL(greedy_pick_k, dim3(B), dim3(256), 0, (hipStream_t)stream, logp, (long)ldl, V1, t, next_ids,
+                       seq_out, (long)ld_seq, lp_out, (long)ld_lp, unfinished);
+    RFN_CHECK_LAUNCH();
+    return RFN_OK;
+}

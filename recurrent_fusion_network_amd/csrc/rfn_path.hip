@@ -1,0 +1,872 @@
+// Host-side sequencing of the recurrent-fusion caption-decoder path on one MI355X.
+//
+// Restates the control flow of RecurrentFusionModel.forward / sample
+// (misc/RecurrentFusionModel.py:198-281, 545-658) as a fixed schedule of HIP launches on one stream:
+//   phase 1 (rfn_prefix_*): fc2h -> T1 x M fusion-stage-I cells -> reason heads -> state mean ->
+//                           T2 fusion-stage-II cells                       (:199-255, 283-343)
+//   phase 2 (rfn_decoder_*): embed -> attention-LSTM decoder -> logit + log_softmax (:257-281)
+// What is different from the reference's per-step Python loop of ~1500 ATen calls:
+//   * every attention feature projection att_2_att_h does not depend on h, so all T1 (stage I),
+//     T2 (stage II) step weights of one encoder are applied in ONE grouped MFMA GEMM before the
+//     recurrence, and the decoder's is applied once instead of 17 times;
+//   * all activations are kept time-major ((step, batch, feature)), so "stack + transpose +
+//     contiguous" (:223-227, 246-251) disappears, the stage-II / decoder attention reads the thought
+//     vectors through strides, and every weight gradient that is shared across steps is ONE GEMM
+//     over (steps*batch) rows;
+//   * the teacher-forced i2h(x_t) and logit(h_t) of all steps are batched GEMMs;
+//   * backward never materialises tanh outputs: the projection slice is overwritten in place by its
+//     gradient, which then feeds the grouped weight-gradient GEMM (the 77 % CPU hotspot).
+// No allocation, no synchronisation, no global state: buffers come from the caller's workspace.
+#include <stdio.h>
+#include <string.h>
+
+#include "rfn_common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// canonical parameter order (names: SURVEY.md 8b)
+// ---------------------------------------------------------------------------------------------
+struct PIdx {
+    int M, T1, T2;
+    explicit PIdx(const rfn_dims* d) : M(d->M), T1(d->T1), T2(d->T2) {}
+    int fc_w(int i) const { return 2 * i; }
+    int fc_b(int i) const { return 2 * i + 1; }
+    int embed() const { return 2 * M; }
+    int logit_w() const { return 2 * M + 1; }
+    int logit_b() const { return 2 * M + 2; }
+    // stage I cell (t, i): k = 0 att_2_att_h.w, 1 .b, 2 h_2_att_h.w, 3 .b, 4 att_h_2_out.w, 5 .b,
+    //                          6 H2h.w, 7 H2h.b, 8 z2h.w, 9 z2h.b
+    int s1(int t, int i, int k) const { return 2 * M + 3 + (t * M + i) * 10 + k; }
+    int rind_w(int i) const { return 2 * M + 3 + T1 * M * 10 + 2 * i; }
+    int rind_b(int i) const { return rind_w(i) + 1; }
+    int s2base(int t) const { return 2 * M + 3 + T1 * M * 10 + 2 * M + t * (2 + 8 * M); }
+    int s2_hh_w(int t) const { return s2base(t); }
+    int s2_hh_b(int t) const { return s2base(t) + 1; }
+    // stage II cell t, encoder i: k = 0 z_2_h.w, 1 .b, 2 att_2_att_h.w, 3 .b, 4 h_2_att_h.w, 5 .b,
+    //                                 6 att_h_2_out.w, 7 .b
+    int s2(int t, int i, int k) const { return s2base(t) + 2 + 8 * i + k; }
+    int r_w() const { return s2base(T2); }
+    int r_b() const { return r_w() + 1; }
+    // decoder: 0 i2h.w, 1 .b, 2 h2h.w, 3 .b, 4 z2h.w, 5 .b, 6 att_2_att_h.w, 7 .b, 8 h_2_att_h.w,
+    //          9 .b, 10 att_h_2_out.w, 11 .b
+    int dec(int k) const { return r_w() + 2 + k; }
+    int count() const { return r_w() + 2 + 12; }
+};
+
+int check_dims(const rfn_dims* d) {
+    if (!d) return RFN_ERR_ARG;
+    if (d->M < 1 || d->M > RFN_MAX_ENC || d->R < 1 || d->A < 1 || d->E < 1 || d->T1 < 1 || d->T2 < 1 || d->K < 1 ||
+        d->V1 < 2)
+        return RFN_ERR_SHAPE;
+    for (int i = 0; i < d->M; ++i)
+        if (d->L[i] < 1 || d->D[i] < 1 || d->F[i] < 1) return RFN_ERR_SHAPE;
+    if (d->review_maxout || d->decoder_maxout) return RFN_ERR_UNSUPPORTED;
+    if (d->drop_fusion < 0 || d->drop_fusion >= 1 || d->drop_reason < 0 || d->drop_reason >= 1 || d->drop_lm < 0 ||
+        d->drop_lm >= 1)
+        return RFN_ERR_SHAPE;
+    return RFN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// GEMM helpers.  lin(): Y = X W^T + b.  dx(): dX = dY W.  dw(): dW = dY^T X.
+// ---------------------------------------------------------------------------------------------
+rfn_gemm_seg seg_lin(const float* X, long ldx, const float* W, long ldw, int K, const float* bias) {
+    rfn_gemm_seg s;
+    memset(&s, 0, sizeof(s));
+    s.A = X; s.lda = ldx; s.a_kfast = 1;
+    s.B = W; s.ldb = ldw; s.b_kfast = 1;
+    s.K = K; s.bias = bias;
+    return s;
+}
+// dX[m, k] = sum_n dY[m, n] W[n, k]   (W is (N, Kout) row-major, ld ldw)
+rfn_gemm_seg seg_dx(const float* dY, long lddy, const float* W, long ldw, int N) {
+    rfn_gemm_seg s;
+    memset(&s, 0, sizeof(s));
+    s.A = dY; s.lda = lddy; s.a_kfast = 1;
+    s.B = W; s.ldb = ldw; s.b_kfast = 0;
+    s.K = N;
+    return s;
+}
+// dW[n, k] = sum_m dY[m, n] X[m, k]
+rfn_gemm_seg seg_dw(const float* dY, long lddy, const float* X, long ldx, int rows) {
+    rfn_gemm_seg s;
+    memset(&s, 0, sizeof(s));
+    s.A = dY; s.lda = lddy; s.a_kfast = 0;
+    s.B = X; s.ldb = ldx; s.b_kfast = 0;
+    s.K = rows;
+    return s;
+}
+rfn_gemm_problem prob1(float* C, long ldc, const rfn_gemm_seg& s) {
+    rfn_gemm_problem p;
+    memset(&p, 0, sizeof(p));
+    p.C = C; p.ldc = ldc; p.nseg = 1; p.seg[0] = s;
+    return p;
+}
+int gemm1(int M, int N, const rfn_gemm_seg& s, float* C, long ldc, int acc, void* st) {
+    rfn_gemm_problem p = prob1(C, ldc, s);
+    return rfn_gemm_f32(M, N, 1, &p, acc, st);
+}
+// any number of K segments into one C (chunks of RFN_GEMM_MAXSEG, later chunks accumulate)
+int gemm_segs(int M, int N, int nseg, const rfn_gemm_seg* segs, float* C, long ldc, int acc, void* st) {
+    for (int s0 = 0; s0 < nseg; s0 += RFN_GEMM_MAXSEG) {
+        rfn_gemm_problem p;
+        memset(&p, 0, sizeof(p));
+        p.C = C; p.ldc = ldc;
+        p.nseg = (nseg - s0 < RFN_GEMM_MAXSEG) ? nseg - s0 : RFN_GEMM_MAXSEG;
+        for (int s = 0; s < p.nseg; ++s) p.seg[s] = segs[s0 + s];
+        RFN_TRY(rfn_gemm_f32(M, N, 1, &p, (s0 > 0) ? 1 : acc, st));
+    }
+    return RFN_OK;
+}
+// any number of same-shape problems (chunks of RFN_GEMM_MAXGROUP)
+int gemm_groups(int M, int N, int n, const rfn_gemm_problem* p, int acc, void* st) {
+    for (int g0 = 0; g0 < n; g0 += RFN_GEMM_MAXGROUP) {
+        const int ng = (n - g0 < RFN_GEMM_MAXGROUP) ? n - g0 : RFN_GEMM_MAXGROUP;
+        RFN_TRY(rfn_gemm_f32(M, N, ng, p + g0, acc, st));
+    }
+    return RFN_OK;
+}
+
+int copy_f32(float* dst, const float* src, size_t n, void* st) {
+    if (hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)st) != hipSuccess)
+        return RFN_ERR_LAUNCH;
+    return RFN_OK;
+}
+int zero_f32(float* dst, size_t n, void* st) {
+    if (hipMemsetAsync(dst, 0, n * sizeof(float), (hipStream_t)st) != hipSuccess) return RFN_ERR_LAUNCH;
+    return RFN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// workspace layouts (offsets in floats, 256-B aligned)
+// ---------------------------------------------------------------------------------------------
+struct Bump {
+    size_t off = 0;
+    size_t take(size_t n) {
+        const size_t o = off;
+        off += (n + 63) & ~(size_t)63;
+        return o;
+    }
+};
+
+struct PrefixLayout {
+    size_t P1[RFN_MAX_ENC], al1[RFN_MAX_ENC], z1[RFN_MAX_ENC], P2[RFN_MAX_ENC], dz1[RFN_MAX_ENC];
+    size_t Hs, Cs, hp1, g1, rmat, rarg, h2, c2, hp2, al2, z2, g2;
+    size_t dHs, dC, dal, dwp, dhp1, dh2e, dhrec, dc2, dz2, dhp2;
+    size_t total;
+};
+PrefixLayout prefix_layout(const rfn_dims* d, int B, int train) {
+    PrefixLayout L;
+    memset(&L, 0, sizeof(L));
+    Bump b;
+    const size_t M = d->M, R = d->R, A = d->A, T1 = d->T1, T2 = d->T2, K = d->K, Bz = B;
+    size_t maxL = T1;
+    for (int i = 0; i < d->M; ++i) {
+        L.P1[i] = b.take(Bz * d->L[i] * T1 * A);
+        L.al1[i] = b.take(T1 * Bz * d->L[i]);
+        L.z1[i] = b.take(T1 * Bz * d->D[i]);
+        L.P2[i] = b.take(T1 * Bz * T2 * A);
+        if ((size_t)d->L[i] > maxL) maxL = d->L[i];
+    }
+    L.Hs = b.take((T1 + 1) * Bz * M * R);
+    L.Cs = b.take((T1 + 1) * Bz * M * R);
+    L.hp1 = b.take(T1 * M * Bz * A);
+    L.g1 = b.take(T1 * M * Bz * 4 * R);
+    L.rmat = b.take((T1 > T2 ? T1 : T2) * Bz * K);
+    L.rarg = b.take((M + 1) * Bz * K);  // int32, same width
+    L.h2 = b.take((T2 + 1) * Bz * R);
+    L.c2 = b.take((T2 + 1) * Bz * R);
+    L.hp2 = b.take(T2 * M * Bz * A);
+    L.al2 = b.take(T2 * M * Bz * T1);
+    L.z2 = b.take(T2 * M * Bz * R);
+    L.g2 = b.take(T2 * Bz * 4 * R);
+    if (train) {
+        for (int i = 0; i < d->M; ++i) L.dz1[i] = b.take(Bz * d->D[i]);
+        L.dHs = b.take((T1 + 1) * Bz * M * R);
+        L.dC = b.take(Bz * M * R);
+        L.dal = b.take(M * Bz * maxL);
+        L.dwp = b.take(M * Bz * A);
+        L.dhp1 = b.take(T1 * M * Bz * A);
+        L.dh2e = b.take(T2 * Bz * R);
+        L.dhrec = b.take(Bz * R);
+        L.dc2 = b.take(Bz * R);
+        L.dz2 = b.take(M * Bz * R);
+        L.dhp2 = b.take(T2 * M * Bz * A);
+    }
+    L.total = b.off;
+    return L;
+}
+
+struct DecoderLayout {
+    size_t Pd, xs, gd, hd, cd, hpd, ald, zd, logits;
+    size_t dhe, dhrec, dc, dz, dal, dwp, dhpd, dPd, dxs;
+    size_t total;
+};
+DecoderLayout decoder_layout(const rfn_dims* d, int B, int S, int train) {
+    DecoderLayout L;
+    memset(&L, 0, sizeof(L));
+    Bump b;
+    const size_t R = d->R, A = d->A, E = d->E, T2 = d->T2, V1 = d->V1, Bz = B, Sz = S;
+    L.Pd = b.take(T2 * Bz * A);
+    L.xs = b.take(Sz * Bz * E);
+    L.gd = b.take(Sz * Bz * 4 * R);
+    L.hd = b.take((Sz + 1) * Bz * R);
+    L.cd = b.take((Sz + 1) * Bz * R);
+    L.hpd = b.take(Sz * Bz * A);
+    L.ald = b.take(Sz * Bz * T2);
+    L.zd = b.take(Sz * Bz * R);
+    L.logits = b.take(Sz * Bz * V1);  // logits in forward, dlogits in backward
+    if (train) {
+        L.dhe = b.take(Sz * Bz * R);
+        L.dhrec = b.take(Bz * R);
+        L.dc = b.take(Bz * R);
+        L.dz = b.take(Bz * R);
+        L.dal = b.take(Bz * T2);
+        L.dwp = b.take(Bz * A);
+        L.dhpd = b.take(Sz * Bz * A);
+        L.dPd = b.take(T2 * Bz * A);
+        L.dxs = b.take(Sz * Bz * E);
+    }
+    L.total = b.off;
+    return L;
+}
+
+const uint64_t OFF_STAGE2 = 1u << 20, OFF_DECODER = 1u << 21;
+
+}  // namespace
+
+// =============================================================================================
+// parameter table
+// =============================================================================================
+extern "C" int rfn_abi_version(void) { return RFN_ABI_VERSION; }
+
+extern "C" const char* rfn_error_string(int code) {
+    switch (code) {
+        case RFN_OK: return "ok";
+        case RFN_ERR_SHAPE: return "unsupported or inconsistent dimensions";
+        case RFN_ERR_UNSUPPORTED: return "configuration not implemented by the HIP path (maxout)";
+        case RFN_ERR_LAUNCH: return "HIP launch / runtime failure";
+        case RFN_ERR_WORKSPACE: return "workspace too small";
+        case RFN_ERR_ARG: return "null or misaligned pointer";
+        default: return "unknown error";
+    }
+}
+
+extern "C" int rfn_param_count(const rfn_dims* d) {
+    const int rc = check_dims(d);
+    if (rc != RFN_OK) return rc;
+    return PIdx(d).count();
+}
+
+static const char* const kAtt[6] = {"att_2_att_h.weight", "att_2_att_h.bias", "h_2_att_h.weight",
+                                    "h_2_att_h.bias",     "att_h_2_out.weight", "att_h_2_out.bias"};
+
+extern "C" int rfn_param_name(const rfn_dims* d, int idx, char* buf, size_t n) {
+    const int rc = check_dims(d);
+    if (rc != RFN_OK) return rc;
+    if (!buf || n == 0) return RFN_ERR_ARG;
+    const PIdx P(d);
+    const int M = d->M;
+    if (idx < 0 || idx >= P.count()) return RFN_ERR_SHAPE;
+    if (idx < 2 * M) {
+        snprintf(buf, n, "fc2h.%d.%s", idx / 2, (idx & 1) ? "bias" : "weight");
+    } else if (idx == P.embed()) {
+        snprintf(buf, n, "embed.weight");
+    } else if (idx == P.logit_w()) {
+        snprintf(buf, n, "logit.weight");
+    } else if (idx == P.logit_b()) {
+        snprintf(buf, n, "logit.bias");
+    } else if (idx < P.rind_w(0)) {
+        const int r = idx - P.s1(0, 0, 0), cell = r / 10, k = r % 10, t = cell / M, i = cell % M;
+        if (k < 6)
+            snprintf(buf, n, "review_steps_individual.%d.lstm.%d.att_model.%s", t, i, kAtt[k]);
+        else
+            snprintf(buf, n, "review_steps_individual.%d.lstm.%d.%s.%s", t, i, (k < 8) ? "H2h" : "z2h",
+                     (k & 1) ? "bias" : "weight");
+    } else if (idx < P.s2base(0)) {
+        const int r = idx - P.rind_w(0);
+        snprintf(buf, n, "reason_linear_individual.%d.%s", r / 2, (r & 1) ? "bias" : "weight");
+    } else if (idx < P.r_w()) {
+        const int per = 2 + 8 * M, r = idx - P.s2base(0), t = r / per, k = r % per;
+        if (k < 2) {
+            snprintf(buf, n, "review_steps.%d.h2h.%s", t, k ? "bias" : "weight");
+        } else {
+            const int i = (k - 2) / 8, kk = (k - 2) % 8;
+            if (kk < 2)
+                snprintf(buf, n, "review_steps.%d.z_2_h.%d.%s", t, i, kk ? "bias" : "weight");
+            else
+                snprintf(buf, n, "review_steps.%d.att_model.%d.%s", t, i, kAtt[kk - 2]);
+        }
+    } else if (idx == P.r_w()) {
+        snprintf(buf, n, "reason_linear.weight");
+    } else if (idx == P.r_b()) {
+        snprintf(buf, n, "reason_linear.bias");
+    } else {
+        const int k = idx - P.dec(0);
+        static const char* const names[3] = {"i2h", "h2h", "z2h"};
+        if (k < 6)
+            snprintf(buf, n, "decoder.%s.%s", names[k / 2], (k & 1) ? "bias" : "weight");
+        else
+            snprintf(buf, n, "decoder.%s", kAtt[k - 6]);
+    }
+    return RFN_OK;
+}
+
+extern "C" int rfn_param_shape(const rfn_dims* d, int idx, int64_t* rows, int64_t* cols) {
+    const int rc = check_dims(d);
+    if (rc != RFN_OK) return rc;
+    if (!rows || !cols) return RFN_ERR_ARG;
+    const PIdx P(d);
+    const int M = d->M, R = d->R, A = d->A;
+    if (idx < 0 || idx >= P.count()) return RFN_ERR_SHAPE;
+    auto att_shape = [&](int k, int feat, int64_t* r, int64_t* c) {
+        const int64_t rr[6] = {A, A, A, A, 1, 1};
+        const int64_t cc[6] = {feat, 1, R, 1, A, 1};
+        *r = rr[k];
+        *c = cc[k];
+    };
+    if (idx < 2 * M) {
+        *rows = R;
+        *cols = (idx & 1) ? 1 : d->F[idx / 2];
+    } else if (idx == P.embed()) {
+        *rows = d->V1; *cols = d->E;
+    } else if (idx == P.logit_w()) {
+        *rows = d->V1; *cols = R;
+    } else if (idx == P.logit_b()) {
+        *rows = d->V1; *cols = 1;
+    } else if (idx < P.rind_w(0)) {
+        const int r = idx - P.s1(0, 0, 0), cell = r / 10, k = r % 10, i = cell % M;
+        if (k < 6) att_shape(k, d->D[i], rows, cols);
+        else { *rows = 4 * R; *cols = (k & 1) ? 1 : (k < 8 ? M * R : d->D[i]); }
+    } else if (idx < P.s2base(0)) {
+        *rows = d->K; *cols = ((idx - P.rind_w(0)) & 1) ? 1 : R;
+    } else if (idx < P.r_w()) {
+        const int per = 2 + 8 * M, k = (idx - P.s2base(0)) % per;
+        if (k < 2) { *rows = 4 * R; *cols = k ? 1 : R; }
+        else {
+            const int kk = (k - 2) % 8;
+            if (kk < 2) { *rows = 4 * R; *cols = kk ? 1 : R; }
+            else att_shape(kk - 2, R, rows, cols);
+        }
+    } else if (idx == P.r_w()) {
+        *rows = d->K; *cols = R;
+    } else if (idx == P.r_b()) {
+        *rows = d->K; *cols = 1;
+    } else {
+        const int k = idx - P.dec(0);
+        if (k < 6) { *rows = 4 * R; *cols = (k & 1) ? 1 : (k < 2 ? d->E : R); }
+        else att_shape(k - 6, R, rows, cols);
+    }
+    return RFN_OK;
+}
+
+// =============================================================================================
+// phase 1: init state + fusion stages I and II
+// =============================================================================================
+extern "C" size_t rfn_prefix_ws_bytes(const rfn_dims* d, int B, int train) {
+    if (check_dims(d) != RFN_OK || B < 1) return 0;
+    return prefix_layout(d, B, train).total * sizeof(float);
+}
+
+extern "C" int rfn_prefix_fwd(const rfn_dims* d, int B, const float* const* prm, const float* const* fc,
+                              const float* const* att, float* comb, float* h_out, float* c_out, float* reason_pred,
+                              void* ws, size_t ws_bytes, int train, uint64_t seed, void* st) {
+    RFN_TRY(check_dims(d));
+    if (B < 1) return RFN_ERR_SHAPE;
+    if (!prm || !fc || !att || !ws) return RFN_ERR_ARG;
+    const PrefixLayout Lo = prefix_layout(d, B, train);
+    if (ws_bytes < Lo.total * sizeof(float)) return RFN_ERR_WORKSPACE;
+    const PIdx P(d);
+    const int M = d->M, R = d->R, A = d->A, T1 = d->T1, T2 = d->T2, K = d->K;
+    const long MR = (long)M * R, BMR = (long)B * MR, BR = (long)B * R;
+    float* W = (float*)ws;
+    float* Hs = W + Lo.Hs;
+    float* Cs = W + Lo.Cs;
+    int32_t* rarg = (int32_t*)(W + Lo.rarg);
+
+    // K0: h0_i = fc2h_i(fc_i) written straight into the concatenated H of step 0; c0 = h0 (:202-208)
+    for (int i = 0; i < M; ++i)
+        RFN_TRY(gemm1(B, R, seg_lin(fc[i], d->F[i], prm[P.fc_w(i)], d->F[i], d->F[i], prm[P.fc_b(i)]), Hs + i * R, MR,
+                      0, st));
+    RFN_TRY(copy_f32(Cs, Hs, BMR, st));
+
+    // hoisted feature projections of stage I: P1_i[(b,l), t*A + a], all T1 step weights grouped
+    rfn_gemm_problem pr[64];
+    for (int i = 0; i < M; ++i) {
+        if (T1 > 64) return RFN_ERR_SHAPE;
+        for (int t = 0; t < T1; ++t)
+            pr[t] = prob1(W + Lo.P1[i] + (long)t * A, (long)T1 * A,
+                          seg_lin(att[i], d->D[i], prm[P.s1(t, i, 0)], d->D[i], d->D[i], prm[P.s1(t, i, 1)]));
+        RFN_TRY(gemm_groups(B * d->L[i], A, T1, pr, 0, st));
+    }
+
+    // ---- stage I: T1 steps x M cells (:213-217, :101-114, :47-74) ---------------------------
+    for (int t = 0; t < T1; ++t) {
+        float* Hc = Hs + t * BMR;
+        float* Hn = Hs + (t + 1) * BMR;
+        float* Cc = Cs + t * BMR;
+        float* Cn = Cs + (t + 1) * BMR;
+        float* hp = W + Lo.hp1 + (long)t * M * B * A;
+        float* g = W + Lo.g1 + (long)t * M * B * 4 * R;
+        for (int i = 0; i < M; ++i)
+            pr[i] = prob1(hp + (long)i * B * A, A,
+                          seg_lin(Hc + i * R, MR, prm[P.s1(t, i, 2)], R, R, prm[P.s1(t, i, 3)]));
+        RFN_TRY(gemm_groups(B, A, M, pr, 0, st));
+        for (int i = 0; i < M; ++i) {
+            const long Li = d->L[i], Di = d->D[i];
+            float* al = W + Lo.al1[i] + (long)t * B * Li;
+            float* z = W + Lo.z1[i] + (long)t * B * Di;
+            RFN_TRY(rfn_attn_scores_fwd(W + Lo.P1[i] + (long)t * A, Li * T1 * A, (long)T1 * A, hp + (long)i * B * A,
+                                        prm[P.s1(t, i, 4)], prm[P.s1(t, i, 5)], B, (int)Li, A, al, st));
+            RFN_TRY(rfn_attn_context_fwd(att[i], Li * Di, Di, al, B, (int)Li, (int)Di, z, Di, st));
+            rfn_gemm_problem& p = pr[i];
+            memset(&p, 0, sizeof(p));
+            p.C = g + (long)i * B * 4 * R;
+            p.ldc = 4 * R;
+            p.nseg = 2;
+            p.seg[0] = seg_lin(Hc, MR, prm[P.s1(t, i, 6)], MR, (int)MR, prm[P.s1(t, i, 7)]);
+            p.seg[1] = seg_lin(z, Di, prm[P.s1(t, i, 8)], Di, (int)Di, prm[P.s1(t, i, 9)]);
+        }
+        RFN_TRY(gemm_groups(B, 4 * R, M, pr, 0, st));
+        for (int i = 0; i < M; ++i)
+            RFN_TRY(rfn_lstm_fwd(g + (long)i * B * 4 * R, 4 * R, Cc + i * R, MR, Cn + i * R, MR, Hn + i * R, MR, B, R,
+                                 train ? d->drop_fusion : 0.f, seed, (uint64_t)(t * M + i), st));
+    }
+
+    // reason heads of stage I: max over steps of reason_linear_individual (:217, :229)
+    float* rmat = W + Lo.rmat;
+    for (int i = 0; i < M; ++i) {
+        RFN_TRY(gemm1(T1 * B, K, seg_lin(Hs + BMR + i * R, MR, prm[P.rind_w(i)], R, R, prm[P.rind_b(i)]), rmat, K, 0,
+                      st));
+        RFN_TRY(rfn_max_over_steps_fwd(rmat, T1, B, K, reason_pred + (long)i * B * K, rarg + (long)i * B * K, st));
+    }
+
+    // state mean over encoders (:233-235): sum first, then divide, as the reference does
+    float* h2 = W + Lo.h2;
+    float* c2 = W + Lo.c2;
+    for (int i = 0; i < M; ++i) {
+        RFN_TRY(rfn_axpby_2d(1.f, Hs + T1 * BMR + i * R, MR, i ? 1.f : 0.f, h2, R, B, R, st));
+        RFN_TRY(rfn_axpby_2d(1.f, Cs + T1 * BMR + i * R, MR, i ? 1.f : 0.f, c2, R, B, R, st));
+    }
+    RFN_TRY(rfn_div_2d(h2, R, B, R, (float)M, st));
+    RFN_TRY(rfn_div_2d(c2, R, B, R, (float)M, st));
+
+    // hoisted thought projections of stage II: rows (t', b) of encoder i's thoughts = Hs[1:]
+    for (int i = 0; i < M; ++i) {
+        if (T2 > 64) return RFN_ERR_SHAPE;
+        for (int t = 0; t < T2; ++t)
+            pr[t] = prob1(W + Lo.P2[i] + (long)t * A, (long)T2 * A,
+                          seg_lin(Hs + BMR + i * R, MR, prm[P.s2(t, i, 2)], R, R, prm[P.s2(t, i, 3)]));
+        RFN_TRY(gemm_groups(T1 * B, A, T2, pr, 0, st));
+    }
+
+    // ---- stage II: T2 steps (:241-244, LSTMSoftMultiAttentionFeatArrayNoInputCore.py:41-73) ---
+    rfn_gemm_seg segs[RFN_MAX_ENC + 1];
+    for (int t = 0; t < T2; ++t) {
+        float* hc = h2 + t * BR;
+        float* hn = h2 + (t + 1) * BR;
+        float* cc = c2 + t * BR;
+        float* cn = c2 + (t + 1) * BR;
+        float* hp = W + Lo.hp2 + (long)t * M * B * A;
+        float* al = W + Lo.al2 + (long)t * M * B * T1;
+        float* z = W + Lo.z2 + (long)t * M * BR;
+        float* g = W + Lo.g2 + (long)t * B * 4 * R;
+        for (int i = 0; i < M; ++i)
+            pr[i] = prob1(hp + (long)i * B * A, A, seg_lin(hc, R, prm[P.s2(t, i, 4)], R, R, prm[P.s2(t, i, 5)]));
+        RFN_TRY(gemm_groups(B, A, M, pr, 0, st));
+        segs[0] = seg_lin(hc, R, prm[P.s2_hh_w(t)], R, R, prm[P.s2_hh_b(t)]);
+        for (int i = 0; i < M; ++i) {
+            RFN_TRY(rfn_attn_scores_fwd(W + Lo.P2[i] + (long)t * A, (long)T2 * A, (long)B * T2 * A,
+                                        hp + (long)i * B * A, prm[P.s2(t, i, 6)], prm[P.s2(t, i, 7)], B, T1, A,
+                                        al + (long)i * B * T1, st));
+            RFN_TRY(rfn_attn_context_fwd(Hs + BMR + i * R, MR, BMR, al + (long)i * B * T1, B, T1, R, z + i * BR, R,
+                                         st));
+            segs[1 + i] = seg_lin(z + i * BR, R, prm[P.s2(t, i, 0)], R, R, prm[P.s2(t, i, 1)]);
+        }
+        RFN_TRY(gemm_segs(B, 4 * R, M + 1, segs, g, 4 * R, 0, st));
+        RFN_TRY(rfn_lstm_fwd(g, 4 * R, cc, R, cn, R, hn, R, B, R, train ? d->drop_reason : 0.f, seed,
+                             OFF_STAGE2 + (uint64_t)t, st));
+    }
+    RFN_TRY(gemm1(T2 * B, K, seg_lin(h2 + BR, R, prm[P.r_w()], R, R, prm[P.r_b()]), rmat, K, 0, st));
+    RFN_TRY(rfn_max_over_steps_fwd(rmat, T2, B, K, reason_pred + (long)M * B * K, rarg + (long)M * B * K, st));
+
+    if (comb) RFN_TRY(copy_f32(comb, h2 + BR, (size_t)T2 * BR, st));
+    if (h_out) RFN_TRY(copy_f32(h_out, h2 + (long)T2 * BR, BR, st));
+    if (c_out) RFN_TRY(copy_f32(c_out, c2 + (long)T2 * BR, BR, st));
+    return RFN_OK;
+}
+
+extern "C" int rfn_prefix_bwd(const rfn_dims* d, int B, const float* const* prm, const float* const* fc,
+                              const float* const* att, const float* d_comb, const float* d_h, const float* d_c,
+                              const float* d_reason, float* const* grd, void* ws, size_t ws_bytes, uint64_t seed,
+                              void* st) {
+    RFN_TRY(check_dims(d));
+    if (B < 1) return RFN_ERR_SHAPE;
+    if (!prm || !fc || !att || !grd || !ws) return RFN_ERR_ARG;
+    const PrefixLayout Lo = prefix_layout(d, B, 1);
+    if (ws_bytes < Lo.total * sizeof(float)) return RFN_ERR_WORKSPACE;
+    const PIdx P(d);
+    const int M = d->M, R = d->R, A = d->A, T1 = d->T1, T2 = d->T2, K = d->K;
+    const long MR = (long)M * R, BMR = (long)B * MR, BR = (long)B * R, BA = (long)B * A;
+    float* W = (float*)ws;
+    float* Hs = W + Lo.Hs;
+    float* Cs = W + Lo.Cs;
+    float* h2 = W + Lo.h2;
+    float* c2 = W + Lo.c2;
+    float* rmat = W + Lo.rmat;
+    const int32_t* rarg = (const int32_t*)(W + Lo.rarg);
+    float* dHs = W + Lo.dHs;
+    float* dC = W + Lo.dC;
+    float* dh2e = W + Lo.dh2e;
+    float* dhrec = W + Lo.dhrec;
+    float* dc2 = W + Lo.dc2;
+    float* dz2 = W + Lo.dz2;
+    float* dal = W + Lo.dal;
+    float* dwp = W + Lo.dwp;
+    rfn_gemm_problem pr[64];
+    rfn_gemm_seg segs[64];
+    if (T1 > 64 || T2 > 64) return RFN_ERR_SHAPE;
+
+    // ---- reason head of stage II (:244, :253) -------------------------------------------------
+    RFN_TRY(rfn_max_over_steps_bwd(d_reason ? d_reason + (long)M * B * K : nullptr, rarg + (long)M * B * K, T2, B, K,
+                                   rmat, st));
+    if (d_comb) RFN_TRY(copy_f32(dh2e, d_comb, (size_t)T2 * BR, st));
+    else RFN_TRY(zero_f32(dh2e, (size_t)T2 * BR, st));
+    RFN_TRY(gemm1(T2 * B, R, seg_dx(rmat, K, prm[P.r_w()], R, K), dh2e, R, 1, st));
+    RFN_TRY(gemm1(K, R, seg_dw(rmat, K, h2 + BR, R, T2 * B), grd[P.r_w()], R, 0, st));
+    RFN_TRY(rfn_colsum_f32(rmat, K, T2 * B, K, grd[P.r_b()], 0, st));
+
+    // gradient w.r.t. the stage-I hidden states: thoughts (through stage II) + reason heads + mean
+    RFN_TRY(zero_f32(dHs, (size_t)(T1 + 1) * BMR, st));
+
+    // ---- stage II backward ------------------------------------------------------------------------
+    for (int t = T2 - 1; t >= 0; --t) {
+        float* hp = W + Lo.hp2 + (long)t * M * BA;
+        float* dhp = W + Lo.dhp2 + (long)t * M * BA;
+        float* al = W + Lo.al2 + (long)t * M * B * T1;
+        float* g = W + Lo.g2 + (long)t * B * 4 * R;
+        float* dht = dh2e + t * BR;  // total dh of h2[t+1]
+        if (t == T2 - 1) {
+            if (d_h) RFN_TRY(rfn_axpby_2d(1.f, d_h, R, 1.f, dht, R, B, R, st));
+        } else {
+            RFN_TRY(rfn_axpby_2d(1.f, dhrec, R, 1.f, dht, R, B, R, st));
+        }
+        const float* dcn = (t == T2 - 1) ? d_c : dc2;
+        RFN_TRY(rfn_lstm_bwd(g, 4 * R, c2 + t * BR, R, c2 + (t + 1) * BR, R, dht, R, dcn, R, dc2, R, B, R,
+                             d->drop_reason, seed, OFF_STAGE2 + (uint64_t)t, st));
+        // dh_rec = dgates . W_hh ; dz_i = dgates . W_z_i   (same shape: one grouped launch)
+        pr[0] = prob1(dhrec, R, seg_dx(g, 4 * R, prm[P.s2_hh_w(t)], R, 4 * R));
+        for (int i = 0; i < M; ++i) pr[1 + i] = prob1(dz2 + i * BR, R, seg_dx(g, 4 * R, prm[P.s2(t, i, 0)], R, 4 * R));
+        RFN_TRY(gemm_groups(B, R, M + 1, pr, 0, st));
+        for (int i = 0; i < M; ++i) {
+            const float* th = Hs + BMR + i * R;  // thoughts_i[b, l] = Hs[1 + l][b, iR:]
+            RFN_TRY(rfn_attn_context_bwd_dalpha(th, MR, BMR, dz2 + i * BR, R, B, T1, R, dal, st));
+            RFN_TRY(rfn_attn_context_bwd_dseq(al + (long)i * B * T1, dz2 + i * BR, R, B, T1, R, dHs + BMR + i * R, MR,
+                                              BMR, st));
+            float* p2 = W + Lo.P2[i] + (long)t * A;
+            RFN_TRY(rfn_attn_scores_bwd(p2, (long)T2 * A, (long)B * T2 * A, hp + i * BA, prm[P.s2(t, i, 6)],
+                                        al + (long)i * B * T1, dal, B, T1, A, p2, (long)T2 * A, (long)B * T2 * A, 0,
+                                        dhp + i * BA, dwp, st));
+            RFN_TRY(rfn_colsum_f32(dwp, A, B, A, grd[P.s2(t, i, 6)], 0, st));
+            RFN_TRY(zero_f32(grd[P.s2(t, i, 7)], 1, st));
+            segs[i] = seg_dx(dhp + i * BA, A, prm[P.s2(t, i, 4)], R, A);
+        }
+        RFN_TRY(gemm_segs(B, R, M, segs, dhrec, R, 1, st));
+    }
+    // weight gradients of stage II, grouped over steps
+    for (int t = 0; t < T2; ++t)
+        pr[t] = prob1(grd[P.s2_hh_w(t)], R, seg_dw(W + Lo.g2 + (long)t * B * 4 * R, 4 * R, h2 + t * BR, R, B));
+    RFN_TRY(gemm_groups(4 * R, R, T2, pr, 0, st));
+    for (int t = 0; t < T2; ++t) {
+        const float* g = W + Lo.g2 + (long)t * B * 4 * R;
+        RFN_TRY(rfn_colsum_f32(g, 4 * R, B, 4 * R, grd[P.s2_hh_b(t)], 0, st));
+        for (int i = 0; i < M; ++i) RFN_TRY(copy_f32(grd[P.s2(t, i, 1)], grd[P.s2_hh_b(t)], 4 * R, st));
+    }
+    for (int i = 0; i < M; ++i) {
+        for (int t = 0; t < T2; ++t)
+            pr[t] = prob1(grd[P.s2(t, i, 0)], R,
+                          seg_dw(W + Lo.g2 + (long)t * B * 4 * R, 4 * R, W + Lo.z2 + ((long)t * M + i) * BR, R, B));
+        RFN_TRY(gemm_groups(4 * R, R, T2, pr, 0, st));
+        for (int t = 0; t < T2; ++t)
+            pr[t] = prob1(grd[P.s2(t, i, 4)], R, seg_dw(W + Lo.dhp2 + ((long)t * M + i) * BA, A, h2 + t * BR, R, B));
+        RFN_TRY(gemm_groups(A, R, T2, pr, 0, st));
+        for (int t = 0; t < T2; ++t) {
+            RFN_TRY(rfn_colsum_f32(W + Lo.dhp2 + ((long)t * M + i) * BA, A, B, A, grd[P.s2(t, i, 5)], 0, st));
+            RFN_TRY(copy_f32(grd[P.s2(t, i, 3)], grd[P.s2(t, i, 5)], A, st));  // d b_a = sum_l dproj = d b_h
+        }
+        // d att_2_att_h.weight[t] = dP2_i[:, t]^T . thoughts_i   (K = T1*B rows)
+        for (int t = 0; t < T2; ++t)
+            pr[t] = prob1(grd[P.s2(t, i, 2)], R,
+                          seg_dw(W + Lo.P2[i] + (long)t * A, (long)T2 * A, Hs + BMR + i * R, MR, T1 * B));
+        RFN_TRY(gemm_groups(A, R, T2, pr, 0, st));
+        // d thoughts_i += sum_t dP2_i[:, t] . W_a[t]
+        for (int t = 0; t < T2; ++t) segs[t] = seg_dx(W + Lo.P2[i] + (long)t * A, (long)T2 * A, prm[P.s2(t, i, 2)], R, A);
+        RFN_TRY(gemm_segs(T1 * B, R, T2, segs, dHs + BMR + i * R, MR, 1, st));
+    }
+
+    // ---- state mean backward (:233-235): every encoder's final (h, c) gets d / M --------------------
+    const float invM = 1.0f / (float)M;
+    for (int i = 0; i < M; ++i) {
+        RFN_TRY(rfn_axpby_2d(invM, dhrec, R, 1.f, dHs + T1 * BMR + i * R, MR, B, R, st));
+        RFN_TRY(rfn_axpby_2d(invM, dc2, R, 0.f, dC + i * R, MR, B, R, st));
+    }
+    // ---- reason heads of stage I ----------------------------------------------------------------------
+    for (int i = 0; i < M; ++i) {
+        RFN_TRY(rfn_max_over_steps_bwd(d_reason ? d_reason + (long)i * B * K : nullptr, rarg + (long)i * B * K, T1, B, K,
+                                       rmat, st));
+        RFN_TRY(gemm1(T1 * B, R, seg_dx(rmat, K, prm[P.rind_w(i)], R, K), dHs + BMR + i * R, MR, 1, st));
+        RFN_TRY(gemm1(K, R, seg_dw(rmat, K, Hs + BMR + i * R, MR, T1 * B), grd[P.rind_w(i)], R, 0, st));
+        RFN_TRY(rfn_colsum_f32(rmat, K, T1 * B, K, grd[P.rind_b(i)], 0, st));
+    }
+
+    // ---- stage I backward --------------------------------------------------------------------------------
+    for (int t = T1 - 1; t >= 0; --t) {
+        float* dHn = dHs + (t + 1) * BMR;  // total gradient of Hs[t+1]
+        float* dHc = dHs + t * BMR;        // external gradient of Hs[t]; the recurrent part is added here
+        float* g = W + Lo.g1 + (long)t * M * B * 4 * R;
+        float* hp = W + Lo.hp1 + (long)t * M * BA;
+        float* dhp = W + Lo.dhp1 + (long)t * M * BA;
+        for (int i = 0; i < M; ++i)
+            RFN_TRY(rfn_lstm_bwd(g + (long)i * B * 4 * R, 4 * R, Cs + t * BMR + i * R, MR, Cs + (t + 1) * BMR + i * R,
+                                 MR, dHn + i * R, MR, dC + i * R, MR, dC + i * R, MR, B, R, d->drop_fusion, seed,
+                                 (uint64_t)(t * M + i), st));
+        // dH_t += sum_i dgates_i . W_H[t,i]   (every cell reads the whole concatenated H, :53)
+        for (int i = 0; i < M; ++i) segs[i] = seg_dx(g + (long)i * B * 4 * R, 4 * R, prm[P.s1(t, i, 6)], MR, 4 * R);
+        RFN_TRY(gemm_segs(B, (int)MR, M, segs, dHc, MR, 1, st));
+        for (int i = 0; i < M; ++i) {
+            const long Li = d->L[i], Di = d->D[i];
+            float* dz = W + Lo.dz1[i];
+            RFN_TRY(gemm1(B, (int)Di, seg_dx(g + (long)i * B * 4 * R, 4 * R, prm[P.s1(t, i, 8)], Di, 4 * R), dz, Di, 0,
+                          st));
+            float* dali = dal + (long)i * B * Li;
+            RFN_TRY(rfn_attn_context_bwd_dalpha(att[i], Li * Di, Di, dz, Di, B, (int)Li, (int)Di, dali, st));
+            float* p1 = W + Lo.P1[i] + (long)t * A;
+            RFN_TRY(rfn_attn_scores_bwd(p1, Li * T1 * A, (long)T1 * A, hp + i * BA, prm[P.s1(t, i, 4)],
+                                        W + Lo.al1[i] + (long)t * B * Li, dali, B, (int)Li, A, p1, Li * T1 * A,
+                                        (long)T1 * A, 0, dhp + i * BA, dwp + i * BA, st));
+            RFN_TRY(rfn_colsum_f32(dwp + i * BA, A, B, A, grd[P.s1(t, i, 4)], 0, st));
+            RFN_TRY(zero_f32(grd[P.s1(t, i, 5)], 1, st));
+            pr[i] = prob1(dHc + i * R, MR, seg_dx(dhp + i * BA, A, prm[P.s1(t, i, 2)], R, A));
+        }
+        RFN_TRY(gemm_groups(B, R, M, pr, 1, st));
+    }
+    // c0 = h0.clone() (:206): dh0 += dc0 ; fc2h gradients
+    RFN_TRY(rfn_axpby_2d(1.f, dC, MR, 1.f, dHs, MR, B, (int)MR, st));
+    for (int i = 0; i < M; ++i) {
+        RFN_TRY(gemm1(R, d->F[i], seg_dw(dHs + i * R, MR, fc[i], d->F[i], B), grd[P.fc_w(i)], d->F[i], 0, st));
+        RFN_TRY(rfn_colsum_f32(dHs + i * R, MR, B, R, grd[P.fc_b(i)], 0, st));
+    }
+    // weight gradients of stage I, grouped over steps per encoder
+    for (int i = 0; i < M; ++i) {
+        const long Li = d->L[i], Di = d->D[i];
+        for (int t = 0; t < T1; ++t)
+            pr[t] = prob1(grd[P.s1(t, i, 6)], MR,
+                          seg_dw(W + Lo.g1 + ((long)t * M + i) * B * 4 * R, 4 * R, Hs + t * BMR, MR, B));
+        RFN_TRY(gemm_groups(4 * R, (int)MR, T1, pr, 0, st));
+        for (int t = 0; t < T1; ++t)
+            pr[t] = prob1(grd[P.s1(t, i, 8)], Di,
+                          seg_dw(W + Lo.g1 + ((long)t * M + i) * B * 4 * R, 4 * R, W + Lo.z1[i] + (long)t * B * Di, Di, B));
+        RFN_TRY(gemm_groups(4 * R, (int)Di, T1, pr, 0, st));
+        for (int t = 0; t < T1; ++t)
+            pr[t] = prob1(grd[P.s1(t, i, 2)], R,
+                          seg_dw(W + Lo.dhp1 + ((long)t * M + i) * BA, A, Hs + t * BMR + i * R, MR, B));
+        RFN_TRY(gemm_groups(A, R, T1, pr, 0, st));
+        for (int t = 0; t < T1; ++t) {
+            const float* g = W + Lo.g1 + ((long)t * M + i) * B * 4 * R;
+            RFN_TRY(rfn_colsum_f32(g, 4 * R, B, 4 * R, grd[P.s1(t, i, 7)], 0, st));
+            RFN_TRY(copy_f32(grd[P.s1(t, i, 9)], grd[P.s1(t, i, 7)], 4 * R, st));
+            RFN_TRY(rfn_colsum_f32(W + Lo.dhp1 + ((long)t * M + i) * BA, A, B, A, grd[P.s1(t, i, 3)], 0, st));
+            RFN_TRY(copy_f32(grd[P.s1(t, i, 1)], grd[P.s1(t, i, 3)], A, st));
+        }
+        // the dominant GEMM of backward: d att_2_att_h.weight[t,i] = dP1_i[:, t]^T . att_i  (K = B*L_i)
+        for (int t = 0; t < T1; ++t)
+            pr[t] = prob1(grd[P.s1(t, i, 0)], Di,
+                          seg_dw(W + Lo.P1[i] + (long)t * A, (long)T1 * A, att[i], Di, (int)(B * Li)));
+        RFN_TRY(gemm_groups(A, (int)Di, T1, pr, 0, st));
+    }
+    return RFN_OK;
+}
+
+// =============================================================================================
+// phase 2: teacher-forced decoder
+// =============================================================================================
+extern "C" size_t rfn_decoder_ws_bytes(const rfn_dims* d, int B, int S, int train) {
+    if (check_dims(d) != RFN_OK || B < 1 || S < 1) return 0;
+    return decoder_layout(d, B, S, train).total * sizeof(float);
+}
+
+extern "C" int rfn_decoder_fwd(const rfn_dims* d, int B, int S, const float* const* prm, const float* comb,
+                               const float* h0, const float* c0, const int64_t* ids, int64_t ld_ids, float* log_prob,
+                               void* ws, size_t ws_bytes, int train, uint64_t seed, void* st) {
+    RFN_TRY(check_dims(d));
+    if (B < 1 || S < 1) return RFN_ERR_SHAPE;
+    if (!prm || !comb || !h0 || !c0 || !ids || !log_prob || !ws) return RFN_ERR_ARG;
+    const DecoderLayout Lo = decoder_layout(d, B, S, train);
+    if (ws_bytes < Lo.total * sizeof(float)) return RFN_ERR_WORKSPACE;
+    const PIdx P(d);
+    const int R = d->R, A = d->A, E = d->E, T2 = d->T2, V1 = d->V1;
+    const long BR = (long)B * R, BA = (long)B * A;
+    float* W = (float*)ws;
+    float* hd = W + Lo.hd;
+    float* cd = W + Lo.cd;
+    float* gd = W + Lo.gd;
+    // loop-invariant projection of the fused thoughts, applied once instead of every step
+    RFN_TRY(gemm1(T2 * B, A, seg_lin(comb, R, prm[P.dec(6)], R, R, prm[P.dec(7)]), W + Lo.Pd, A, 0, st));
+    // all token embeddings and their i2h projections in one go (teacher forcing: ids are known)
+    RFN_TRY(rfn_embed_fwd(prm[P.embed()], E, V1, ids, B, ld_ids, 1, S * B, W + Lo.xs, E, st));
+    RFN_TRY(gemm1(S * B, 4 * R, seg_lin(W + Lo.xs, E, prm[P.dec(0)], E, E, prm[P.dec(1)]), gd, 4 * R, 0, st));
+    RFN_TRY(copy_f32(hd, h0, BR, st));
+    RFN_TRY(copy_f32(cd, c0, BR, st));
+    rfn_gemm_seg segs[2];
+    for (int s = 0; s < S; ++s) {
+        float* hc = hd + s * BR;
+        float* hp = W + Lo.hpd + s * BA;
+        float* al = W + Lo.ald + (long)s * B * T2;
+        float* z = W + Lo.zd + s * BR;
+        float* g = gd + (long)s * B * 4 * R;
+        RFN_TRY(gemm1(B, A, seg_lin(hc, R, prm[P.dec(8)], R, R, prm[P.dec(9)]), hp, A, 0, st));
+        RFN_TRY(rfn_attn_scores_fwd(W + Lo.Pd, A, BA, hp, prm[P.dec(10)], prm[P.dec(11)], B, T2, A, al, st));
+        RFN_TRY(rfn_attn_context_fwd(comb, R, BR, al, B, T2, R, z, R, st));
+        segs[0] = seg_lin(hc, R, prm[P.dec(2)], R, R, prm[P.dec(3)]);
+        segs[1] = seg_lin(z, R, prm[P.dec(4)], R, R, prm[P.dec(5)]);
+        RFN_TRY(gemm_segs(B, 4 * R, 2, segs, g, 4 * R, 1, st));
+        RFN_TRY(rfn_lstm_fwd(g, 4 * R, cd + s * BR, R, cd + (s + 1) * BR, R, hd + (s + 1) * BR, R, B, R,
+                             train ? d->drop_lm : 0.f, seed, OFF_DECODER + (uint64_t)s, st));
+    }
+    // logits of all steps, then log-softmax written in the reference's (B, S, V+1) layout
+    RFN_TRY(gemm1(S * B, V1, seg_lin(hd + BR, R, prm[P.logit_w()], R, R, prm[P.logit_b()]), W + Lo.logits, V1, 0, st));
+    RFN_TRY(rfn_log_softmax_fwd(W + Lo.logits, V1, S * B, V1, B, (long)S * V1, V1, log_prob, st));
+    return RFN_OK;
+}
+
+extern "C" int rfn_decoder_bwd(const rfn_dims* d, int B, int S, const float* const* prm, const float* comb,
+                               const float* h0, const float* c0, const int64_t* ids, int64_t ld_ids,
+                               const float* log_prob, const float* d_log_prob, float* d_comb, float* d_h0,
+                               float* d_c0, float* const* grd, void* ws, size_t ws_bytes, uint64_t seed, void* st) {
+    RFN_TRY(check_dims(d));
+    if (B < 1 || S < 1) return RFN_ERR_SHAPE;
+    if (!prm || !comb || !ids || !log_prob || !d_log_prob || !d_comb || !d_h0 || !d_c0 || !grd || !ws)
+        return RFN_ERR_ARG;
+    (void)h0; (void)c0;
+    const DecoderLayout Lo = decoder_layout(d, B, S, 1);
+    if (ws_bytes < Lo.total * sizeof(float)) return RFN_ERR_WORKSPACE;
+    const PIdx P(d);
+    const int R = d->R, A = d->A, E = d->E, T2 = d->T2, V1 = d->V1;
+    const long BR = (long)B * R, BA = (long)B * A;
+    float* W = (float*)ws;
+    float* hd = W + Lo.hd;
+    float* cd = W + Lo.cd;
+    float* gd = W + Lo.gd;
+    float* dlg = W + Lo.logits;
+    float* dhe = W + Lo.dhe;
+    float* dhrec = W + Lo.dhrec;
+    float* dc = W + Lo.dc;
+    float* dz = W + Lo.dz;
+    float* dPd = W + Lo.dPd;
+    // log-softmax backward into time-major rows, then the batched logit layer
+    RFN_TRY(rfn_log_softmax_bwd(d_log_prob, log_prob, S * B, V1, B, (long)S * V1, V1, dlg, V1, st));
+    RFN_TRY(gemm1(V1, R, seg_dw(dlg, V1, hd + BR, R, S * B), grd[P.logit_w()], R, 0, st));
+    RFN_TRY(rfn_colsum_f32(dlg, V1, S * B, V1, grd[P.logit_b()], 0, st));
+    RFN_TRY(gemm1(S * B, R, seg_dx(dlg, V1, prm[P.logit_w()], R, V1), dhe, R, 0, st));
+    RFN_TRY(zero_f32(d_comb, (size_t)T2 * BR, st));
+    RFN_TRY(zero_f32(dPd, (size_t)T2 * BA, st));
+    rfn_gemm_problem pr[2];
+    for (int s = S - 1; s >= 0; --s) {
+        float* g = gd + (long)s * B * 4 * R;
+        float* dht = dhe + s * BR;
+        if (s < S - 1) RFN_TRY(rfn_axpby_2d(1.f, dhrec, R, 1.f, dht, R, B, R, st));
+        RFN_TRY(rfn_lstm_bwd(g, 4 * R, cd + s * BR, R, cd + (s + 1) * BR, R, dht, R, (s < S - 1) ? dc : nullptr, R, dc,
+                             R, B, R, d->drop_lm, seed, OFF_DECODER + (uint64_t)s, st));
+        pr[0] = prob1(dhrec, R, seg_dx(g, 4 * R, prm[P.dec(2)], R, 4 * R));
+        pr[1] = prob1(dz, R, seg_dx(g, 4 * R, prm[P.dec(4)], R, 4 * R));
+        RFN_TRY(gemm_groups(B, R, 2, pr, 0, st));
+        float* al = W + Lo.ald + (long)s * B * T2;
+        RFN_TRY(rfn_attn_context_bwd_dalpha(comb, R, BR, dz, R, B, T2, R, W + Lo.dal, st));
+        RFN_TRY(rfn_attn_context_bwd_dseq(al, dz, R, B, T2, R, d_comb, R, BR, st));
+        float* dhp = W + Lo.dhpd + s * BA;
+        RFN_TRY(rfn_attn_scores_bwd(W + Lo.Pd, A, BA, W + Lo.hpd + s * BA, prm[P.dec(10)], al, W + Lo.dal, B, T2, A,
+                                    dPd, A, BA, 1, dhp, W + Lo.dwp, st));
+        RFN_TRY(rfn_colsum_f32(W + Lo.dwp, A, B, A, grd[P.dec(10)], (s < S - 1) ? 1 : 0, st));
+        RFN_TRY(gemm1(B, R, seg_dx(dhp, A, prm[P.dec(8)], R, A), dhrec, R, 1, st));
+    }
+    RFN_TRY(copy_f32(d_h0, dhrec, BR, st));
+    RFN_TRY(copy_f32(d_c0, dc, BR, st));
+    RFN_TRY(zero_f32(grd[P.dec(11)], 1, st));
+    // attention projection of the fused thoughts (shared by all steps)
+    RFN_TRY(gemm1(T2 * B, R, seg_dx(dPd, A, prm[P.dec(6)], R, A), d_comb, R, 1, st));
+    RFN_TRY(gemm1(A, R, seg_dw(dPd, A, comb, R, T2 * B), grd[P.dec(6)], R, 0, st));
+    RFN_TRY(rfn_colsum_f32(dPd, A, T2 * B, A, grd[P.dec(7)], 0, st));
+    // weights shared across steps: one GEMM over (S*B) time-major rows each
+    RFN_TRY(gemm1(A, R, seg_dw(W + Lo.dhpd, A, hd, R, S * B), grd[P.dec(8)], R, 0, st));
+    RFN_TRY(rfn_colsum_f32(W + Lo.dhpd, A, S * B, A, grd[P.dec(9)], 0, st));
+    RFN_TRY(gemm1(4 * R, R, seg_dw(gd, 4 * R, hd, R, S * B), grd[P.dec(2)], R, 0, st));
+    RFN_TRY(gemm1(4 * R, R, seg_dw(gd, 4 * R, W + Lo.zd, R, S * B), grd[P.dec(4)], R, 0, st));
+    RFN_TRY(gemm1(4 * R, E, seg_dw(gd, 4 * R, W + Lo.xs, E, S * B), grd[P.dec(0)], E, 0, st));
+    RFN_TRY(rfn_colsum_f32(gd, 4 * R, S * B, 4 * R, grd[P.dec(1)], 0, st));
+    RFN_TRY(copy_f32(grd[P.dec(3)], grd[P.dec(1)], 4 * R, st));
+    RFN_TRY(copy_f32(grd[P.dec(5)], grd[P.dec(1)], 4 * R, st));
+    // embedding: dx = dgates . W_i2h, then the fixed-order scatter
+    RFN_TRY(gemm1(S * B, E, seg_dx(gd, 4 * R, prm[P.dec(0)], E, 4 * R), W + Lo.dxs, E, 0, st));
+    RFN_TRY(rfn_embed_bwd(W + Lo.dxs, E, ids, B, ld_ids, 1, S * B, E, V1, grd[P.embed()], st));
+    return RFN_OK;
+}
+
+// =============================================================================================
+// free-running decoder step (sample / beam / one_time_step)
+// =============================================================================================
+extern "C" size_t rfn_decoder_step_ws_bytes(const rfn_dims* d, int B) {
+    if (check_dims(d) != RFN_OK || B < 1) return 0;
+    Bump b;
+    b.take((size_t)B * d->E);
+    b.take((size_t)B * d->A);
+    b.take((size_t)B * d->T2);
+    b.take((size_t)B * d->R);
+    b.take((size_t)B * 4 * d->R);
+    b.take((size_t)B * d->V1);
+    return b.off * sizeof(float);
+}
+
+extern "C" int rfn_decoder_prepare(const rfn_dims* d, int B, const float* const* prm, const float* comb, float* cproj,
+                                   void* st) {
+    RFN_TRY(check_dims(d));
+    if (B < 1) return RFN_ERR_SHAPE;
+    if (!prm || !comb || !cproj) return RFN_ERR_ARG;
+    const PIdx P(d);
+    return gemm1(d->T2 * B, d->A, seg_lin(comb, d->R, prm[P.dec(6)], d->R, d->R, prm[P.dec(7)]), cproj, d->A, 0, st);
+}
+
+extern "C" int rfn_decoder_step(const rfn_dims* d, int B, const float* const* prm, const float* comb,
+                                const float* cproj, const int64_t* ids, float* h, float* c, float* logits, float* logp,
+                                void* ws, size_t ws_bytes, void* st) {
+    RFN_TRY(check_dims(d));
+    if (B < 1) return RFN_ERR_SHAPE;
+    if (!prm || !comb || !cproj || !ids || !h || !c || !ws) return RFN_ERR_ARG;
+    if (ws_bytes < rfn_decoder_step_ws_bytes(d, B)) return RFN_ERR_WORKSPACE;
+    const PIdx P(d);
+    const int R = d->R, A = d->A, E = d->E, T2 = d->T2, V1 = d->V1;
+    const long BR = (long)B * R, BA = (long)B * A;
+    Bump b;
+    float* W = (float*)ws;
+    float* x = W + b.take((size_t)B * E);
+    float* hp = W + b.take((size_t)B * A);
+    float* al = W + b.take((size_t)B * T2);
+    float* z = W + b.take((size_t)B * R);
+    float* g = W + b.take((size_t)B * 4 * R);
+    float* lg = logits ? logits : W + b.take((size_t)B * V1);
+    RFN_TRY(rfn_embed_fwd(prm[P.embed()], E, V1, ids, B, 1, 0, B, x, E, st));
+    RFN_TRY(gemm1(B, A, seg_lin(h, R, prm[P.dec(8)], R, R, prm[P.dec(9)]), hp, A, 0, st));
+    RFN_TRY(rfn_attn_scores_fwd(cproj, A, BA, hp, prm[P.dec(10)], prm[P.dec(11)], B, T2, A, al, st));
+    RFN_TRY(rfn_attn_context_fwd(comb, R, BR, al, B, T2, R, z, R, st));
+    rfn_gemm_seg segs[3];
+    segs[0] = seg_lin(x, E, prm[P.dec(0)], E, E, prm[P.dec(1)]);
+    segs[1] = seg_lin(h, R, prm[P.dec(2)], R, R, prm[P.dec(3)]);
+    segs[2] = seg_lin(z, R, prm[P.dec(4)], R, R, prm[P.dec(5)]);
+    RFN_TRY(gemm_segs(B, 4 * R, 3, segs, g, 4 * R, 0, st));
+    RFN_TRY(rfn_lstm_fwd(g, 4 * R, c, R, c, R, h, R, B, R, 0.f, 0, 0, st));  // eval: no dropout
+    if (logits || logp) {
+        RFN_TRY(gemm1(B, V1, seg_lin(h, R, prm[P.logit_w()], R, R, prm[P.logit_b()]), lg, V1, 0, st));
+        if (logp) RFN_TRY(rfn_log_softmax_fwd(lg, V1, B, V1, B, V1, 0, logp, st));
+    }
+    return RFN_OK;
+}
