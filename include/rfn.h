@@ -204,12 +204,14 @@ int rfn_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float
                   int step, void* stream);
 
 /* greedy pick of sample() (misc/RecurrentFusionModel.py:619-649) for one step t >= 1:
- * it = argmax_v logp[b,:] (first maximum), sample_lp[b] = that value,
- * unfinished[b] = (t==1 ? 1 : unfinished[b]) & (it>0), seq_out[b] = it*unfinished,
- * next_ids[b] = it (UNMASKED: the reference embeds the raw argmax, :637). */
+ * it = argmax_v logp[b,:] (first maximum), lp_out[b] = that value,
+ * unf_out[b] = (t==1 ? 1 : unf_prev[b]) & (it>0), seq_out[b] = it*unf_out[b],
+ * next_ids[b] = it (UNMASKED: the reference embeds the raw argmax, :637).
+ * Keeping one unf_out row per step lets the host apply the reference's early exit (:645) with a
+ * single device read after the loop instead of one sync per step. */
 int rfn_greedy_pick(const float* logp, int64_t ldl, int B, int V1, int t, int64_t* next_ids,
                     int64_t* seq_out, int64_t ld_seq, float* lp_out, int64_t ld_lp,
-                    int32_t* unfinished, void* stream);
+                    const int32_t* unf_prev, int32_t* unf_out, void* stream);
 
 /* ---- whole-path entry points ---------------------------------------------------------------- */
 /* Phase 1 = get_init_state + get_thought_vectors (misc/RecurrentFusionModel.py:333-343, 283-331;
@@ -260,7 +262,8 @@ int rfn_decoder_prepare(const rfn_dims* d, int B, const float* const* params, co
                         float* cproj, void* stream);
 int rfn_decoder_step(const rfn_dims* d, int B, const float* const* params, const float* comb,
                      const float* cproj, const int64_t* ids, float* h, float* c, float* logits,
-                     float* logp, void* ws, size_t ws_bytes, void* stream);
+                     float* logp, int64_t ld_logp /* row stride of logp, >= V1 */, void* ws,
+                     size_t ws_bytes, void* stream);
 
 #ifdef __cplusplus
 }

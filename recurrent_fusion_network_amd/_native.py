@@ -1,0 +1,183 @@
+"""ctypes binding of librfn_hip.so (include/rfn.h).
+
+The HIP library IS the product: there is no CPU or PyTorch-op fallback.  Importing this module
+without the built library raises, and every call that returns a non-zero status raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'librfn_hip.so')
+
+RFN_MAX_ENC = 8
+RFN_GEMM_MAXSEG = 8
+RFN_GEMM_MAXGROUP = 8
+ABI_VERSION = 1
+
+
+class RfnError(RuntimeError):
+    pass
+
+
+class Dims(C.Structure):
+    _fields_ = [('M', C.c_int32), ('R', C.c_int32), ('A', C.c_int32), ('E', C.c_int32), ('T1', C.c_int32),
+                ('T2', C.c_int32), ('K', C.c_int32), ('V1', C.c_int32),
+                ('L', C.c_int32 * RFN_MAX_ENC), ('D', C.c_int32 * RFN_MAX_ENC), ('F', C.c_int32 * RFN_MAX_ENC),
+                ('review_maxout', C.c_int32), ('decoder_maxout', C.c_int32),
+                ('drop_fusion', C.c_float), ('drop_reason', C.c_float), ('drop_lm', C.c_float)]
+
+
+class GemmSeg(C.Structure):
+    _fields_ = [('A', C.c_void_p), ('B', C.c_void_p), ('bias', C.c_void_p), ('lda', C.c_int64),
+                ('ldb', C.c_int64), ('K', C.c_int32), ('a_kfast', C.c_int32), ('b_kfast', C.c_int32),
+                ('pad_', C.c_int32)]
+
+
+class GemmProblem(C.Structure):
+    _fields_ = [('C', C.c_void_p), ('ldc', C.c_int64), ('nseg', C.c_int32), ('pad_', C.c_int32),
+                ('seg', GemmSeg * RFN_GEMM_MAXSEG)]
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise RfnError(
+            'librfn_hip.so is missing (%s). Build it with `python -c "import __graft_entry__ as g; g.build()"` '
+            'or `make -C recurrent_fusion_network_amd/csrc`. There is no fallback path.' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    if lib.rfn_abi_version() != ABI_VERSION:
+        raise RfnError('librfn_hip.so ABI %d != binding ABI %d: rebuild' % (lib.rfn_abi_version(), ABI_VERSION))
+    lib.rfn_error_string.restype = C.c_char_p
+    P, I, L, F, SZ, U64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t, C.c_uint64
+    DP = C.POINTER(Dims)
+    sig = {
+        'rfn_param_count': (C.c_int, [DP]),
+        'rfn_param_name': (C.c_int, [DP, I, C.c_char_p, SZ]),
+        'rfn_param_shape': (C.c_int, [DP, I, C.POINTER(L), C.POINTER(L)]),
+        'rfn_gemm_f32': (C.c_int, [I, I, I, C.POINTER(GemmProblem), I, P]),
+        'rfn_colsum_f32': (C.c_int, [P, L, I, I, P, I, P]),
+        'rfn_attn_scores_fwd': (C.c_int, [P, L, L, P, P, P, I, I, I, P, P]),
+        'rfn_attn_context_fwd': (C.c_int, [P, L, L, P, I, I, I, P, L, P]),
+        'rfn_attn_context_bwd_dalpha': (C.c_int, [P, L, L, P, L, I, I, I, P, P]),
+        'rfn_attn_context_bwd_dseq': (C.c_int, [P, P, L, I, I, I, P, L, L, P]),
+        'rfn_attn_scores_bwd': (C.c_int, [P, L, L, P, P, P, P, I, I, I, P, L, L, I, P, P, P]),
+        'rfn_lstm_fwd': (C.c_int, [P, L, P, L, P, L, P, L, I, I, F, U64, U64, P]),
+        'rfn_lstm_bwd': (C.c_int, [P, L, P, L, P, L, P, L, P, L, P, L, I, I, F, U64, U64, P]),
+        'rfn_embed_fwd': (C.c_int, [P, I, L, P, I, L, L, I, P, L, P]),
+        'rfn_embed_bwd': (C.c_int, [P, L, P, I, L, L, I, I, L, P, P]),
+        'rfn_log_softmax_fwd': (C.c_int, [P, L, I, I, I, L, L, P, P]),
+        'rfn_log_softmax_bwd': (C.c_int, [P, P, I, I, I, L, L, P, L, P]),
+        'rfn_max_over_steps_fwd': (C.c_int, [P, I, I, I, P, P, P]),
+        'rfn_max_over_steps_bwd': (C.c_int, [P, P, I, I, I, P, P]),
+        'rfn_axpby_2d': (C.c_int, [F, P, L, F, P, L, I, I, P]),
+        'rfn_div_2d': (C.c_int, [P, L, I, I, F, P]),
+        'rfn_xe_loss': (C.c_int, [P, I, I, I, P, L, P, L, F, F, P, P, I, P, P]),
+        'rfn_multilabel_margin': (C.c_int, [P, I, I, P, F, F, P, P, I, P, P]),
+        'rfn_adam_step': (C.c_int, [P, P, P, P, L, F, F, F, F, F, F, F, I, P]),
+        'rfn_greedy_pick': (C.c_int, [P, L, I, I, I, P, P, L, P, L, P, P, P]),
+        'rfn_prefix_ws_bytes': (SZ, [DP, I, I]),
+        'rfn_prefix_fwd': (C.c_int, [DP, I, P, P, P, P, P, P, P, P, SZ, I, U64, P]),
+        'rfn_prefix_bwd': (C.c_int, [DP, I, P, P, P, P, P, P, P, P, P, SZ, U64, P]),
+        'rfn_decoder_ws_bytes': (SZ, [DP, I, I, I]),
+        'rfn_decoder_fwd': (C.c_int, [DP, I, I, P, P, P, P, P, L, P, P, SZ, I, U64, P]),
+        'rfn_decoder_bwd': (C.c_int, [DP, I, I, P, P, P, P, P, L, P, P, P, P, P, P, P, SZ, U64, P]),
+        'rfn_decoder_step_ws_bytes': (SZ, [DP, I]),
+        'rfn_decoder_prepare': (C.c_int, [DP, I, P, P, P, P]),
+        'rfn_decoder_step': (C.c_int, [DP, I, P, P, P, P, P, P, P, P, L, P, SZ, P]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    return lib, sorted(sig) + ['rfn_abi_version', 'rfn_error_string']
+
+
+lib, EXPORTS = _load()
+
+
+def check(rc: int, what: str = '') -> None:
+    if rc != 0:
+        raise RfnError('%s failed: %s (code %d)' % (what or 'librfn_hip call', lib.rfn_error_string(rc).decode(), rc))
+
+
+def stream_ptr() -> int:
+    """The current PyTorch HIP stream as a raw hipStream_t."""
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t) -> int:
+    return 0 if t is None else t.data_ptr()
+
+
+def require_cuda_f32(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise RfnError('%s must live on the GPU: the HIP path has no CPU fallback' % name)
+    if t.dtype != torch.float32:
+        raise RfnError('%s must be float32, got %s' % (name, t.dtype))
+    return t.contiguous()
+
+
+def ptr_array(tensors):
+    arr = (C.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = None if t is None else t.data_ptr()
+    return arr
+
+
+def make_dims(M, R, A, E, T1, T2, K, V1, L, D, Fc, review_maxout=0, decoder_maxout=0, drop_fusion=0.0,
+              drop_reason=0.0, drop_lm=0.0) -> Dims:
+    if M > RFN_MAX_ENC:
+        raise RfnError('at most %d encoders are supported' % RFN_MAX_ENC)
+    d = Dims()
+    d.M, d.R, d.A, d.E, d.T1, d.T2, d.K, d.V1 = M, R, A, E, T1, T2, K, V1
+    for i in range(M):
+        d.L[i], d.D[i], d.F[i] = L[i], D[i], Fc[i]
+    d.review_maxout, d.decoder_maxout = int(review_maxout), int(decoder_maxout)
+    d.drop_fusion, d.drop_reason, d.drop_lm = drop_fusion, drop_reason, drop_lm
+    return d
+
+
+def param_names(d: Dims):
+    n = lib.rfn_param_count(C.byref(d))
+    if n < 0:
+        check(n, 'rfn_param_count')
+    buf = C.create_string_buffer(160)
+    out = []
+    for i in range(n):
+        check(lib.rfn_param_name(C.byref(d), i, buf, 160), 'rfn_param_name')
+        out.append(buf.value.decode())
+    return out
+
+
+def param_shape(d: Dims, idx: int):
+    r, c = C.c_int64(), C.c_int64()
+    check(lib.rfn_param_shape(C.byref(d), idx, C.byref(r), C.byref(c)), 'rfn_param_shape')
+    return r.value, c.value
+
+
+# ---- thin helpers over the primitive operators (used by the model shell and by the tests) ---------
+def gemm(M, N, problems, accumulate=False):
+    """problems: list of (C, ldc, [(A, lda, a_kfast, B, ldb, b_kfast, K, bias), ...])."""
+    arr = (GemmProblem * len(problems))()
+    for g, (Ct, ldc, segs) in enumerate(problems):
+        arr[g].C, arr[g].ldc, arr[g].nseg = Ct.data_ptr(), ldc, len(segs)
+        for s, (A, lda, ak, B, ldb, bk, K, bias) in enumerate(segs):
+            sg = arr[g].seg[s]
+            sg.A, sg.lda, sg.a_kfast = A.data_ptr(), lda, int(ak)
+            sg.B, sg.ldb, sg.b_kfast = B.data_ptr(), ldb, int(bk)
+            sg.K, sg.bias = K, ptr(bias)
+    check(lib.rfn_gemm_f32(M, N, len(problems), arr, int(accumulate), stream_ptr()), 'rfn_gemm_f32')
+
+
+def linear(x: torch.Tensor, weight: torch.Tensor, bias=None) -> torch.Tensor:
+    """y = x W^T + b through the MFMA GEMM (no autograd)."""
+    x = require_cuda_f32(x, 'x')
+    weight = require_cuda_f32(weight, 'weight')
+    rows, K = x.shape
+    N = weight.shape[0]
+    y = torch.empty(rows, N, device=x.device, dtype=torch.float32)
+    gemm(rows, N, [(y, N, [(x, K, 1, weight, K, 1, K, bias)])])
+    return y

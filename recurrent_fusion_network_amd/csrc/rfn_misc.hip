@@ -395,7 +395,7 @@ extern "C" int rfn_adam_step(float* p, const float* g, float* m, float* v, int64
 __global__ __launch_bounds__(256) void greedy_pick_k(const float* __restrict__ logp, long ldl, int V1, int t,
                                                      int64_t* __restrict__ next_ids, int64_t* __restrict__ seq_out,
                                                      long ld_seq, float* __restrict__ lp_out, long ld_lp,
-                                                     int32_t* __restrict__ unfinished) {
+                                                     const int32_t* unf_prev, int32_t* unf_out) {
     __shared__ float vs[4];
     __shared__ int is[4];
     const int b = blockIdx.x;
@@ -430,21 +430,21 @@ __global__ __launch_bounds__(256) void greedy_pick_k(const float* __restrict__ l
                 m = vs[w];
                 mi = is[w];
             }
-        int unf = (t == 1) ? 1 : unfinished[b];
+        int unf = (t == 1) ? 1 : unf_prev[b];
         unf = unf && (mi > 0);
-        unfinished[b] = unf;
+        unf_out[b] = unf;
         next_ids[b] = mi;
         seq_out[b * ld_seq] = unf ? mi : 0;
         lp_out[b * ld_lp] = m;
     }
 }
 extern "C" int rfn_greedy_pick(const float* logp, int64_t ldl, int B, int V1, int t, int64_t* next_ids,
-                               int64_t* seq_out, int64_t ld_seq, float* lp_out, int64_t ld_lp, int32_t* unfinished,
-                               void* stream) {
+                               int64_t* seq_out, int64_t ld_seq, float* lp_out, int64_t ld_lp,
+                               const int32_t* unf_prev, int32_t* unf_out, void* stream) {
     if (B <= 0 || V1 <= 0 || t < 1) return RFN_ERR_SHAPE;
-    if (!logp || !next_ids || !seq_out || !lp_out || !unfinished) return RFN_ERR_ARG;
+    if (!logp || !next_ids || !seq_out || !lp_out || !unf_out || (t > 1 && !unf_prev)) return RFN_ERR_ARG;
     hipLaunchKernelGGL(greedy_pick_k, dim3(B), dim3(256), 0, (hipStream_t)stream, logp, (long)ldl, V1, t, next_ids,
-                       seq_out, (long)ld_seq, lp_out, (long)ld_lp, unfinished);
+                       seq_out, (long)ld_seq, lp_out, (long)ld_lp, unf_prev, unf_out);
     RFN_CHECK_LAUNCH();
     return RFN_OK;
 }

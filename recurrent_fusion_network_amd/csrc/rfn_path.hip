@@ -838,7 +838,7 @@ extern "C" int rfn_decoder_prepare(const rfn_dims* d, int B, const float* const*
 
 extern "C" int rfn_decoder_step(const rfn_dims* d, int B, const float* const* prm, const float* comb,
                                 const float* cproj, const int64_t* ids, float* h, float* c, float* logits, float* logp,
-                                void* ws, size_t ws_bytes, void* st) {
+                                int64_t ld_logp, void* ws, size_t ws_bytes, void* st) {
     RFN_TRY(check_dims(d));
     if (B < 1) return RFN_ERR_SHAPE;
     if (!prm || !comb || !cproj || !ids || !h || !c || !ws) return RFN_ERR_ARG;
@@ -866,7 +866,10 @@ extern "C" int rfn_decoder_step(const rfn_dims* d, int B, const float* const* pr
     RFN_TRY(rfn_lstm_fwd(g, 4 * R, c, R, c, R, h, R, B, R, 0.f, 0, 0, st));  // eval: no dropout
     if (logits || logp) {
         RFN_TRY(gemm1(B, V1, seg_lin(h, R, prm[P.logit_w()], R, R, prm[P.logit_b()]), lg, V1, 0, st));
-        if (logp) RFN_TRY(rfn_log_softmax_fwd(lg, V1, B, V1, B, V1, 0, logp, st));
+        if (logp) {
+            if (ld_logp < V1) return RFN_ERR_SHAPE;
+            RFN_TRY(rfn_log_softmax_fwd(lg, V1, B, V1, B, ld_logp, 0, logp, st));
+        }
     }
     return RFN_OK;
 }

@@ -1,0 +1,552 @@
+"""RecurrentFusionModel: host-side mirror of the reference's module for the HIP path.
+
+Same constructor argument (an ``opt`` Namespace), same ``forward(fc_feats, att_feats, seq)`` /
+``sample(fc_feats, att_feats, opt)`` / ``sample_beam`` / ``get_init_state`` / ``get_thought_vectors`` /
+``one_time_step`` surface and the same ``state_dict`` keys and shapes as the reference's
+``misc/RecurrentFusionModel.py:117-658`` -- so ``models.setup(opt)``, ``train.py`` and ``eval.py`` drop in.
+All arithmetic runs in librfn_hip.so (include/rfn.h); PyTorch only owns device memory, the stream and
+the autograd graph edges between the two phases.  There is no CPU path: inputs must be on the GPU.
+
+The sub-modules below (``_AttParams`` ...) hold parameters only; they exist to reproduce the reference's
+parameter names (``review_steps_individual.{t}.lstm.{i}.att_model.att_2_att_h.weight`` ...).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from . import _native as N
+
+_INIT = 0.1
+
+
+def _uniform(*tensors):
+    for t in tensors:
+        t.data.uniform_(-_INIT, _INIT)
+
+
+class _AttParams(nn.Module):
+    """Parameters of AttentionModelCore (misc/AttentionModelCore.py:16-29)."""
+
+    def __init__(self, rnn_size, feat_size, att_hid):
+        super().__init__()
+        self.att_2_att_h = nn.Linear(feat_size, att_hid)
+        self.h_2_att_h = nn.Linear(rnn_size, att_hid)
+        self.att_h_2_out = nn.Linear(att_hid, 1)
+        for lin in (self.att_2_att_h, self.h_2_att_h, self.att_h_2_out):
+            _uniform(lin.weight, lin.bias)
+
+
+class _FusionCellParams(nn.Module):
+    """Parameters of LSTMFusionNoInputCore (misc/RecurrentFusionModel.py:30-45); biases keep nn.Linear's
+    default init as in the reference."""
+
+    def __init__(self, H_size, rnn_size, feat_size, att_hid):
+        super().__init__()
+        self.att_model = _AttParams(rnn_size, feat_size, att_hid)
+        self.H2h = nn.Linear(H_size, 4 * rnn_size)
+        self.z2h = nn.Linear(feat_size, 4 * rnn_size)
+        _uniform(self.H2h.weight, self.z2h.weight)
+
+
+class _FusionStepParams(nn.Module):
+    """FeatArrayFusionNoInputCore (misc/RecurrentFusionModel.py:93-97)."""
+
+    def __init__(self, M, rnn_size, feat_sizes, att_hid):
+        super().__init__()
+        self.lstm = nn.ModuleList([_FusionCellParams(M * rnn_size, rnn_size, feat_sizes[i], att_hid) for i in range(M)])
+
+
+class _ReviewStepParams(nn.Module):
+    """LSTMSoftMultiAttentionFeatArrayNoInputCore (misc/LSTMSoftMultiAttentionFeatArrayNoInputCore.py:24-38)."""
+
+    def __init__(self, M, rnn_size, att_hid):
+        super().__init__()
+        self.h2h = nn.Linear(rnn_size, 4 * rnn_size)
+        self.z_2_h = nn.ModuleList([nn.Linear(rnn_size, 4 * rnn_size) for _ in range(M)])
+        self.att_model = nn.ModuleList([_AttParams(rnn_size, rnn_size, att_hid) for _ in range(M)])
+        _uniform(self.h2h.weight, self.h2h.bias)
+
+
+class _DecoderParams(nn.Module):
+    """LSTMSoftAttentionCore (misc/LSTMSoftAttentionCore.py:24-58)."""
+
+    def __init__(self, enc_size, rnn_size, att_hid):
+        super().__init__()
+        self.i2h = nn.Linear(enc_size, 4 * rnn_size)
+        self.h2h = nn.Linear(rnn_size, 4 * rnn_size)
+        self.z2h = nn.Linear(rnn_size, 4 * rnn_size)
+        self.att_2_att_h = nn.Linear(rnn_size, att_hid)
+        self.h_2_att_h = nn.Linear(rnn_size, att_hid)
+        self.att_h_2_out = nn.Linear(att_hid, 1)
+        for lin in (self.i2h, self.h2h, self.z2h, self.att_2_att_h, self.h_2_att_h, self.att_h_2_out):
+            _uniform(lin.weight, lin.bias)
+
+
+def _fresh_seed() -> int:
+    # dropout masks are Philox streams keyed by this seed; drawn from torch's CPU generator so that
+    # torch.manual_seed(seed + rank) (train.py:23) makes runs reproducible
+    return int(torch.randint(0, 2 ** 62, (1,)).item())
+
+
+class _PrefixFn(torch.autograd.Function):
+    """Phase 1 (fc2h + fusion stages I and II) as one autograd node: rfn_prefix_fwd / rfn_prefix_bwd."""
+
+    @staticmethod
+    def forward(ctx, model, save_bwd, drop, seed, M, *tensors):
+        fc = [N.require_cuda_f32(t, 'fc_feats') for t in tensors[:M]]
+        att = [N.require_cuda_f32(t, 'att_feats') for t in tensors[M:2 * M]]
+        params = tensors[2 * M:]
+        d = model._dims_for(drop)
+        train = bool(save_bwd)
+        B = fc[0].shape[0]
+        dev = fc[0].device
+        R, T2, K = d.R, d.T2, d.K
+        table = model._param_table(params, model._prefix_slots)
+        ws_bytes = N.lib.rfn_prefix_ws_bytes(C.byref(d), B, int(train))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        comb = torch.empty(T2, B, R, device=dev)
+        h = torch.empty(B, R, device=dev)
+        c = torch.empty(B, R, device=dev)
+        reason = torch.empty(M + 1, B, K, device=dev)
+        N.check(N.lib.rfn_prefix_fwd(C.byref(d), B, table, N.ptr_array(fc), N.ptr_array(att), comb.data_ptr(),
+                                     h.data_ptr(), c.data_ptr(), reason.data_ptr(), ws.data_ptr(), ws_bytes,
+                                     int(train), seed, N.stream_ptr()), 'rfn_prefix_fwd')
+        if train:
+            ctx.model, ctx.seed, ctx.M, ctx.B, ctx.drop = model, seed, M, B, drop
+            ctx.ws, ctx.fc, ctx.att, ctx.params = ws, fc, att, params
+        return comb, h, c, reason
+
+    @staticmethod
+    def backward(ctx, d_comb, d_h, d_c, d_reason):
+        model, M, B = ctx.model, ctx.M, ctx.B
+        d = model._dims_for(ctx.drop)
+        dev = ctx.fc[0].device
+        table = model._param_table(ctx.params, model._prefix_slots)
+        flat, views, gtable = model._grad_buffers(ctx.params, model._prefix_slots, dev)
+        cont = lambda t: None if t is None else t.contiguous()  # noqa: E731
+        d_comb, d_h, d_c, d_reason = cont(d_comb), cont(d_h), cont(d_c), cont(d_reason)
+        ws_bytes = ctx.ws.numel()
+        N.check(N.lib.rfn_prefix_bwd(C.byref(d), B, table, N.ptr_array(ctx.fc), N.ptr_array(ctx.att), N.ptr(d_comb),
+                                     N.ptr(d_h), N.ptr(d_c), N.ptr(d_reason), gtable, ctx.ws.data_ptr(), ws_bytes,
+                                     ctx.seed, N.stream_ptr()), 'rfn_prefix_bwd')
+        model._last_flat_grads['prefix'] = flat
+        ctx.ws = None
+        return (None, None, None, None, None) + (None,) * (2 * M) + tuple(views)
+
+
+class _DecoderFn(torch.autograd.Function):
+    """Phase 2 (teacher-forced decoder + logit + log-softmax): rfn_decoder_fwd / rfn_decoder_bwd."""
+
+    @staticmethod
+    def forward(ctx, model, save_bwd, drop, seed, ids, comb, h0, c0, *params):
+        d = model._dims_for(drop)
+        train = bool(save_bwd)
+        B, S = ids.shape
+        dev = comb.device
+        comb, h0, c0 = comb.contiguous(), h0.contiguous(), c0.contiguous()
+        ids = ids.contiguous()
+        table = model._param_table(params, model._decoder_slots)
+        ws_bytes = N.lib.rfn_decoder_ws_bytes(C.byref(d), B, S, int(train))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        log_prob = torch.empty(B, S, d.V1, device=dev)
+        N.check(N.lib.rfn_decoder_fwd(C.byref(d), B, S, table, comb.data_ptr(), h0.data_ptr(), c0.data_ptr(),
+                                      ids.data_ptr(), ids.stride(0), log_prob.data_ptr(), ws.data_ptr(), ws_bytes,
+                                      int(train), seed, N.stream_ptr()), 'rfn_decoder_fwd')
+        if train:
+            ctx.model, ctx.seed, ctx.B, ctx.S, ctx.drop = model, seed, B, S, drop
+            ctx.ws, ctx.ids, ctx.params = ws, ids, params
+            ctx.save_for_backward(comb, h0, c0, log_prob)
+        return log_prob
+
+    @staticmethod
+    def backward(ctx, d_log_prob):
+        model, B, S = ctx.model, ctx.B, ctx.S
+        comb, h0, c0, log_prob = ctx.saved_tensors
+        d = model._dims_for(ctx.drop)
+        dev = comb.device
+        table = model._param_table(ctx.params, model._decoder_slots)
+        flat, views, gtable = model._grad_buffers(ctx.params, model._decoder_slots, dev)
+        d_log_prob = d_log_prob.contiguous()
+        d_comb = torch.empty_like(comb)
+        d_h0 = torch.empty_like(h0)
+        d_c0 = torch.empty_like(c0)
+        N.check(N.lib.rfn_decoder_bwd(C.byref(d), B, S, table, comb.data_ptr(), h0.data_ptr(), c0.data_ptr(),
+                                      ctx.ids.data_ptr(), ctx.ids.stride(0), log_prob.data_ptr(),
+                                      d_log_prob.data_ptr(), d_comb.data_ptr(), d_h0.data_ptr(), d_c0.data_ptr(),
+                                      gtable, ctx.ws.data_ptr(), ctx.ws.numel(), ctx.seed, N.stream_ptr()),
+                'rfn_decoder_bwd')
+        model._last_flat_grads['decoder'] = flat
+        ctx.ws = None
+        return (None, None, None, None, None, d_comb, d_h0, d_c0) + tuple(views)
+
+
+class RecurrentFusionModel(nn.Module):
+    def __init__(self, opt):
+        super().__init__()
+        # the fields the reference reads (misc/RecurrentFusionModel.py:120-151)
+        self.vocab_size = opt.vocab_size
+        self.input_encoding_size = opt.input_encoding_size
+        self.rnn_type = getattr(opt, 'rnn_type', 'lstm')
+        self.rnn_size = opt.rnn_size
+        self.num_layers = getattr(opt, 'num_layers', 1)
+        self.drop_prob_lm = opt.drop_prob_lm
+        self.drop_prob_reason = opt.drop_prob_reason
+        self.drop_prob_fusion = opt.drop_prob_fusion
+        self.seq_length = opt.seq_length
+        self.num_review_steps = opt.num_review_steps
+        self.num_review_steps_0 = opt.num_review_steps_0
+        self.top_words_count = opt.top_words_count
+        self.att_hid_size = opt.att_hid_size
+        self.ss_prob = 0.0
+        self.review_maxout = opt.review_maxout
+        self.decoder_maxout = opt.maxout
+        self.fusion_maxout = opt.fusion_maxout  # accepted and ignored, exactly like the reference (:94-96)
+        self.use_cuda = getattr(opt, 'use_cuda', 1)
+        if self.review_maxout or self.decoder_maxout:
+            raise N.RfnError('review_maxout / maxout are not implemented by the HIP path')
+        self.feat_array_info = opt.feat_array_info
+        M = self.num_feat_array = len(self.feat_array_info)
+        self.fc_feat_size = [f['fc_feat_size'] for f in self.feat_array_info]
+        self.att_feat_size = [f['att_feat_size'] for f in self.feat_array_info]
+        self.att_num = [f['att_num'] for f in self.feat_array_info]
+        R, A, E = self.rnn_size, self.att_hid_size, self.input_encoding_size
+
+        self.fc2h = nn.ModuleList([nn.Linear(self.fc_feat_size[i], R) for i in range(M)])
+        self.embed = nn.Embedding(self.vocab_size + 1, E)
+        self.logit = nn.Linear(R, self.vocab_size + 1)
+        self.review_steps_individual = nn.ModuleList(
+            [_FusionStepParams(M, R, self.att_feat_size, A) for _ in range(self.num_review_steps_0)])
+        self.reason_linear_individual = nn.ModuleList([nn.Linear(R, self.top_words_count) for _ in range(M)])
+        self.review_steps = nn.ModuleList([_ReviewStepParams(M, R, A) for _ in range(self.num_review_steps)])
+        self.reason_linear = nn.Linear(R, self.top_words_count)
+        self.decoder = _DecoderParams(E, R, A)
+        self.init_weights()
+
+        self._dims = {}
+        self._param_cache = {}
+        self._slot_names = N.param_names(self._dims_for(False))
+        schema = dict(self.named_parameters())
+        missing = [n for n in self._slot_names if n not in schema]
+        if missing or len(schema) != len(self._slot_names):
+            raise N.RfnError('parameter schema mismatch between module and librfn_hip.so: %s' % missing[:3])
+        is_dec = lambda n: n.startswith(('embed.', 'logit.', 'decoder.'))  # noqa: E731
+        self._prefix_slots = [i for i, n in enumerate(self._slot_names) if not is_dec(n)]
+        self._decoder_slots = [i for i, n in enumerate(self._slot_names) if is_dec(n)]
+        self._last_flat_grads = {}
+        self.done_beams = []
+
+    def init_weights(self):
+        """misc/RecurrentFusionModel.py:188-196."""
+        _uniform(self.embed.weight, self.logit.weight, self.reason_linear.weight)
+        self.logit.bias.data.fill_(0)
+        for i in range(self.num_feat_array):
+            _uniform(self.reason_linear_individual[i].weight, self.fc2h[i].weight)
+
+    # ---- plumbing -------------------------------------------------------------------------------
+    def _dims_for(self, train: bool) -> N.Dims:
+        key = bool(train)
+        if key not in self._dims:
+            self._dims[key] = N.make_dims(
+                self.num_feat_array, self.rnn_size, self.att_hid_size, self.input_encoding_size,
+                self.num_review_steps_0, self.num_review_steps, self.top_words_count, self.vocab_size + 1,
+                self.att_num, self.att_feat_size, self.fc_feat_size,
+                drop_fusion=self.drop_prob_fusion if train else 0.0,
+                drop_reason=self.drop_prob_reason if train else 0.0,
+                drop_lm=self.drop_prob_lm if train else 0.0)
+        return self._dims[key]
+
+    def _params_of(self, slots):
+        # Parameter objects are stable under .cuda()/.to() (their .data is swapped in place), so the
+        # by-name lookup is done once per slot list
+        key = id(slots)
+        if key not in self._param_cache:
+            named = dict(self.named_parameters())
+            self._param_cache[key] = [named[self._slot_names[i]] for i in slots]
+        return self._param_cache[key]
+
+    def _param_table(self, params, slots):
+        table = (C.c_void_p * len(self._slot_names))()
+        for p, i in zip(params, slots):
+            if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
+                raise N.RfnError('parameter %s must be a contiguous float32 GPU tensor' % self._slot_names[i])
+            table[i] = p.data_ptr()
+        return table
+
+    def _grad_buffers(self, params, slots, dev):
+        """One flat gradient buffer per phase (a single all-reduce bucket); returns (flat, views, table)."""
+        offs, total = [], 0
+        for p in params:
+            offs.append(total)
+            total += (p.numel() + 3) & ~3
+        flat = torch.empty(total, device=dev, dtype=torch.float32)
+        views = [flat[o:o + p.numel()].view_as(p) for o, p in zip(offs, params)]
+        table = (C.c_void_p * len(self._slot_names))()
+        for v, i in zip(views, slots):
+            table[i] = v.data_ptr()
+        return flat, views, table
+
+    def _check_inputs(self, fc_feats, att_feats):
+        M = self.num_feat_array
+        if len(fc_feats) != M or len(att_feats) != M:
+            raise N.RfnError('expected %d fc / att feature tensors' % M)
+        B = fc_feats[0].size(0)
+        for i in range(M):
+            if tuple(fc_feats[i].shape) != (B, self.fc_feat_size[i]):
+                raise N.RfnError('fc_feats[%d] has shape %s, expected %s' % (
+                    i, tuple(fc_feats[i].shape), (B, self.fc_feat_size[i])))
+            if tuple(att_feats[i].shape) != (B, self.att_num[i], self.att_feat_size[i]):
+                raise N.RfnError('att_feats[%d] has shape %s, expected %s' % (
+                    i, tuple(att_feats[i].shape), (B, self.att_num[i], self.att_feat_size[i])))
+        return B
+
+    def _prefix(self, fc_feats, att_feats, drop, seed):
+        """-> comb (T2,B,R) time-major, h, c (B,R), reason (M+1,B,K).  `drop`: apply dropout (training mode)."""
+        self._check_inputs(fc_feats, att_feats)
+        params = self._params_of(self._prefix_slots)
+        return _PrefixFn.apply(self, torch.is_grad_enabled(), bool(drop), seed, self.num_feat_array, *fc_feats,
+                               *att_feats, *params)
+
+    def _decode_teacher_forced(self, ids, comb, h, c, drop, seed):
+        params = self._params_of(self._decoder_slots)
+        return _DecoderFn.apply(self, torch.is_grad_enabled(), bool(drop), seed, ids, comb, h, c, *params)
+
+    # ---- reference API ----------------------------------------------------------------------------
+    def forward(self, fc_feats, att_feats, seq):
+        """misc/RecurrentFusionModel.py:198-281 -> (log_prob (B,T,V+1), reason_pred list[M+1] of (B,K))."""
+        train = bool(self.training)
+        seed = _fresh_seed() if train else 0
+        comb, h, c, reason = self._prefix(fc_feats, att_feats, train, seed)
+        # number of decoder steps: the reference breaks at the first all-zero column i >= 1 (:274)
+        nz = (seq != 0).any(0).tolist()
+        S = seq.size(1)
+        for i in range(1, seq.size(1)):
+            if not nz[i]:
+                S = i
+                break
+        ids = seq[:, :S]
+        if self.ss_prob > 0.0 and S > 1:
+            ids = self._scheduled_sampling_ids(ids, comb.detach(), h.detach(), c.detach())
+        log_prob = self._decode_teacher_forced(ids, comb, h, c, train, seed)
+        return log_prob, [reason[j] for j in range(self.num_feat_array + 1)]
+
+    def _scheduled_sampling_ids(self, ids, comb, h, c):
+        """misc/RecurrentFusionModel.py:260-270: with probability ss_prob a row's input token is drawn from the
+        model's previous output distribution.  The draws need the free-running distributions, so they are made
+        in a no-grad stepwise pass; the gradient pass is then teacher-forced on the drawn ids (identical
+        outputs, since the decoder is deterministic given its inputs at dropout 0)."""
+        B, S = ids.shape
+        ids = ids.clone()
+        with torch.no_grad():
+            stepper = _Stepper(self, comb, h.clone(), c.clone())
+            logp = stepper.step(ids[:, 0].contiguous())
+            for i in range(1, S):
+                mask = torch.rand(B, device=ids.device) < self.ss_prob
+                if bool(mask.any()):
+                    draw = torch.multinomial(torch.exp(logp), 1).view(-1)
+                    ids[:, i] = torch.where(mask, draw, ids[:, i])
+                if i < S - 1:
+                    logp = stepper.step(ids[:, i].contiguous())
+        return ids
+
+    def get_init_state(self, fc_feats):
+        """misc/RecurrentFusionModel.py:333-343 (inference helper, no autograd)."""
+        out = []
+        with torch.no_grad():
+            for i in range(self.num_feat_array):
+                h0 = N.linear(fc_feats[i], self.fc2h[i].weight, self.fc2h[i].bias).unsqueeze(0)
+                out.append((h0, h0.clone()))
+        return out
+
+    def get_thought_vectors(self, fc_feats, att_feats, state_list=None):
+        """misc/RecurrentFusionModel.py:283-331 -> (thought_vectors_comb (B,T2,R), reason_pred, state_review).
+        The initial state is recomputed from fc_feats (it is what get_init_state returns)."""
+        with torch.no_grad():
+            comb, h, c, reason = self._prefix(fc_feats, att_feats, False, 0)
+        return (comb.transpose(0, 1).contiguous(), [reason[j] for j in range(self.num_feat_array + 1)],
+                (h.unsqueeze(0), c.unsqueeze(0)))
+
+    def one_time_step(self, xt_ids, fc_feats, thought_vectors_comb, state_decode):
+        """misc/RecurrentFusionModel.py:345-350 -> (logit (B,V+1) pre-softmax, state).  Takes token ids (the
+        reference takes the embedded xt; embedding is fused into the step here)."""
+        with torch.no_grad():
+            comb = thought_vectors_comb.transpose(0, 1).contiguous()
+            stepper = _Stepper(self, comb, state_decode[0][-1].clone(), state_decode[1][-1].clone())
+            logits = stepper.step(xt_ids.contiguous(), want='logits')
+            return logits, (stepper.h.unsqueeze(0), stepper.c.unsqueeze(0))
+
+    def sample(self, fc_feats, att_feats, opt={}):
+        """misc/RecurrentFusionModel.py:545-658."""
+        sample_max = opt.get('sample_max', 1)
+        beam_size = opt.get('beam_size', 1)
+        temperature = opt.get('temperature', 1.0)
+        if beam_size > 1:
+            return self.sample_beam(fc_feats, att_feats, opt)
+        want_grad = torch.is_grad_enabled() and not sample_max
+        train = bool(self.training) and want_grad
+        seed = _fresh_seed() if train else 0
+        with torch.set_grad_enabled(want_grad):
+            comb, h, c, reason = self._prefix(fc_feats, att_feats, train, seed)
+        B, S, V1 = fc_feats[0].size(0), self.seq_length, self.vocab_size + 1
+        dev = comb.device
+        reason_pred = [reason[j] for j in range(self.num_feat_array + 1)]
+        force = opt.get('force_ids', None)
+        with torch.no_grad():
+            stepper = _Stepper(self, comb.detach(), h.detach().clone(), c.detach().clone())
+            logp_all = torch.empty(B, S + 1, V1, device=dev)
+            seq = torch.zeros(B, S, dtype=torch.long, device=dev)
+            seq_lp = torch.zeros(B, S, device=dev)
+            raw = torch.zeros(B, S + 1, dtype=torch.long, device=dev)  # column t = token fed at step t
+            unf = torch.zeros(S + 1, B, dtype=torch.int32, device=dev)
+            it = torch.zeros(B, dtype=torch.long, device=dev)
+            for t in range(S + 1):
+                if t >= 1:
+                    prev = logp_all[:, t - 1]
+                    if sample_max and force is None:
+                        N.check(N.lib.rfn_greedy_pick(prev.data_ptr(), prev.stride(0), B, V1, t, it.data_ptr(),
+                                                      seq[:, t - 1].data_ptr(), seq.stride(0),
+                                                      seq_lp[:, t - 1].data_ptr(), seq_lp.stride(0),
+                                                      unf[t - 1].data_ptr() if t > 1 else None, unf[t].data_ptr(),
+                                                      N.stream_ptr()), 'rfn_greedy_pick')
+                    else:
+                        if force is not None:
+                            it = force[:, t - 1].to(dev).contiguous()
+                        else:  # :623-631 (the reference draws on the CPU; the stream is not portable anyway)
+                            p = torch.exp(prev if temperature == 1.0 else prev / temperature)
+                            it = torch.multinomial(p, 1).view(-1)
+                        u = (it > 0) if t == 1 else (unf[t - 1].bool() & (it > 0))
+                        unf[t] = u.int()
+                        seq[:, t - 1] = it * u.long()
+                        seq_lp[:, t - 1] = prev.gather(1, it.view(-1, 1)).view(-1)
+                    raw[:, t] = it
+                stepper.step(it, out=logp_all[:, t])
+            # the reference's early exit (:645): stop at the first t >= 1 with no unfinished row
+            alive = unf[1:].sum(1).tolist()
+        t_stop = S + 1
+        for t in range(1, S + 1):
+            if alive[t - 1] == 0:
+                t_stop = t
+                break
+        n_seq = t_stop - 1
+        if want_grad:
+            # differentiable log-probs (train_rl.py:160-166): teacher-force the drawn ids through phase 2
+            logp_g = self._decode_teacher_forced(raw[:, :t_stop].contiguous(), comb, h, c, train, seed)
+            seq_lp_g = logp_g[:, :n_seq].gather(2, raw[:, 1:t_stop].unsqueeze(2)).squeeze(2)
+            return seq[:, :n_seq], seq_lp_g, logp_g, reason_pred
+        return seq[:, :n_seq], seq_lp[:, :n_seq], logp_all[:, :t_stop].contiguous(), reason_pred
+
+    def sample_beam(self, fc_feats, att_feats, opt={}):
+        """misc/RecurrentFusionModel.py:352-543.  Stages I/II run ONCE for the whole batch (the reference
+        recomputes them per image on beam_size identical rows); the per-image beam bookkeeping follows the
+        reference's candidate order and tie-breaking exactly."""
+        beam_size = opt.get('beam_size', 10)
+        B, S, V1 = fc_feats[0].size(0), self.seq_length, self.vocab_size + 1
+        assert beam_size <= V1
+        with torch.no_grad():
+            comb_all, h_all, c_all, reason = self._prefix(fc_feats, att_feats, False, 0)
+        dev = comb_all.device
+        seq = torch.zeros(S, B, dtype=torch.long)
+        seq_lp = torch.zeros(S, B)
+        top_seq, top_prob = [], [[] for _ in range(B)]
+        self.done_beams = [[] for _ in range(B)]
+        reason_batch = []
+        for k in range(B):
+            reason_batch.append([reason[j, k:k + 1].expand(beam_size, -1).contiguous()
+                                 for j in range(self.num_feat_array + 1)])
+            with torch.no_grad():
+                comb = comb_all[:, k:k + 1].expand(-1, beam_size, -1).contiguous()
+                stepper = _Stepper(self, comb, h_all[k:k + 1].expand(beam_size, -1).contiguous(),
+                                   c_all[k:k + 1].expand(beam_size, -1).contiguous())
+                beam_seq = torch.zeros(S, beam_size, dtype=torch.long)
+                beam_lp = torch.zeros(S, beam_size)
+                beam_sum = torch.zeros(beam_size)
+                logprobs = None
+                for t in range(S + 1):
+                    if t == 0:
+                        it = torch.zeros(beam_size, dtype=torch.long, device=dev)
+                    else:
+                        ys, ix = torch.sort(logprobs.float().cpu(), 1, True)
+                        cands = []
+                        cols = min(beam_size, ys.size(1))
+                        rows = 1 if t == 1 else beam_size
+                        ysl, ixl, bsl = ys[:, :cols].tolist(), ix[:, :cols].tolist(), beam_sum.tolist()
+                        for cc in range(cols):
+                            for q in range(rows):
+                                if t > 1 and int(beam_seq[t - 2, q]) == 0:
+                                    continue
+                                local = ysl[q][cc]
+                                p = float(torch.tensor(bsl[q], dtype=torch.float32) +
+                                          torch.tensor(local, dtype=torch.float32))
+                                cands.append(dict(c=ixl[q][cc], q=q, p=p, r=local))
+                        if len(cands) == 0:
+                            break
+                        cands = sorted(cands, key=lambda x: -x['p'])
+                        if t > 1:
+                            prev_seq = beam_seq[:t - 1].clone()
+                            prev_lp = beam_lp[:t - 1].clone()
+                        order = []
+                        for vix in range(min(beam_size, len(cands))):
+                            v = cands[vix]
+                            if t > 1:
+                                beam_seq[:t - 1, vix] = prev_seq[:, v['q']]
+                                beam_lp[:t - 1, vix] = prev_lp[:, v['q']]
+                            order.append(v['q'])
+                            beam_seq[t - 1, vix] = v['c']
+                            beam_lp[t - 1, vix] = v['r']
+                            beam_sum[vix] = v['p']
+                            if v['c'] == 0 or t == S:
+                                self.done_beams[k].append({'seq': beam_seq[:, vix].clone(),
+                                                           'logps': beam_lp[:, vix].clone(),
+                                                           'p': float(beam_sum[vix])})
+                        # rows beyond len(cands) keep their previous state, as new_state = clone(state) does
+                        order = order + list(range(len(order), beam_size))
+                        stepper.reorder(torch.tensor(order, dtype=torch.long, device=dev))
+                        it = beam_seq[t - 1].to(dev)
+                    logprobs = stepper.step(it.contiguous())
+            self.done_beams[k] = sorted(self.done_beams[k], key=lambda x: -x['p'])
+            seq[:, k] = self.done_beams[k][0]['seq']
+            seq_lp[:, k] = self.done_beams[k][0]['logps']
+            cur = torch.zeros(len(self.done_beams[k]), S, dtype=torch.long)
+            for j, db in enumerate(self.done_beams[k]):
+                cur[j] = db['seq']
+                top_prob[k].append(db['p'])
+            top_seq.append(cur)
+        return seq.t().to(dev), seq_lp.t().to(dev), top_seq, top_prob, reason_batch
+
+
+class _Stepper:
+    """Free-running decoder state for sample / beam / one_time_step: rfn_decoder_prepare + rfn_decoder_step."""
+
+    def __init__(self, model, comb, h, c):
+        self.model = model
+        self.d = model._dims_for(False)
+        self.comb = comb.contiguous()
+        self.h, self.c = h.contiguous(), c.contiguous()
+        self.B = self.h.size(0)
+        dev = self.h.device
+        self.table = model._param_table(model._params_of(model._decoder_slots), model._decoder_slots)
+        self.cproj = torch.empty(self.d.T2 * self.B, self.d.A, device=dev)
+        N.check(N.lib.rfn_decoder_prepare(C.byref(self.d), self.B, self.table, self.comb.data_ptr(),
+                                          self.cproj.data_ptr(), N.stream_ptr()), 'rfn_decoder_prepare')
+        self.ws_bytes = N.lib.rfn_decoder_step_ws_bytes(C.byref(self.d), self.B)
+        self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev)
+
+    def step(self, ids, out=None, want='logp'):
+        V1 = self.d.V1
+        if out is None:
+            out = torch.empty(self.B, V1, device=self.h.device)
+        if ids.dtype != torch.long or not ids.is_contiguous():
+            ids = ids.long().contiguous()
+        logits_ptr = out.data_ptr() if want == 'logits' else None
+        logp_ptr = out.data_ptr() if want == 'logp' else None
+        N.check(N.lib.rfn_decoder_step(C.byref(self.d), self.B, self.table, self.comb.data_ptr(),
+                                       self.cproj.data_ptr(), ids.data_ptr(), self.h.data_ptr(), self.c.data_ptr(),
+                                       logits_ptr, logp_ptr, out.stride(0), self.ws.data_ptr(), self.ws_bytes,
+                                       N.stream_ptr()), 'rfn_decoder_step')
+        return out
+
+    def reorder(self, index):
+        self.h = self.h.index_select(0, index).contiguous()
+        self.c = self.c.index_select(0, index).contiguous()

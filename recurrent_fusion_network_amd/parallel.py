@@ -1,0 +1,66 @@
+"""Synchronous data parallelism for the caption batch: one process per GPU, RCCL over xGMI.
+
+The reference has no data parallelism (its "8 GPUs" are 8 independent seeds); this is the
+north-star's sharded training.  Every batch row is independent through the whole path, so
+the batch is split on dim 0, each rank runs the full path on its shard, and the ONLY exchange is one sum
+all-reduce per flat gradient buffer (2 buffers: decoder first, as soon as its backward finishes, then the
+fusion stages).  The reference divides the loss by the LOCAL batch size, so the sum is scaled by
+1/world_size inside the fused optimizer BEFORE the element-wise clamp -- which keeps an N-rank step equal
+to the 1-rank step on the concatenated batch.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torch.distributed.run).  Returns (rank, world, local)."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        if backend == 'nccl':
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_rows(n_rows, rank, world):
+    """Contiguous, near-equal row ranges; the shard of `rank` is [lo, hi)."""
+    base, rem = divmod(n_rows, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def allreduce_flat(buffers, world, async_op=False):
+    """Sum all-reduce of the flat gradient buffers, in the given order.  Returns work handles when async."""
+    if world <= 1:
+        return []
+    works = []
+    for b in buffers:
+        w = dist.all_reduce(b, op=dist.ReduceOp.SUM, async_op=async_op)
+        if async_op:
+            works.append(w)
+    return works
+
+
+def allreduce_model_grads(model, world):
+    """All-reduce the gradients the last backward produced (decoder bucket first: it is ready first)."""
+    flats = getattr(model, '_last_flat_grads', {})
+    order = [flats[k] for k in ('decoder', 'prefix') if k in flats]
+    allreduce_flat(order, world)
+    return 1.0 / world
+
+
+def max_over_ranks(value, world, device):
+    """MAX all-reduce of a Python float (the bench timing rule)."""
+    if world <= 1:
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

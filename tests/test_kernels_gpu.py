@@ -1,0 +1,369 @@
+"""Parity of every primitive HIP operator (called through the C ABI) against an fp64 PyTorch-CPU
+restatement of the same math.  fp32 kernels, tolerances are stated per test."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def N():
+    import recurrent_fusion_network_amd._native as n
+    return n
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).float()
+
+
+def maxerr(a, b):
+    return float((a.detach().double().cpu() - b.detach().double().cpu()).abs().max())
+
+
+# ------------------------------------------------------------------------------------------------
+# GEMM: all four operand layouts, vector and scalar staging, ragged tails, K segments, groups
+# ------------------------------------------------------------------------------------------------
+GEMM_SHAPES = [
+    # M, N, K          (tile tails on every axis; K < 32; K not multiple of 32)
+    (256, 512, 512), (130, 70, 100), (64, 64, 32), (3, 51, 16), (200, 2048, 40), (1000, 24, 260),
+    (50, 36, 7),     # K % 4 != 0 -> scalar staging
+    (33, 45, 64),    # N % 4 != 0 for transposed B -> scalar staging
+    (1024, 768, 96),  # >= 384 tiles of 128 -> big tile
+]
+
+
+@pytest.mark.parametrize('ak', [1, 0])
+@pytest.mark.parametrize('bk', [1, 0])
+@pytest.mark.parametrize('shape', GEMM_SHAPES)
+def test_gemm_layouts(dev, shape, ak, bk):
+    n = N()
+    M, Nn, K = shape
+    A = rnd(M, K, seed=1)          # logical A[m,k]
+    Bm = rnd(Nn, K, seed=2)        # logical B[n,k]
+    bias = rnd(Nn, seed=3)
+    ref = A.double() @ Bm.double().t() + bias.double()
+    A_st = (A if ak else A.t().contiguous()).to(dev)
+    B_st = (Bm if bk else Bm.t().contiguous()).to(dev)
+    lda = K if ak else M
+    ldb = K if bk else Nn
+    Cd = torch.full((M, Nn), float('nan'), device=dev)
+    n.gemm(M, Nn, [(Cd, Nn, [(A_st, lda, ak, B_st, ldb, bk, K, bias.to(dev))])])
+    tol = 2e-6 * K * 1.0 + 1e-5
+    assert maxerr(Cd, ref) < tol
+    # accumulate on top of existing C, no bias, with a padded ldc
+    Cpad = torch.zeros(M, Nn + 8, device=dev)
+    Cpad[:, :Nn] = 1.5
+    n.gemm(M, Nn, [(Cpad, Nn + 8, [(A_st, lda, ak, B_st, ldb, bk, K, None)])], accumulate=True)
+    assert maxerr(Cpad[:, :Nn], A.double() @ Bm.double().t() + 1.5) < tol
+    assert float(Cpad[:, Nn:].abs().max()) == 0.0
+
+
+def test_gemm_segments_and_groups(dev):
+    n = N()
+    M, Nn = 96, 160
+    Ks = [64, 40, 128]
+    groups = []
+    refs = []
+    for g in range(3):
+        segs = []
+        ref = torch.zeros(M, Nn, dtype=torch.float64)
+        for s, K in enumerate(Ks):
+            A, Bm, b = rnd(M, K, seed=10 * g + s), rnd(Nn, K, seed=50 + 10 * g + s), rnd(Nn, seed=90 + s)
+            ref += A.double() @ Bm.double().t() + b.double()
+            segs.append((A.to(dev), K, 1, Bm.to(dev), K, 1, K, b.to(dev)))
+        Cd = torch.empty(M, Nn, device=dev)
+        groups.append((Cd, Nn, segs))
+        refs.append(ref)
+    n.gemm(M, Nn, groups)
+    for (Cd, _, _), ref in zip(groups, refs):
+        assert maxerr(Cd, ref) < 1e-3
+
+
+def test_gemm_strided_views_like_the_path(dev):
+    """The path feeds column blocks of wider buffers (lda > K, ldc > N): e.g. encoder i's slice of H."""
+    n = N()
+    B, MR, R, A_ = 70, 4 * 64, 64, 48
+    H = rnd(B, MR, seed=5).to(dev)
+    W = rnd(A_, R, seed=6).to(dev)
+    out = torch.zeros(B, 3 * A_, device=dev)
+    n.gemm(B, A_, [(out[:, A_:], 3 * A_, [(H[:, 2 * R:], MR, 1, W, R, 1, R, None)])])
+    ref = H[:, 2 * R:3 * R].double().cpu() @ W.double().cpu().t()
+    assert maxerr(out[:, A_:2 * A_], ref) < 1e-4
+    assert float(out[:, :A_].abs().max()) == 0.0 and float(out[:, 2 * A_:].abs().max()) == 0.0
+
+
+def test_gemm_rejects_bad_arguments(dev):
+    n = N()
+    with pytest.raises(n.RfnError):
+        n.check(n.lib.rfn_gemm_f32(8, 8, 0, None, 0, None), 'gemm')
+    with pytest.raises(n.RfnError):
+        n.check(n.lib.rfn_gemm_f32(8, 8, 99, None, 0, None), 'gemm')
+
+
+# ------------------------------------------------------------------------------------------------
+# attention
+# ------------------------------------------------------------------------------------------------
+def attn_ref(proj, hp, w, bo, x):
+    e = torch.tanh(proj.double() + hp.double()[:, None, :])
+    s = e @ w.double() + bo.double()
+    al = torch.softmax(s, 1)
+    z = (al[:, :, None] * x.double()).sum(1)
+    return al, z
+
+
+@pytest.mark.parametrize('B,L,A,D', [(5, 196, 512, 256), (3, 7, 16, 24), (4, 49, 30, 18), (2, 8, 64, 64), (6, 300, 96, 40)])
+def test_attention_forward_backward(dev, B, L, A, D):
+    n = N()
+    proj, hp, w, bo = rnd(B, L, A, seed=1), rnd(B, A, seed=2), rnd(A, seed=3, scale=0.3), rnd(1, seed=4)
+    x, dz = rnd(B, L, D, seed=5), rnd(B, D, seed=6)
+    projd, hpd, wd, bod, xd, dzd = [t.to(dev) for t in (proj, hp, w, bo, x, dz)]
+    alpha = torch.empty(B, L, device=dev)
+    z = torch.empty(B, D, device=dev)
+    st = n.stream_ptr()
+    n.check(n.lib.rfn_attn_scores_fwd(projd.data_ptr(), L * A, A, hpd.data_ptr(), wd.data_ptr(), bod.data_ptr(), B, L,
+                                      A, alpha.data_ptr(), st))
+    n.check(n.lib.rfn_attn_context_fwd(xd.data_ptr(), L * D, D, alpha.data_ptr(), B, L, D, z.data_ptr(), D, st))
+    # fp64 autograd reference
+    pr, hr, wr, xr = [t.double().requires_grad_(True) for t in (proj, hp, w, x)]
+    al_ref, z_ref = attn_ref(pr, hr, wr, bo, xr)
+    assert maxerr(alpha, al_ref) < 2e-6
+    assert maxerr(z, z_ref) < 1e-5
+    z_ref.backward(dz.double())
+    dal = torch.empty(B, L, device=dev)
+    n.check(n.lib.rfn_attn_context_bwd_dalpha(xd.data_ptr(), L * D, D, dzd.data_ptr(), D, B, L, D, dal.data_ptr(), st))
+    dproj = torch.empty(B, L, A, device=dev)
+    dhp = torch.empty(B, A, device=dev)
+    dwp = torch.empty(B, A, device=dev)
+    n.check(n.lib.rfn_attn_scores_bwd(projd.data_ptr(), L * A, A, hpd.data_ptr(), wd.data_ptr(), alpha.data_ptr(),
+                                      dal.data_ptr(), B, L, A, dproj.data_ptr(), L * A, A, 0, dhp.data_ptr(),
+                                      dwp.data_ptr(), st))
+    assert maxerr(dproj, pr.grad) < 2e-5
+    assert maxerr(dhp, hr.grad) < 1e-4
+    assert maxerr(dwp.sum(0), wr.grad) < 1e-4 * max(1.0, float(wr.grad.abs().max()))
+    # d att_seq through the context path only (the projection path is a GEMM)
+    dx = torch.zeros(B, L, D, device=dev)
+    n.check(n.lib.rfn_attn_context_bwd_dseq(alpha.data_ptr(), dzd.data_ptr(), D, B, L, D, dx.data_ptr(), L * D, D, st))
+    assert maxerr(dx, al_ref.detach()[:, :, None] * dz.double()[:, None, :]) < 1e-5
+    # in-place + accumulate variants
+    acc = torch.ones(B, L, A, device=dev)
+    n.check(n.lib.rfn_attn_scores_bwd(projd.data_ptr(), L * A, A, hpd.data_ptr(), wd.data_ptr(), alpha.data_ptr(),
+                                      dal.data_ptr(), B, L, A, acc.data_ptr(), L * A, A, 1, dhp.data_ptr(),
+                                      dwp.data_ptr(), st))
+    assert maxerr(acc, pr.grad + 1.0) < 2e-5
+    inpl = projd.clone()
+    n.check(n.lib.rfn_attn_scores_bwd(inpl.data_ptr(), L * A, A, hpd.data_ptr(), wd.data_ptr(), alpha.data_ptr(),
+                                      dal.data_ptr(), B, L, A, inpl.data_ptr(), L * A, A, 0, dhp.data_ptr(),
+                                      dwp.data_ptr(), st))
+    assert maxerr(inpl, pr.grad) < 2e-5
+
+
+def test_attention_time_major_strides(dev):
+    """Stage II / decoder read thoughts stored (step, batch, feature): stride_b = R, stride_l = B*R."""
+    n = N()
+    B, L, A, D = 6, 8, 32, 32
+    proj_tm, x_tm = rnd(L, B, A, seed=1), rnd(L, B, D, seed=2)
+    hp, w, bo = rnd(B, A, seed=3), rnd(A, seed=4, scale=0.3), rnd(1, seed=5)
+    al_ref, z_ref = attn_ref(proj_tm.transpose(0, 1), hp, w, bo, x_tm.transpose(0, 1))
+    alpha = torch.empty(B, L, device=dev)
+    z = torch.empty(B, D, device=dev)
+    pd, xd, hpd, wd, bod = [t.to(dev) for t in (proj_tm, x_tm, hp, w, bo)]  # keep the device tensors alive
+    n.check(n.lib.rfn_attn_scores_fwd(pd.data_ptr(), A, B * A, hpd.data_ptr(), wd.data_ptr(), bod.data_ptr(), B, L, A,
+                                      alpha.data_ptr(), n.stream_ptr()))
+    n.check(n.lib.rfn_attn_context_fwd(xd.data_ptr(), D, B * D, alpha.data_ptr(), B, L, D, z.data_ptr(), D,
+                                       n.stream_ptr()))
+    assert maxerr(alpha, al_ref) < 2e-6 and maxerr(z, z_ref) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------
+# LSTM epilogue
+# ------------------------------------------------------------------------------------------------
+def test_lstm_forward_backward(dev):
+    n = N()
+    B, R = 7, 48
+    sums, c0 = rnd(B, 4 * R, seed=1), rnd(B, R, seed=2)
+    dh, dcn = rnd(B, R, seed=3), rnd(B, R, seed=4)
+    sr, cr = sums.double().requires_grad_(True), c0.double().requires_grad_(True)
+    sig = torch.sigmoid(sr[:, :3 * R])
+    g = torch.tanh(sr[:, 3 * R:])
+    c1 = sig[:, R:2 * R] * cr + sig[:, :R] * g
+    h1 = sig[:, 2 * R:] * torch.tanh(c1)
+    (h1 * dh.double()).sum().add((c1 * dcn.double()).sum()).backward()
+    gd, c0d = sums.to(dev), c0.to(dev)
+    c1d, h1d = torch.empty(B, R, device=dev), torch.empty(B, R, device=dev)
+    st = n.stream_ptr()
+    n.check(n.lib.rfn_lstm_fwd(gd.data_ptr(), 4 * R, c0d.data_ptr(), R, c1d.data_ptr(), R, h1d.data_ptr(), R, B, R,
+                               0.0, 0, 0, st))
+    assert maxerr(h1d, h1) < 1e-6 and maxerr(c1d, c1) < 1e-6
+    dcp = torch.empty(B, R, device=dev)
+    dhd, dcnd = dh.to(dev), dcn.to(dev)
+    n.check(n.lib.rfn_lstm_bwd(gd.data_ptr(), 4 * R, c0d.data_ptr(), R, c1d.data_ptr(), R, dhd.data_ptr(), R,
+                               dcnd.data_ptr(), R, dcp.data_ptr(), R, B, R, 0.0, 0, 0, st))
+    assert maxerr(gd, sr.grad) < 2e-6 and maxerr(dcp, cr.grad) < 2e-6
+
+
+def test_lstm_dropout_mask_is_regenerated(dev):
+    n = N()
+    B, R, p = 64, 256, 0.3
+    sums, c0 = rnd(B, 4 * R, seed=1), rnd(B, R, seed=2)
+    outs = []
+    c0d = c0.to(dev)
+    for seed in (11, 11, 12):
+        gd = sums.to(dev).clone()
+        c1d, h1d = torch.empty(B, R, device=dev), torch.empty(B, R, device=dev)
+        n.check(n.lib.rfn_lstm_fwd(gd.data_ptr(), 4 * R, c0d.data_ptr(), R, c1d.data_ptr(), R, h1d.data_ptr(),
+                                   R, B, R, p, seed, 5, n.stream_ptr()))
+        outs.append((gd, c1d, h1d))
+    assert torch.equal(outs[0][2], outs[1][2]) and not torch.equal(outs[0][2], outs[2][2])
+    keep = (outs[0][2] != 0).float().mean().item()
+    assert abs(keep - (1 - p)) < 0.02
+    # backward applies the same mask: dgates of dropped units get no o-gate gradient
+    gd, c1d, h1d = outs[0]
+    dh = torch.ones(B, R, device=dev)
+    dcp = torch.empty(B, R, device=dev)
+    act = gd.clone()
+    n.check(n.lib.rfn_lstm_bwd(gd.data_ptr(), 4 * R, c0d.data_ptr(), R, c1d.data_ptr(), R, dh.data_ptr(), R,
+                               None, R, dcp.data_ptr(), R, B, R, p, 11, 5, n.stream_ptr()))
+    dropped = (h1d == 0) & (act[:, 2 * R:3 * R] * torch.tanh(c1d) != 0)
+    assert float(gd[:, 2 * R:3 * R][dropped].abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------------------------------------
+# small kernels
+# ------------------------------------------------------------------------------------------------
+def test_colsum_embed_logsoftmax_max(dev):
+    n = N()
+    st = n.stream_ptr()
+    X = rnd(301, 77, seed=1)
+    out = torch.full((77,), 2.0, device=dev)
+    Xd = X.to(dev)
+    n.check(n.lib.rfn_colsum_f32(Xd.data_ptr(), 77, 301, 77, out.data_ptr(), 1, st))
+    assert maxerr(out, X.double().sum(0) + 2.0) < 1e-4
+    # embedding gather + deterministic scatter, ids laid out (B, ld) read as (step, batch) rows
+    V1, E, B, S = 51, 20, 5, 4
+    W = rnd(V1, E, seed=2)
+    ids = torch.randint(0, V1, (B, S + 2), generator=torch.Generator().manual_seed(3))
+    xs = torch.empty(S * B, E, device=dev)
+    idd = ids.to(dev)
+    Wd = W.to(dev)
+    n.check(n.lib.rfn_embed_fwd(Wd.data_ptr(), E, V1, idd.data_ptr(), B, S + 2, 1, S * B, xs.data_ptr(), E, st))
+    ref = W[ids[:, :S].t().reshape(-1)]
+    assert maxerr(xs, ref) == 0.0
+    dxs = rnd(S * B, E, seed=4)
+    dW = torch.full((V1, E), float('nan'), device=dev)
+    dxsd = dxs.to(dev)
+    n.check(n.lib.rfn_embed_bwd(dxsd.data_ptr(), E, idd.data_ptr(), B, S + 2, 1, S * B, E, V1, dW.data_ptr(), st))
+    refW = torch.zeros(V1, E, dtype=torch.float64).index_add_(0, ids[:, :S].t().reshape(-1), dxs.double())
+    assert maxerr(dW, refW) < 1e-5
+    # log-softmax with the (step,batch) -> (batch,step) row mapping, and its backward
+    V1 = 9488
+    lg = rnd(S * B, V1, seed=5, scale=3.0)
+    lp = torch.empty(B, S, V1, device=dev)
+    lgd = lg.to(dev)
+    n.check(n.lib.rfn_log_softmax_fwd(lgd.data_ptr(), V1, S * B, V1, B, S * V1, V1, lp.data_ptr(), st))
+    ref = torch.log_softmax(lg.double(), 1).view(S, B, V1).transpose(0, 1)
+    assert maxerr(lp, ref) < 5e-6
+    g = rnd(B, S, V1, seed=6)
+    dl = torch.empty(S * B, V1, device=dev)
+    gdv = g.to(dev)
+    n.check(n.lib.rfn_log_softmax_bwd(gdv.data_ptr(), lp.data_ptr(), S * B, V1, B, S * V1, V1, dl.data_ptr(), V1, st))
+    gr = g.double().transpose(0, 1).reshape(S * B, V1)
+    refd = gr - torch.softmax(lg.double(), 1) * gr.sum(1, keepdim=True)
+    assert maxerr(dl, refd) < 2e-4
+    # max over steps
+    Xs = rnd(6, 9, 33, seed=7)
+    mo = torch.empty(9, 33, device=dev)
+    arg = torch.empty(9, 33, dtype=torch.int32, device=dev)
+    Xsd = Xs.to(dev)
+    n.check(n.lib.rfn_max_over_steps_fwd(Xsd.data_ptr(), 6, 9, 33, mo.data_ptr(), arg.data_ptr(), st))
+    mref, aref = Xs.max(0)
+    assert maxerr(mo, mref) == 0.0 and torch.equal(arg.cpu().long(), aref)
+    dmo = rnd(9, 33, seed=8)
+    dX = torch.empty(6, 9, 33, device=dev)
+    dmod = dmo.to(dev)
+    n.check(n.lib.rfn_max_over_steps_bwd(dmod.data_ptr(), arg.data_ptr(), 6, 9, 33, dX.data_ptr(), st))
+    refdX = torch.zeros(6, 9, 33).scatter_(0, aref.unsqueeze(0), dmo.unsqueeze(0))
+    assert maxerr(dX, refdX) == 0.0
+    # axpby / div
+    y = rnd(5, 12, seed=9).to(dev)
+    y0 = y.clone()
+    xx = rnd(5, 4, seed=10).to(dev)
+    n.check(n.lib.rfn_axpby_2d(2.0, xx.data_ptr(), 4, 1.0, y[:, 4:].data_ptr(), 12, 5, 4, st))
+    assert maxerr(y[:, 4:8], y0[:, 4:8] + 2 * xx) < 1e-6 and torch.equal(y[:, :4], y0[:, :4])
+    n.check(n.lib.rfn_div_2d(y.data_ptr(), 12, 5, 12, 3.0, st))
+    y0[:, 4:8] += 2 * xx
+    # IEEE division, compared with the CPU result (torch's GPU scalar division multiplies by 1/3)
+    assert torch.equal(y.cpu(), y0.cpu() / 3.0)
+
+
+@pytest.mark.parametrize('eps', [0.0, 0.1])
+def test_criteria_match_torch(dev, eps):
+    import torch.nn.functional as F
+    n = N()
+    B, T, V1, K = 6, 5, 301, 50
+    lp = torch.log_softmax(rnd(B, T, V1, seed=1), 2)
+    g = torch.Generator().manual_seed(2)
+    labels = torch.randint(0, V1, (B, T + 2), generator=g)
+    mask = (torch.rand(B, T + 2, generator=g) > 0.3).float()
+    target, mk = labels[:, 1:], mask[:, 1:]          # strided views, as train.py passes them
+    pred = rnd(B, K, seed=3)
+    top = -torch.ones(B, K, dtype=torch.long)
+    for b in range(B):
+        k = b % 4                                     # includes a row with no targets
+        top[b, :k] = torch.randperm(K, generator=g)[:k]
+    top[1, 1] = top[1, 0]                             # duplicated target id
+    lpr = lp.double().requires_grad_(True)
+    pr = pred.double().requires_grad_(True)
+    oh = torch.zeros(B, T, V1, dtype=torch.float64).scatter_(2, target[:, :T].unsqueeze(2), 1.0)
+    q = oh * (1 - eps) + eps / V1 if eps > 0 else oh
+    ref = (-(lpr * q).sum(2) * mk[:, :T].double()).sum() / B + 0.7 * F.multilabel_margin_loss(pr, top)
+    ref.backward()
+    from recurrent_fusion_network_amd.criteria import _XEFn
+    lpd = lp.to(dev).requires_grad_(True)
+    pd = pred.to(dev).requires_grad_(True)
+    loss = _XEFn.apply(eps, 0.7, target.to(dev), mk.to(dev), top.to(dev), lpd, pd)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(ref.detach())) < 1e-5 * max(1.0, abs(float(ref.detach())))
+    assert maxerr(lpd.grad, lpr.grad) < 1e-7
+    assert maxerr(pd.grad, pr.grad) < 1e-7
+
+
+def test_adam_and_greedy_pick(dev):
+    n = N()
+    st = n.stream_ptr()
+    nel = 10007
+    p, g = rnd(nel, seed=1), rnd(nel, seed=2, scale=2.0)
+    pr = p.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pr], lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5)
+    pd, m, v = p.to(dev), torch.zeros(nel, device=dev), torch.zeros(nel, device=dev)
+    for step in (1, 2, 3):
+        pr.grad = (g * 0.5 * step).clamp(-1, 1)
+        opt.step()
+        gstep = (g * step).to(dev)
+        n.check(n.lib.rfn_adam_step(pd.data_ptr(), gstep.data_ptr(), m.data_ptr(), v.data_ptr(), nel, 5e-4,
+                                    0.9, 0.999, 1e-8, 1e-5, 1.0, 0.5, step, st))
+    assert maxerr(pd, pr) < 2e-6
+    # greedy pick: first maximum, unfinished bookkeeping, unmasked next ids
+    B, V1 = 5, 9488
+    lp = torch.log_softmax(rnd(B, V1, seed=3), 1)
+    lp[2, 0] = 5.0          # row 2 picks END
+    lp[3, 17] = lp[3, 400] = 6.0   # tie -> first index
+    lpd = lp.to(dev)
+    nxt = torch.empty(B, dtype=torch.long, device=dev)
+    seq = torch.zeros(B, 4, dtype=torch.long, device=dev)
+    slp = torch.zeros(B, 4, device=dev)
+    unf = torch.zeros(3, B, dtype=torch.int32, device=dev)
+    n.check(n.lib.rfn_greedy_pick(lpd.data_ptr(), V1, B, V1, 1, nxt.data_ptr(), seq[:, 0].data_ptr(), 4,
+                                  slp[:, 0].data_ptr(), 4, None, unf[1].data_ptr(), st))
+    val, idx = lp.max(1)
+    assert torch.equal(nxt.cpu(), idx) and int(nxt[3]) == 17 and int(nxt[2]) == 0
+    assert torch.equal(unf[1].cpu(), (idx > 0).int())
+    assert torch.equal(seq[:, 0].cpu(), idx * (idx > 0).long()) and maxerr(slp[:, 0], val) == 0.0
+    lp2 = lp.clone()
+    lp2[2, 0] = -50.0       # row 2 would continue, but it is already finished
+    lp2d = lp2.to(dev)
+    n.check(n.lib.rfn_greedy_pick(lp2d.data_ptr(), V1, B, V1, 2, nxt.data_ptr(), seq[:, 1].data_ptr(), 4,
+                                  slp[:, 1].data_ptr(), 4, unf[1].data_ptr(), unf[2].data_ptr(), st))
+    assert int(unf[2, 2]) == 0 and int(seq[2, 1]) == 0 and int(nxt[2]) == int(lp2[2].argmax())

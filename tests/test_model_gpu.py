@@ -1,0 +1,238 @@
+"""Whole-path parity on the GPU: RecurrentFusionModel (HIP) vs the golden vectors produced by the
+reference and vs the CPU oracle on the same seeded inputs.
+
+Tolerances (north star): log-probs / logits within 1e-3 absolute in fp32 (measured ~1e-5); greedy token
+ids bit-exact; gradients within 1e-3 relative to each tensor's max |g| (+ a small absolute floor).
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_case
+
+pytestmark = pytest.mark.gpu
+
+LOGP_TOL = 1e-3
+
+
+def build(cfg, P, dev, train=False):
+    import recurrent_fusion_network_amd as R
+    model = R.RecurrentFusionModel(cfg)
+    model.load_state_dict(P)
+    model = model.to(dev)
+    model.train(train)
+    return model
+
+
+def to_dev(batch, dev):
+    fc, att, labels, masks, top = batch
+    return [t.to(dev) for t in fc], [t.to(dev) for t in att], labels.to(dev), masks.to(dev), top.to(dev)
+
+
+def maxerr(a, b):
+    return float((a.detach().double().cpu() - torch.as_tensor(b).double()).abs().max())
+
+
+@pytest.mark.parametrize('name', ['tiny0', 'tiny1', 'mid'])
+def test_forward_loss_grads_full(dev, name):
+    import recurrent_fusion_network_amd as R
+    from oracle import rfn_oracle as O
+    cfg, spec, P, batch, gold = load_case(name)
+    model = build(cfg, P, dev)
+    fc, att, labels, masks, top = to_dev(batch, dev)
+    log_prob, top_pred = model(fc, att, labels)
+    assert tuple(log_prob.shape) == tuple(gold['log_prob_shape'])
+    assert maxerr(log_prob, gold['log_prob']) < LOGP_TOL
+    for j, r in enumerate(top_pred):
+        assert maxerr(r, gold['reason_pred_%d' % j]) < LOGP_TOL
+    crit = R.ReviewNetEnsembleCriterion(cfg)
+    loss = crit(log_prob, labels[:, 1:], masks[:, 1:], top_pred, top, 1.0)
+    assert abs(float(loss) - float(gold['xe_loss'])) < 1e-4 * max(1.0, abs(float(gold['xe_loss'])))
+    loss.backward()
+    o_loss, o_grads = O.train_step_loss_and_grads(cfg, P, *batch, 1.0)
+    named = dict(model.named_parameters())
+    worst = ('', 0.0)
+    for k, g in o_grads.items():
+        got = named[k].grad
+        assert got is not None, k
+        tol = 1e-5 + 1e-3 * float(g.abs().max())
+        err = maxerr(got, g)
+        if err / tol > worst[1]:
+            worst = (k, err / tol)
+        assert err < tol, (k, err, tol)
+        assert abs(float(got.double().norm()) - float(gold['gradnorm/' + k])) <= 1e-5 + 2e-3 * float(gold['gradnorm/' + k])
+    # label smoothing variant of the criterion
+    cfg.use_label_smoothing = 1
+    crit_ls = R.ReviewNetEnsembleCriterion(cfg)
+    loss_ls = crit_ls(log_prob.detach(), labels[:, 1:], masks[:, 1:], [t.detach() for t in top_pred], top, 1.0)
+    assert abs(float(loss_ls) - float(gold['xe_loss_ls'])) < 1e-4 * max(1.0, abs(float(gold['xe_loss_ls'])))
+
+
+@pytest.mark.parametrize('name', ['c2', 'c3'])
+def test_forward_loss_grads_shape_true(dev, name):
+    """Shape-true tiers (R=A=E=512, V+1=9488; c3: M=4, L=196, D=2048): goldens hold top-5 log-probs, target
+    log-probs, loss, and per-parameter gradient norms + strided slices."""
+    import recurrent_fusion_network_amd as R
+    cfg, spec, P, batch, gold = load_case(name)
+    model = build(cfg, P, dev)
+    fc, att, labels, masks, top = to_dev(batch, dev)
+    log_prob, top_pred = model(fc, att, labels)
+    assert tuple(log_prob.shape) == tuple(gold['log_prob_shape'])
+    lp = log_prob.detach().cpu()
+    idx = torch.from_numpy(gold['log_prob_top5_idx'])
+    assert float((lp.gather(2, idx) - torch.from_numpy(gold['log_prob_top5_val'])).abs().max()) < LOGP_TOL
+    tgt = labels.cpu()[:, 1:1 + lp.size(1)]
+    assert float((lp.gather(2, tgt.unsqueeze(2)).squeeze(2) - torch.from_numpy(gold['log_prob_target'])).abs().max()) < LOGP_TOL
+    # top-1 of every step agrees wherever the reference's own margin is not razor thin
+    top2 = torch.from_numpy(gold['log_prob_top5_val'])
+    safe = (top2[:, :, 0] - top2[:, :, 1]) > 1e-4
+    assert torch.equal(lp.argmax(2)[safe], idx[:, :, 0][safe])
+    for j, r in enumerate(top_pred):
+        assert maxerr(r[:, :32], gold['reason_pred_%d' % j]) < LOGP_TOL
+        assert float((r.detach().double().sum(1).cpu() - torch.from_numpy(gold['reason_pred_rowsum_%d' % j])).abs().max()) < 2e-2
+    crit = R.ReviewNetEnsembleCriterion(cfg)
+    loss = crit(log_prob, labels[:, 1:], masks[:, 1:], top_pred, top, 1.0)
+    assert abs(float(loss) - float(gold['xe_loss'])) < 1e-4 * abs(float(gold['xe_loss']))
+    loss.backward()
+    for k, p in model.named_parameters():
+        gn = float(gold['gradnorm/' + k])
+        got = p.grad.detach().reshape(-1)
+        assert abs(float(got.double().norm()) - gn) <= 1e-6 + 2e-3 * gn, (k, float(got.double().norm()), gn)
+        stride = max(1, got.numel() // 16)
+        sl = got[::stride][:16].cpu().double()
+        ref = torch.from_numpy(gold['gradslice/' + k]).double()
+        assert float((sl - ref).abs().max()) <= 1e-6 + 2e-3 * max(float(ref.abs().max()), gn / max(1.0, got.numel() ** 0.5)), k
+
+
+@pytest.mark.parametrize('name', ['tiny0', 'tiny1', 'mid', 'c2', 'c3'])
+def test_greedy_sample_ids_bit_exact(dev, name):
+    cfg, spec, P, batch, gold = load_case(name)
+    model = build(cfg, P, dev)
+    fc, att, labels, masks, top = to_dev(batch, dev)
+    with torch.no_grad():
+        seq, seq_lp, lp_all, reason = model.sample(fc, att, {'sample_max': 1, 'beam_size': 1})
+    ref_seq = torch.from_numpy(gold['greedy_seq'])
+    margin = torch.from_numpy(gold['greedy_margin'])
+    assert tuple(lp_all.shape) == tuple(gold['greedy_logprobs_all_shape'])
+    assert tuple(seq.shape) == tuple(ref_seq.shape)
+    assert torch.equal(seq.cpu(), ref_seq), 'greedy ids differ (smallest reference margin %.3g)' % float(margin.min())
+    assert maxerr(seq_lp, gold['greedy_seq_logprobs']) < LOGP_TOL
+    if 'greedy_logprobs_all' in gold:
+        assert maxerr(lp_all, gold['greedy_logprobs_all']) < LOGP_TOL
+    else:
+        idx = torch.from_numpy(gold['greedy_top5_idx'])
+        assert float((lp_all.cpu().gather(2, idx) - torch.from_numpy(gold['greedy_top5_val'])).abs().max()) < LOGP_TOL
+
+
+@pytest.mark.parametrize('name', ['tiny0', 'mid'])
+def test_adam_step_matches_reference(dev, name):
+    """One clamp + Adam step (train.py:162-163) through FusedClampAdam on the flat buffers."""
+    import recurrent_fusion_network_amd as R
+    from oracle import rfn_oracle as O
+    cfg, spec, P, batch, gold = load_case(name)
+    model = build(cfg, P, dev)
+    opt = R.FusedClampAdam(model, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5, grad_clip=1.0)
+    fc, att, labels, masks, top = to_dev(batch, dev)
+    crit = R.ReviewNetEnsembleCriterion(cfg)
+    opt.zero_grad()
+    log_prob, top_pred = model(fc, att, labels)
+    crit(log_prob, labels[:, 1:], masks[:, 1:], top_pred, top, 1.0).backward()
+    opt.step()
+    o_loss, o_grads = O.train_step_loss_and_grads(cfg, P, *batch, 1.0)
+    named = dict(model.named_parameters())
+    for k in P:
+        # the first Adam step is lr*g/(|g|+eps): compare where |g| >> eps (see oracle/make_golden.py)
+        sel = o_grads[k].abs() > 1e-5
+        if not bool(sel.any()):
+            continue
+        if name == 'tiny0':
+            want = torch.from_numpy(gold['stepped/' + k])
+        else:
+            want = O.clip_and_adam({k: P[k].clone()}, {k: o_grads[k]}, {}, lr=5e-4, weight_decay=1e-5)[k]
+        got = named[k].detach().cpu()
+        assert float((got[sel] - want[sel]).abs().max()) < 5e-6, k
+
+
+@pytest.mark.parametrize('name', ['tiny0', 'tiny1', 'mid', 'c2'])
+def test_rl_sample_replay_and_reward_criterion(dev, name):
+    """train_rl.py:160-191: multinomial sample with grad (ids replayed from the reference's draw), reward
+    criterion, backward."""
+    import recurrent_fusion_network_amd as R
+    cfg, spec, P, batch, gold = load_case(name)
+    model = build(cfg, P, dev)
+    fc, att, labels, masks, top = to_dev(batch, dev)
+    raw = torch.from_numpy(gold['rl_raw_ids'])
+    seq, seq_lp, lp_all, reason = model.sample(fc, att, {'sample_max': 0, 'force_ids': raw})
+    assert torch.equal(seq.cpu(), torch.from_numpy(gold['rl_seq']))
+    assert maxerr(seq_lp, gold['rl_seq_logprobs']) < LOGP_TOL
+    crit = R.ReviewNetRewardCriterion(cfg)
+    reward = torch.from_numpy(gold['rl_reward']).to(dev)
+    loss = crit(seq_lp, seq, reward, lp_all, 0.01, reason, top, 1.0, None, cfg)
+    assert abs(float(loss) - float(gold['rl_loss'])) < 1e-4 * max(1.0, abs(float(gold['rl_loss'])))
+    loss.backward()
+    for k, p in model.named_parameters():
+        gn = float(gold['rl_gradnorm/' + k])
+        assert abs(float(p.grad.double().norm()) - gn) <= 1e-5 + 3e-3 * gn, k
+
+
+@pytest.mark.parametrize('name', ['tiny0', 'mid', 'c2'])
+def test_beam_search_matches_reference(dev, name):
+    cfg, spec, P, batch, gold = load_case(name)
+    model = build(cfg, P, dev)
+    fc, att, labels, masks, top = to_dev(batch, dev)
+    nb = gold['beam_seq'].shape[0]
+    beam = int(gold['beam_size'])
+    out = model.sample([f[:nb] for f in fc], [a[:nb] for a in att], {'beam_size': beam})
+    seq, seq_lp, top_seq, top_prob, reason = out
+    assert torch.equal(seq.cpu(), torch.from_numpy(gold['beam_seq']))
+    assert maxerr(seq_lp, gold['beam_seq_logprobs']) < LOGP_TOL
+    for k in range(nb):
+        assert torch.equal(top_seq[k], torch.from_numpy(gold['beam_top_seq_%d' % k]))
+        assert np.allclose(np.array(top_prob[k]), gold['beam_top_prob_%d' % k], atol=1e-3)
+    assert len(model.done_beams) == nb
+
+
+def test_dropout_training_mode_runs_and_is_seeded(dev):
+    cfg, spec, P, batch, gold = load_case('tiny0')
+    cfg.drop_prob_lm, cfg.drop_prob_reason, cfg.drop_prob_fusion = 0.3, 0.2, 0.1
+    model = build(cfg, P, dev, train=True)
+    fc, att, labels, masks, top = to_dev(batch, dev)
+    torch.manual_seed(5)
+    a, _ = model(fc, att, labels)
+    torch.manual_seed(5)
+    b, _ = model(fc, att, labels)
+    torch.manual_seed(6)
+    c, _ = model(fc, att, labels)
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    a.sum().backward()
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters())
+    model.eval()
+    e, _ = model(fc, att, labels)
+    assert maxerr(e, gold['log_prob']) < LOGP_TOL
+
+
+def test_inference_hooks(dev):
+    """get_init_state / get_thought_vectors / one_time_step (misc/RecurrentFusionModel.py:283-350)."""
+    from oracle import rfn_oracle as O
+    cfg, spec, P, batch, gold = load_case('mid')
+    model = build(cfg, P, dev)
+    fc, att, labels, masks, top = to_dev(batch, dev)
+    state = model.get_init_state(fc)
+    hs, cs = O.init_state(cfg, P, batch[0])
+    for i in range(len(hs)):
+        assert maxerr(state[i][0][0], hs[i]) < 1e-4
+    comb, reason, st = model.get_thought_vectors(fc, att, state)
+    o_comb, o_reason, (oh, oc) = O.thought_vectors(cfg, P, batch[1], hs, cs)
+    assert maxerr(comb, o_comb) < 1e-4 and maxerr(st[0][0], oh) < 1e-4
+    ids = torch.zeros(fc[0].size(0), dtype=torch.long, device=dev)
+    logit, st2 = model.one_time_step(ids, fc, comb, st)
+    o_logit, oh2, oc2 = O.one_time_step(cfg, P, P['embed.weight'][ids.cpu()], o_comb, oh, oc)
+    assert maxerr(logit, o_logit) < 1e-4 and maxerr(st2[1][0], oc2) < 1e-4
+
+
+def test_cpu_inputs_fail_loudly():
+    import recurrent_fusion_network_amd as R
+    cfg, spec, P, batch, gold = load_case('tiny0')
+    model = R.RecurrentFusionModel(cfg)
+    with pytest.raises(R._native.RfnError):
+        model(batch[0], batch[1], batch[2])
