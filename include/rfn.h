@@ -95,6 +95,9 @@ typedef struct rfn_gemm_problem {
     int64_t ldc;
     int32_t nseg;
     int32_t pad_;
+    /* optional, only with a_kfast = 0: a_colsum[m] (=|+=) sum_s sum_k A_s[k, m].  For dW = dY^T X this is
+     * the bias gradient colsum(dY), produced by the GEMM that already streams dY (no extra pass). */
+    float* a_colsum;
     rfn_gemm_seg seg[RFN_GEMM_MAXSEG];
 } rfn_gemm_problem;
 int rfn_gemm_f32(int M, int N, int ngroups, const rfn_gemm_problem* problems_host, int accumulate,
@@ -103,6 +106,9 @@ int rfn_gemm_f32(int M, int N, int ngroups, const rfn_gemm_problem* problems_hos
 /* out[n] (+)= sum_r X[r*ldx + n]   (bias gradients) */
 int rfn_colsum_f32(const float* X, int64_t ldx, int rows, int cols, float* out, int accumulate,
                    void* stream);
+/* the same for `ngroups` matrices X + g*group_stride, each into its own outs_host[g] (one launch) */
+int rfn_colsum_grouped_f32(const float* X, int64_t group_stride, int64_t ldx, int rows, int cols,
+                           float* const* outs_host, int ngroups, void* stream);
 
 /* Additive soft attention, AttentionModelCore.forward (misc/AttentionModelCore.py:31-48; inlined
  * copy misc/LSTMSoftAttentionCore.py:64-79), split at the GEMM boundary:

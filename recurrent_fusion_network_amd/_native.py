@@ -39,7 +39,7 @@ class GemmSeg(C.Structure):
 
 class GemmProblem(C.Structure):
     _fields_ = [('C', C.c_void_p), ('ldc', C.c_int64), ('nseg', C.c_int32), ('pad_', C.c_int32),
-                ('seg', GemmSeg * RFN_GEMM_MAXSEG)]
+                ('a_colsum', C.c_void_p), ('seg', GemmSeg * RFN_GEMM_MAXSEG)]
 
 
 def _load():
@@ -59,6 +59,7 @@ def _load():
         'rfn_param_shape': (C.c_int, [DP, I, C.POINTER(L), C.POINTER(L)]),
         'rfn_gemm_f32': (C.c_int, [I, I, I, C.POINTER(GemmProblem), I, P]),
         'rfn_colsum_f32': (C.c_int, [P, L, I, I, P, I, P]),
+        'rfn_colsum_grouped_f32': (C.c_int, [P, L, L, I, I, P, I, P]),
         'rfn_attn_scores_fwd': (C.c_int, [P, L, L, P, P, P, I, I, I, P, P]),
         'rfn_attn_context_fwd': (C.c_int, [P, L, L, P, I, I, I, P, L, P]),
         'rfn_attn_context_bwd_dalpha': (C.c_int, [P, L, L, P, L, I, I, I, P, P]),
@@ -160,10 +161,12 @@ def param_shape(d: Dims, idx: int):
 
 # ---- thin helpers over the primitive operators (used by the model shell and by the tests) ---------
 def gemm(M, N, problems, accumulate=False):
-    """problems: list of (C, ldc, [(A, lda, a_kfast, B, ldb, b_kfast, K, bias), ...])."""
+    """problems: list of (C, ldc, [(A, lda, a_kfast, B, ldb, b_kfast, K, bias), ...][, a_colsum])."""
     arr = (GemmProblem * len(problems))()
-    for g, (Ct, ldc, segs) in enumerate(problems):
+    for g, prob in enumerate(problems):
+        Ct, ldc, segs = prob[:3]
         arr[g].C, arr[g].ldc, arr[g].nseg = Ct.data_ptr(), ldc, len(segs)
+        arr[g].a_colsum = ptr(prob[3]) if len(prob) > 3 else None
         for s, (A, lda, ak, B, ldb, bk, K, bias) in enumerate(segs):
             sg = arr[g].seg[s]
             sg.A, sg.lda, sg.a_kfast = A.data_ptr(), lda, int(ak)

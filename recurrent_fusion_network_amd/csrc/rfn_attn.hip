@@ -27,10 +27,10 @@ __device__ __forceinline__ float row_tanh_dot(const float* __restrict__ p, const
             const f32x4 hh = *reinterpret_cast<const f32x4*>(hp_s + a);
             const f32x4 ww = *reinterpret_cast<const f32x4*>(w_s + a);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) part += tanhf(x[e] + hh[e]) * ww[e];
+            for (int e = 0; e < 4; ++e) part += rfn_tanh_fast(x[e] + hh[e]) * ww[e];
         }
     } else {
-        for (int a = lane; a < A; a += 64) part += tanhf(p[a] + hp_s[a]) * w_s[a];
+        for (int a = lane; a < A; a += 64) part += rfn_tanh_fast(p[a] + hp_s[a]) * w_s[a];
     }
     return rfn_wave_sum(part);
 }
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_scores_bwd_k(
                 }
 #pragma unroll
                 for (int e = 0; e < W; ++e) {
-                    const float t = tanhf(xv[e] + hh[e]);
+                    const float t = rfn_tanh_fast(xv[e] + hh[e]);
                     const float dpre = dsl_v * ww[e] * (1.0f - t * t);
                     ov[e] = dpre;
                     ah[e] += dpre;

@@ -38,4 +38,11 @@ __device__ __forceinline__ float rfn_wave_max(float v) {
     return v;
 }
 __device__ __forceinline__ float rfn_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+// tanh for the attention score kernels, which evaluate B*L*A of them per call and were VALU-bound on
+// ocml's tanhf: 1 - 2/(exp(2x)+1) on v_exp_f32 + v_rcp_f32.  Absolute error <= ~1.5e-7 over the whole
+// range (the 1/(e+1) term is <= 1, each hardware op is 1 ulp), saturates cleanly to +-1.
+__device__ __forceinline__ float rfn_tanh_fast(float x) {
+    const float e = __expf(2.0f * x);
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+}
 #endif

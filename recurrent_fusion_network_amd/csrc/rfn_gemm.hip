@@ -123,6 +123,20 @@ struct Stage {
         }
     }
 
+    // partial column sums of the tile just loaded (only meaningful for [k][row] operands): with float4
+    // staging a thread owns rows 4*(tid % RQ)..+3, with scalar staging the single row tid % ROWS
+    __device__ __forceinline__ void add_rowsum(float (&ps)[4]) const {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            if constexpr (VEC) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ps[e] += v[j][e];
+            } else {
+                ps[0] += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+            }
+        }
+    }
+
     // the 4 k-values (k = 8q + 4h + c, c = 0..3) of tile row `row` for this lane's k-half h
     __device__ __forceinline__ static f32x4 frag(const float* __restrict__ lds, int row, int q, int h) {
         if constexpr (KFAST) {
@@ -193,11 +207,19 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void rfn_gemm_kernel(const GemmArg
     int total_iters = 0;
     for (int s = 0; s < P.nseg; ++s) total_iters += (P.seg[s].K + GEMM_BK - 1) / GEMM_BK;
 
+    // bias gradient riding on the weight-gradient GEMM: column sums of the [k][row] A operand, taken from
+    // the staging registers by the blocks of the first column tile
+    const bool do_colsum = !AK && (tn == 0) && (P.a_colsum != nullptr);
+    float ps[4] = {0.f, 0.f, 0.f, 0.f};
+
     int seg = 0, k0 = 0;
     auto issue_load = [&]() {
         const rfn_gemm_seg& S = P.seg[seg];
         stA.load(S.A, S.lda, row0, M, k0, S.K, tid);
         stB.load(S.B, S.ldb, col0, N, k0, S.K, tid);
+        if constexpr (!AK) {
+            if (do_colsum) stA.add_rowsum(ps);
+        }
         k0 += GEMM_BK;
         if (k0 >= S.K) {
             k0 = 0;
@@ -240,6 +262,26 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void rfn_gemm_kernel(const GemmArg
             stB.store(sB0 + (cur ^ 1) * StB::LDS_FLOATS, tid);
         }
         __syncthreads();
+    }
+
+    if constexpr (!AK) {
+        if (do_colsum) {  // block-uniform; the K loop's last barrier has retired every LDS read
+            constexpr int PARTS = VEC ? GEMM_THREADS / (BM / 4) : GEMM_THREADS / BM;
+            if constexpr (VEC) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) smem[(tid / (BM / 4)) * BM + 4 * (tid % (BM / 4)) + e] = ps[e];
+            } else {
+                smem[(tid / BM) * BM + tid % BM] = ps[0];
+            }
+            __syncthreads();
+            if (tid < BM && row0 + tid < M) {
+                float t = 0.f;
+#pragma unroll
+                for (int p2 = 0; p2 < PARTS; ++p2) t += smem[p2 * BM + tid];
+                float* o = P.a_colsum + row0 + tid;
+                *o = args.accumulate ? *o + t : t;
+            }
+        }
     }
 
     // ---- epilogue: bias, optional accumulate, bounds-checked store --------------------------

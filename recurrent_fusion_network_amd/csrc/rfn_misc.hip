@@ -51,6 +51,40 @@ extern "C" int rfn_colsum_f32(const float* X, int64_t ldx, int rows, int cols, f
     return RFN_OK;
 }
 
+struct ColsumOuts { float* out[64]; };
+__global__ __launch_bounds__(256) void colsum_grouped_k(const float* __restrict__ X, long gstride, long ldx,
+                                                        int rows, int cols, const ColsumOuts outs) {
+    __shared__ float red[4][64];
+    const float* Xg = X + blockIdx.y * gstride;
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+    float acc = 0.f;
+    if (c < cols)
+        for (int r = rl; r < rows; r += 4) acc += Xg[r * ldx + c];
+    red[rl][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (rl == 0 && c < cols) {
+        const int l = threadIdx.x & 63;
+        outs.out[blockIdx.y][c] = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+    }
+}
+extern "C" int rfn_colsum_grouped_f32(const float* X, int64_t group_stride, int64_t ldx, int rows, int cols,
+                                      float* const* outs, int ngroups, void* stream) {
+    if (rows < 0 || cols <= 0 || ngroups < 1) return RFN_ERR_SHAPE;
+    if (!X || !outs) return RFN_ERR_ARG;
+    for (int g0 = 0; g0 < ngroups; g0 += 64) {
+        ColsumOuts o;
+        const int ng = ngroups - g0 < 64 ? ngroups - g0 : 64;
+        for (int g = 0; g < ng; ++g) {
+            if (!outs[g0 + g]) return RFN_ERR_ARG;
+            o.out[g] = outs[g0 + g];
+        }
+        hipLaunchKernelGGL(colsum_grouped_k, dim3(rfn_cdiv(cols, 64), ng), dim3(256), 0, (hipStream_t)stream,
+                           X + (long)g0 * group_stride, (long)group_stride, (long)ldx, rows, cols, o);
+        RFN_CHECK_LAUNCH();
+    }
+    return RFN_OK;
+}
+
 // ---- embedding ----------------------------------------------------------------------------------
 __global__ __launch_bounds__(128) void embed_fwd_k(const float* __restrict__ W, int E, long V1,
                                                    const int64_t* __restrict__ ids, int inner, long si, long so,
@@ -69,27 +103,56 @@ extern "C" int rfn_embed_fwd(const float* W, int E, int64_t V1, const int64_t* i
     RFN_CHECK_LAUNCH();
     return RFN_OK;
 }
-// one block per vocabulary row scans the token list in order: deterministic, no atomics.
+// One block per vocabulary row.  The token list is scanned 64 rows at a time: every lane tests one row,
+// a ballot gives the matching rows, and they are added in ascending row order -- deterministic, no float
+// atomics, and ~rows/64 iterations per block instead of a serial scan.
+template <bool VEC>
 __global__ __launch_bounds__(128) void embed_bwd_k(const float* __restrict__ dout, long ldo,
                                                    const int64_t* __restrict__ ids, int inner, long si, long so,
                                                    int rows, int E, float* __restrict__ dW) {
+    constexpr int W = VEC ? 4 : 1;
     const long v = blockIdx.x;
-    for (int e0 = 0; e0 < E; e0 += 128) {
-        const int e = e0 + threadIdx.x;
-        float acc = 0.f;
-        for (int r = 0; r < rows; ++r) {
-            const long id = ids[(long)(r % inner) * si + (long)(r / inner) * so];
-            if (id == v && e < E) acc += dout[r * ldo + e];
+    const int lane = threadIdx.x & 63;
+    for (int e0 = 0; e0 < E; e0 += 128 * W) {
+        const int e = e0 + threadIdx.x * W;
+        float acc[W];
+#pragma unroll
+        for (int k = 0; k < W; ++k) acc[k] = 0.f;
+        for (int base = 0; base < rows; base += 64) {
+            const int r = base + lane;
+            long id = -1;
+            if (r < rows) id = ids[(long)(r % inner) * si + (long)(r / inner) * so];
+            unsigned long long m = __ballot(id == v);
+            while (m) {
+                const int rr = base + __builtin_ctzll(m);
+                m &= m - 1;
+                if (e < E) {
+                    if constexpr (VEC) {
+                        const float4 x = *reinterpret_cast<const float4*>(dout + rr * ldo + e);
+                        acc[0] += x.x; acc[1] += x.y; acc[2] += x.z; acc[3] += x.w;
+                    } else {
+                        acc[0] += dout[rr * ldo + e];
+                    }
+                }
+            }
         }
-        if (e < E) dW[v * E + e] = acc;
+        if (e < E) {
+#pragma unroll
+            for (int k = 0; k < W; ++k) dW[v * E + e + k] = acc[k];
+        }
     }
 }
 extern "C" int rfn_embed_bwd(const float* dout, int64_t ldo, const int64_t* ids, int inner, int64_t ids_s_inner,
                              int64_t ids_s_outer, int rows, int E, int64_t V1, float* dW, void* stream) {
     if (rows < 0 || E <= 0 || V1 <= 0 || inner <= 0) return RFN_ERR_SHAPE;
     if (!dout || !ids || !dW) return RFN_ERR_ARG;
-    hipLaunchKernelGGL(embed_bwd_k, dim3((unsigned)V1), dim3(128), 0, (hipStream_t)stream, dout, (long)ldo, ids,
-                       inner, (long)ids_s_inner, (long)ids_s_outer, rows, E, dW);
+    const bool vec = (E % 4 == 0) && (ldo % 4 == 0) && rfn_aligned16(dout);
+    if (vec)
+        hipLaunchKernelGGL(embed_bwd_k<true>, dim3((unsigned)V1), dim3(128), 0, (hipStream_t)stream, dout, (long)ldo,
+                           ids, inner, (long)ids_s_inner, (long)ids_s_outer, rows, E, dW);
+    else
+        hipLaunchKernelGGL(embed_bwd_k<false>, dim3((unsigned)V1), dim3(128), 0, (hipStream_t)stream, dout,
+                           (long)ldo, ids, inner, (long)ids_s_inner, (long)ids_s_outer, rows, E, dW);
     RFN_CHECK_LAUNCH();
     return RFN_OK;
 }

@@ -103,9 +103,21 @@ rfn_gemm_problem prob1(float* C, long ldc, const rfn_gemm_seg& s) {
     p.C = C; p.ldc = ldc; p.nseg = 1; p.seg[0] = s;
     return p;
 }
+// weight gradient + its bias gradient (column sums of dY) in one problem
+rfn_gemm_problem prob_dw(float* dW, long ldw, float* db, const float* dY, long lddy, const float* X, long ldx,
+                         int rows) {
+    rfn_gemm_problem p = prob1(dW, ldw, seg_dw(dY, lddy, X, ldx, rows));
+    p.a_colsum = db;
+    return p;
+}
 int gemm1(int M, int N, const rfn_gemm_seg& s, float* C, long ldc, int acc, void* st) {
     rfn_gemm_problem p = prob1(C, ldc, s);
     return rfn_gemm_f32(M, N, 1, &p, acc, st);
+}
+int gemm_dw(int N, int K, float* dW, long ldw, float* db, const float* dY, long lddy, const float* X, long ldx,
+            int rows, void* st) {
+    rfn_gemm_problem p = prob_dw(dW, ldw, db, dY, lddy, X, ldx, rows);
+    return rfn_gemm_f32(N, K, 1, &p, 0, st);
 }
 // any number of K segments into one C (chunks of RFN_GEMM_MAXSEG, later chunks accumulate)
 int gemm_segs(int M, int N, int nseg, const rfn_gemm_seg* segs, float* C, long ldc, int acc, void* st) {
@@ -186,7 +198,7 @@ PrefixLayout prefix_layout(const rfn_dims* d, int B, int train) {
         L.dHs = b.take((T1 + 1) * Bz * M * R);
         L.dC = b.take(Bz * M * R);
         L.dal = b.take(M * Bz * maxL);
-        L.dwp = b.take(M * Bz * A);
+        L.dwp = b.take((T1 > T2 ? T1 : T2) * M * Bz * A);
         L.dhp1 = b.take(T1 * M * Bz * A);
         L.dh2e = b.take(T2 * Bz * R);
         L.dhrec = b.take(Bz * R);
@@ -223,7 +235,7 @@ DecoderLayout decoder_layout(const rfn_dims* d, int B, int S, int train) {
         L.dc = b.take(Bz * R);
         L.dz = b.take(Bz * R);
         L.dal = b.take(Bz * T2);
-        L.dwp = b.take(Bz * A);
+        L.dwp = b.take(Sz * Bz * A);
         L.dhpd = b.take(Sz * Bz * A);
         L.dPd = b.take(T2 * Bz * A);
         L.dxs = b.take(Sz * Bz * E);
@@ -534,8 +546,7 @@ extern "C" int rfn_prefix_bwd(const rfn_dims* d, int B, const float* const* prm,
     if (d_comb) RFN_TRY(copy_f32(dh2e, d_comb, (size_t)T2 * BR, st));
     else RFN_TRY(zero_f32(dh2e, (size_t)T2 * BR, st));
     RFN_TRY(gemm1(T2 * B, R, seg_dx(rmat, K, prm[P.r_w()], R, K), dh2e, R, 1, st));
-    RFN_TRY(gemm1(K, R, seg_dw(rmat, K, h2 + BR, R, T2 * B), grd[P.r_w()], R, 0, st));
-    RFN_TRY(rfn_colsum_f32(rmat, K, T2 * B, K, grd[P.r_b()], 0, st));
+    RFN_TRY(gemm_dw(K, R, grd[P.r_w()], R, grd[P.r_b()], rmat, K, h2 + BR, R, T2 * B, st));
 
     // gradient w.r.t. the stage-I hidden states: thoughts (through stage II) + reason heads + mean
     RFN_TRY(zero_f32(dHs, (size_t)(T1 + 1) * BMR, st));
@@ -567,38 +578,37 @@ extern "C" int rfn_prefix_bwd(const rfn_dims* d, int B, const float* const* prm,
             float* p2 = W + Lo.P2[i] + (long)t * A;
             RFN_TRY(rfn_attn_scores_bwd(p2, (long)T2 * A, (long)B * T2 * A, hp + i * BA, prm[P.s2(t, i, 6)],
                                         al + (long)i * B * T1, dal, B, T1, A, p2, (long)T2 * A, (long)B * T2 * A, 0,
-                                        dhp + i * BA, dwp, st));
-            RFN_TRY(rfn_colsum_f32(dwp, A, B, A, grd[P.s2(t, i, 6)], 0, st));
+                                        dhp + i * BA, dwp + ((long)t * M + i) * BA, st));
             RFN_TRY(zero_f32(grd[P.s2(t, i, 7)], 1, st));
             segs[i] = seg_dx(dhp + i * BA, A, prm[P.s2(t, i, 4)], R, A);
         }
         RFN_TRY(gemm_segs(B, R, M, segs, dhrec, R, 1, st));
     }
-    // weight gradients of stage II, grouped over steps
-    for (int t = 0; t < T2; ++t)
-        pr[t] = prob1(grd[P.s2_hh_w(t)], R, seg_dw(W + Lo.g2 + (long)t * B * 4 * R, 4 * R, h2 + t * BR, R, B));
-    RFN_TRY(gemm_groups(4 * R, R, T2, pr, 0, st));
-    for (int t = 0; t < T2; ++t) {
-        const float* g = W + Lo.g2 + (long)t * B * 4 * R;
-        RFN_TRY(rfn_colsum_f32(g, 4 * R, B, 4 * R, grd[P.s2_hh_b(t)], 0, st));
-        for (int i = 0; i < M; ++i) RFN_TRY(copy_f32(grd[P.s2(t, i, 1)], grd[P.s2_hh_b(t)], 4 * R, st));
+    // weight gradients of stage II, grouped over steps; every bias gradient rides on the GEMM that streams
+    // the same dY (h2h.b = z_2_h[i].b = colsum(dgates); h_2_att_h.b = att_2_att_h.b = colsum over (b) resp. (l,b))
+    {
+        float* outs[64];
+        for (int t = 0; t < T2; ++t)
+            for (int i = 0; i < M; ++i) outs[t * M + i] = grd[P.s2(t, i, 6)];
+        if (T2 * M > 64) return RFN_ERR_SHAPE;
+        RFN_TRY(rfn_colsum_grouped_f32(dwp, BA, A, B, A, outs, T2 * M, st));
     }
+    for (int t = 0; t < T2; ++t)
+        pr[t] = prob_dw(grd[P.s2_hh_w(t)], R, grd[P.s2_hh_b(t)], W + Lo.g2 + (long)t * B * 4 * R, 4 * R, h2 + t * BR, R, B);
+    RFN_TRY(gemm_groups(4 * R, R, T2, pr, 0, st));
     for (int i = 0; i < M; ++i) {
         for (int t = 0; t < T2; ++t)
-            pr[t] = prob1(grd[P.s2(t, i, 0)], R,
-                          seg_dw(W + Lo.g2 + (long)t * B * 4 * R, 4 * R, W + Lo.z2 + ((long)t * M + i) * BR, R, B));
+            pr[t] = prob_dw(grd[P.s2(t, i, 0)], R, grd[P.s2(t, i, 1)], W + Lo.g2 + (long)t * B * 4 * R, 4 * R,
+                            W + Lo.z2 + ((long)t * M + i) * BR, R, B);
         RFN_TRY(gemm_groups(4 * R, R, T2, pr, 0, st));
         for (int t = 0; t < T2; ++t)
-            pr[t] = prob1(grd[P.s2(t, i, 4)], R, seg_dw(W + Lo.dhp2 + ((long)t * M + i) * BA, A, h2 + t * BR, R, B));
+            pr[t] = prob_dw(grd[P.s2(t, i, 4)], R, grd[P.s2(t, i, 5)], W + Lo.dhp2 + ((long)t * M + i) * BA, A,
+                            h2 + t * BR, R, B);
         RFN_TRY(gemm_groups(A, R, T2, pr, 0, st));
-        for (int t = 0; t < T2; ++t) {
-            RFN_TRY(rfn_colsum_f32(W + Lo.dhp2 + ((long)t * M + i) * BA, A, B, A, grd[P.s2(t, i, 5)], 0, st));
-            RFN_TRY(copy_f32(grd[P.s2(t, i, 3)], grd[P.s2(t, i, 5)], A, st));  // d b_a = sum_l dproj = d b_h
-        }
         // d att_2_att_h.weight[t] = dP2_i[:, t]^T . thoughts_i   (K = T1*B rows)
         for (int t = 0; t < T2; ++t)
-            pr[t] = prob1(grd[P.s2(t, i, 2)], R,
-                          seg_dw(W + Lo.P2[i] + (long)t * A, (long)T2 * A, Hs + BMR + i * R, MR, T1 * B));
+            pr[t] = prob_dw(grd[P.s2(t, i, 2)], R, grd[P.s2(t, i, 3)], W + Lo.P2[i] + (long)t * A, (long)T2 * A,
+                            Hs + BMR + i * R, MR, T1 * B);
         RFN_TRY(gemm_groups(A, R, T2, pr, 0, st));
         // d thoughts_i += sum_t dP2_i[:, t] . W_a[t]
         for (int t = 0; t < T2; ++t) segs[t] = seg_dx(W + Lo.P2[i] + (long)t * A, (long)T2 * A, prm[P.s2(t, i, 2)], R, A);
@@ -616,8 +626,7 @@ extern "C" int rfn_prefix_bwd(const rfn_dims* d, int B, const float* const* prm,
         RFN_TRY(rfn_max_over_steps_bwd(d_reason ? d_reason + (long)i * B * K : nullptr, rarg + (long)i * B * K, T1, B, K,
                                        rmat, st));
         RFN_TRY(gemm1(T1 * B, R, seg_dx(rmat, K, prm[P.rind_w(i)], R, K), dHs + BMR + i * R, MR, 1, st));
-        RFN_TRY(gemm1(K, R, seg_dw(rmat, K, Hs + BMR + i * R, MR, T1 * B), grd[P.rind_w(i)], R, 0, st));
-        RFN_TRY(rfn_colsum_f32(rmat, K, T1 * B, K, grd[P.rind_b(i)], 0, st));
+        RFN_TRY(gemm_dw(K, R, grd[P.rind_w(i)], R, grd[P.rind_b(i)], rmat, K, Hs + BMR + i * R, MR, T1 * B, st));
     }
 
     // ---- stage I backward --------------------------------------------------------------------------------
@@ -644,8 +653,7 @@ extern "C" int rfn_prefix_bwd(const rfn_dims* d, int B, const float* const* prm,
             float* p1 = W + Lo.P1[i] + (long)t * A;
             RFN_TRY(rfn_attn_scores_bwd(p1, Li * T1 * A, (long)T1 * A, hp + i * BA, prm[P.s1(t, i, 4)],
                                         W + Lo.al1[i] + (long)t * B * Li, dali, B, (int)Li, A, p1, Li * T1 * A,
-                                        (long)T1 * A, 0, dhp + i * BA, dwp + i * BA, st));
-            RFN_TRY(rfn_colsum_f32(dwp + i * BA, A, B, A, grd[P.s1(t, i, 4)], 0, st));
+                                        (long)T1 * A, 0, dhp + i * BA, dwp + ((long)t * M + i) * BA, st));
             RFN_TRY(zero_f32(grd[P.s1(t, i, 5)], 1, st));
             pr[i] = prob1(dHc + i * R, MR, seg_dx(dhp + i * BA, A, prm[P.s1(t, i, 2)], R, A));
         }
@@ -653,36 +661,34 @@ extern "C" int rfn_prefix_bwd(const rfn_dims* d, int B, const float* const* prm,
     }
     // c0 = h0.clone() (:206): dh0 += dc0 ; fc2h gradients
     RFN_TRY(rfn_axpby_2d(1.f, dC, MR, 1.f, dHs, MR, B, (int)MR, st));
-    for (int i = 0; i < M; ++i) {
-        RFN_TRY(gemm1(R, d->F[i], seg_dw(dHs + i * R, MR, fc[i], d->F[i], B), grd[P.fc_w(i)], d->F[i], 0, st));
-        RFN_TRY(rfn_colsum_f32(dHs + i * R, MR, B, R, grd[P.fc_b(i)], 0, st));
+    for (int i = 0; i < M; ++i)
+        RFN_TRY(gemm_dw(R, d->F[i], grd[P.fc_w(i)], d->F[i], grd[P.fc_b(i)], dHs + i * R, MR, fc[i], d->F[i], B, st));
+    {
+        float* outs[64];
+        if (T1 * M > 64) return RFN_ERR_SHAPE;
+        for (int t = 0; t < T1; ++t)
+            for (int i = 0; i < M; ++i) outs[t * M + i] = grd[P.s1(t, i, 4)];
+        RFN_TRY(rfn_colsum_grouped_f32(dwp, BA, A, B, A, outs, T1 * M, st));
     }
-    // weight gradients of stage I, grouped over steps per encoder
+    // weight gradients of stage I, grouped over steps per encoder (bias gradients ride along)
     for (int i = 0; i < M; ++i) {
         const long Li = d->L[i], Di = d->D[i];
         for (int t = 0; t < T1; ++t)
-            pr[t] = prob1(grd[P.s1(t, i, 6)], MR,
-                          seg_dw(W + Lo.g1 + ((long)t * M + i) * B * 4 * R, 4 * R, Hs + t * BMR, MR, B));
+            pr[t] = prob_dw(grd[P.s1(t, i, 6)], MR, grd[P.s1(t, i, 7)], W + Lo.g1 + ((long)t * M + i) * B * 4 * R, 4 * R,
+                            Hs + t * BMR, MR, B);
         RFN_TRY(gemm_groups(4 * R, (int)MR, T1, pr, 0, st));
         for (int t = 0; t < T1; ++t)
-            pr[t] = prob1(grd[P.s1(t, i, 8)], Di,
-                          seg_dw(W + Lo.g1 + ((long)t * M + i) * B * 4 * R, 4 * R, W + Lo.z1[i] + (long)t * B * Di, Di, B));
+            pr[t] = prob_dw(grd[P.s1(t, i, 8)], Di, grd[P.s1(t, i, 9)], W + Lo.g1 + ((long)t * M + i) * B * 4 * R, 4 * R,
+                            W + Lo.z1[i] + (long)t * B * Di, Di, B);
         RFN_TRY(gemm_groups(4 * R, (int)Di, T1, pr, 0, st));
         for (int t = 0; t < T1; ++t)
-            pr[t] = prob1(grd[P.s1(t, i, 2)], R,
-                          seg_dw(W + Lo.dhp1 + ((long)t * M + i) * BA, A, Hs + t * BMR + i * R, MR, B));
+            pr[t] = prob_dw(grd[P.s1(t, i, 2)], R, grd[P.s1(t, i, 3)], W + Lo.dhp1 + ((long)t * M + i) * BA, A,
+                            Hs + t * BMR + i * R, MR, B);
         RFN_TRY(gemm_groups(A, R, T1, pr, 0, st));
-        for (int t = 0; t < T1; ++t) {
-            const float* g = W + Lo.g1 + ((long)t * M + i) * B * 4 * R;
-            RFN_TRY(rfn_colsum_f32(g, 4 * R, B, 4 * R, grd[P.s1(t, i, 7)], 0, st));
-            RFN_TRY(copy_f32(grd[P.s1(t, i, 9)], grd[P.s1(t, i, 7)], 4 * R, st));
-            RFN_TRY(rfn_colsum_f32(W + Lo.dhp1 + ((long)t * M + i) * BA, A, B, A, grd[P.s1(t, i, 3)], 0, st));
-            RFN_TRY(copy_f32(grd[P.s1(t, i, 1)], grd[P.s1(t, i, 3)], A, st));
-        }
         // the dominant GEMM of backward: d att_2_att_h.weight[t,i] = dP1_i[:, t]^T . att_i  (K = B*L_i)
         for (int t = 0; t < T1; ++t)
-            pr[t] = prob1(grd[P.s1(t, i, 0)], Di,
-                          seg_dw(W + Lo.P1[i] + (long)t * A, (long)T1 * A, att[i], Di, (int)(B * Li)));
+            pr[t] = prob_dw(grd[P.s1(t, i, 0)], Di, grd[P.s1(t, i, 1)], W + Lo.P1[i] + (long)t * A, (long)T1 * A, att[i], Di,
+                            (int)(B * Li));
         RFN_TRY(gemm_groups(A, (int)Di, T1, pr, 0, st));
     }
     return RFN_OK;
@@ -766,8 +772,7 @@ extern "C" int rfn_decoder_bwd(const rfn_dims* d, int B, int S, const float* con
     float* dPd = W + Lo.dPd;
     // log-softmax backward into time-major rows, then the batched logit layer
     RFN_TRY(rfn_log_softmax_bwd(d_log_prob, log_prob, S * B, V1, B, (long)S * V1, V1, dlg, V1, st));
-    RFN_TRY(gemm1(V1, R, seg_dw(dlg, V1, hd + BR, R, S * B), grd[P.logit_w()], R, 0, st));
-    RFN_TRY(rfn_colsum_f32(dlg, V1, S * B, V1, grd[P.logit_b()], 0, st));
+    RFN_TRY(gemm_dw(V1, R, grd[P.logit_w()], R, grd[P.logit_b()], dlg, V1, hd + BR, R, S * B, st));
     RFN_TRY(gemm1(S * B, R, seg_dx(dlg, V1, prm[P.logit_w()], R, V1), dhe, R, 0, st));
     RFN_TRY(zero_f32(d_comb, (size_t)T2 * BR, st));
     RFN_TRY(zero_f32(dPd, (size_t)T2 * BA, st));
@@ -786,8 +791,7 @@ extern "C" int rfn_decoder_bwd(const rfn_dims* d, int B, int S, const float* con
         RFN_TRY(rfn_attn_context_bwd_dseq(al, dz, R, B, T2, R, d_comb, R, BR, st));
         float* dhp = W + Lo.dhpd + s * BA;
         RFN_TRY(rfn_attn_scores_bwd(W + Lo.Pd, A, BA, W + Lo.hpd + s * BA, prm[P.dec(10)], al, W + Lo.dal, B, T2, A,
-                                    dPd, A, BA, 1, dhp, W + Lo.dwp, st));
-        RFN_TRY(rfn_colsum_f32(W + Lo.dwp, A, B, A, grd[P.dec(10)], (s < S - 1) ? 1 : 0, st));
+                                    dPd, A, BA, 1, dhp, W + Lo.dwp + s * BA, st));
         RFN_TRY(gemm1(B, R, seg_dx(dhp, A, prm[P.dec(8)], R, A), dhrec, R, 1, st));
     }
     RFN_TRY(copy_f32(d_h0, dhrec, BR, st));
@@ -795,17 +799,13 @@ extern "C" int rfn_decoder_bwd(const rfn_dims* d, int B, int S, const float* con
     RFN_TRY(zero_f32(grd[P.dec(11)], 1, st));
     // attention projection of the fused thoughts (shared by all steps)
     RFN_TRY(gemm1(T2 * B, R, seg_dx(dPd, A, prm[P.dec(6)], R, A), d_comb, R, 1, st));
-    RFN_TRY(gemm1(A, R, seg_dw(dPd, A, comb, R, T2 * B), grd[P.dec(6)], R, 0, st));
-    RFN_TRY(rfn_colsum_f32(dPd, A, T2 * B, A, grd[P.dec(7)], 0, st));
-    // weights shared across steps: one GEMM over (S*B) time-major rows each
-    RFN_TRY(gemm1(A, R, seg_dw(W + Lo.dhpd, A, hd, R, S * B), grd[P.dec(8)], R, 0, st));
-    RFN_TRY(rfn_colsum_f32(W + Lo.dhpd, A, S * B, A, grd[P.dec(9)], 0, st));
-    RFN_TRY(gemm1(4 * R, R, seg_dw(gd, 4 * R, hd, R, S * B), grd[P.dec(2)], R, 0, st));
-    RFN_TRY(gemm1(4 * R, R, seg_dw(gd, 4 * R, W + Lo.zd, R, S * B), grd[P.dec(4)], R, 0, st));
-    RFN_TRY(gemm1(4 * R, E, seg_dw(gd, 4 * R, W + Lo.xs, E, S * B), grd[P.dec(0)], E, 0, st));
-    RFN_TRY(rfn_colsum_f32(gd, 4 * R, S * B, 4 * R, grd[P.dec(1)], 0, st));
-    RFN_TRY(copy_f32(grd[P.dec(3)], grd[P.dec(1)], 4 * R, st));
-    RFN_TRY(copy_f32(grd[P.dec(5)], grd[P.dec(1)], 4 * R, st));
+    RFN_TRY(gemm_dw(A, R, grd[P.dec(6)], R, grd[P.dec(7)], dPd, A, comb, R, T2 * B, st));
+    // weights shared across steps: one GEMM over (S*B) time-major rows each, bias gradients ride along
+    RFN_TRY(rfn_colsum_f32(W + Lo.dwp, A, S * B, A, grd[P.dec(10)], 0, st));
+    RFN_TRY(gemm_dw(A, R, grd[P.dec(8)], R, grd[P.dec(9)], W + Lo.dhpd, A, hd, R, S * B, st));
+    RFN_TRY(gemm_dw(4 * R, R, grd[P.dec(2)], R, grd[P.dec(3)], gd, 4 * R, hd, R, S * B, st));
+    RFN_TRY(gemm_dw(4 * R, R, grd[P.dec(4)], R, grd[P.dec(5)], gd, 4 * R, W + Lo.zd, R, S * B, st));
+    RFN_TRY(gemm_dw(4 * R, E, grd[P.dec(0)], E, grd[P.dec(1)], gd, 4 * R, W + Lo.xs, E, S * B, st));
     // embedding: dx = dgates . W_i2h, then the fixed-order scatter
     RFN_TRY(gemm1(S * B, E, seg_dx(gd, 4 * R, prm[P.dec(0)], E, 4 * R), W + Lo.dxs, E, 0, st));
     RFN_TRY(rfn_embed_bwd(W + Lo.dxs, E, ids, B, ld_ids, 1, S * B, E, V1, grd[P.embed()], st));

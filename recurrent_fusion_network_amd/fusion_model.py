@@ -236,6 +236,7 @@ class RecurrentFusionModel(nn.Module):
         self._prefix_slots = [i for i, n in enumerate(self._slot_names) if not is_dec(n)]
         self._decoder_slots = [i for i, n in enumerate(self._slot_names) if is_dec(n)]
         self._last_flat_grads = {}
+        self._steps_cache = None
         self.done_beams = []
 
     def init_weights(self):
@@ -318,19 +319,30 @@ class RecurrentFusionModel(nn.Module):
         """misc/RecurrentFusionModel.py:198-281 -> (log_prob (B,T,V+1), reason_pred list[M+1] of (B,K))."""
         train = bool(self.training)
         seed = _fresh_seed() if train else 0
+        S = self._decoder_steps(seq)          # may read `seq` back once: do it before queueing phase 1
         comb, h, c, reason = self._prefix(fc_feats, att_feats, train, seed)
-        # number of decoder steps: the reference breaks at the first all-zero column i >= 1 (:274)
+        ids = seq[:, :S]
+        if self.ss_prob > 0.0 and S > 1:
+            ids = self._scheduled_sampling_ids(ids, comb.detach(), h.detach(), c.detach())
+        log_prob = self._decode_teacher_forced(ids, comb, h, c, train, seed)
+        return log_prob, [reason[j] for j in range(self.num_feat_array + 1)]
+
+    def _decoder_steps(self, seq):
+        """Number of decoder steps: the reference breaks at the first all-zero column i >= 1 (:274).  The
+        answer for a given (tensor, version) is cached, so a caller that reuses one label tensor pays the
+        device read-back once instead of the reference's 17 syncs per forward."""
+        key = (seq.data_ptr(), seq._version, tuple(seq.shape))
+        hit = self._steps_cache
+        if hit is not None and hit[0] == key and hit[1] is seq:
+            return hit[2]
         nz = (seq != 0).any(0).tolist()
         S = seq.size(1)
         for i in range(1, seq.size(1)):
             if not nz[i]:
                 S = i
                 break
-        ids = seq[:, :S]
-        if self.ss_prob > 0.0 and S > 1:
-            ids = self._scheduled_sampling_ids(ids, comb.detach(), h.detach(), c.detach())
-        log_prob = self._decode_teacher_forced(ids, comb, h, c, train, seed)
-        return log_prob, [reason[j] for j in range(self.num_feat_array + 1)]
+        self._steps_cache = (key, seq, S)     # holds `seq` so its storage cannot be recycled under the key
+        return S
 
     def _scheduled_sampling_ids(self, ids, comb, h, c):
         """misc/RecurrentFusionModel.py:260-270: with probability ss_prob a row's input token is drawn from the
