@@ -102,6 +102,11 @@ typedef struct rfn_gemm_problem {
 } rfn_gemm_problem;
 int rfn_gemm_f32(int M, int N, int ngroups, const rfn_gemm_problem* problems_host, int accumulate,
                  void* stream);
+/* Same, with a scratch buffer (>= 1 MiB, 16-B aligned).  Skinny problems (M = batch rows, few output tiles)
+ * are then cut along K across thread blocks; the partial tiles are summed in a fixed order by a second
+ * kernel, so the result is deterministic (it differs from the unsplit result only by fp32 re-association). */
+int rfn_gemm_f32_ws(int M, int N, int ngroups, const rfn_gemm_problem* problems_host, int accumulate,
+                    void* ws, size_t ws_bytes, void* stream);
 
 /* out[n] (+)= sum_r X[r*ldx + n]   (bias gradients) */
 int rfn_colsum_f32(const float* X, int64_t ldx, int rows, int cols, float* out, int accumulate,

@@ -58,6 +58,7 @@ def _load():
         'rfn_param_name': (C.c_int, [DP, I, C.c_char_p, SZ]),
         'rfn_param_shape': (C.c_int, [DP, I, C.POINTER(L), C.POINTER(L)]),
         'rfn_gemm_f32': (C.c_int, [I, I, I, C.POINTER(GemmProblem), I, P]),
+        'rfn_gemm_f32_ws': (C.c_int, [I, I, I, C.POINTER(GemmProblem), I, P, SZ, P]),
         'rfn_colsum_f32': (C.c_int, [P, L, I, I, P, I, P]),
         'rfn_colsum_grouped_f32': (C.c_int, [P, L, L, I, I, P, I, P]),
         'rfn_attn_scores_fwd': (C.c_int, [P, L, L, P, P, P, I, I, I, P, P]),
@@ -160,8 +161,9 @@ def param_shape(d: Dims, idx: int):
 
 
 # ---- thin helpers over the primitive operators (used by the model shell and by the tests) ---------
-def gemm(M, N, problems, accumulate=False):
-    """problems: list of (C, ldc, [(A, lda, a_kfast, B, ldb, b_kfast, K, bias), ...][, a_colsum])."""
+def gemm(M, N, problems, accumulate=False, ws=None):
+    """problems: list of (C, ldc, [(A, lda, a_kfast, B, ldb, b_kfast, K, bias), ...][, a_colsum]).
+    ws: optional uint8 scratch tensor enabling split-K for skinny problems."""
     arr = (GemmProblem * len(problems))()
     for g, prob in enumerate(problems):
         Ct, ldc, segs = prob[:3]
@@ -172,6 +174,10 @@ def gemm(M, N, problems, accumulate=False):
             sg.A, sg.lda, sg.a_kfast = A.data_ptr(), lda, int(ak)
             sg.B, sg.ldb, sg.b_kfast = B.data_ptr(), ldb, int(bk)
             sg.K, sg.bias = K, ptr(bias)
+    if ws is not None:
+        check(lib.rfn_gemm_f32_ws(M, N, len(problems), arr, int(accumulate), ws.data_ptr(), ws.numel(), stream_ptr()),
+              'rfn_gemm_f32_ws')
+        return
     check(lib.rfn_gemm_f32(M, N, len(problems), arr, int(accumulate), stream_ptr()), 'rfn_gemm_f32')
 
 

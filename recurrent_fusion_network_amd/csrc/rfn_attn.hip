@@ -35,38 +35,54 @@ __device__ __forceinline__ float row_tanh_dot(const float* __restrict__ p, const
     return rfn_wave_sum(part);
 }
 
+// Raw scores s[b,l] on a (L-chunk, batch) grid: 16 rows per block, 4 per wave, so B*ceil(L/16) blocks keep every
+// CU full of independent row streams (one block per batch row left 4 waves per CU waiting on their own loads).
+#define SC_ROWS 16
 template <bool VEC>
-__global__ __launch_bounds__(ATT_THREADS) void attn_scores_fwd_k(const float* __restrict__ proj, long sb, long sl,
+__global__ __launch_bounds__(ATT_THREADS) void attn_scores_raw_k(const float* __restrict__ proj, long sb, long sl,
                                                                 const float* __restrict__ hproj,
                                                                 const float* __restrict__ w_out,
                                                                 const float* __restrict__ b_out, int L, int A,
-                                                                float* __restrict__ alpha) {
+                                                                float* __restrict__ scores) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int Ap = (A + 3) & ~3;
     float* hp_s = sm;
     float* w_s = sm + Ap;
-    float* s_s = sm + 2 * Ap;
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int a = tid; a < A; a += ATT_THREADS) {
         hp_s[a] = hproj[(long)b * A + a];
         w_s[a] = w_out[a];
     }
     __syncthreads();
     const float bo = b_out ? b_out[0] : 0.f;
-    for (int l = wave; l < L; l += ATT_WAVES) {
-        const float s = row_tanh_dot<VEC>(proj + b * sb + l * sl, hp_s, w_s, A, lane) + bo;
-        if (lane == 0) s_s[l] = s;
+    const int l0 = blockIdx.x * SC_ROWS;
+    for (int r = wave; r < SC_ROWS; r += ATT_WAVES) {
+        const int l = l0 + r;
+        if (l >= L) break;
+        const float sc = row_tanh_dot<VEC>(proj + b * sb + l * sl, hp_s, w_s, A, lane) + bo;
+        if (lane == 0) scores[(long)b * L + l] = sc;
     }
-    __syncthreads();
-    // softmax over L: every wave reduces redundantly (L is small), then all threads write
+}
+
+// alpha = softmax_l(scores) in place, one block per batch row (L values: trivial)
+__global__ __launch_bounds__(ATT_THREADS) void attn_softmax_k(float* __restrict__ alpha, int L) {
+    __shared__ float red[ATT_WAVES];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* a = alpha + (long)b * L;
     float m = -INFINITY;
-    for (int l = lane; l < L; l += 64) m = fmaxf(m, s_s[l]);
+    for (int l = tid; l < L; l += ATT_THREADS) m = fmaxf(m, a[l]);
     m = rfn_wave_max(m);
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
     float sum = 0.f;
-    for (int l = lane; l < L; l += 64) sum += expf(s_s[l] - m);
+    for (int l = tid; l < L; l += ATT_THREADS) sum += expf(a[l] - m);
     sum = rfn_wave_sum(sum);
-    const float inv = 1.0f / sum;
-    for (int l = tid; l < L; l += ATT_THREADS) alpha[(long)b * L + l] = expf(s_s[l] - m) * inv;
+    if (lane == 0) red[wave] = sum;
+    __syncthreads();
+    const float inv = 1.0f / ((red[0] + red[1]) + (red[2] + red[3]));
+    for (int l = tid; l < L; l += ATT_THREADS) a[l] = expf(a[l] - m) * inv;
 }
 
 extern "C" int rfn_attn_scores_fwd(const float* proj, int64_t proj_sb, int64_t proj_sl, const float* hproj,
@@ -74,16 +90,19 @@ extern "C" int rfn_attn_scores_fwd(const float* proj, int64_t proj_sb, int64_t p
                                    void* stream) {
     if (B <= 0 || L <= 0 || A <= 0) return RFN_ERR_SHAPE;
     if (!proj || !hproj || !w_out || !alpha) return RFN_ERR_ARG;
-    const size_t lds = (2 * ((A + 3) & ~3) + L) * sizeof(float);
+    const size_t lds = (2 * ((A + 3) & ~3)) * sizeof(float);
     if (lds > 64 * 1024) return RFN_ERR_SHAPE;
     const bool vec = (A % 4 == 0) && rfn_aligned16(proj) && (proj_sb % 4 == 0) && (proj_sl % 4 == 0);
     hipStream_t st = (hipStream_t)stream;
+    dim3 grid(rfn_cdiv(L, SC_ROWS), B);
     if (vec)
-        hipLaunchKernelGGL(attn_scores_fwd_k<true>, dim3(B), dim3(ATT_THREADS), lds, st, proj, (long)proj_sb,
+        hipLaunchKernelGGL(attn_scores_raw_k<true>, grid, dim3(ATT_THREADS), lds, st, proj, (long)proj_sb,
                            (long)proj_sl, hproj, w_out, b_out, L, A, alpha);
     else
-        hipLaunchKernelGGL(attn_scores_fwd_k<false>, dim3(B), dim3(ATT_THREADS), lds, st, proj, (long)proj_sb,
+        hipLaunchKernelGGL(attn_scores_raw_k<false>, grid, dim3(ATT_THREADS), lds, st, proj, (long)proj_sb,
                            (long)proj_sl, hproj, w_out, b_out, L, A, alpha);
+    RFN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(attn_softmax_k, dim3(B), dim3(ATT_THREADS), 0, st, alpha, L);
     RFN_CHECK_LAUNCH();
     return RFN_OK;
 }
@@ -216,8 +235,10 @@ extern "C" int rfn_attn_context_bwd_dseq(const float* alpha, const float* dz, in
 // One block per batch row.  For each 64*W-wide chunk of A (W = 4 with 16-B accesses) every wave
 // sweeps its rows l = wave, wave+4, ... keeping the chunk's column sums (dhproj, dw) in registers;
 // the four waves' sums are combined through LDS in a fixed order (deterministic).
+#define SB_THREADS 1024
+#define SB_WAVES 16
 template <bool VEC>
-__global__ __launch_bounds__(ATT_THREADS) void attn_scores_bwd_k(
+__global__ __launch_bounds__(SB_THREADS) void attn_scores_bwd_k(
     const float* proj /* may alias dproj */, long sb, long sl, const float* __restrict__ hproj,
     const float* __restrict__ w_out, const float* __restrict__ alpha, const float* __restrict__ dalpha, int L, int A,
     float* dproj, long dsb, long dsl, int accumulate, float* __restrict__ dhproj, float* __restrict__ dw_part) {
@@ -226,23 +247,25 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_scores_bwd_k(
     const int Ap = (A + 3) & ~3;
     float* hp_s = sm;             // [Ap]
     float* w_s = sm + Ap;         // [Ap]
-    float* red_h = sm + 2 * Ap;   // [4][Ap]
-    float* red_w = sm + 6 * Ap;   // [4][Ap]
-    float* dot_s = sm + 10 * Ap;  // [4]
-    float* ds_s = sm + 10 * Ap + 4;  // [L]
+    float* red_h = sm + 2 * Ap;                    // [SB_WAVES][Ap]
+    float* red_w = sm + (2 + SB_WAVES) * Ap;       // [SB_WAVES][Ap]
+    float* dot_s = sm + (2 + 2 * SB_WAVES) * Ap;   // [SB_WAVES]
+    float* ds_s = dot_s + SB_WAVES;                // [L]
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int a = tid; a < A; a += ATT_THREADS) {
+    for (int a = tid; a < A; a += SB_THREADS) {
         hp_s[a] = hproj[(long)b * A + a];
         w_s[a] = w_out[a];
     }
     // softmax backward: ds = alpha * (dalpha - <alpha, dalpha>)
     float part = 0.f;
-    for (int l = tid; l < L; l += ATT_THREADS) part += alpha[(long)b * L + l] * dalpha[(long)b * L + l];
+    for (int l = tid; l < L; l += SB_THREADS) part += alpha[(long)b * L + l] * dalpha[(long)b * L + l];
     part = rfn_wave_sum(part);
     if (lane == 0) dot_s[wave] = part;
     __syncthreads();
-    const float dot = (dot_s[0] + dot_s[1]) + (dot_s[2] + dot_s[3]);
-    for (int l = tid; l < L; l += ATT_THREADS)
+    float dot = 0.f;
+#pragma unroll
+    for (int w2 = 0; w2 < SB_WAVES; ++w2) dot += dot_s[w2];
+    for (int l = tid; l < L; l += SB_THREADS)
         ds_s[l] = alpha[(long)b * L + l] * (dalpha[(long)b * L + l] - dot);
     __syncthreads();
 
@@ -258,7 +281,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_scores_bwd_k(
                 hh[e] = hp_s[a + e];
                 ww[e] = w_s[a + e];
             }
-            for (int l = wave; l < L; l += ATT_WAVES) {
+            for (int l = wave; l < L; l += SB_WAVES) {
                 const float dsl_v = ds_s[l];
                 const float* p = proj + b * sb + l * sl + a;
                 float* o = dproj + b * dsb + l * dsl + a;
@@ -293,9 +316,15 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_scores_bwd_k(
         }
     }
     __syncthreads();
-    for (int a = tid; a < A; a += ATT_THREADS) {
-        dhproj[(long)b * A + a] = (red_h[a] + red_h[Ap + a]) + (red_h[2 * Ap + a] + red_h[3 * Ap + a]);
-        dw_part[(long)b * A + a] = (red_w[a] + red_w[Ap + a]) + (red_w[2 * Ap + a] + red_w[3 * Ap + a]);
+    for (int a = tid; a < A; a += SB_THREADS) {
+        float th = 0.f, tw = 0.f;
+#pragma unroll
+        for (int w2 = 0; w2 < SB_WAVES; ++w2) {  // fixed order over the waves
+            th += red_h[w2 * Ap + a];
+            tw += red_w[w2 * Ap + a];
+        }
+        dhproj[(long)b * A + a] = th;
+        dw_part[(long)b * A + a] = tw;
     }
 }
 
@@ -305,21 +334,21 @@ extern "C" int rfn_attn_scores_bwd(const float* proj, int64_t proj_sb, int64_t p
                                    float* dhproj, float* dw_part, void* stream) {
     if (B <= 0 || L <= 0 || A <= 0) return RFN_ERR_SHAPE;
     if (!proj || !hproj || !w_out || !alpha || !dalpha || !dproj || !dhproj || !dw_part) return RFN_ERR_ARG;
-    const size_t lds = (size_t)(10 * ((A + 3) & ~3) + 4 + L) * sizeof(float);
-    if (lds > 96 * 1024) return RFN_ERR_SHAPE;
+    const size_t lds = (size_t)((2 + 2 * SB_WAVES) * ((A + 3) & ~3) + SB_WAVES + L) * sizeof(float);
+    if (lds > 150 * 1024) return RFN_ERR_SHAPE;
     const bool vec = (A % 4 == 0) && rfn_aligned16(proj) && rfn_aligned16(dproj) && (proj_sb % 4 == 0) &&
                      (proj_sl % 4 == 0) && (dproj_sb % 4 == 0) && (dproj_sl % 4 == 0);
     hipStream_t st = (hipStream_t)stream;
     if (vec) {
         auto k = attn_scores_bwd_k<true>;
         if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k, dim3(B), dim3(ATT_THREADS), lds, st, proj, (long)proj_sb, (long)proj_sl, hproj, w_out,
+        hipLaunchKernelGGL(k, dim3(B), dim3(SB_THREADS), lds, st, proj, (long)proj_sb, (long)proj_sl, hproj, w_out,
                            alpha, dalpha, L, A, dproj, (long)dproj_sb, (long)dproj_sl, accumulate_dproj, dhproj,
                            dw_part);
     } else {
         auto k = attn_scores_bwd_k<false>;
         if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k, dim3(B), dim3(ATT_THREADS), lds, st, proj, (long)proj_sb, (long)proj_sl, hproj, w_out,
+        hipLaunchKernelGGL(k, dim3(B), dim3(SB_THREADS), lds, st, proj, (long)proj_sb, (long)proj_sl, hproj, w_out,
                            alpha, dalpha, L, A, dproj, (long)dproj_sb, (long)dproj_sl, accumulate_dproj, dhproj,
                            dw_part);
     }

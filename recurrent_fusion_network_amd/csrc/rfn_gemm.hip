@@ -44,6 +44,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 struct GemmArgs {
     int M, N, ngroups, accumulate;
     int tiles_m, tiles_n;
+    int splitk;   // > 1: each tile's K iterations are cut into `splitk` ranges, raw partial tiles go to `part`
+    int pad_;
+    float* part;  // [ngroups][splitk][M][N]
     rfn_gemm_problem g[RFN_GEMM_MAXGROUP];
 };
 
@@ -187,7 +190,8 @@ __global__ __launch_bounds__(GEMM_THREADS, GEMM_MIN_WAVES) void rfn_gemm_kernel(
 
     // ---- block -> (group, tile_m, tile_n): bijective XCD remap, then 8-row bands ------------
     const int NC = args.ngroups * args.tiles_n;
-    const int nblk = NC * args.tiles_m;
+    const int splitk = args.splitk;
+    const int nblk = NC * args.tiles_m * splitk;
     int lid;
     {
         const int bid = blockIdx.x;
@@ -198,6 +202,8 @@ __global__ __launch_bounds__(GEMM_THREADS, GEMM_MIN_WAVES) void rfn_gemm_kernel(
         lid = bid;
 #endif
     }
+    const int ks = lid % splitk;  // the K ranges of one tile run next to each other
+    lid /= splitk;
     const int per_band = 8 * NC;
     const int band = lid / per_band;
     const int rem = lid - band * per_band;
@@ -228,10 +234,24 @@ __global__ __launch_bounds__(GEMM_THREADS, GEMM_MIN_WAVES) void rfn_gemm_kernel(
 
     // bias gradient riding on the weight-gradient GEMM: column sums of the [k][row] A operand, taken from
     // the staging registers by the blocks of the first column tile
-    const bool do_colsum = !AK && (tn == 0) && (P.a_colsum != nullptr);
+    const bool do_colsum = !AK && (tn == 0) && (P.a_colsum != nullptr) && (splitk == 1);
     float ps[4] = {0.f, 0.f, 0.f, 0.f};
 
+    // split-K: this block owns iterations [it_begin, it_end) of the flattened (segment, k) space
     int seg = 0, k0 = 0;
+    if (splitk > 1) {
+        const int per = (total_iters + splitk - 1) / splitk;
+        int it_begin = ks * per;
+        const int it_end = min(total_iters, it_begin + per);
+        total_iters = max(0, it_end - it_begin);
+        while (seg < P.nseg) {  // locate (seg, k0) of it_begin
+            const int n = (P.seg[seg].K + GEMM_BK - 1) / GEMM_BK;
+            if (it_begin < n) break;
+            it_begin -= n;
+            ++seg;
+        }
+        k0 = it_begin * GEMM_BK;
+    }
     auto issue_load = [&]() {
         const rfn_gemm_seg& S = P.seg[seg];
         stA.load(S.A, S.lda, row0, M, k0, S.K, tid);
@@ -316,6 +336,23 @@ __global__ __launch_bounds__(GEMM_THREADS, GEMM_MIN_WAVES) void rfn_gemm_kernel(
         }
     }
 
+    if (splitk > 1) {  // raw partial tile; rfn_gemm_reduce_k adds the bias / previous C in a fixed order
+        float* part = args.part + ((long)grp * splitk + ks) * (long)M * N;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int col = col0 + wn * (BN / 2) + j * 32 + l31;
+            if (col >= N) continue;
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = row0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (row < M) part[(long)row * N + col] = acc[i][j][r];
+                }
+        }
+        return;
+    }
+
     // ---- epilogue: bias, optional accumulate, bounds-checked store --------------------------
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
@@ -344,12 +381,29 @@ __global__ __launch_bounds__(GEMM_THREADS, GEMM_MIN_WAVES) void rfn_gemm_kernel(
     }
 }
 
+// C = sum_ks part[g][ks] + sum_s bias_s (+ C): fixed summation order, one thread per output element
+__global__ __launch_bounds__(256) void rfn_gemm_reduce_k(const GemmArgs args) {
+    const long MN = (long)args.M * args.N;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= MN) return;
+    const int grp = blockIdx.y;
+    const rfn_gemm_problem& P = args.g[grp];
+    const int row = (int)(i / args.N), col = (int)(i - (long)row * args.N);
+    const float* part = args.part + (long)grp * args.splitk * MN + i;
+    float s = 0.f;
+    for (int k = 0; k < args.splitk; ++k) s += part[k * MN];
+    for (int sg = 0; sg < P.nseg; ++sg)
+        if (P.seg[sg].bias) s += P.seg[sg].bias[col];
+    float* c = P.C + (long)row * P.ldc + col;
+    *c = args.accumulate ? *c + s : s;
+}
+
 template <int BM, int BN, bool AK, bool BKF, bool VEC, int STAGES>
 static int launch_cfg(const GemmArgs& a, hipStream_t st) {
     using StA = Stage<BM, AK, VEC>;
     using StB = Stage<BN, BKF, VEC>;
     const size_t lds = STAGES * (StA::LDS_FLOATS + StB::LDS_FLOATS) * sizeof(float);
-    const int nblk = a.ngroups * a.tiles_m * a.tiles_n;
+    const int nblk = a.ngroups * a.tiles_m * a.tiles_n * a.splitk;
     auto k = rfn_gemm_kernel<BM, BN, AK, BKF, VEC, STAGES>;
     static bool attr_set = false;  // idempotent; a race only repeats the same call
     if (!attr_set) {
@@ -358,6 +412,10 @@ static int launch_cfg(const GemmArgs& a, hipStream_t st) {
     }
     hipLaunchKernelGGL(k, dim3(nblk), dim3(GEMM_THREADS), lds, st, a);
     RFN_CHECK_LAUNCH();
+    if (a.splitk > 1) {
+        hipLaunchKernelGGL(rfn_gemm_reduce_k, dim3(rfn_cdiv((long)a.M * a.N, 256), a.ngroups), dim3(256), 0, st, a);
+        RFN_CHECK_LAUNCH();
+    }
     return RFN_OK;
 }
 
@@ -373,11 +431,31 @@ static int launch_tile(GemmArgs& a, hipStream_t st) {
     }
     a.tiles_m = rfn_cdiv(a.M, 64);
     a.tiles_n = rfn_cdiv(a.N, 64);
+    // Skinny problems (M = batch) give too few tiles for 256 CUs and long serial MFMA chains: cut K across
+    // blocks when a workspace is available.  Target ~3 blocks per CU, at least 4 K-iterations per block.
+    if (a.part) {
+        const long tiles = (long)a.tiles_m * a.tiles_n * a.ngroups;
+        int iters = 0;
+        bool colsum = false;
+        for (int s = 0; s < a.g[0].nseg; ++s) iters += rfn_cdiv(a.g[0].seg[s].K, GEMM_BK);
+        for (int g = 0; g < a.ngroups; ++g) colsum = colsum || (a.g[g].a_colsum != nullptr);
+        long want = tiles > 0 ? 768 / tiles : 1;
+        if (want > iters / 4) want = iters / 4;
+        if (want > 16) want = 16;
+        const long cap = (long)(a.pad_ /* ws MiB */) * (1 << 18) / ((long)a.M * a.N * a.ngroups);  // floats
+        if (want > cap) want = cap;
+        a.splitk = (!colsum && want >= 2) ? (int)want : 1;
+    }
     return launch_cfg<64, 64, AK, BKF, VEC, 2>(a, st);
 }
 
 extern "C" int rfn_gemm_f32(int M, int N, int ngroups, const rfn_gemm_problem* problems, int accumulate,
                             void* stream) {
+    return rfn_gemm_f32_ws(M, N, ngroups, problems, accumulate, nullptr, 0, stream);
+}
+
+extern "C" int rfn_gemm_f32_ws(int M, int N, int ngroups, const rfn_gemm_problem* problems, int accumulate,
+                               void* ws, size_t ws_bytes, void* stream) {
     if (M <= 0 || N <= 0) return RFN_OK;
     if (ngroups < 1 || ngroups > RFN_GEMM_MAXGROUP || !problems) return RFN_ERR_SHAPE;
     GemmArgs a;
@@ -385,6 +463,9 @@ extern "C" int rfn_gemm_f32(int M, int N, int ngroups, const rfn_gemm_problem* p
     a.N = N;
     a.ngroups = ngroups;
     a.accumulate = accumulate;
+    a.splitk = 1;
+    a.part = (ws && ws_bytes >= (1u << 20) && rfn_aligned16(ws)) ? (float*)ws : nullptr;
+    a.pad_ = (int)(ws_bytes >> 20);  // workspace size in MiB (host-side only)
     const int ak = problems[0].seg[0].a_kfast, bk = problems[0].seg[0].b_kfast;
     bool vec = true;
     for (int g = 0; g < ngroups; ++g) {

@@ -97,6 +97,12 @@ rfn_gemm_seg seg_dw(const float* dY, long lddy, const float* X, long ldx, int ro
     s.K = rows;
     return s;
 }
+// stream + split-K scratch handed to every GEMM of a phase
+struct GemmCtx {
+    void* st;
+    float* ws;
+    size_t ws_bytes;
+};
 rfn_gemm_problem prob1(float* C, long ldc, const rfn_gemm_seg& s) {
     rfn_gemm_problem p;
     memset(&p, 0, sizeof(p));
@@ -110,32 +116,32 @@ rfn_gemm_problem prob_dw(float* dW, long ldw, float* db, const float* dY, long l
     p.a_colsum = db;
     return p;
 }
-int gemm1(int M, int N, const rfn_gemm_seg& s, float* C, long ldc, int acc, void* st) {
+int gemm1(int M, int N, const rfn_gemm_seg& s, float* C, long ldc, int acc, const GemmCtx& gx) {
     rfn_gemm_problem p = prob1(C, ldc, s);
-    return rfn_gemm_f32(M, N, 1, &p, acc, st);
+    return rfn_gemm_f32_ws(M, N, 1, &p, acc, gx.ws, gx.ws_bytes, gx.st);
 }
 int gemm_dw(int N, int K, float* dW, long ldw, float* db, const float* dY, long lddy, const float* X, long ldx,
-            int rows, void* st) {
+            int rows, const GemmCtx& gx) {
     rfn_gemm_problem p = prob_dw(dW, ldw, db, dY, lddy, X, ldx, rows);
-    return rfn_gemm_f32(N, K, 1, &p, 0, st);
+    return rfn_gemm_f32_ws(N, K, 1, &p, 0, gx.ws, gx.ws_bytes, gx.st);
 }
 // any number of K segments into one C (chunks of RFN_GEMM_MAXSEG, later chunks accumulate)
-int gemm_segs(int M, int N, int nseg, const rfn_gemm_seg* segs, float* C, long ldc, int acc, void* st) {
+int gemm_segs(int M, int N, int nseg, const rfn_gemm_seg* segs, float* C, long ldc, int acc, const GemmCtx& gx) {
     for (int s0 = 0; s0 < nseg; s0 += RFN_GEMM_MAXSEG) {
         rfn_gemm_problem p;
         memset(&p, 0, sizeof(p));
         p.C = C; p.ldc = ldc;
         p.nseg = (nseg - s0 < RFN_GEMM_MAXSEG) ? nseg - s0 : RFN_GEMM_MAXSEG;
         for (int s = 0; s < p.nseg; ++s) p.seg[s] = segs[s0 + s];
-        RFN_TRY(rfn_gemm_f32(M, N, 1, &p, (s0 > 0) ? 1 : acc, st));
+        RFN_TRY(rfn_gemm_f32_ws(M, N, 1, &p, (s0 > 0) ? 1 : acc, gx.ws, gx.ws_bytes, gx.st));
     }
     return RFN_OK;
 }
 // any number of same-shape problems (chunks of RFN_GEMM_MAXGROUP)
-int gemm_groups(int M, int N, int n, const rfn_gemm_problem* p, int acc, void* st) {
+int gemm_groups(int M, int N, int n, const rfn_gemm_problem* p, int acc, const GemmCtx& gx) {
     for (int g0 = 0; g0 < n; g0 += RFN_GEMM_MAXGROUP) {
         const int ng = (n - g0 < RFN_GEMM_MAXGROUP) ? n - g0 : RFN_GEMM_MAXGROUP;
-        RFN_TRY(rfn_gemm_f32(M, N, ng, p + g0, acc, st));
+        RFN_TRY(rfn_gemm_f32_ws(M, N, ng, p + g0, acc, gx.ws, gx.ws_bytes, gx.st));
     }
     return RFN_OK;
 }
@@ -162,10 +168,13 @@ struct Bump {
     }
 };
 
+const size_t GEMM_WS_FLOATS = (size_t)12 << 20;  // 48 MiB of split-K partial tiles
+
 struct PrefixLayout {
     size_t P1[RFN_MAX_ENC], al1[RFN_MAX_ENC], z1[RFN_MAX_ENC], P2[RFN_MAX_ENC], dz1[RFN_MAX_ENC];
     size_t Hs, Cs, hp1, g1, rmat, rarg, h2, c2, hp2, al2, z2, g2;
     size_t dHs, dC, dal, dwp, dhp1, dh2e, dhrec, dc2, dz2, dhp2;
+    size_t gws;
     size_t total;
 };
 PrefixLayout prefix_layout(const rfn_dims* d, int B, int train) {
@@ -193,6 +202,7 @@ PrefixLayout prefix_layout(const rfn_dims* d, int B, int train) {
     L.al2 = b.take(T2 * M * Bz * T1);
     L.z2 = b.take(T2 * M * Bz * R);
     L.g2 = b.take(T2 * Bz * 4 * R);
+    L.gws = b.take(GEMM_WS_FLOATS);
     if (train) {
         for (int i = 0; i < d->M; ++i) L.dz1[i] = b.take(Bz * d->D[i]);
         L.dHs = b.take((T1 + 1) * Bz * M * R);
@@ -213,6 +223,7 @@ PrefixLayout prefix_layout(const rfn_dims* d, int B, int train) {
 struct DecoderLayout {
     size_t Pd, xs, gd, hd, cd, hpd, ald, zd, logits;
     size_t dhe, dhrec, dc, dz, dal, dwp, dhpd, dPd, dxs;
+    size_t gws;
     size_t total;
 };
 DecoderLayout decoder_layout(const rfn_dims* d, int B, int S, int train) {
@@ -229,6 +240,7 @@ DecoderLayout decoder_layout(const rfn_dims* d, int B, int S, int train) {
     L.ald = b.take(Sz * Bz * T2);
     L.zd = b.take(Sz * Bz * R);
     L.logits = b.take(Sz * Bz * V1);  // logits in forward, dlogits in backward
+    L.gws = b.take(GEMM_WS_FLOATS);
     if (train) {
         L.dhe = b.take(Sz * Bz * R);
         L.dhrec = b.take(Bz * R);
@@ -393,6 +405,7 @@ extern "C" int rfn_prefix_fwd(const rfn_dims* d, int B, const float* const* prm,
     const int M = d->M, R = d->R, A = d->A, T1 = d->T1, T2 = d->T2, K = d->K;
     const long MR = (long)M * R, BMR = (long)B * MR, BR = (long)B * R;
     float* W = (float*)ws;
+    const GemmCtx gx{st, W + Lo.gws, GEMM_WS_FLOATS * sizeof(float)};
     float* Hs = W + Lo.Hs;
     float* Cs = W + Lo.Cs;
     int32_t* rarg = (int32_t*)(W + Lo.rarg);
@@ -400,7 +413,7 @@ extern "C" int rfn_prefix_fwd(const rfn_dims* d, int B, const float* const* prm,
     // K0: h0_i = fc2h_i(fc_i) written straight into the concatenated H of step 0; c0 = h0 (:202-208)
     for (int i = 0; i < M; ++i)
         RFN_TRY(gemm1(B, R, seg_lin(fc[i], d->F[i], prm[P.fc_w(i)], d->F[i], d->F[i], prm[P.fc_b(i)]), Hs + i * R, MR,
-                      0, st));
+                      0, gx));
     RFN_TRY(copy_f32(Cs, Hs, BMR, st));
 
     // hoisted feature projections of stage I: P1_i[(b,l), t*A + a], all T1 step weights grouped
@@ -410,7 +423,7 @@ extern "C" int rfn_prefix_fwd(const rfn_dims* d, int B, const float* const* prm,
         for (int t = 0; t < T1; ++t)
             pr[t] = prob1(W + Lo.P1[i] + (long)t * A, (long)T1 * A,
                           seg_lin(att[i], d->D[i], prm[P.s1(t, i, 0)], d->D[i], d->D[i], prm[P.s1(t, i, 1)]));
-        RFN_TRY(gemm_groups(B * d->L[i], A, T1, pr, 0, st));
+        RFN_TRY(gemm_groups(B * d->L[i], A, T1, pr, 0, gx));
     }
 
     // ---- stage I: T1 steps x M cells (:213-217, :101-114, :47-74) ---------------------------
@@ -424,7 +437,7 @@ extern "C" int rfn_prefix_fwd(const rfn_dims* d, int B, const float* const* prm,
         for (int i = 0; i < M; ++i)
             pr[i] = prob1(hp + (long)i * B * A, A,
                           seg_lin(Hc + i * R, MR, prm[P.s1(t, i, 2)], R, R, prm[P.s1(t, i, 3)]));
-        RFN_TRY(gemm_groups(B, A, M, pr, 0, st));
+        RFN_TRY(gemm_groups(B, A, M, pr, 0, gx));
         for (int i = 0; i < M; ++i) {
             const long Li = d->L[i], Di = d->D[i];
             float* al = W + Lo.al1[i] + (long)t * B * Li;
@@ -440,7 +453,7 @@ extern "C" int rfn_prefix_fwd(const rfn_dims* d, int B, const float* const* prm,
             p.seg[0] = seg_lin(Hc, MR, prm[P.s1(t, i, 6)], MR, (int)MR, prm[P.s1(t, i, 7)]);
             p.seg[1] = seg_lin(z, Di, prm[P.s1(t, i, 8)], Di, (int)Di, prm[P.s1(t, i, 9)]);
         }
-        RFN_TRY(gemm_groups(B, 4 * R, M, pr, 0, st));
+        RFN_TRY(gemm_groups(B, 4 * R, M, pr, 0, gx));
         for (int i = 0; i < M; ++i)
             RFN_TRY(rfn_lstm_fwd(g + (long)i * B * 4 * R, 4 * R, Cc + i * R, MR, Cn + i * R, MR, Hn + i * R, MR, B, R,
                                  train ? d->drop_fusion : 0.f, seed, (uint64_t)(t * M + i), st));
@@ -449,8 +462,7 @@ extern "C" int rfn_prefix_fwd(const rfn_dims* d, int B, const float* const* prm,
     // reason heads of stage I: max over steps of reason_linear_individual (:217, :229)
     float* rmat = W + Lo.rmat;
     for (int i = 0; i < M; ++i) {
-        RFN_TRY(gemm1(T1 * B, K, seg_lin(Hs + BMR + i * R, MR, prm[P.rind_w(i)], R, R, prm[P.rind_b(i)]), rmat, K, 0,
-                      st));
+        RFN_TRY(gemm1(T1 * B, K, seg_lin(Hs + BMR + i * R, MR, prm[P.rind_w(i)], R, R, prm[P.rind_b(i)]), rmat, K, 0, gx));
         RFN_TRY(rfn_max_over_steps_fwd(rmat, T1, B, K, reason_pred + (long)i * B * K, rarg + (long)i * B * K, st));
     }
 
@@ -470,7 +482,7 @@ extern "C" int rfn_prefix_fwd(const rfn_dims* d, int B, const float* const* prm,
         for (int t = 0; t < T2; ++t)
             pr[t] = prob1(W + Lo.P2[i] + (long)t * A, (long)T2 * A,
                           seg_lin(Hs + BMR + i * R, MR, prm[P.s2(t, i, 2)], R, R, prm[P.s2(t, i, 3)]));
-        RFN_TRY(gemm_groups(T1 * B, A, T2, pr, 0, st));
+        RFN_TRY(gemm_groups(T1 * B, A, T2, pr, 0, gx));
     }
 
     // ---- stage II: T2 steps (:241-244, LSTMSoftMultiAttentionFeatArrayNoInputCore.py:41-73) ---
@@ -486,7 +498,7 @@ extern "C" int rfn_prefix_fwd(const rfn_dims* d, int B, const float* const* prm,
         float* g = W + Lo.g2 + (long)t * B * 4 * R;
         for (int i = 0; i < M; ++i)
             pr[i] = prob1(hp + (long)i * B * A, A, seg_lin(hc, R, prm[P.s2(t, i, 4)], R, R, prm[P.s2(t, i, 5)]));
-        RFN_TRY(gemm_groups(B, A, M, pr, 0, st));
+        RFN_TRY(gemm_groups(B, A, M, pr, 0, gx));
         segs[0] = seg_lin(hc, R, prm[P.s2_hh_w(t)], R, R, prm[P.s2_hh_b(t)]);
         for (int i = 0; i < M; ++i) {
             RFN_TRY(rfn_attn_scores_fwd(W + Lo.P2[i] + (long)t * A, (long)T2 * A, (long)B * T2 * A,
@@ -496,11 +508,11 @@ extern "C" int rfn_prefix_fwd(const rfn_dims* d, int B, const float* const* prm,
                                          st));
             segs[1 + i] = seg_lin(z + i * BR, R, prm[P.s2(t, i, 0)], R, R, prm[P.s2(t, i, 1)]);
         }
-        RFN_TRY(gemm_segs(B, 4 * R, M + 1, segs, g, 4 * R, 0, st));
+        RFN_TRY(gemm_segs(B, 4 * R, M + 1, segs, g, 4 * R, 0, gx));
         RFN_TRY(rfn_lstm_fwd(g, 4 * R, cc, R, cn, R, hn, R, B, R, train ? d->drop_reason : 0.f, seed,
                              OFF_STAGE2 + (uint64_t)t, st));
     }
-    RFN_TRY(gemm1(T2 * B, K, seg_lin(h2 + BR, R, prm[P.r_w()], R, R, prm[P.r_b()]), rmat, K, 0, st));
+    RFN_TRY(gemm1(T2 * B, K, seg_lin(h2 + BR, R, prm[P.r_w()], R, R, prm[P.r_b()]), rmat, K, 0, gx));
     RFN_TRY(rfn_max_over_steps_fwd(rmat, T2, B, K, reason_pred + (long)M * B * K, rarg + (long)M * B * K, st));
 
     if (comb) RFN_TRY(copy_f32(comb, h2 + BR, (size_t)T2 * BR, st));
@@ -522,6 +534,7 @@ extern "C" int rfn_prefix_bwd(const rfn_dims* d, int B, const float* const* prm,
     const int M = d->M, R = d->R, A = d->A, T1 = d->T1, T2 = d->T2, K = d->K;
     const long MR = (long)M * R, BMR = (long)B * MR, BR = (long)B * R, BA = (long)B * A;
     float* W = (float*)ws;
+    const GemmCtx gx{st, W + Lo.gws, GEMM_WS_FLOATS * sizeof(float)};
     float* Hs = W + Lo.Hs;
     float* Cs = W + Lo.Cs;
     float* h2 = W + Lo.h2;
@@ -545,8 +558,8 @@ extern "C" int rfn_prefix_bwd(const rfn_dims* d, int B, const float* const* prm,
                                    rmat, st));
     if (d_comb) RFN_TRY(copy_f32(dh2e, d_comb, (size_t)T2 * BR, st));
     else RFN_TRY(zero_f32(dh2e, (size_t)T2 * BR, st));
-    RFN_TRY(gemm1(T2 * B, R, seg_dx(rmat, K, prm[P.r_w()], R, K), dh2e, R, 1, st));
-    RFN_TRY(gemm_dw(K, R, grd[P.r_w()], R, grd[P.r_b()], rmat, K, h2 + BR, R, T2 * B, st));
+    RFN_TRY(gemm1(T2 * B, R, seg_dx(rmat, K, prm[P.r_w()], R, K), dh2e, R, 1, gx));
+    RFN_TRY(gemm_dw(K, R, grd[P.r_w()], R, grd[P.r_b()], rmat, K, h2 + BR, R, T2 * B, gx));
 
     // gradient w.r.t. the stage-I hidden states: thoughts (through stage II) + reason heads + mean
     RFN_TRY(zero_f32(dHs, (size_t)(T1 + 1) * BMR, st));
@@ -569,7 +582,7 @@ extern "C" int rfn_prefix_bwd(const rfn_dims* d, int B, const float* const* prm,
         // dh_rec = dgates . W_hh ; dz_i = dgates . W_z_i   (same shape: one grouped launch)
         pr[0] = prob1(dhrec, R, seg_dx(g, 4 * R, prm[P.s2_hh_w(t)], R, 4 * R));
         for (int i = 0; i < M; ++i) pr[1 + i] = prob1(dz2 + i * BR, R, seg_dx(g, 4 * R, prm[P.s2(t, i, 0)], R, 4 * R));
-        RFN_TRY(gemm_groups(B, R, M + 1, pr, 0, st));
+        RFN_TRY(gemm_groups(B, R, M + 1, pr, 0, gx));
         for (int i = 0; i < M; ++i) {
             const float* th = Hs + BMR + i * R;  // thoughts_i[b, l] = Hs[1 + l][b, iR:]
             RFN_TRY(rfn_attn_context_bwd_dalpha(th, MR, BMR, dz2 + i * BR, R, B, T1, R, dal, st));
@@ -582,7 +595,7 @@ extern "C" int rfn_prefix_bwd(const rfn_dims* d, int B, const float* const* prm,
             RFN_TRY(zero_f32(grd[P.s2(t, i, 7)], 1, st));
             segs[i] = seg_dx(dhp + i * BA, A, prm[P.s2(t, i, 4)], R, A);
         }
-        RFN_TRY(gemm_segs(B, R, M, segs, dhrec, R, 1, st));
+        RFN_TRY(gemm_segs(B, R, M, segs, dhrec, R, 1, gx));
     }
     // weight gradients of stage II, grouped over steps; every bias gradient rides on the GEMM that streams
     // the same dY (h2h.b = z_2_h[i].b = colsum(dgates); h_2_att_h.b = att_2_att_h.b = colsum over (b) resp. (l,b))
@@ -595,24 +608,24 @@ extern "C" int rfn_prefix_bwd(const rfn_dims* d, int B, const float* const* prm,
     }
     for (int t = 0; t < T2; ++t)
         pr[t] = prob_dw(grd[P.s2_hh_w(t)], R, grd[P.s2_hh_b(t)], W + Lo.g2 + (long)t * B * 4 * R, 4 * R, h2 + t * BR, R, B);
-    RFN_TRY(gemm_groups(4 * R, R, T2, pr, 0, st));
+    RFN_TRY(gemm_groups(4 * R, R, T2, pr, 0, gx));
     for (int i = 0; i < M; ++i) {
         for (int t = 0; t < T2; ++t)
             pr[t] = prob_dw(grd[P.s2(t, i, 0)], R, grd[P.s2(t, i, 1)], W + Lo.g2 + (long)t * B * 4 * R, 4 * R,
                             W + Lo.z2 + ((long)t * M + i) * BR, R, B);
-        RFN_TRY(gemm_groups(4 * R, R, T2, pr, 0, st));
+        RFN_TRY(gemm_groups(4 * R, R, T2, pr, 0, gx));
         for (int t = 0; t < T2; ++t)
             pr[t] = prob_dw(grd[P.s2(t, i, 4)], R, grd[P.s2(t, i, 5)], W + Lo.dhp2 + ((long)t * M + i) * BA, A,
                             h2 + t * BR, R, B);
-        RFN_TRY(gemm_groups(A, R, T2, pr, 0, st));
+        RFN_TRY(gemm_groups(A, R, T2, pr, 0, gx));
         // d att_2_att_h.weight[t] = dP2_i[:, t]^T . thoughts_i   (K = T1*B rows)
         for (int t = 0; t < T2; ++t)
             pr[t] = prob_dw(grd[P.s2(t, i, 2)], R, grd[P.s2(t, i, 3)], W + Lo.P2[i] + (long)t * A, (long)T2 * A,
                             Hs + BMR + i * R, MR, T1 * B);
-        RFN_TRY(gemm_groups(A, R, T2, pr, 0, st));
+        RFN_TRY(gemm_groups(A, R, T2, pr, 0, gx));
         // d thoughts_i += sum_t dP2_i[:, t] . W_a[t]
         for (int t = 0; t < T2; ++t) segs[t] = seg_dx(W + Lo.P2[i] + (long)t * A, (long)T2 * A, prm[P.s2(t, i, 2)], R, A);
-        RFN_TRY(gemm_segs(T1 * B, R, T2, segs, dHs + BMR + i * R, MR, 1, st));
+        RFN_TRY(gemm_segs(T1 * B, R, T2, segs, dHs + BMR + i * R, MR, 1, gx));
     }
 
     // ---- state mean backward (:233-235): every encoder's final (h, c) gets d / M --------------------
@@ -625,8 +638,8 @@ extern "C" int rfn_prefix_bwd(const rfn_dims* d, int B, const float* const* prm,
     for (int i = 0; i < M; ++i) {
         RFN_TRY(rfn_max_over_steps_bwd(d_reason ? d_reason + (long)i * B * K : nullptr, rarg + (long)i * B * K, T1, B, K,
                                        rmat, st));
-        RFN_TRY(gemm1(T1 * B, R, seg_dx(rmat, K, prm[P.rind_w(i)], R, K), dHs + BMR + i * R, MR, 1, st));
-        RFN_TRY(gemm_dw(K, R, grd[P.rind_w(i)], R, grd[P.rind_b(i)], rmat, K, Hs + BMR + i * R, MR, T1 * B, st));
+        RFN_TRY(gemm1(T1 * B, R, seg_dx(rmat, K, prm[P.rind_w(i)], R, K), dHs + BMR + i * R, MR, 1, gx));
+        RFN_TRY(gemm_dw(K, R, grd[P.rind_w(i)], R, grd[P.rind_b(i)], rmat, K, Hs + BMR + i * R, MR, T1 * B, gx));
     }
 
     // ---- stage I backward --------------------------------------------------------------------------------
@@ -642,12 +655,11 @@ extern "C" int rfn_prefix_bwd(const rfn_dims* d, int B, const float* const* prm,
                                  (uint64_t)(t * M + i), st));
         // dH_t += sum_i dgates_i . W_H[t,i]   (every cell reads the whole concatenated H, :53)
         for (int i = 0; i < M; ++i) segs[i] = seg_dx(g + (long)i * B * 4 * R, 4 * R, prm[P.s1(t, i, 6)], MR, 4 * R);
-        RFN_TRY(gemm_segs(B, (int)MR, M, segs, dHc, MR, 1, st));
+        RFN_TRY(gemm_segs(B, (int)MR, M, segs, dHc, MR, 1, gx));
         for (int i = 0; i < M; ++i) {
             const long Li = d->L[i], Di = d->D[i];
             float* dz = W + Lo.dz1[i];
-            RFN_TRY(gemm1(B, (int)Di, seg_dx(g + (long)i * B * 4 * R, 4 * R, prm[P.s1(t, i, 8)], Di, 4 * R), dz, Di, 0,
-                          st));
+            RFN_TRY(gemm1(B, (int)Di, seg_dx(g + (long)i * B * 4 * R, 4 * R, prm[P.s1(t, i, 8)], Di, 4 * R), dz, Di, 0, gx));
             float* dali = dal + (long)i * B * Li;
             RFN_TRY(rfn_attn_context_bwd_dalpha(att[i], Li * Di, Di, dz, Di, B, (int)Li, (int)Di, dali, st));
             float* p1 = W + Lo.P1[i] + (long)t * A;
@@ -657,12 +669,12 @@ extern "C" int rfn_prefix_bwd(const rfn_dims* d, int B, const float* const* prm,
             RFN_TRY(zero_f32(grd[P.s1(t, i, 5)], 1, st));
             pr[i] = prob1(dHc + i * R, MR, seg_dx(dhp + i * BA, A, prm[P.s1(t, i, 2)], R, A));
         }
-        RFN_TRY(gemm_groups(B, R, M, pr, 1, st));
+        RFN_TRY(gemm_groups(B, R, M, pr, 1, gx));
     }
     // c0 = h0.clone() (:206): dh0 += dc0 ; fc2h gradients
     RFN_TRY(rfn_axpby_2d(1.f, dC, MR, 1.f, dHs, MR, B, (int)MR, st));
     for (int i = 0; i < M; ++i)
-        RFN_TRY(gemm_dw(R, d->F[i], grd[P.fc_w(i)], d->F[i], grd[P.fc_b(i)], dHs + i * R, MR, fc[i], d->F[i], B, st));
+        RFN_TRY(gemm_dw(R, d->F[i], grd[P.fc_w(i)], d->F[i], grd[P.fc_b(i)], dHs + i * R, MR, fc[i], d->F[i], B, gx));
     {
         float* outs[64];
         if (T1 * M > 64) return RFN_ERR_SHAPE;
@@ -676,20 +688,20 @@ extern "C" int rfn_prefix_bwd(const rfn_dims* d, int B, const float* const* prm,
         for (int t = 0; t < T1; ++t)
             pr[t] = prob_dw(grd[P.s1(t, i, 6)], MR, grd[P.s1(t, i, 7)], W + Lo.g1 + ((long)t * M + i) * B * 4 * R, 4 * R,
                             Hs + t * BMR, MR, B);
-        RFN_TRY(gemm_groups(4 * R, (int)MR, T1, pr, 0, st));
+        RFN_TRY(gemm_groups(4 * R, (int)MR, T1, pr, 0, gx));
         for (int t = 0; t < T1; ++t)
             pr[t] = prob_dw(grd[P.s1(t, i, 8)], Di, grd[P.s1(t, i, 9)], W + Lo.g1 + ((long)t * M + i) * B * 4 * R, 4 * R,
                             W + Lo.z1[i] + (long)t * B * Di, Di, B);
-        RFN_TRY(gemm_groups(4 * R, (int)Di, T1, pr, 0, st));
+        RFN_TRY(gemm_groups(4 * R, (int)Di, T1, pr, 0, gx));
         for (int t = 0; t < T1; ++t)
             pr[t] = prob_dw(grd[P.s1(t, i, 2)], R, grd[P.s1(t, i, 3)], W + Lo.dhp1 + ((long)t * M + i) * BA, A,
                             Hs + t * BMR + i * R, MR, B);
-        RFN_TRY(gemm_groups(A, R, T1, pr, 0, st));
+        RFN_TRY(gemm_groups(A, R, T1, pr, 0, gx));
         // the dominant GEMM of backward: d att_2_att_h.weight[t,i] = dP1_i[:, t]^T . att_i  (K = B*L_i)
         for (int t = 0; t < T1; ++t)
             pr[t] = prob_dw(grd[P.s1(t, i, 0)], Di, grd[P.s1(t, i, 1)], W + Lo.P1[i] + (long)t * A, (long)T1 * A, att[i], Di,
                             (int)(B * Li));
-        RFN_TRY(gemm_groups(A, (int)Di, T1, pr, 0, st));
+        RFN_TRY(gemm_groups(A, (int)Di, T1, pr, 0, gx));
     }
     return RFN_OK;
 }
@@ -714,14 +726,15 @@ extern "C" int rfn_decoder_fwd(const rfn_dims* d, int B, int S, const float* con
     const int R = d->R, A = d->A, E = d->E, T2 = d->T2, V1 = d->V1;
     const long BR = (long)B * R, BA = (long)B * A;
     float* W = (float*)ws;
+    const GemmCtx gx{st, W + Lo.gws, GEMM_WS_FLOATS * sizeof(float)};
     float* hd = W + Lo.hd;
     float* cd = W + Lo.cd;
     float* gd = W + Lo.gd;
     // loop-invariant projection of the fused thoughts, applied once instead of every step
-    RFN_TRY(gemm1(T2 * B, A, seg_lin(comb, R, prm[P.dec(6)], R, R, prm[P.dec(7)]), W + Lo.Pd, A, 0, st));
+    RFN_TRY(gemm1(T2 * B, A, seg_lin(comb, R, prm[P.dec(6)], R, R, prm[P.dec(7)]), W + Lo.Pd, A, 0, gx));
     // all token embeddings and their i2h projections in one go (teacher forcing: ids are known)
     RFN_TRY(rfn_embed_fwd(prm[P.embed()], E, V1, ids, B, ld_ids, 1, S * B, W + Lo.xs, E, st));
-    RFN_TRY(gemm1(S * B, 4 * R, seg_lin(W + Lo.xs, E, prm[P.dec(0)], E, E, prm[P.dec(1)]), gd, 4 * R, 0, st));
+    RFN_TRY(gemm1(S * B, 4 * R, seg_lin(W + Lo.xs, E, prm[P.dec(0)], E, E, prm[P.dec(1)]), gd, 4 * R, 0, gx));
     RFN_TRY(copy_f32(hd, h0, BR, st));
     RFN_TRY(copy_f32(cd, c0, BR, st));
     rfn_gemm_seg segs[2];
@@ -731,17 +744,17 @@ extern "C" int rfn_decoder_fwd(const rfn_dims* d, int B, int S, const float* con
         float* al = W + Lo.ald + (long)s * B * T2;
         float* z = W + Lo.zd + s * BR;
         float* g = gd + (long)s * B * 4 * R;
-        RFN_TRY(gemm1(B, A, seg_lin(hc, R, prm[P.dec(8)], R, R, prm[P.dec(9)]), hp, A, 0, st));
+        RFN_TRY(gemm1(B, A, seg_lin(hc, R, prm[P.dec(8)], R, R, prm[P.dec(9)]), hp, A, 0, gx));
         RFN_TRY(rfn_attn_scores_fwd(W + Lo.Pd, A, BA, hp, prm[P.dec(10)], prm[P.dec(11)], B, T2, A, al, st));
         RFN_TRY(rfn_attn_context_fwd(comb, R, BR, al, B, T2, R, z, R, st));
         segs[0] = seg_lin(hc, R, prm[P.dec(2)], R, R, prm[P.dec(3)]);
         segs[1] = seg_lin(z, R, prm[P.dec(4)], R, R, prm[P.dec(5)]);
-        RFN_TRY(gemm_segs(B, 4 * R, 2, segs, g, 4 * R, 1, st));
+        RFN_TRY(gemm_segs(B, 4 * R, 2, segs, g, 4 * R, 1, gx));
         RFN_TRY(rfn_lstm_fwd(g, 4 * R, cd + s * BR, R, cd + (s + 1) * BR, R, hd + (s + 1) * BR, R, B, R,
                              train ? d->drop_lm : 0.f, seed, OFF_DECODER + (uint64_t)s, st));
     }
     // logits of all steps, then log-softmax written in the reference's (B, S, V+1) layout
-    RFN_TRY(gemm1(S * B, V1, seg_lin(hd + BR, R, prm[P.logit_w()], R, R, prm[P.logit_b()]), W + Lo.logits, V1, 0, st));
+    RFN_TRY(gemm1(S * B, V1, seg_lin(hd + BR, R, prm[P.logit_w()], R, R, prm[P.logit_b()]), W + Lo.logits, V1, 0, gx));
     RFN_TRY(rfn_log_softmax_fwd(W + Lo.logits, V1, S * B, V1, B, (long)S * V1, V1, log_prob, st));
     return RFN_OK;
 }
@@ -761,6 +774,7 @@ extern "C" int rfn_decoder_bwd(const rfn_dims* d, int B, int S, const float* con
     const int R = d->R, A = d->A, E = d->E, T2 = d->T2, V1 = d->V1;
     const long BR = (long)B * R, BA = (long)B * A;
     float* W = (float*)ws;
+    const GemmCtx gx{st, W + Lo.gws, GEMM_WS_FLOATS * sizeof(float)};
     float* hd = W + Lo.hd;
     float* cd = W + Lo.cd;
     float* gd = W + Lo.gd;
@@ -772,8 +786,8 @@ extern "C" int rfn_decoder_bwd(const rfn_dims* d, int B, int S, const float* con
     float* dPd = W + Lo.dPd;
     // log-softmax backward into time-major rows, then the batched logit layer
     RFN_TRY(rfn_log_softmax_bwd(d_log_prob, log_prob, S * B, V1, B, (long)S * V1, V1, dlg, V1, st));
-    RFN_TRY(gemm_dw(V1, R, grd[P.logit_w()], R, grd[P.logit_b()], dlg, V1, hd + BR, R, S * B, st));
-    RFN_TRY(gemm1(S * B, R, seg_dx(dlg, V1, prm[P.logit_w()], R, V1), dhe, R, 0, st));
+    RFN_TRY(gemm_dw(V1, R, grd[P.logit_w()], R, grd[P.logit_b()], dlg, V1, hd + BR, R, S * B, gx));
+    RFN_TRY(gemm1(S * B, R, seg_dx(dlg, V1, prm[P.logit_w()], R, V1), dhe, R, 0, gx));
     RFN_TRY(zero_f32(d_comb, (size_t)T2 * BR, st));
     RFN_TRY(zero_f32(dPd, (size_t)T2 * BA, st));
     rfn_gemm_problem pr[2];
@@ -785,29 +799,29 @@ extern "C" int rfn_decoder_bwd(const rfn_dims* d, int B, int S, const float* con
                              R, B, R, d->drop_lm, seed, OFF_DECODER + (uint64_t)s, st));
         pr[0] = prob1(dhrec, R, seg_dx(g, 4 * R, prm[P.dec(2)], R, 4 * R));
         pr[1] = prob1(dz, R, seg_dx(g, 4 * R, prm[P.dec(4)], R, 4 * R));
-        RFN_TRY(gemm_groups(B, R, 2, pr, 0, st));
+        RFN_TRY(gemm_groups(B, R, 2, pr, 0, gx));
         float* al = W + Lo.ald + (long)s * B * T2;
         RFN_TRY(rfn_attn_context_bwd_dalpha(comb, R, BR, dz, R, B, T2, R, W + Lo.dal, st));
         RFN_TRY(rfn_attn_context_bwd_dseq(al, dz, R, B, T2, R, d_comb, R, BR, st));
         float* dhp = W + Lo.dhpd + s * BA;
         RFN_TRY(rfn_attn_scores_bwd(W + Lo.Pd, A, BA, W + Lo.hpd + s * BA, prm[P.dec(10)], al, W + Lo.dal, B, T2, A,
                                     dPd, A, BA, 1, dhp, W + Lo.dwp + s * BA, st));
-        RFN_TRY(gemm1(B, R, seg_dx(dhp, A, prm[P.dec(8)], R, A), dhrec, R, 1, st));
+        RFN_TRY(gemm1(B, R, seg_dx(dhp, A, prm[P.dec(8)], R, A), dhrec, R, 1, gx));
     }
     RFN_TRY(copy_f32(d_h0, dhrec, BR, st));
     RFN_TRY(copy_f32(d_c0, dc, BR, st));
     RFN_TRY(zero_f32(grd[P.dec(11)], 1, st));
     // attention projection of the fused thoughts (shared by all steps)
-    RFN_TRY(gemm1(T2 * B, R, seg_dx(dPd, A, prm[P.dec(6)], R, A), d_comb, R, 1, st));
-    RFN_TRY(gemm_dw(A, R, grd[P.dec(6)], R, grd[P.dec(7)], dPd, A, comb, R, T2 * B, st));
+    RFN_TRY(gemm1(T2 * B, R, seg_dx(dPd, A, prm[P.dec(6)], R, A), d_comb, R, 1, gx));
+    RFN_TRY(gemm_dw(A, R, grd[P.dec(6)], R, grd[P.dec(7)], dPd, A, comb, R, T2 * B, gx));
     // weights shared across steps: one GEMM over (S*B) time-major rows each, bias gradients ride along
     RFN_TRY(rfn_colsum_f32(W + Lo.dwp, A, S * B, A, grd[P.dec(10)], 0, st));
-    RFN_TRY(gemm_dw(A, R, grd[P.dec(8)], R, grd[P.dec(9)], W + Lo.dhpd, A, hd, R, S * B, st));
-    RFN_TRY(gemm_dw(4 * R, R, grd[P.dec(2)], R, grd[P.dec(3)], gd, 4 * R, hd, R, S * B, st));
-    RFN_TRY(gemm_dw(4 * R, R, grd[P.dec(4)], R, grd[P.dec(5)], gd, 4 * R, W + Lo.zd, R, S * B, st));
-    RFN_TRY(gemm_dw(4 * R, E, grd[P.dec(0)], E, grd[P.dec(1)], gd, 4 * R, W + Lo.xs, E, S * B, st));
+    RFN_TRY(gemm_dw(A, R, grd[P.dec(8)], R, grd[P.dec(9)], W + Lo.dhpd, A, hd, R, S * B, gx));
+    RFN_TRY(gemm_dw(4 * R, R, grd[P.dec(2)], R, grd[P.dec(3)], gd, 4 * R, hd, R, S * B, gx));
+    RFN_TRY(gemm_dw(4 * R, R, grd[P.dec(4)], R, grd[P.dec(5)], gd, 4 * R, W + Lo.zd, R, S * B, gx));
+    RFN_TRY(gemm_dw(4 * R, E, grd[P.dec(0)], E, grd[P.dec(1)], gd, 4 * R, W + Lo.xs, E, S * B, gx));
     // embedding: dx = dgates . W_i2h, then the fixed-order scatter
-    RFN_TRY(gemm1(S * B, E, seg_dx(gd, 4 * R, prm[P.dec(0)], E, 4 * R), W + Lo.dxs, E, 0, st));
+    RFN_TRY(gemm1(S * B, E, seg_dx(gd, 4 * R, prm[P.dec(0)], E, 4 * R), W + Lo.dxs, E, 0, gx));
     RFN_TRY(rfn_embed_bwd(W + Lo.dxs, E, ids, B, ld_ids, 1, S * B, E, V1, grd[P.embed()], st));
     return RFN_OK;
 }
@@ -833,7 +847,8 @@ extern "C" int rfn_decoder_prepare(const rfn_dims* d, int B, const float* const*
     if (B < 1) return RFN_ERR_SHAPE;
     if (!prm || !comb || !cproj) return RFN_ERR_ARG;
     const PIdx P(d);
-    return gemm1(d->T2 * B, d->A, seg_lin(comb, d->R, prm[P.dec(6)], d->R, d->R, prm[P.dec(7)]), cproj, d->A, 0, st);
+    const GemmCtx gx{st, nullptr, 0};
+    return gemm1(d->T2 * B, d->A, seg_lin(comb, d->R, prm[P.dec(6)], d->R, d->R, prm[P.dec(7)]), cproj, d->A, 0, gx);
 }
 
 extern "C" int rfn_decoder_step(const rfn_dims* d, int B, const float* const* prm, const float* comb,
@@ -848,6 +863,7 @@ extern "C" int rfn_decoder_step(const rfn_dims* d, int B, const float* const* pr
     const long BR = (long)B * R, BA = (long)B * A;
     Bump b;
     float* W = (float*)ws;
+    const GemmCtx gx{st, nullptr, 0};
     float* x = W + b.take((size_t)B * E);
     float* hp = W + b.take((size_t)B * A);
     float* al = W + b.take((size_t)B * T2);
@@ -855,17 +871,17 @@ extern "C" int rfn_decoder_step(const rfn_dims* d, int B, const float* const* pr
     float* g = W + b.take((size_t)B * 4 * R);
     float* lg = logits ? logits : W + b.take((size_t)B * V1);
     RFN_TRY(rfn_embed_fwd(prm[P.embed()], E, V1, ids, B, 1, 0, B, x, E, st));
-    RFN_TRY(gemm1(B, A, seg_lin(h, R, prm[P.dec(8)], R, R, prm[P.dec(9)]), hp, A, 0, st));
+    RFN_TRY(gemm1(B, A, seg_lin(h, R, prm[P.dec(8)], R, R, prm[P.dec(9)]), hp, A, 0, gx));
     RFN_TRY(rfn_attn_scores_fwd(cproj, A, BA, hp, prm[P.dec(10)], prm[P.dec(11)], B, T2, A, al, st));
     RFN_TRY(rfn_attn_context_fwd(comb, R, BR, al, B, T2, R, z, R, st));
     rfn_gemm_seg segs[3];
     segs[0] = seg_lin(x, E, prm[P.dec(0)], E, E, prm[P.dec(1)]);
     segs[1] = seg_lin(h, R, prm[P.dec(2)], R, R, prm[P.dec(3)]);
     segs[2] = seg_lin(z, R, prm[P.dec(4)], R, R, prm[P.dec(5)]);
-    RFN_TRY(gemm_segs(B, 4 * R, 3, segs, g, 4 * R, 0, st));
+    RFN_TRY(gemm_segs(B, 4 * R, 3, segs, g, 4 * R, 0, gx));
     RFN_TRY(rfn_lstm_fwd(g, 4 * R, c, R, c, R, h, R, B, R, 0.f, 0, 0, st));  // eval: no dropout
     if (logits || logp) {
-        RFN_TRY(gemm1(B, V1, seg_lin(h, R, prm[P.logit_w()], R, R, prm[P.logit_b()]), lg, V1, 0, st));
+        RFN_TRY(gemm1(B, V1, seg_lin(h, R, prm[P.logit_w()], R, R, prm[P.logit_b()]), lg, V1, 0, gx));
         if (logp) {
             if (ld_logp < V1) return RFN_ERR_SHAPE;
             RFN_TRY(rfn_log_softmax_fwd(lg, V1, B, V1, B, ld_logp, 0, logp, st));

@@ -82,6 +82,63 @@ def test_gemm_segments_and_groups(dev):
         assert maxerr(Cd, ref) < 1e-3
 
 
+@pytest.mark.parametrize('ak,bk', [(1, 1), (1, 0), (0, 0)])
+def test_gemm_split_k_is_deterministic_and_correct(dev, ak, bk):
+    """Skinny problems (M = batch) with a workspace are cut along K across blocks; the fixed-order reduce must
+    give the same bits on every call and match fp64 within fp32 re-association error."""
+    n = N()
+    ws = torch.empty(48 << 20, dtype=torch.uint8, device=dev)
+    M, Nn = 256, 512
+    Ks = [2048, 512, 96]                       # three K segments, the last one ragged vs the split
+    segs, ref = [], torch.zeros(M, Nn, dtype=torch.float64)
+    keep = []
+    for s_, K in enumerate(Ks):
+        A, Bm, b = rnd(M, K, seed=s_), rnd(Nn, K, seed=10 + s_), rnd(Nn, seed=20 + s_)
+        ref += A.double() @ Bm.double().t() + b.double()
+        A_st = (A if ak else A.t().contiguous()).to(dev)
+        B_st = (Bm if bk else Bm.t().contiguous()).to(dev)
+        bd = b.to(dev)
+        keep += [A_st, B_st, bd]
+        segs.append((A_st, K if ak else M, ak, B_st, K if bk else Nn, bk, K, bd))
+    outs = []
+    for rep in range(2):
+        Cd = torch.full((M, Nn), 0.25, device=dev)
+        n.gemm(M, Nn, [(Cd, Nn, segs)], accumulate=True, ws=ws)
+        outs.append(Cd)
+    assert torch.equal(outs[0], outs[1])
+    assert maxerr(outs[0], ref + 0.25) < 2e-3
+    # and the unsplit path agrees to rounding
+    C0 = torch.full((M, Nn), 0.25, device=dev)
+    n.gemm(M, Nn, [(C0, Nn, segs)], accumulate=True)
+    assert maxerr(outs[0], C0) < 1e-3
+    # grouped + split, tails on M and N
+    M2, N2, K2 = 200, 130, 1024
+    groups, refs = [], []
+    for g in range(3):
+        A, Bm = rnd(M2, K2, seed=30 + g), rnd(N2, K2, seed=40 + g)
+        Ad, Bd = A.to(dev), Bm.to(dev)
+        keep += [Ad, Bd]
+        Cg = torch.empty(M2, N2, device=dev)
+        groups.append((Cg, N2, [(Ad, K2, 1, Bd, K2, 1, K2, None)]))
+        refs.append(A.double() @ Bm.double().t())
+    n.gemm(M2, N2, groups, ws=ws)
+    for (Cg, _, _), r in zip(groups, refs):
+        assert maxerr(Cg, r) < 1e-3
+
+
+def test_gemm_weight_gradient_emits_bias_gradient(dev):
+    """dW = dY^T X with a_colsum = colsum(dY) riding on the same launch (both tile sizes, vec and scalar)."""
+    n = N()
+    for rows, Nn, K in [(256, 2048, 512), (300, 70, 36), (37, 51, 16)]:
+        dY, X = rnd(rows, Nn, seed=1), rnd(rows, K, seed=2)
+        dYd, Xd = dY.to(dev), X.to(dev)
+        dW = torch.empty(Nn, K, device=dev)
+        db = torch.full((Nn,), float('nan'), device=dev)
+        n.gemm(Nn, K, [(dW, K, [(dYd, Nn, 0, Xd, K, 0, rows, None)], db)])
+        assert maxerr(dW, dY.double().t() @ X.double()) < 1e-3
+        assert maxerr(db, dY.double().sum(0)) < 1e-4
+
+
 def test_gemm_strided_views_like_the_path(dev):
     """The path feeds column blocks of wider buffers (lda > K, ldc > N): e.g. encoder i's slice of H."""
     n = N()
