@@ -24,8 +24,6 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-#define GEMM_BK 32
-#define GEMM_LDK 36 /* [row][k] row length in floats: 32 + 4 pad */
 #define GEMM_THREADS 256
 // ---- tuning / ablation knobs (tools/gemm_bench.hip builds variants; the product uses the defaults) ----
 #ifndef GEMM_MIN_WAVES
@@ -33,6 +31,15 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #endif
 #ifndef GEMM_XCD_REMAP
 #define GEMM_XCD_REMAP 1
+#endif
+#ifndef GEMM_FRAG_PIPE
+#define GEMM_FRAG_PIPE 0   /* explicit register double-buffering of the LDS fragments */
+#endif
+#ifndef GEMM_BIG_BK
+#define GEMM_BIG_BK 32     /* K step of the 128x128 tile */
+#endif
+#ifndef GEMM_XX_STAGES
+#define GEMM_XX_STAGES 2   /* LDS stages of the big tile for the other layouts */
 #endif
 #ifndef GEMM_NT_STAGES
 #define GEMM_NT_STAGES 1   /* LDS stages of the big NT tile: measured 131 TF single-buffered (3 blocks/CU) vs 125 */
@@ -50,57 +57,61 @@ struct GemmArgs {
     rfn_gemm_problem g[RFN_GEMM_MAXGROUP];
 };
 
-// ---- staging of one ROWS x 32 operand tile ---------------------------------------------------
-template <int ROWS, bool KFAST, bool VEC>
+// ---- staging of one ROWS x BK operand tile ---------------------------------------------------
+// [row][k] tiles have BK+4 floats per row: 36 and 68 both put the 16 rows of a ds_read_b128 lane group on 16
+// distinct 16-B bank slots (row*36 mod 64 and row*68 mod 64 = 4*row mod 64 are all different for 16 rows).
+template <int ROWS, bool KFAST, bool VEC, int BK>
 struct Stage {
-    static constexpr int NV = ROWS / 32;  // float4 per thread (ROWS*32 floats / 256 threads / 4)
-    static constexpr int LDR = ROWS + 4;  // [k][row] row length
-    static constexpr int LDS_FLOATS = KFAST ? ROWS * GEMM_LDK : GEMM_BK * LDR;
+    static constexpr int NV = ROWS * BK / 4 / GEMM_THREADS;  // float4 per thread
+    static constexpr int LDK = BK + 4;                       // [row][k] row length
+    static constexpr int LDR = ROWS + 4;                     // [k][row] row length
+    static constexpr int LDS_FLOATS = KFAST ? ROWS * LDK : BK * LDR;
+    static constexpr int KQ = BK / 4;                        // float4 per [row][k] row
+    static constexpr int RPASS = GEMM_THREADS / KQ;          // rows covered per pass (kfast, vec)
+    static constexpr int RQ = ROWS / 4;                      // float4 per [k][row] row
+    static constexpr int KPASS = GEMM_THREADS / RQ;          // k rows covered per pass (rowfast, vec)
+    static constexpr int RPASS_S = GEMM_THREADS / BK;        // rows per pass (kfast, scalar)
+    static constexpr int KPASS_S = GEMM_THREADS / ROWS;      // k rows per pass (rowfast, scalar)
     f32x4 v[NV];
 
-    // rows [row0, row0+ROWS) x k [k0, k0+32) of an operand with `nrows` valid rows and K valid k.
+    // rows [row0, row0+ROWS) x k [k0, k0+BK) of an operand with `nrows` valid rows and K valid k.
     __device__ __forceinline__ void load(const float* __restrict__ base, long ld, int row0,
                                          int nrows, int k0, int K, int tid) {
         if constexpr (VEC && KFAST) {
-            const int c4 = tid & 7;
+            const int k = k0 + 4 * (tid % KQ);
 #pragma unroll
             for (int j = 0; j < NV; ++j) {
-                const int r = row0 + (tid >> 3) + 32 * j;
-                const int k = k0 + 4 * c4;
+                const int r = row0 + tid / KQ + RPASS * j;
                 f32x4 x = {0.f, 0.f, 0.f, 0.f};
                 if (r < nrows && k < K) x = *reinterpret_cast<const f32x4*>(base + (long)r * ld + k);
                 v[j] = x;
             }
         } else if constexpr (VEC && !KFAST) {
-            constexpr int RQ = ROWS / 4;            // float4 per k row
-            constexpr int KSTEP = GEMM_THREADS / RQ;  // k rows covered per pass
             const int r = row0 + 4 * (tid % RQ);
 #pragma unroll
             for (int j = 0; j < NV; ++j) {
-                const int k = k0 + tid / RQ + KSTEP * j;
+                const int k = k0 + tid / RQ + KPASS * j;
                 f32x4 x = {0.f, 0.f, 0.f, 0.f};
                 if (r < nrows && k < K) x = *reinterpret_cast<const f32x4*>(base + (long)k * ld + r);
                 v[j] = x;
             }
         } else if constexpr (KFAST) {
-            const int kk = tid & 31;
+            const int k = k0 + tid % BK;
 #pragma unroll
             for (int j = 0; j < NV; ++j) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const int r = row0 + (tid >> 5) + 8 * (4 * j + e);
-                    const int k = k0 + kk;
+                    const int r = row0 + tid / BK + RPASS_S * (4 * j + e);
                     v[j][e] = (r < nrows && k < K) ? base[(long)r * ld + k] : 0.f;
                 }
             }
         } else {
-            constexpr int KSTEP = GEMM_THREADS / ROWS;  // 2 (ROWS=128) or 4 (ROWS=64)
             const int r = row0 + tid % ROWS;
 #pragma unroll
             for (int j = 0; j < NV; ++j) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const int k = k0 + tid / ROWS + KSTEP * (4 * j + e);
+                    const int k = k0 + tid / ROWS + KPASS_S * (4 * j + e);
                     v[j][e] = (r < nrows && k < K) ? base[(long)k * ld + r] : 0.f;
                 }
             }
@@ -109,33 +120,24 @@ struct Stage {
 
     __device__ __forceinline__ void store(float* __restrict__ lds, int tid) const {
         if constexpr (VEC && KFAST) {
-            const int c4 = tid & 7;
 #pragma unroll
-            for (int j = 0; j < NV; ++j) {
-                const int r = (tid >> 3) + 32 * j;
-                *reinterpret_cast<f32x4*>(lds + r * GEMM_LDK + 4 * c4) = v[j];
-            }
+            for (int j = 0; j < NV; ++j)
+                *reinterpret_cast<f32x4*>(lds + (tid / KQ + RPASS * j) * LDK + 4 * (tid % KQ)) = v[j];
         } else if constexpr (VEC && !KFAST) {
-            constexpr int RQ = ROWS / 4;
-            constexpr int KSTEP = GEMM_THREADS / RQ;
 #pragma unroll
-            for (int j = 0; j < NV; ++j) {
-                const int k = tid / RQ + KSTEP * j;
-                *reinterpret_cast<f32x4*>(lds + k * LDR + 4 * (tid % RQ)) = v[j];
-            }
+            for (int j = 0; j < NV; ++j)
+                *reinterpret_cast<f32x4*>(lds + (tid / RQ + KPASS * j) * LDR + 4 * (tid % RQ)) = v[j];
         } else if constexpr (KFAST) {
-            const int kk = tid & 31;
 #pragma unroll
             for (int j = 0; j < NV; ++j)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) lds[((tid >> 5) + 8 * (4 * j + e)) * GEMM_LDK + kk] = v[j][e];
+                for (int e = 0; e < 4; ++e) lds[(tid / BK + RPASS_S * (4 * j + e)) * LDK + tid % BK] = v[j][e];
         } else {
-            constexpr int KSTEP = GEMM_THREADS / ROWS;
 #pragma unroll
             for (int j = 0; j < NV; ++j)
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    lds[(tid / ROWS + KSTEP * (4 * j + e)) * LDR + tid % ROWS] = v[j][e];
+                    lds[(tid / ROWS + KPASS_S * (4 * j + e)) * LDR + tid % ROWS] = v[j][e];
         }
     }
 
@@ -156,7 +158,7 @@ struct Stage {
     // the 4 k-values (k = 8q + 4h + c, c = 0..3) of tile row `row` for this lane's k-half h
     __device__ __forceinline__ static f32x4 frag(const float* __restrict__ lds, int row, int q, int h) {
         if constexpr (KFAST) {
-            return *reinterpret_cast<const f32x4*>(lds + row * GEMM_LDK + 8 * q + 4 * h);
+            return *reinterpret_cast<const f32x4*>(lds + row * LDK + 8 * q + 4 * h);
         } else {
             f32x4 x;
             const float* p = lds + (8 * q + 4 * h) * LDR + row;
@@ -171,12 +173,12 @@ struct Stage {
 
 // STAGES = 2: double-buffered LDS, one barrier per K step (2 blocks/CU at 128x128).
 // STAGES = 1: single buffer, two barriers per K step, half the LDS -> 3 blocks/CU cover each other's stalls.
-template <int BM, int BN, bool AK, bool BKF, bool VEC, int STAGES>
+template <int BM, int BN, bool AK, bool BKF, bool VEC, int STAGES, int BK>
 __global__ __launch_bounds__(GEMM_THREADS, GEMM_MIN_WAVES) void rfn_gemm_kernel(const GemmArgs args) {
     constexpr int MT = BM / 64;  // 32x32 MFMA tiles per wave along M
     constexpr int NT = BN / 64;
-    using StA = Stage<BM, AK, VEC>;
-    using StB = Stage<BN, BKF, VEC>;
+    using StA = Stage<BM, AK, VEC, BK>;
+    using StB = Stage<BN, BKF, VEC, BK>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // LDS: [A buf0 | A buf1 | B buf0 | B buf1]; pointers are computed, not tabulated
     float* const sA0 = smem;
@@ -230,7 +232,7 @@ __global__ __launch_bounds__(GEMM_THREADS, GEMM_MIN_WAVES) void rfn_gemm_kernel(
 
     // flattened (segment, k0) iteration space so the prefetch runs across segment boundaries
     int total_iters = 0;
-    for (int s = 0; s < P.nseg; ++s) total_iters += (P.seg[s].K + GEMM_BK - 1) / GEMM_BK;
+    for (int s = 0; s < P.nseg; ++s) total_iters += (P.seg[s].K + BK - 1) / BK;
 
     // bias gradient riding on the weight-gradient GEMM: column sums of the [k][row] A operand, taken from
     // the staging registers by the blocks of the first column tile
@@ -245,12 +247,12 @@ __global__ __launch_bounds__(GEMM_THREADS, GEMM_MIN_WAVES) void rfn_gemm_kernel(
         const int it_end = min(total_iters, it_begin + per);
         total_iters = max(0, it_end - it_begin);
         while (seg < P.nseg) {  // locate (seg, k0) of it_begin
-            const int n = (P.seg[seg].K + GEMM_BK - 1) / GEMM_BK;
+            const int n = (P.seg[seg].K + BK - 1) / BK;
             if (it_begin < n) break;
             it_begin -= n;
             ++seg;
         }
-        k0 = it_begin * GEMM_BK;
+        k0 = it_begin * BK;
     }
     auto issue_load = [&]() {
         const rfn_gemm_seg& S = P.seg[seg];
@@ -259,7 +261,7 @@ __global__ __launch_bounds__(GEMM_THREADS, GEMM_MIN_WAVES) void rfn_gemm_kernel(
         if constexpr (!AK) {
             if (do_colsum) stA.add_rowsum(ps);
         }
-        k0 += GEMM_BK;
+        k0 += BK;
         if (k0 >= S.K) {
             k0 = 0;
             ++seg;
@@ -284,8 +286,34 @@ __global__ __launch_bounds__(GEMM_THREADS, GEMM_MIN_WAVES) void rfn_gemm_kernel(
 
         const float* a_l = sA0 + cur * StA::LDS_FLOATS;
         const float* b_l = sB0 + cur * StB::LDS_FLOATS;
+#if GEMM_FRAG_PIPE
+        // fragments of k-group q+1 are requested before the MFMAs of group q are issued, so their LDS
+        // latency hides under a full 16-MFMA group instead of the last two MFMAs
+        f32x4 af[2][MT], bf[2][NT];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int i = 0; i < MT; ++i) af[0][i] = StA::frag(a_l, wm * (BM / 2) + i * 32 + l31, 0, h);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bf[0][j] = StB::frag(b_l, wn * (BN / 2) + j * 32 + l31, 0, h);
+#pragma unroll
+        for (int q = 0; q < BK / 8; ++q) {
+            const int cb = q & 1, nb = cb ^ 1;
+            if (q + 1 < BK / 8) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i) af[nb][i] = StA::frag(a_l, wm * (BM / 2) + i * 32 + l31, q + 1, h);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) bf[nb][j] = StB::frag(b_l, wn * (BN / 2) + j * 32 + l31, q + 1, h);
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cb][i][c], bf[cb][j][c], acc[i][j], 0, 0, 0);
+        }
+#else
+#pragma unroll
+        for (int q = 0; q < BK / 8; ++q) {
             f32x4 af[MT], bf[NT];
 #pragma unroll
             for (int i = 0; i < MT; ++i) af[i] = StA::frag(a_l, wm * (BM / 2) + i * 32 + l31, q, h);
@@ -299,6 +327,7 @@ __global__ __launch_bounds__(GEMM_THREADS, GEMM_MIN_WAVES) void rfn_gemm_kernel(
                     for (int j = 0; j < NT; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][c], bf[j][c], acc[i][j], 0, 0, 0);
         }
+#endif
 
         if constexpr (STAGES == 2) {
             if (more) {
@@ -398,13 +427,13 @@ __global__ __launch_bounds__(256) void rfn_gemm_reduce_k(const GemmArgs args) {
     *c = args.accumulate ? *c + s : s;
 }
 
-template <int BM, int BN, bool AK, bool BKF, bool VEC, int STAGES>
+template <int BM, int BN, bool AK, bool BKF, bool VEC, int STAGES, int BK>
 static int launch_cfg(const GemmArgs& a, hipStream_t st) {
-    using StA = Stage<BM, AK, VEC>;
-    using StB = Stage<BN, BKF, VEC>;
+    using StA = Stage<BM, AK, VEC, BK>;
+    using StB = Stage<BN, BKF, VEC, BK>;
     const size_t lds = STAGES * (StA::LDS_FLOATS + StB::LDS_FLOATS) * sizeof(float);
     const int nblk = a.ngroups * a.tiles_m * a.tiles_n * a.splitk;
-    auto k = rfn_gemm_kernel<BM, BN, AK, BKF, VEC, STAGES>;
+    auto k = rfn_gemm_kernel<BM, BN, AK, BKF, VEC, STAGES, BK>;
     static bool attr_set = false;  // idempotent; a race only repeats the same call
     if (!attr_set) {
         hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -427,7 +456,7 @@ static int launch_tile(GemmArgs& a, hipStream_t st) {
     if (big >= 384) {
         a.tiles_m = rfn_cdiv(a.M, 128);
         a.tiles_n = rfn_cdiv(a.N, 128);
-        return launch_cfg<128, 128, AK, BKF, VEC, (AK && BKF) ? GEMM_NT_STAGES : 2>(a, st);
+        return launch_cfg<128, 128, AK, BKF, VEC, (AK && BKF) ? GEMM_NT_STAGES : GEMM_XX_STAGES, GEMM_BIG_BK>(a, st);
     }
     a.tiles_m = rfn_cdiv(a.M, 64);
     a.tiles_n = rfn_cdiv(a.N, 64);
@@ -437,7 +466,7 @@ static int launch_tile(GemmArgs& a, hipStream_t st) {
         const long tiles = (long)a.tiles_m * a.tiles_n * a.ngroups;
         int iters = 0;
         bool colsum = false;
-        for (int s = 0; s < a.g[0].nseg; ++s) iters += rfn_cdiv(a.g[0].seg[s].K, GEMM_BK);
+        for (int s = 0; s < a.g[0].nseg; ++s) iters += rfn_cdiv(a.g[0].seg[s].K, 32);
         for (int g = 0; g < a.ngroups; ++g) colsum = colsum || (a.g[g].a_colsum != nullptr);
         long want = tiles > 0 ? 768 / tiles : 1;
         if (want > iters / 4) want = iters / 4;
@@ -446,7 +475,7 @@ static int launch_tile(GemmArgs& a, hipStream_t st) {
         if (want > cap) want = cap;
         a.splitk = (!colsum && want >= 2) ? (int)want : 1;
     }
-    return launch_cfg<64, 64, AK, BKF, VEC, 2>(a, st);
+    return launch_cfg<64, 64, AK, BKF, VEC, 2, 32>(a, st);
 }
 
 extern "C" int rfn_gemm_f32(int M, int N, int ngroups, const rfn_gemm_problem* problems, int accumulate,

@@ -134,7 +134,8 @@ class _PrefixFn(torch.autograd.Function):
                                      ctx.seed, N.stream_ptr()), 'rfn_prefix_bwd')
         model._last_flat_grads['prefix'] = flat
         ctx.ws = None
-        return (None, None, None, None, None) + (None,) * (2 * M) + tuple(views)
+        model._deliver_grads(ctx.params, views)
+        return (None, None, None, None, None) + (None,) * (2 * M) + (None,) * len(views)
 
 
 class _DecoderFn(torch.autograd.Function):
@@ -180,7 +181,8 @@ class _DecoderFn(torch.autograd.Function):
                 'rfn_decoder_bwd')
         model._last_flat_grads['decoder'] = flat
         ctx.ws = None
-        return (None, None, None, None, None, d_comb, d_h0, d_c0) + tuple(views)
+        model._deliver_grads(ctx.params, views)
+        return (None, None, None, None, None, d_comb, d_h0, d_c0) + (None,) * len(views)
 
 
 class RecurrentFusionModel(nn.Module):
@@ -288,6 +290,20 @@ class RecurrentFusionModel(nn.Module):
         for v, i in zip(views, slots):
             table[i] = v.data_ptr()
         return flat, views, table
+
+    @staticmethod
+    def _deliver_grads(params, views):
+        """Hands the parameter gradients over as VIEWS of the phase's flat buffer (so `.grad`, the all-reduce
+        bucket and the fused optimizer operand are the same memory).  Returning them through autograd instead
+        makes AccumulateGrad clone most of them (hundreds of small D2D copies per step); a second backward
+        before zero_grad accumulates, as autograd would."""
+        for p, v in zip(params, views):
+            if not p.requires_grad:
+                continue
+            if p.grad is None:
+                p.grad = v
+            else:
+                p.grad = p.grad + v
 
     def _check_inputs(self, fc_feats, att_feats):
         M = self.num_feat_array
