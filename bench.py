@@ -11,7 +11,7 @@ M=4 encoders, L=196 regions, D=2048, B=256 captions per GPU, R=A=E=512, T1=T2=8,
 weights, resident in HBM before the timed region.
 
 One step = the reference's timed region train.py:143-166: zero_grad -> forward -> ReviewNetEnsembleCriterion ->
-backward -> (N>1: RCCL sum all-reduce of the two flat gradient buffers) -> clamp + Adam.  fp32 throughout.
+backward -> (N>1: one RCCL sum all-reduce per gradient bucket, overlapped with backward) -> clamp + Adam.  fp32 throughout.
 Rank 0 prints ONE JSON line; `value` is the whole-job aggregate over all N GPUs.
 """
 import argparse
@@ -135,12 +135,14 @@ def main():
     opt = R.FusedClampAdam(model, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5, grad_clip=1.0)
     fc, att, labels, masks, top = synthetic_inputs(cfg, B, 100 + rank, dev)
 
+    sync = DP.GradSync(model, world)     # per-bucket async all-reduce, overlapped with the rest of backward
+
     def step():
         opt.zero_grad()
         log_prob, top_pred = model(fc, att, labels)
         loss = crit(log_prob, labels[:, 1:], masks[:, 1:], top_pred, top, 1.0)
         loss.backward()
-        scale = DP.allreduce_model_grads(model, world) if world > 1 else 1.0
+        scale = sync.finish()              # 1/world: applied before the clamp inside the fused update
         opt.step(grad_scale=scale)
         return loss
 

@@ -245,7 +245,13 @@ int rfn_prefix_bwd(const rfn_dims* d, int B, const float* const* params,
                    const float* const* fc_feats, const float* const* att_feats,
                    const float* d_comb, const float* d_h, const float* d_c,
                    const float* d_reason_pred, float* const* grads, void* ws, size_t ws_bytes,
-                   uint64_t seed, void* stream);
+                   uint64_t seed, int defer_wgrad, void* stream);
+/* With defer_wgrad != 0, rfn_prefix_bwd leaves out the stage-I weight gradients of the encoders
+ * (review_steps_individual.{t}.lstm.{enc}.{att_model.att_2_att_h, att_model.h_2_att_h, H2h, z2h}.{weight,bias}
+ * for all t); this call produces them for one encoder from the same workspace.  A data-parallel host
+ * all-reduces encoder i's gradient bucket while encoder i+1's GEMMs (the largest of backward) run. */
+int rfn_prefix_bwd_wgrad(const rfn_dims* d, int B, const float* const* att_feats, float* const* grads,
+                         void* ws, size_t ws_bytes, int enc, void* stream);
 
 /* Phase 2 = the teacher-forced decoder loop of forward() (misc/RecurrentFusionModel.py:257-281):
  * for s < S: xt = embed(ids[b,s]); decoder cell (misc/LSTMSoftAttentionCore.py:60-102);

@@ -524,7 +524,7 @@ extern "C" int rfn_prefix_fwd(const rfn_dims* d, int B, const float* const* prm,
 extern "C" int rfn_prefix_bwd(const rfn_dims* d, int B, const float* const* prm, const float* const* fc,
                               const float* const* att, const float* d_comb, const float* d_h, const float* d_c,
                               const float* d_reason, float* const* grd, void* ws, size_t ws_bytes, uint64_t seed,
-                              void* st) {
+                              int defer_wgrad, void* st) {
     RFN_TRY(check_dims(d));
     if (B < 1) return RFN_ERR_SHAPE;
     if (!prm || !fc || !att || !grd || !ws) return RFN_ERR_ARG;
@@ -682,27 +682,48 @@ extern "C" int rfn_prefix_bwd(const rfn_dims* d, int B, const float* const* prm,
             for (int i = 0; i < M; ++i) outs[t * M + i] = grd[P.s1(t, i, 4)];
         RFN_TRY(rfn_colsum_grouped_f32(dwp, BA, A, B, A, outs, T1 * M, st));
     }
-    // weight gradients of stage I, grouped over steps per encoder (bias gradients ride along)
-    for (int i = 0; i < M; ++i) {
-        const long Li = d->L[i], Di = d->D[i];
-        for (int t = 0; t < T1; ++t)
-            pr[t] = prob_dw(grd[P.s1(t, i, 6)], MR, grd[P.s1(t, i, 7)], W + Lo.g1 + ((long)t * M + i) * B * 4 * R, 4 * R,
-                            Hs + t * BMR, MR, B);
-        RFN_TRY(gemm_groups(4 * R, (int)MR, T1, pr, 0, gx));
-        for (int t = 0; t < T1; ++t)
-            pr[t] = prob_dw(grd[P.s1(t, i, 8)], Di, grd[P.s1(t, i, 9)], W + Lo.g1 + ((long)t * M + i) * B * 4 * R, 4 * R,
-                            W + Lo.z1[i] + (long)t * B * Di, Di, B);
-        RFN_TRY(gemm_groups(4 * R, (int)Di, T1, pr, 0, gx));
-        for (int t = 0; t < T1; ++t)
-            pr[t] = prob_dw(grd[P.s1(t, i, 2)], R, grd[P.s1(t, i, 3)], W + Lo.dhp1 + ((long)t * M + i) * BA, A,
-                            Hs + t * BMR + i * R, MR, B);
-        RFN_TRY(gemm_groups(A, R, T1, pr, 0, gx));
-        // the dominant GEMM of backward: d att_2_att_h.weight[t,i] = dP1_i[:, t]^T . att_i  (K = B*L_i)
-        for (int t = 0; t < T1; ++t)
-            pr[t] = prob_dw(grd[P.s1(t, i, 0)], Di, grd[P.s1(t, i, 1)], W + Lo.P1[i] + (long)t * A, (long)T1 * A, att[i], Di,
-                            (int)(B * Li));
-        RFN_TRY(gemm_groups(A, (int)Di, T1, pr, 0, gx));
-    }
+    // weight gradients of stage I (per encoder; see rfn_prefix_bwd_wgrad) unless the caller defers them
+    if (!defer_wgrad)
+        for (int i = 0; i < M; ++i) RFN_TRY(rfn_prefix_bwd_wgrad(d, B, att, grd, ws, ws_bytes, i, st));
+    return RFN_OK;
+}
+
+// Stage-I weight gradients of ONE encoder, grouped over the T1 steps (bias gradients ride along):
+// H2h, z2h, h_2_att_h and the dominant d att_2_att_h.weight[t,i] = dP1_i[:, t]^T . att_i (K = B*L_i).
+// Reads only the workspace rfn_prefix_bwd left behind, so a data-parallel host can all-reduce encoder i's
+// gradient bucket while encoder i+1's GEMMs run.
+extern "C" int rfn_prefix_bwd_wgrad(const rfn_dims* d, int B, const float* const* att, float* const* grd, void* ws,
+                                    size_t ws_bytes, int enc, void* st) {
+    RFN_TRY(check_dims(d));
+    if (B < 1 || enc < 0 || enc >= d->M) return RFN_ERR_SHAPE;
+    if (!att || !grd || !ws) return RFN_ERR_ARG;
+    const PrefixLayout Lo = prefix_layout(d, B, 1);
+    if (ws_bytes < Lo.total * sizeof(float)) return RFN_ERR_WORKSPACE;
+    const PIdx P(d);
+    const int M = d->M, R = d->R, A = d->A, T1 = d->T1, i = enc;
+    if (T1 > 64) return RFN_ERR_SHAPE;
+    const long MR = (long)M * R, BMR = (long)B * MR, BA = (long)B * A;
+    float* W = (float*)ws;
+    const GemmCtx gx{st, W + Lo.gws, GEMM_WS_FLOATS * sizeof(float)};
+    const float* Hs = W + Lo.Hs;
+    rfn_gemm_problem pr[64];
+    const long Li = d->L[i], Di = d->D[i];
+    for (int t = 0; t < T1; ++t)
+        pr[t] = prob_dw(grd[P.s1(t, i, 6)], MR, grd[P.s1(t, i, 7)], W + Lo.g1 + ((long)t * M + i) * B * 4 * R, 4 * R,
+                        Hs + t * BMR, MR, B);
+    RFN_TRY(gemm_groups(4 * R, (int)MR, T1, pr, 0, gx));
+    for (int t = 0; t < T1; ++t)
+        pr[t] = prob_dw(grd[P.s1(t, i, 8)], Di, grd[P.s1(t, i, 9)], W + Lo.g1 + ((long)t * M + i) * B * 4 * R, 4 * R,
+                        W + Lo.z1[i] + (long)t * B * Di, Di, B);
+    RFN_TRY(gemm_groups(4 * R, (int)Di, T1, pr, 0, gx));
+    for (int t = 0; t < T1; ++t)
+        pr[t] = prob_dw(grd[P.s1(t, i, 2)], R, grd[P.s1(t, i, 3)], W + Lo.dhp1 + ((long)t * M + i) * BA, A,
+                        Hs + t * BMR + i * R, MR, B);
+    RFN_TRY(gemm_groups(A, R, T1, pr, 0, gx));
+    for (int t = 0; t < T1; ++t)
+        pr[t] = prob_dw(grd[P.s1(t, i, 0)], Di, grd[P.s1(t, i, 1)], W + Lo.P1[i] + (long)t * A, (long)T1 * A, att[i], Di,
+                        (int)(B * Li));
+    RFN_TRY(gemm_groups(A, (int)Di, T1, pr, 0, gx));
     return RFN_OK;
 }
 

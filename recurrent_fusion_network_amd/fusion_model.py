@@ -13,6 +13,7 @@ parameter names (``review_steps_individual.{t}.lstm.{i}.att_model.att_2_att_h.we
 from __future__ import annotations
 
 import ctypes as C
+import re
 
 import torch
 import torch.nn as nn
@@ -125,17 +126,25 @@ class _PrefixFn(torch.autograd.Function):
         d = model._dims_for(ctx.drop)
         dev = ctx.fc[0].device
         table = model._param_table(ctx.params, model._prefix_slots)
-        flat, views, gtable = model._grad_buffers(ctx.params, model._prefix_slots, dev)
+        flats, by_slot, gtable = model._grad_buffers(model._prefix_buckets, dev)
         cont = lambda t: None if t is None else t.contiguous()  # noqa: E731
         d_comb, d_h, d_c, d_reason = cont(d_comb), cont(d_h), cont(d_c), cont(d_reason)
         ws_bytes = ctx.ws.numel()
-        N.check(N.lib.rfn_prefix_bwd(C.byref(d), B, table, N.ptr_array(ctx.fc), N.ptr_array(ctx.att), N.ptr(d_comb),
+        att_ptrs = N.ptr_array(ctx.att)
+        # everything except the per-encoder stage-I weight gradients ...
+        N.check(N.lib.rfn_prefix_bwd(C.byref(d), B, table, N.ptr_array(ctx.fc), att_ptrs, N.ptr(d_comb),
                                      N.ptr(d_h), N.ptr(d_c), N.ptr(d_reason), gtable, ctx.ws.data_ptr(), ws_bytes,
-                                     ctx.seed, N.stream_ptr()), 'rfn_prefix_bwd')
-        model._last_flat_grads['prefix'] = flat
+                                     ctx.seed, 1, N.stream_ptr()), 'rfn_prefix_bwd')
+        model._bucket_done('core', flats['core'])
+        # ... then one encoder at a time, so a data-parallel host overlaps bucket i's all-reduce with the
+        # GEMMs of encoder i+1 (the largest of backward)
+        for i in range(M):
+            N.check(N.lib.rfn_prefix_bwd_wgrad(C.byref(d), B, att_ptrs, gtable, ctx.ws.data_ptr(), ws_bytes, i,
+                                               N.stream_ptr()), 'rfn_prefix_bwd_wgrad')
+            model._bucket_done('enc%d' % i, flats['enc%d' % i])
         ctx.ws = None
-        model._deliver_grads(ctx.params, views)
-        return (None, None, None, None, None) + (None,) * (2 * M) + (None,) * len(views)
+        model._deliver_grads(ctx.params, [by_slot[sl] for sl in model._prefix_slots])
+        return (None, None, None, None, None) + (None,) * (2 * M) + (None,) * len(ctx.params)
 
 
 class _DecoderFn(torch.autograd.Function):
@@ -169,7 +178,7 @@ class _DecoderFn(torch.autograd.Function):
         d = model._dims_for(ctx.drop)
         dev = comb.device
         table = model._param_table(ctx.params, model._decoder_slots)
-        flat, views, gtable = model._grad_buffers(ctx.params, model._decoder_slots, dev)
+        flats, by_slot, gtable = model._grad_buffers(['decoder'], dev)
         d_log_prob = d_log_prob.contiguous()
         d_comb = torch.empty_like(comb)
         d_h0 = torch.empty_like(h0)
@@ -179,10 +188,10 @@ class _DecoderFn(torch.autograd.Function):
                                       d_log_prob.data_ptr(), d_comb.data_ptr(), d_h0.data_ptr(), d_c0.data_ptr(),
                                       gtable, ctx.ws.data_ptr(), ctx.ws.numel(), ctx.seed, N.stream_ptr()),
                 'rfn_decoder_bwd')
-        model._last_flat_grads['decoder'] = flat
+        model._bucket_done('decoder', flats['decoder'])
         ctx.ws = None
-        model._deliver_grads(ctx.params, views)
-        return (None, None, None, None, None, d_comb, d_h0, d_c0) + (None,) * len(views)
+        model._deliver_grads(ctx.params, [by_slot[sl] for sl in model._decoder_slots])
+        return (None, None, None, None, None, d_comb, d_h0, d_c0) + (None,) * len(ctx.params)
 
 
 class RecurrentFusionModel(nn.Module):
@@ -237,6 +246,18 @@ class RecurrentFusionModel(nn.Module):
         is_dec = lambda n: n.startswith(('embed.', 'logit.', 'decoder.'))  # noqa: E731
         self._prefix_slots = [i for i, n in enumerate(self._slot_names) if not is_dec(n)]
         self._decoder_slots = [i for i, n in enumerate(self._slot_names) if is_dec(n)]
+        # gradient buckets, in the order their gradients become final during backward: the decoder, the
+        # fusion "core" (everything of phase 1 except the per-encoder stage-I weights) and one bucket per
+        # encoder (rfn_prefix_bwd_wgrad).  Each bucket is one flat buffer = one all-reduce = one Adam launch.
+        enc_re = re.compile(r'^review_steps_individual\.\d+\.lstm\.(\d+)\.(att_model\.att_2_att_h|att_model\.h_2_att_h|H2h|z2h)\.')
+        self._bucket_slots = {'decoder': list(self._decoder_slots), 'core': []}
+        for i in range(M):
+            self._bucket_slots['enc%d' % i] = []
+        for idx in self._prefix_slots:
+            m = enc_re.match(self._slot_names[idx])
+            self._bucket_slots['enc%s' % m.group(1) if m else 'core'].append(idx)
+        self._prefix_buckets = ['core'] + ['enc%d' % i for i in range(M)]
+        self.grad_ready_hook = None      # callable(bucket_name, flat_grad_tensor), see parallel.GradSync
         self._last_flat_grads = {}
         self._steps_cache = None
         self.done_beams = []
@@ -278,18 +299,36 @@ class RecurrentFusionModel(nn.Module):
             table[i] = p.data_ptr()
         return table
 
-    def _grad_buffers(self, params, slots, dev):
-        """One flat gradient buffer per phase (a single all-reduce bucket); returns (flat, views, table)."""
+    def bucket_names(self):
+        return ['decoder'] + list(self._prefix_buckets)
+
+    def bucket_layout(self, name):
+        """(params, offsets, total) of one bucket: parameters back to back, each start 16-B aligned."""
+        params = self._params_of(self._bucket_slots[name])
         offs, total = [], 0
         for p in params:
             offs.append(total)
             total += (p.numel() + 3) & ~3
-        flat = torch.empty(total, device=dev, dtype=torch.float32)
-        views = [flat[o:o + p.numel()].view_as(p) for o, p in zip(offs, params)]
+        return params, offs, total
+
+    def _grad_buffers(self, buckets, dev):
+        """One flat gradient buffer per bucket; returns ({name: flat}, {slot: view}, pointer table)."""
+        flats, by_slot = {}, {}
         table = (C.c_void_p * len(self._slot_names))()
-        for v, i in zip(views, slots):
-            table[i] = v.data_ptr()
-        return flat, views, table
+        for name in buckets:
+            params, offs, total = self.bucket_layout(name)
+            flat = torch.empty(total, device=dev, dtype=torch.float32)
+            flats[name] = flat
+            for slot, p, o in zip(self._bucket_slots[name], params, offs):
+                v = flat[o:o + p.numel()].view_as(p)
+                by_slot[slot] = v
+                table[slot] = v.data_ptr()
+        return flats, by_slot, table
+
+    def _bucket_done(self, name, flat):
+        self._last_flat_grads[name] = flat
+        if self.grad_ready_hook is not None:
+            self.grad_ready_hook(name, flat)
 
     @staticmethod
     def _deliver_grads(params, views):

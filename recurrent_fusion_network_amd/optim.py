@@ -1,9 +1,9 @@
 """Fused clip_gradient + Adam (misc/utils.py:292-296 + train.py:69-71,162-163) on flat buffers.
 
-The model keeps one flat gradient buffer per phase (fusion stages / decoder); ``FusedClampAdam`` re-points
-the parameters at flat buffers with the same layout, so the whole update -- clamp to +-grad_clip, L2 weight
-decay, Adam moments, bias correction -- is one rfn_adam_step launch per phase (7 streams over 1.56 GB at the
-headline config) instead of ~625 per-tensor updates, and a data-parallel run all-reduces two buffers.
+The model keeps one flat gradient buffer per bucket (decoder, fusion core, one per encoder); ``FusedClampAdam``
+re-points the parameters at flat buffers with the same layout, so the whole update -- clamp to +-grad_clip, L2
+weight decay, Adam moments, bias correction -- is one rfn_adam_step launch per bucket (7 streams over 1.56 GB at
+the headline config) instead of ~625 per-tensor updates, and a data-parallel run all-reduces M+2 buffers.
 """
 import torch
 
@@ -17,20 +17,15 @@ class FusedClampAdam:
         self.weight_decay, self.grad_clip = weight_decay, grad_clip
         self.step_count = 0
         self.flat = {}
-        for phase, slots in (('prefix', model._prefix_slots), ('decoder', model._decoder_slots)):
-            params = model._params_of(slots)
-            dev = params[0].device
-            if not params[0].is_cuda:
-                raise N.RfnError('move the model to the GPU before building FusedClampAdam')
-            offs, total = [], 0
-            for p in params:
-                offs.append(total)
-                total += (p.numel() + 3) & ~3      # same layout as RecurrentFusionModel._grad_buffers
-            buf = torch.zeros(total, device=dev, dtype=torch.float32)
+        if not next(model.parameters()).is_cuda:
+            raise N.RfnError('move the model to the GPU before building FusedClampAdam')
+        for name in model.bucket_names():
+            params, offs, total = model.bucket_layout(name)     # same layout as the gradient buckets
+            buf = torch.zeros(total, device=params[0].device, dtype=torch.float32)
             for o, p in zip(offs, params):
                 buf[o:o + p.numel()].copy_(p.data.reshape(-1))
                 p.data = buf[o:o + p.numel()].view_as(p)
-            self.flat[phase] = dict(p=buf, m=torch.zeros_like(buf), v=torch.zeros_like(buf), n=total)
+            self.flat[name] = dict(p=buf, m=torch.zeros_like(buf), v=torch.zeros_like(buf), n=total)
 
     def zero_grad(self):
         for p in self.model.parameters():
@@ -43,8 +38,8 @@ class FusedClampAdam:
     def step(self, grad_scale=1.0):
         """grad_scale multiplies the gradient before the clamp (1/world_size after a sum all-reduce)."""
         self.step_count += 1
-        for phase, st in self.flat.items():
-            g = self.model._last_flat_grads.get(phase)
+        for name, st in self.flat.items():
+            g = self.model._last_flat_grads.get(name)
             if g is None:
                 continue
             if g.numel() != st['n']:

@@ -49,10 +49,36 @@ def allreduce_flat(buffers, world, async_op=False):
     return works
 
 
+class GradSync:
+    """Overlapped gradient exchange: registers as the model's `grad_ready_hook`, launches one asynchronous SUM
+    all-reduce per gradient bucket the moment backward has queued the kernels that finish it (decoder first,
+    then the fusion core, then one bucket per encoder), and `finish()` makes the compute stream wait for all of
+    them.  Each collective starts behind the compute stream at its call point (process-group semantics), so
+    bucket i's transfer runs under the weight-gradient GEMMs of the encoders after it."""
+
+    def __init__(self, model, world):
+        self.world = world
+        self.works = []
+        self.buckets = []
+        model.grad_ready_hook = self.on_bucket
+
+    def on_bucket(self, name, flat):
+        self.buckets.append(name)
+        if self.world > 1:
+            self.works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True))
+
+    def finish(self):
+        for w in self.works:
+            w.wait()
+        self.works.clear()
+        self.buckets.clear()
+        return 1.0 / self.world
+
+
 def allreduce_model_grads(model, world):
     """All-reduce the gradients the last backward produced (decoder bucket first: it is ready first)."""
     flats = getattr(model, '_last_flat_grads', {})
-    order = [flats[k] for k in ('decoder', 'prefix') if k in flats]
+    order = [flats[k] for k in model.bucket_names() if k in flats]
     allreduce_flat(order, world)
     return 1.0 / world
 

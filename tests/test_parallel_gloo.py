@@ -33,8 +33,18 @@ def _worker(rank, world, port, q):
                                               sl(top), 1.0)
     keys = sorted(grads)
     flat = torch.cat([grads[k].reshape(-1) * 40.0 for k in keys])     # x40: make the clamp bite
-    DP.allreduce_flat([flat], world)
-    scale = 1.0 / world
+    # the overlapped path of bench.py: buckets are handed to GradSync as backward finishes them
+    class _M:                       # the two attributes GradSync touches
+        grad_ready_hook = None
+    holder = _M()
+    sync = DP.GradSync(holder, world)
+    n3 = flat.numel() // 3
+    chunks = [flat[:n3], flat[n3:2 * n3], flat[2 * n3:]]          # views: reduced in place
+    for i, c in enumerate(chunks):
+        holder.grad_ready_hook('bucket%d' % i, c)
+    assert sync.buckets == ['bucket0', 'bucket1', 'bucket2']
+    scale = sync.finish()
+    assert scale == 1.0 / world and not sync.works
     t = DP.max_over_ranks(float(rank + 1), world, torch.device('cpu'))
     assert t == float(world)
     # clamp AFTER averaging, then Adam -- as rfn_adam_step does with grad_scale
