@@ -150,12 +150,25 @@ int rfn_attn_scores_bwd(const float* proj, int64_t proj_sb, int64_t proj_sl, con
 int rfn_lstm_fwd(float* gates, int64_t ldg, const float* c_prev, int64_t ldcp, float* c_next,
                  int64_t ldcn, float* h_next, int64_t ldh, int B, int R, float drop_p,
                  uint64_t seed, uint64_t offset, void* stream);
+/* G independent cells in one launch (the M encoders of a stage-I step): group g uses gates + g*gs_gates,
+ * c_prev + g*gs_cprev, c_next + g*gs_cnext, h_next + g*gs_h and dropout stream offset + g. */
+int rfn_lstm_fwd_grouped(float* gates, int64_t ldg, const float* c_prev, int64_t ldcp, float* c_next,
+                         int64_t ldcn, float* h_next, int64_t ldh, int B, int R, float drop_p,
+                         uint64_t seed, uint64_t offset, int G, int64_t gs_gates, int64_t gs_cprev,
+                         int64_t gs_cnext, int64_t gs_h, void* stream);
 /* dgates (in place over the activations), dc_prev = dc_next_total * f.
  * dh / dc_next are the TOTAL incoming gradients of h_next / c_next (dc_next may be NULL). */
 int rfn_lstm_bwd(float* gates, int64_t ldg, const float* c_prev, int64_t ldcp, const float* c_next,
                  int64_t ldcn, const float* dh, int64_t lddh, const float* dc_next, int64_t lddcn,
                  float* dc_prev, int64_t lddcp, int B, int R, float drop_p, uint64_t seed,
                  uint64_t offset, void* stream);
+
+/* grouped backward: c_prev and c_next share gs_c; dc_next and dc_prev share gs_dc */
+int rfn_lstm_bwd_grouped(float* gates, int64_t ldg, const float* c_prev, int64_t ldcp, const float* c_next,
+                         int64_t ldcn, const float* dh, int64_t lddh, const float* dc_next, int64_t lddcn,
+                         float* dc_prev, int64_t lddcp, int B, int R, float drop_p, uint64_t seed,
+                         uint64_t offset, int G, int64_t gs_gates, int64_t gs_c, int64_t gs_dh, int64_t gs_dc,
+                         void* stream);
 
 /* nn.Embedding gather (misc/RecurrentFusionModel.py:276): out[r,:] = W[id(r), :] with
  * id(r) = ids[(r % inner)*ids_s_inner + (r / inner)*ids_s_outer]  (row r = (step, batch) reads

@@ -68,6 +68,8 @@ def _load():
         'rfn_attn_scores_bwd': (C.c_int, [P, L, L, P, P, P, P, I, I, I, P, L, L, I, P, P, P]),
         'rfn_lstm_fwd': (C.c_int, [P, L, P, L, P, L, P, L, I, I, F, U64, U64, P]),
         'rfn_lstm_bwd': (C.c_int, [P, L, P, L, P, L, P, L, P, L, P, L, I, I, F, U64, U64, P]),
+        'rfn_lstm_fwd_grouped': (C.c_int, [P, L, P, L, P, L, P, L, I, I, F, U64, U64, I, L, L, L, L, P]),
+        'rfn_lstm_bwd_grouped': (C.c_int, [P, L, P, L, P, L, P, L, P, L, P, L, I, I, F, U64, U64, I, L, L, L, L, P]),
         'rfn_embed_fwd': (C.c_int, [P, I, L, P, I, L, L, I, P, L, P]),
         'rfn_embed_bwd': (C.c_int, [P, L, P, I, L, L, I, I, L, P, P]),
         'rfn_log_softmax_fwd': (C.c_int, [P, L, I, I, I, L, L, P, P]),

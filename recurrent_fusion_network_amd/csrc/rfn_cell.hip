@@ -28,9 +28,13 @@ __device__ __forceinline__ float rfn_philox_uniform(uint64_t seed, uint64_t offs
 __global__ __launch_bounds__(256) void lstm_fwd_k(float* __restrict__ gates, long ldg, const float* c_prev /* may alias c_next */,
                                                   long ldcp, float* c_next, long ldcn,
                                                   float* __restrict__ h_next, long ldh, int B, int R, float drop_p,
-                                                  uint64_t seed, uint64_t offset) {
+                                                  uint64_t seed, uint64_t offset, long gs_g, long gs_cp, long gs_cn,
+                                                  long gs_h) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (long)B * R) return;
+    const int grp = blockIdx.y;   // independent cells of one step (the M encoders of stage I)
+    gates += grp * gs_g; c_prev += grp * gs_cp; c_next += grp * gs_cn; h_next += grp * gs_h;
+    offset += (uint64_t)grp;
     const int b = (int)(idx / R), j = (int)(idx - (long)b * R);
     float* g = gates + b * ldg;
     const float ig = rfn_sigmoid(g[j]);
@@ -51,16 +55,23 @@ __global__ __launch_bounds__(256) void lstm_fwd_k(float* __restrict__ gates, lon
     h_next[b * ldh + j] = hv;
 }
 
+extern "C" int rfn_lstm_fwd_grouped(float* gates, int64_t ldg, const float* c_prev, int64_t ldcp, float* c_next,
+                                    int64_t ldcn, float* h_next, int64_t ldh, int B, int R, float drop_p,
+                                    uint64_t seed, uint64_t offset, int G, int64_t gs_gates, int64_t gs_cprev,
+                                    int64_t gs_cnext, int64_t gs_h, void* stream) {
+    if (B <= 0 || R <= 0 || G < 1 || drop_p < 0.f || drop_p >= 1.f) return RFN_ERR_SHAPE;
+    if (!gates || !c_prev || !c_next || !h_next) return RFN_ERR_ARG;
+    hipLaunchKernelGGL(lstm_fwd_k, dim3(rfn_cdiv((long)B * R, 256), G), dim3(256), 0, (hipStream_t)stream, gates,
+                       (long)ldg, c_prev, (long)ldcp, c_next, (long)ldcn, h_next, (long)ldh, B, R, drop_p, seed,
+                       offset, (long)gs_gates, (long)gs_cprev, (long)gs_cnext, (long)gs_h);
+    RFN_CHECK_LAUNCH();
+    return RFN_OK;
+}
 extern "C" int rfn_lstm_fwd(float* gates, int64_t ldg, const float* c_prev, int64_t ldcp, float* c_next,
                             int64_t ldcn, float* h_next, int64_t ldh, int B, int R, float drop_p, uint64_t seed,
                             uint64_t offset, void* stream) {
-    if (B <= 0 || R <= 0 || drop_p < 0.f || drop_p >= 1.f) return RFN_ERR_SHAPE;
-    if (!gates || !c_prev || !c_next || !h_next) return RFN_ERR_ARG;
-    hipLaunchKernelGGL(lstm_fwd_k, dim3(rfn_cdiv((long)B * R, 256)), dim3(256), 0, (hipStream_t)stream, gates,
-                       (long)ldg, c_prev, (long)ldcp, c_next, (long)ldcn, h_next, (long)ldh, B, R, drop_p, seed,
-                       offset);
-    RFN_CHECK_LAUNCH();
-    return RFN_OK;
+    return rfn_lstm_fwd_grouped(gates, ldg, c_prev, ldcp, c_next, ldcn, h_next, ldh, B, R, drop_p, seed, offset, 1, 0,
+                                0, 0, 0, stream);
 }
 
 __global__ __launch_bounds__(256) void lstm_bwd_k(float* __restrict__ gates, long ldg, const float* __restrict__ c_prev,
@@ -68,9 +79,15 @@ __global__ __launch_bounds__(256) void lstm_bwd_k(float* __restrict__ gates, lon
                                                   const float* __restrict__ dh, long lddh,
                                                   const float* dc_next /* may alias dc_prev */, long lddcn,
                                                   float* dc_prev, long lddcp, int B, int R, float drop_p,
-                                                  uint64_t seed, uint64_t offset) {
+                                                  uint64_t seed, uint64_t offset, long gs_g, long gs_c, long gs_dh,
+                                                  long gs_dc) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (long)B * R) return;
+    const int grp = blockIdx.y;
+    gates += grp * gs_g; c_prev += grp * gs_c; c_next += grp * gs_c; dh += grp * gs_dh;
+    if (dc_next) dc_next += grp * gs_dc;
+    dc_prev += grp * gs_dc;
+    offset += (uint64_t)grp;
     const int b = (int)(idx / R), j = (int)(idx - (long)b * R);
     float* g = gates + b * ldg;
     const float ig = g[j], fg = g[R + j], og = g[2 * R + j], gg = g[3 * R + j];
@@ -93,15 +110,24 @@ __global__ __launch_bounds__(256) void lstm_bwd_k(float* __restrict__ gates, lon
     dc_prev[b * lddcp + j] = dc * fg;
 }
 
+extern "C" int rfn_lstm_bwd_grouped(float* gates, int64_t ldg, const float* c_prev, int64_t ldcp,
+                                    const float* c_next, int64_t ldcn, const float* dh, int64_t lddh,
+                                    const float* dc_next, int64_t lddcn, float* dc_prev, int64_t lddcp, int B, int R,
+                                    float drop_p, uint64_t seed, uint64_t offset, int G, int64_t gs_gates,
+                                    int64_t gs_c, int64_t gs_dh, int64_t gs_dc, void* stream) {
+    if (B <= 0 || R <= 0 || G < 1 || drop_p < 0.f || drop_p >= 1.f) return RFN_ERR_SHAPE;
+    if (!gates || !c_prev || !c_next || !dh || !dc_prev) return RFN_ERR_ARG;
+    hipLaunchKernelGGL(lstm_bwd_k, dim3(rfn_cdiv((long)B * R, 256), G), dim3(256), 0, (hipStream_t)stream, gates,
+                       (long)ldg, c_prev, (long)ldcp, c_next, (long)ldcn, dh, (long)lddh, dc_next, (long)lddcn,
+                       dc_prev, (long)lddcp, B, R, drop_p, seed, offset, (long)gs_gates, (long)gs_c, (long)gs_dh,
+                       (long)gs_dc);
+    RFN_CHECK_LAUNCH();
+    return RFN_OK;
+}
 extern "C" int rfn_lstm_bwd(float* gates, int64_t ldg, const float* c_prev, int64_t ldcp, const float* c_next,
                             int64_t ldcn, const float* dh, int64_t lddh, const float* dc_next, int64_t lddcn,
                             float* dc_prev, int64_t lddcp, int B, int R, float drop_p, uint64_t seed, uint64_t offset,
                             void* stream) {
-    if (B <= 0 || R <= 0 || drop_p < 0.f || drop_p >= 1.f) return RFN_ERR_SHAPE;
-    if (!gates || !c_prev || !c_next || !dh || !dc_prev) return RFN_ERR_ARG;
-    hipLaunchKernelGGL(lstm_bwd_k, dim3(rfn_cdiv((long)B * R, 256)), dim3(256), 0, (hipStream_t)stream, gates,
-                       (long)ldg, c_prev, (long)ldcp, c_next, (long)ldcn, dh, (long)lddh, dc_next, (long)lddcn,
-                       dc_prev, (long)lddcp, B, R, drop_p, seed, offset);
-    RFN_CHECK_LAUNCH();
-    return RFN_OK;
+    return rfn_lstm_bwd_grouped(gates, ldg, c_prev, ldcp, c_next, ldcn, dh, lddh, dc_next, lddcn, dc_prev, lddcp, B, R,
+                                drop_p, seed, offset, 1, 0, 0, 0, 0, stream);
 }

@@ -35,6 +35,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef GEMM_FRAG_PIPE
 #define GEMM_FRAG_PIPE 0   /* explicit register double-buffering of the LDS fragments */
 #endif
+#ifndef GEMM_BIG_BM
+#define GEMM_BIG_BM 128
+#endif
+#ifndef GEMM_BIG_BN
+#define GEMM_BIG_BN 128
+#endif
 #ifndef GEMM_BIG_BK
 #define GEMM_BIG_BK 32     /* K step of the 128x128 tile */
 #endif
@@ -454,9 +460,9 @@ static int launch_tile(GemmArgs& a, hipStream_t st) {
     // per-step GEMMs (M = batch) so that more CUs get a tile.
     const long big = (long)rfn_cdiv(a.M, 128) * rfn_cdiv(a.N, 128) * a.ngroups;
     if (big >= 384) {
-        a.tiles_m = rfn_cdiv(a.M, 128);
-        a.tiles_n = rfn_cdiv(a.N, 128);
-        return launch_cfg<128, 128, AK, BKF, VEC, (AK && BKF) ? GEMM_NT_STAGES : GEMM_XX_STAGES, GEMM_BIG_BK>(a, st);
+        a.tiles_m = rfn_cdiv(a.M, GEMM_BIG_BM);
+        a.tiles_n = rfn_cdiv(a.N, GEMM_BIG_BN);
+        return launch_cfg<GEMM_BIG_BM, GEMM_BIG_BN, AK, BKF, VEC, (AK && BKF) ? GEMM_NT_STAGES : GEMM_XX_STAGES, GEMM_BIG_BK>(a, st);
     }
     a.tiles_m = rfn_cdiv(a.M, 64);
     a.tiles_n = rfn_cdiv(a.N, 64);

@@ -454,9 +454,9 @@ extern "C" int rfn_prefix_fwd(const rfn_dims* d, int B, const float* const* prm,
             p.seg[1] = seg_lin(z, Di, prm[P.s1(t, i, 8)], Di, (int)Di, prm[P.s1(t, i, 9)]);
         }
         RFN_TRY(gemm_groups(B, 4 * R, M, pr, 0, gx));
-        for (int i = 0; i < M; ++i)
-            RFN_TRY(rfn_lstm_fwd(g + (long)i * B * 4 * R, 4 * R, Cc + i * R, MR, Cn + i * R, MR, Hn + i * R, MR, B, R,
-                                 train ? d->drop_fusion : 0.f, seed, (uint64_t)(t * M + i), st));
+        // the M cells of this step in one launch: encoder i's state is column block i of the (B, M*R) rows
+        RFN_TRY(rfn_lstm_fwd_grouped(g, 4 * R, Cc, MR, Cn, MR, Hn, MR, B, R, train ? d->drop_fusion : 0.f, seed,
+                                     (uint64_t)(t * M), M, (long)B * 4 * R, R, R, R, st));
     }
 
     // reason heads of stage I: max over steps of reason_linear_individual (:217, :229)
@@ -649,10 +649,8 @@ extern "C" int rfn_prefix_bwd(const rfn_dims* d, int B, const float* const* prm,
         float* g = W + Lo.g1 + (long)t * M * B * 4 * R;
         float* hp = W + Lo.hp1 + (long)t * M * BA;
         float* dhp = W + Lo.dhp1 + (long)t * M * BA;
-        for (int i = 0; i < M; ++i)
-            RFN_TRY(rfn_lstm_bwd(g + (long)i * B * 4 * R, 4 * R, Cs + t * BMR + i * R, MR, Cs + (t + 1) * BMR + i * R,
-                                 MR, dHn + i * R, MR, dC + i * R, MR, dC + i * R, MR, B, R, d->drop_fusion, seed,
-                                 (uint64_t)(t * M + i), st));
+        RFN_TRY(rfn_lstm_bwd_grouped(g, 4 * R, Cs + t * BMR, MR, Cs + (t + 1) * BMR, MR, dHn, MR, dC, MR, dC, MR, B, R,
+                                     d->drop_fusion, seed, (uint64_t)(t * M), M, (long)B * 4 * R, R, R, R, st));
         // dH_t += sum_i dgates_i . W_H[t,i]   (every cell reads the whole concatenated H, :53)
         for (int i = 0; i < M; ++i) segs[i] = seg_dx(g + (long)i * B * 4 * R, 4 * R, prm[P.s1(t, i, 6)], MR, 4 * R);
         RFN_TRY(gemm_segs(B, (int)MR, M, segs, dHc, MR, 1, gx));
