@@ -237,6 +237,20 @@ int rfn_greedy_pick(const float* logp, int64_t ldl, int B, int V1, int t, int64_
                     int64_t* seq_out, int64_t ld_seq, float* lp_out, int64_t ld_lp,
                     const int32_t* unf_prev, int32_t* unf_out, void* stream);
 
+/* Batched beam-search bookkeeping of sample_beam (misc/RecurrentFusionModel.py:451-531) for step t in [1, S]:
+ * one block per image consumes the log-probs of its W beam rows (rows k*W .. k*W+W-1 of `logp`), reproduces the
+ * reference's candidate order / stable sort / fork / done-beam rules on the device and emits
+ *   order[r]    source row whose recurrent state row r continues (feed rfn_gather_rows),
+ *   next_ids[r] token row r feeds to the next decoder step,
+ * updating beam_seq / beam_lp (S, NB, W), beam_sum (NB, W), the done-beam arrays (NB, max_done, ...) and
+ * active[k] (0 once image k has no candidate left, :480).  W <= 16, S <= 32. */
+int rfn_beam_step(const float* logp, int64_t ldl, int V1, int W, int S, int t, int NB, int max_done,
+                  int64_t* beam_seq, float* beam_lp, float* beam_sum, int32_t* order, int64_t* next_ids,
+                  int64_t* done_seq, float* done_lp, float* done_p, int32_t* done_n, int32_t* active,
+                  void* stream);
+/* dst[r,:] = src[order[r],:]  (src != dst) */
+int rfn_gather_rows(const float* src, float* dst, const int32_t* order, int rows, int R, void* stream);
+
 /* ---- whole-path entry points ---------------------------------------------------------------- */
 /* Phase 1 = get_init_state + get_thought_vectors (misc/RecurrentFusionModel.py:333-343, 283-331;
  * the same code is inlined in forward :199-255 and sample :557-612): fc2h, T1 fusion-stage-I steps

@@ -82,6 +82,8 @@ def _load():
         'rfn_multilabel_margin': (C.c_int, [P, I, I, P, F, F, P, P, I, P, P]),
         'rfn_adam_step': (C.c_int, [P, P, P, P, L, F, F, F, F, F, F, F, I, P]),
         'rfn_greedy_pick': (C.c_int, [P, L, I, I, I, P, P, L, P, L, P, P, P]),
+        'rfn_beam_step': (C.c_int, [P, L, I, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P]),
+        'rfn_gather_rows': (C.c_int, [P, P, P, I, I, P]),
         'rfn_prefix_ws_bytes': (SZ, [DP, I, I]),
         'rfn_prefix_fwd': (C.c_int, [DP, I, P, P, P, P, P, P, P, P, SZ, I, U64, P]),
         'rfn_prefix_bwd': (C.c_int, [DP, I, P, P, P, P, P, P, P, P, P, SZ, U64, I, P]),

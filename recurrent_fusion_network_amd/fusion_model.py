@@ -505,77 +505,67 @@ class RecurrentFusionModel(nn.Module):
         return seq[:, :n_seq], seq_lp[:, :n_seq], logp_all[:, :t_stop].contiguous(), reason_pred
 
     def sample_beam(self, fc_feats, att_feats, opt={}):
-        """misc/RecurrentFusionModel.py:352-543.  Stages I/II run ONCE for the whole batch (the reference
-        recomputes them per image on beam_size identical rows); the per-image beam bookkeeping follows the
-        reference's candidate order and tie-breaking exactly."""
+        """misc/RecurrentFusionModel.py:352-543, batched and device-resident.
+
+        Stages I/II run ONCE for the batch (the reference recomputes them per image on beam_size identical rows),
+        all images' beams share one decoder batch of B*beam rows, and rfn_beam_step does the reference's
+        candidate / stable-sort / fork / done-beam bookkeeping on the device -- no per-step host read-back.  The
+        done beams are sorted (stably, by -p, as :529) on the host once at the end."""
         beam_size = opt.get('beam_size', 10)
         B, S, V1 = fc_feats[0].size(0), self.seq_length, self.vocab_size + 1
-        assert beam_size <= V1
+        assert beam_size <= V1, 'lets assume this for now'
+        if beam_size > 16 or S > 32:
+            raise N.RfnError('beam search supports beam_size <= 16 and seq_length <= 32')
+        W = beam_size
         with torch.no_grad():
-            comb_all, h_all, c_all, reason = self._prefix(fc_feats, att_feats, False, 0)
-        dev = comb_all.device
+            comb_b, h_b, c_b, reason = self._prefix(fc_feats, att_feats, False, 0)
+            dev = comb_b.device
+            comb = comb_b.repeat_interleave(W, dim=1).contiguous()         # (T2, B*W, R): row k*W+q = image k
+            stepper = _Stepper(self, comb, h_b.repeat_interleave(W, dim=0).contiguous(),
+                               c_b.repeat_interleave(W, dim=0).contiguous())
+            rows, max_done = B * W, W * S
+            bs = torch.zeros(S, B, W, dtype=torch.long, device=dev)
+            bl = torch.zeros(S, B, W, device=dev)
+            bsum = torch.zeros(B, W, device=dev)
+            order = torch.zeros(rows, dtype=torch.int32, device=dev)
+            ids = torch.zeros(rows, dtype=torch.long, device=dev)
+            done_seq = torch.zeros(B, max_done, S, dtype=torch.long, device=dev)
+            done_lp = torch.zeros(B, max_done, S, device=dev)
+            done_p = torch.zeros(B, max_done, device=dev)
+            done_n = torch.zeros(B, dtype=torch.int32, device=dev)
+            active = torch.ones(B, dtype=torch.int32, device=dev)
+            logp = torch.empty(rows, V1, device=dev)
+            h_alt, c_alt = torch.empty_like(stepper.h), torch.empty_like(stepper.c)
+            R = self.rnn_size
+            for t in range(S + 1):
+                if t >= 1:
+                    N.check(N.lib.rfn_beam_step(logp.data_ptr(), V1, V1, W, S, t, B, max_done, bs.data_ptr(),
+                                                bl.data_ptr(), bsum.data_ptr(), order.data_ptr(), ids.data_ptr(),
+                                                done_seq.data_ptr(), done_lp.data_ptr(), done_p.data_ptr(),
+                                                done_n.data_ptr(), active.data_ptr(), N.stream_ptr()),
+                            'rfn_beam_step')
+                    if t == S:
+                        break    # the reference still runs one more decoder step whose output is never used
+                    st = N.stream_ptr()
+                    N.check(N.lib.rfn_gather_rows(stepper.h.data_ptr(), h_alt.data_ptr(), order.data_ptr(), rows, R, st))
+                    N.check(N.lib.rfn_gather_rows(stepper.c.data_ptr(), c_alt.data_ptr(), order.data_ptr(), rows, R, st))
+                    stepper.h, h_alt = h_alt, stepper.h
+                    stepper.c, c_alt = c_alt, stepper.c
+                stepper.step(ids, out=logp)
+            n_done = done_n.cpu().tolist()
+            d_seq, d_lp, d_p = done_seq.cpu(), done_lp.cpu(), done_p.cpu()
         seq = torch.zeros(S, B, dtype=torch.long)
         seq_lp = torch.zeros(S, B)
-        top_seq, top_prob = [], [[] for _ in range(B)]
+        top_seq, top_prob, reason_batch = [], [[] for _ in range(B)], []
         self.done_beams = [[] for _ in range(B)]
-        reason_batch = []
         for k in range(B):
-            reason_batch.append([reason[j, k:k + 1].expand(beam_size, -1).contiguous()
-                                 for j in range(self.num_feat_array + 1)])
-            with torch.no_grad():
-                comb = comb_all[:, k:k + 1].expand(-1, beam_size, -1).contiguous()
-                stepper = _Stepper(self, comb, h_all[k:k + 1].expand(beam_size, -1).contiguous(),
-                                   c_all[k:k + 1].expand(beam_size, -1).contiguous())
-                beam_seq = torch.zeros(S, beam_size, dtype=torch.long)
-                beam_lp = torch.zeros(S, beam_size)
-                beam_sum = torch.zeros(beam_size)
-                logprobs = None
-                for t in range(S + 1):
-                    if t == 0:
-                        it = torch.zeros(beam_size, dtype=torch.long, device=dev)
-                    else:
-                        ys, ix = torch.sort(logprobs.float().cpu(), 1, True)
-                        cands = []
-                        cols = min(beam_size, ys.size(1))
-                        rows = 1 if t == 1 else beam_size
-                        ysl, ixl, bsl = ys[:, :cols].tolist(), ix[:, :cols].tolist(), beam_sum.tolist()
-                        for cc in range(cols):
-                            for q in range(rows):
-                                if t > 1 and int(beam_seq[t - 2, q]) == 0:
-                                    continue
-                                local = ysl[q][cc]
-                                p = float(torch.tensor(bsl[q], dtype=torch.float32) +
-                                          torch.tensor(local, dtype=torch.float32))
-                                cands.append(dict(c=ixl[q][cc], q=q, p=p, r=local))
-                        if len(cands) == 0:
-                            break
-                        cands = sorted(cands, key=lambda x: -x['p'])
-                        if t > 1:
-                            prev_seq = beam_seq[:t - 1].clone()
-                            prev_lp = beam_lp[:t - 1].clone()
-                        order = []
-                        for vix in range(min(beam_size, len(cands))):
-                            v = cands[vix]
-                            if t > 1:
-                                beam_seq[:t - 1, vix] = prev_seq[:, v['q']]
-                                beam_lp[:t - 1, vix] = prev_lp[:, v['q']]
-                            order.append(v['q'])
-                            beam_seq[t - 1, vix] = v['c']
-                            beam_lp[t - 1, vix] = v['r']
-                            beam_sum[vix] = v['p']
-                            if v['c'] == 0 or t == S:
-                                self.done_beams[k].append({'seq': beam_seq[:, vix].clone(),
-                                                           'logps': beam_lp[:, vix].clone(),
-                                                           'p': float(beam_sum[vix])})
-                        # rows beyond len(cands) keep their previous state, as new_state = clone(state) does
-                        order = order + list(range(len(order), beam_size))
-                        stepper.reorder(torch.tensor(order, dtype=torch.long, device=dev))
-                        it = beam_seq[t - 1].to(dev)
-                    logprobs = stepper.step(it.contiguous())
-            self.done_beams[k] = sorted(self.done_beams[k], key=lambda x: -x['p'])
+            reason_batch.append([reason[j, k:k + 1].expand(W, -1).contiguous() for j in range(self.num_feat_array + 1)])
+            beams = [{'seq': d_seq[k, n].clone(), 'logps': d_lp[k, n].clone(), 'p': float(d_p[k, n])}
+                     for n in range(n_done[k])]
+            self.done_beams[k] = sorted(beams, key=lambda x: -x['p'])          # stable, as the reference (:529)
             seq[:, k] = self.done_beams[k][0]['seq']
             seq_lp[:, k] = self.done_beams[k][0]['logps']
-            cur = torch.zeros(len(self.done_beams[k]), S, dtype=torch.long)
+            cur = torch.zeros(len(beams), S, dtype=torch.long)
             for j, db in enumerate(self.done_beams[k]):
                 cur[j] = db['seq']
                 top_prob[k].append(db['p'])

@@ -424,3 +424,77 @@ def test_adam_and_greedy_pick(dev):
     n.check(n.lib.rfn_greedy_pick(lp2d.data_ptr(), V1, B, V1, 2, nxt.data_ptr(), seq[:, 1].data_ptr(), 4,
                                   slp[:, 1].data_ptr(), 4, unf[1].data_ptr(), unf[2].data_ptr(), st))
     assert int(unf[2, 2]) == 0 and int(seq[2, 1]) == 0 and int(nxt[2]) == int(lp2[2].argmax())
+
+
+def _beam_reference(logps, W, S):
+    """Pure-Python restatement of misc/RecurrentFusionModel.py:451-531 driven by a fixed log-prob table per step
+    (rows are re-gathered exactly as the recurrent state would be)."""
+    V1 = logps[0].shape[1]
+    beam_seq = np.zeros((S, W), dtype=np.int64)
+    beam_lp = np.zeros((S, W), dtype=np.float32)
+    beam_sum = np.zeros(W, dtype=np.float32)
+    done, src = [], np.arange(W)
+    for t in range(1, S + 1):
+        lp = logps[t - 1][src]                       # state of row r descends from row src[r]
+        ixs = np.argsort(-lp, axis=1, kind='stable')
+        cols, rows = min(W, V1), (1 if t == 1 else W)
+        cands = []
+        for c in range(cols):
+            for q in range(rows):
+                if t > 1 and beam_seq[t - 2, q] == 0:
+                    continue
+                local = lp[q, ixs[q, c]]
+                cands.append(dict(c=int(ixs[q, c]), q=q, p=np.float32(beam_sum[q] + local), r=local))
+        if not cands:
+            break
+        cands = sorted(cands, key=lambda x: -x['p'])
+        prev_seq, prev_lp = beam_seq.copy(), beam_lp.copy()
+        new_src = np.arange(W)
+        for vix in range(min(W, len(cands))):
+            v = cands[vix]
+            beam_seq[:t - 1, vix] = prev_seq[:t - 1, v['q']]
+            beam_lp[:t - 1, vix] = prev_lp[:t - 1, v['q']]
+            new_src[vix] = v['q']
+            beam_seq[t - 1, vix], beam_lp[t - 1, vix], beam_sum[vix] = v['c'], v['r'], v['p']
+            if v['c'] == 0 or t == S:
+                done.append((beam_seq[:, vix].copy(), beam_lp[:, vix].copy(), float(beam_sum[vix])))
+        src = new_src                                  # rows >= len(cands) keep their own state
+    return done
+
+
+@pytest.mark.parametrize('W,V1,S', [(3, 7, 5), (5, 40, 6), (4, 3, 4)])
+def test_beam_step_kernel_matches_python_bookkeeping(dev, W, V1, S):
+    """rfn_beam_step against the reference's bookkeeping with END tokens frequent enough to finish beams early
+    (and, for the tiny vocabulary, to exhaust every candidate -> the early break)."""
+    n = N()
+    NB = 4
+    g = torch.Generator().manual_seed(W * 100 + V1)
+    tables = [torch.log_softmax(torch.randn(NB * W, V1, generator=g) * 2.0, 1) for _ in range(S)]
+    for tb in tables:
+        tb[:, 0] += 1.5                                  # make END (id 0) likely
+    st = n.stream_ptr()
+    bs = torch.zeros(S, NB, W, dtype=torch.long, device=dev)
+    bl = torch.zeros(S, NB, W, device=dev)
+    bsum = torch.zeros(NB, W, device=dev)
+    order = torch.arange(NB * W, dtype=torch.int32, device=dev)
+    ids = torch.zeros(NB * W, dtype=torch.long, device=dev)
+    MAXD = W * S
+    dseq = torch.zeros(NB, MAXD, S, dtype=torch.long, device=dev)
+    dlp = torch.zeros(NB, MAXD, S, device=dev)
+    dp = torch.zeros(NB, MAXD, device=dev)
+    dn = torch.zeros(NB, dtype=torch.int32, device=dev)
+    act = torch.ones(NB, dtype=torch.int32, device=dev)
+    src = torch.arange(NB * W, device=dev)                 # which original row each state row descends from
+    for t in range(1, S + 1):
+        cur = tables[t - 1].to(dev)[src].contiguous()
+        n.check(n.lib.rfn_beam_step(cur.data_ptr(), V1, V1, W, S, t, NB, MAXD, bs.data_ptr(), bl.data_ptr(),
+                                    bsum.data_ptr(), order.data_ptr(), ids.data_ptr(), dseq.data_ptr(), dlp.data_ptr(),
+                                    dp.data_ptr(), dn.data_ptr(), act.data_ptr(), st))
+        src = order.long()                                 # next step's row r descends from row order[r]
+    for k in range(NB):
+        ref = _beam_reference([tb[k * W:(k + 1) * W].numpy() for tb in tables], W, S)
+        assert int(dn[k]) == len(ref), (k, int(dn[k]), len(ref))
+        for j, (rs, rl, rp) in enumerate(ref):
+            assert np.array_equal(dseq[k, j].cpu().numpy(), rs)
+            assert np.allclose(dlp[k, j].cpu().numpy(), rl, atol=1e-6)
+            assert abs(float(dp[k, j]) - rp) < 1e-5

@@ -192,6 +192,27 @@ def test_beam_search_matches_reference(dev, name):
     assert len(model.done_beams) == nb
 
 
+def test_beam_search_is_independent_of_batch_composition(dev):
+    """All images share one decoder batch; an image's result must not depend on its neighbours, and beam
+    scores must be sorted (cumulative log-probs non-increasing)."""
+    cfg, spec, P, batch, gold = load_case('mid')
+    model = build(cfg, P, dev)
+    fc, att, labels, masks, top = to_dev(batch, dev)
+    together = model.sample(fc, att, {'beam_size': 5})
+    done_together = [list(d) for d in model.done_beams]
+    for k in (0, 3, 5):
+        alone = model.sample([f[k:k + 1] for f in fc], [a[k:k + 1] for a in att], {'beam_size': 5})
+        assert torch.equal(alone[0][0], together[0][k])
+        assert maxerr(alone[1][0], together[1][k].cpu()) < 1e-5
+        assert torch.equal(alone[2][0], together[2][k])
+        p = np.array(together[3][k])
+        assert np.all(np.diff(p) <= 1e-6) and len(p) == len(done_together[k])
+    # greedy == best beam's first token when the beam is wide enough to contain the greedy path's prefix
+    with torch.no_grad():
+        g = model.sample(fc, att, {'sample_max': 1})[0]
+    assert g.shape[0] == together[0].shape[0]
+
+
 def test_dropout_training_mode_runs_and_is_seeded(dev):
     cfg, spec, P, batch, gold = load_case('tiny0')
     cfg.drop_prob_lm, cfg.drop_prob_reason, cfg.drop_prob_fusion = 0.3, 0.2, 0.1
