@@ -258,6 +258,11 @@ class RecurrentFusionModel(nn.Module):
             self._bucket_slots['enc%s' % m.group(1) if m else 'core'].append(idx)
         self._prefix_buckets = ['core'] + ['enc%d' % i for i in range(M)]
         self.grad_ready_hook = None      # callable(bucket_name, flat_grad_tensor), see parallel.GradSync
+        # Opt-in: real batches hold each image's features `seq_per_img` times in a row (dataloader.py:251-252).
+        # With this set to that count, stages I/II run once per image and their outputs are fanned out to the
+        # caption rows (exactly the same numbers: rows are independent); only legal while drop_prob_fusion and
+        # drop_prob_reason are 0, which forward() checks.
+        self.dedup_seq_per_img = 0
         self._last_flat_grads = {}
         self._steps_cache = None
         self.done_beams = []
@@ -375,7 +380,18 @@ class RecurrentFusionModel(nn.Module):
         train = bool(self.training)
         seed = _fresh_seed() if train else 0
         S = self._decoder_steps(seq)          # may read `seq` back once: do it before queueing phase 1
-        comb, h, c, reason = self._prefix(fc_feats, att_feats, train, seed)
+        g = int(self.dedup_seq_per_img)
+        if g > 1:
+            if train and (self.drop_prob_fusion > 0 or self.drop_prob_reason > 0):
+                raise N.RfnError('dedup_seq_per_img needs drop_prob_fusion = drop_prob_reason = 0')
+            if fc_feats[0].size(0) % g:
+                raise N.RfnError('batch size is not a multiple of dedup_seq_per_img')
+            comb, h, c, reason = self._prefix([f[::g] for f in fc_feats], [a[::g] for a in att_feats], train, seed)
+            comb = comb.repeat_interleave(g, dim=1)       # autograd sums the caption rows back onto the image
+            h, c = h.repeat_interleave(g, dim=0), c.repeat_interleave(g, dim=0)
+            reason = reason.repeat_interleave(g, dim=1)
+        else:
+            comb, h, c, reason = self._prefix(fc_feats, att_feats, train, seed)
         ids = seq[:, :S]
         if self.ss_prob > 0.0 and S > 1:
             ids = self._scheduled_sampling_ids(ids, comb.detach(), h.detach(), c.detach())

@@ -232,6 +232,31 @@ def test_dropout_training_mode_runs_and_is_seeded(dev):
     assert maxerr(e, gold['log_prob']) < LOGP_TOL
 
 
+def test_dedup_of_replicated_images_is_exact(dev):
+    """dataloader.py:251-252 repeats every image seq_per_img times; running stages I/II once per image must give
+    the same log-probs and the same gradients as the plain path on the replicated batch."""
+    import recurrent_fusion_network_amd as R
+    cfg, spec, P, batch, gold = load_case('mid')
+    fc, att, labels, masks, top = to_dev(batch, dev)
+    g = 3
+    rep = lambda t: t[:2].repeat_interleave(g, dim=0).contiguous()  # noqa: E731   (2 images x 3 captions)
+    fc_r, att_r = [rep(f) for f in fc], [rep(a) for a in att]
+    crit = R.ReviewNetEnsembleCriterion(cfg)
+    outs = []
+    for dedup in (0, g):
+        model = build(cfg, P, dev)
+        model.dedup_seq_per_img = dedup
+        lp, reason = model(fc_r, att_r, labels)
+        crit(lp, labels[:, 1:], masks[:, 1:], reason, top, 1.0).backward()
+        outs.append((lp.detach(), [r.detach() for r in reason], {k: p.grad.clone() for k, p in model.named_parameters()}))
+    assert torch.equal(outs[0][0], outs[1][0])
+    for a, b in zip(outs[0][1], outs[1][1]):
+        assert torch.equal(a, b)
+    for k in outs[0][2]:
+        ref = outs[0][2][k]
+        assert maxerr(outs[1][2][k], ref.cpu()) <= 1e-6 + 1e-4 * float(ref.abs().max()), k
+
+
 def test_inference_hooks(dev):
     """get_init_state / get_thought_vectors / one_time_step (misc/RecurrentFusionModel.py:283-350)."""
     from oracle import rfn_oracle as O
