@@ -32,6 +32,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef GEMM_XCD_REMAP
 #define GEMM_XCD_REMAP 1
 #endif
+#ifndef GEMM_FAST_PATH
+#define GEMM_FAST_PATH 1   /* unchecked pointer-increment staging for interior single-segment problems */
+#endif
 #ifndef GEMM_FRAG_PIPE
 #define GEMM_FRAG_PIPE 0   /* explicit register double-buffering of the LDS fragments */
 #endif
@@ -124,6 +127,25 @@ struct Stage {
         }
     }
 
+    // interior tiles of single-segment problems: per-thread source pointers are computed once and advanced by
+    // a constant per K step -- no bounds checks, no exec-masked branches, no 64-bit multiplies in the loop
+    __device__ __forceinline__ void init_ptrs(const float* (&p)[NV], const float* __restrict__ base, long ld,
+                                              int row0, int tid) const {
+        static_assert(VEC, "fast path needs float4 staging");
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            if constexpr (KFAST) p[j] = base + (long)(row0 + tid / KQ + RPASS * j) * ld + 4 * (tid % KQ);
+            else p[j] = base + (long)(tid / RQ + KPASS * j) * ld + row0 + 4 * (tid % RQ);
+        }
+    }
+    __device__ __forceinline__ void load_fast(const float* (&p)[NV], long step) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            v[j] = *reinterpret_cast<const f32x4*>(p[j]);
+            p[j] += step;
+        }
+    }
+
     __device__ __forceinline__ void store(float* __restrict__ lds, int tid) const {
         if constexpr (VEC && KFAST) {
 #pragma unroll
@@ -179,7 +201,8 @@ struct Stage {
 
 // STAGES = 2: double-buffered LDS, one barrier per K step (2 blocks/CU at 128x128).
 // STAGES = 1: single buffer, two barriers per K step, half the LDS -> 3 blocks/CU cover each other's stalls.
-template <int BM, int BN, bool AK, bool BKF, bool VEC, int STAGES, int BK>
+// FAST: every tile is interior (M % BM == N % BN == K % BK == 0), one K segment, no split-K.
+template <int BM, int BN, bool AK, bool BKF, bool VEC, int STAGES, int BK, bool FAST>
 __global__ __launch_bounds__(GEMM_THREADS, GEMM_MIN_WAVES) void rfn_gemm_kernel(const GemmArgs args) {
     constexpr int MT = BM / 64;  // 32x32 MFMA tiles per wave along M
     constexpr int NT = BN / 64;
@@ -260,17 +283,49 @@ __global__ __launch_bounds__(GEMM_THREADS, GEMM_MIN_WAVES) void rfn_gemm_kernel(
         }
         k0 = it_begin * BK;
     }
-    auto issue_load = [&]() {
-        const rfn_gemm_seg& S = P.seg[seg];
-        stA.load(S.A, S.lda, row0, M, k0, S.K, tid);
-        stB.load(S.B, S.ldb, col0, N, k0, S.K, tid);
-        if constexpr (!AK) {
-            if (do_colsum) stA.add_rowsum(ps);
+    // current segment's operands live in registers; the kernarg table is re-read only when the segment changes
+    const float* segA = nullptr;
+    const float* segB = nullptr;
+    long seg_lda = 0, seg_ldb = 0;
+    int segK = 0;
+    auto fetch_seg = [&]() {
+        if (seg < P.nseg) {
+            segA = P.seg[seg].A;
+            segB = P.seg[seg].B;
+            seg_lda = P.seg[seg].lda;
+            seg_ldb = P.seg[seg].ldb;
+            segK = P.seg[seg].K;
         }
-        k0 += BK;
-        if (k0 >= S.K) {
-            k0 = 0;
-            ++seg;
+    };
+    fetch_seg();
+    const float* pa[StA::NV];
+    const float* pb[StB::NV];
+    long stepA = 0, stepB = 0;
+    if constexpr (FAST) {
+        stA.init_ptrs(pa, segA, seg_lda, row0, tid);
+        stB.init_ptrs(pb, segB, seg_ldb, col0, tid);
+        stepA = AK ? BK : (long)BK * seg_lda;
+        stepB = BKF ? BK : (long)BK * seg_ldb;
+    }
+    auto issue_load = [&]() {
+        if constexpr (FAST) {
+            stA.load_fast(pa, stepA);
+            stB.load_fast(pb, stepB);
+            if constexpr (!AK) {
+                if (do_colsum) stA.add_rowsum(ps);
+            }
+        } else {
+            stA.load(segA, seg_lda, row0, M, k0, segK, tid);
+            stB.load(segB, seg_ldb, col0, N, k0, segK, tid);
+            if constexpr (!AK) {
+                if (do_colsum) stA.add_rowsum(ps);
+            }
+            k0 += BK;
+            if (k0 >= segK) {
+                k0 = 0;
+                ++seg;
+                fetch_seg();
+            }
         }
     };
 
@@ -433,13 +488,13 @@ __global__ __launch_bounds__(256) void rfn_gemm_reduce_k(const GemmArgs args) {
     *c = args.accumulate ? *c + s : s;
 }
 
-template <int BM, int BN, bool AK, bool BKF, bool VEC, int STAGES, int BK>
+template <int BM, int BN, bool AK, bool BKF, bool VEC, int STAGES, int BK, bool FAST = false>
 static int launch_cfg(const GemmArgs& a, hipStream_t st) {
     using StA = Stage<BM, AK, VEC, BK>;
     using StB = Stage<BN, BKF, VEC, BK>;
     const size_t lds = STAGES * (StA::LDS_FLOATS + StB::LDS_FLOATS) * sizeof(float);
     const int nblk = a.ngroups * a.tiles_m * a.tiles_n * a.splitk;
-    auto k = rfn_gemm_kernel<BM, BN, AK, BKF, VEC, STAGES, BK>;
+    auto k = rfn_gemm_kernel<BM, BN, AK, BKF, VEC, STAGES, BK, FAST>;
     static bool attr_set = false;  // idempotent; a race only repeats the same call
     if (!attr_set) {
         hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -462,6 +517,16 @@ static int launch_tile(GemmArgs& a, hipStream_t st) {
     if (big >= 384) {
         a.tiles_m = rfn_cdiv(a.M, GEMM_BIG_BM);
         a.tiles_n = rfn_cdiv(a.N, GEMM_BIG_BN);
+#if GEMM_FAST_PATH
+        if constexpr (VEC) {
+            bool fast = (a.M % GEMM_BIG_BM == 0) && (a.N % GEMM_BIG_BN == 0);
+            for (int g = 0; g < a.ngroups; ++g)
+                fast = fast && a.g[g].nseg == 1 && a.g[g].seg[0].K > 0 && (a.g[g].seg[0].K % GEMM_BIG_BK == 0);
+            if (fast)
+                return launch_cfg<GEMM_BIG_BM, GEMM_BIG_BN, AK, BKF, true, (AK && BKF) ? GEMM_NT_STAGES : GEMM_XX_STAGES,
+                                  GEMM_BIG_BK, true>(a, st);
+        }
+#endif
         return launch_cfg<GEMM_BIG_BM, GEMM_BIG_BN, AK, BKF, VEC, (AK && BKF) ? GEMM_NT_STAGES : GEMM_XX_STAGES, GEMM_BIG_BK>(a, st);
     }
     a.tiles_m = rfn_cdiv(a.M, 64);
