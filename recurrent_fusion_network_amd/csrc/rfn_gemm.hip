@@ -32,6 +32,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef GEMM_XCD_REMAP
 #define GEMM_XCD_REMAP 1
 #endif
+#ifndef GEMM_BAND_ROWS
+#define GEMM_BAND_ROWS 8    /* row tiles per band of the block order (B-operand panels are re-fetched once per band) */
+#endif
 #ifndef GEMM_FAST_PATH
 #define GEMM_FAST_PATH 1   /* unchecked pointer-increment staging for interior single-segment problems */
 #endif
@@ -235,12 +238,12 @@ __global__ __launch_bounds__(GEMM_THREADS, GEMM_MIN_WAVES) void rfn_gemm_kernel(
     }
     const int ks = lid % splitk;  // the K ranges of one tile run next to each other
     lid /= splitk;
-    const int per_band = 8 * NC;
+    const int per_band = GEMM_BAND_ROWS * NC;
     const int band = lid / per_band;
     const int rem = lid - band * per_band;
-    const int band_rows = min(8, args.tiles_m - band * 8);
+    const int band_rows = min(GEMM_BAND_ROWS, args.tiles_m - band * GEMM_BAND_ROWS);
     const int vcol = rem / band_rows;
-    const int tm = band * 8 + (rem - vcol * band_rows);
+    const int tm = band * GEMM_BAND_ROWS + (rem - vcol * band_rows);
     const int grp = vcol / args.tiles_n;
     const int tn = vcol - grp * args.tiles_n;
 

@@ -19,14 +19,18 @@ def init_from_env(backend=None):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1 and not dist.is_initialized():
+    force = os.environ.get('RFN_FORCE_DIST', '0') == '1'   # test hook: build a process group even for one rank
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend is None:
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'
         if backend == 'nccl':
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            dist.init_process_group(backend=backend, rank=rank, world_size=world,
+                                    device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
 
 
@@ -64,7 +68,7 @@ class GradSync:
 
     def on_bucket(self, name, flat):
         self.buckets.append(name)
-        if self.world > 1:
+        if self.world > 1 or (dist.is_available() and dist.is_initialized()):
             self.works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True))
 
     def finish(self):

@@ -5,8 +5,8 @@ cd "$(dirname "$0")/.."
 mkdir -p /tmp/gb
 build() { hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-unused-value -Wno-unused-result -DVARIANT="\"$1\"" $2 tools/gemm_bench.hip -o /tmp/gb/$1; }
 build default ""
-build xx1 "-DGEMM_XX_STAGES=1"
-build nt2 "-DGEMM_NT_STAGES=2"
-build xx1_w3 "-DGEMM_XX_STAGES=1 -DGEMM_MIN_WAVES=3"
-build fragpipe "-DGEMM_FRAG_PIPE=1"
-for v in default xx1 nt2 xx1_w3 fragpipe; do /tmp/gb/$v; done
+build band4 "-DGEMM_BAND_ROWS=4"
+build band16 "-DGEMM_BAND_ROWS=16"
+build band32 "-DGEMM_BAND_ROWS=32"
+build band64 "-DGEMM_BAND_ROWS=64"
+for v in default band4 band16 band32 band64; do /tmp/gb/$v; done
