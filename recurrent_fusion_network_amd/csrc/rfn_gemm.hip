@@ -32,6 +32,21 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef GEMM_XCD_REMAP
 #define GEMM_XCD_REMAP 1
 #endif
+#ifndef GEMM_SMALL_BK
+#define GEMM_SMALL_BK 32     /* K step of the 64x64 tile */
+#endif
+#ifndef GEMM_SMALL_STAGES
+#define GEMM_SMALL_STAGES 2
+#endif
+#ifndef GEMM_MEDIUM_MIN_FLOPS
+#define GEMM_MEDIUM_MIN_FLOPS 6e9 /* per launch; below this the 64x64 tile + split-K stays */
+#endif
+#ifndef GEMM_SPLIT_MIN_ITERS
+#define GEMM_SPLIT_MIN_ITERS 4 /* K iterations every split block keeps at least */
+#endif
+#ifndef GEMM_SPLIT_TARGET
+#define GEMM_SPLIT_TARGET 768 /* blocks a split-K launch aims for */
+#endif
 #ifndef GEMM_BAND_ROWS
 #define GEMM_BAND_ROWS 8    /* row tiles per band of the block order (B-operand panels are re-fetched once per band) */
 #endif
@@ -134,11 +149,12 @@ struct Stage {
     // a constant per K step -- no bounds checks, no exec-masked branches, no 64-bit multiplies in the loop
     __device__ __forceinline__ void init_ptrs(const float* (&p)[NV], const float* __restrict__ base, long ld,
                                               int row0, int tid) const {
-        static_assert(VEC, "fast path needs float4 staging");
+        if constexpr (VEC) {   // the fast path exists for float4 staging only; never called otherwise
 #pragma unroll
-        for (int j = 0; j < NV; ++j) {
-            if constexpr (KFAST) p[j] = base + (long)(row0 + tid / KQ + RPASS * j) * ld + 4 * (tid % KQ);
-            else p[j] = base + (long)(tid / RQ + KPASS * j) * ld + row0 + 4 * (tid % RQ);
+            for (int j = 0; j < NV; ++j) {
+                if constexpr (KFAST) p[j] = base + (long)(row0 + tid / KQ + RPASS * j) * ld + 4 * (tid % KQ);
+                else p[j] = base + (long)(tid / RQ + KPASS * j) * ld + row0 + 4 * (tid % RQ);
+            }
         }
     }
     __device__ __forceinline__ void load_fast(const float* (&p)[NV], long step) {
@@ -204,7 +220,7 @@ struct Stage {
 
 // STAGES = 2: double-buffered LDS, one barrier per K step (2 blocks/CU at 128x128).
 // STAGES = 1: single buffer, two barriers per K step, half the LDS -> 3 blocks/CU cover each other's stalls.
-// FAST: every tile is interior (M % BM == N % BN == K % BK == 0), one K segment, no split-K.
+// FAST: every tile is interior (M % BM == N % BN == 0 and every segment's K % BK == 0).
 template <int BM, int BN, bool AK, bool BKF, bool VEC, int STAGES, int BK, bool FAST>
 __global__ __launch_bounds__(GEMM_THREADS, GEMM_MIN_WAVES) void rfn_gemm_kernel(const GemmArgs args) {
     constexpr int MT = BM / 64;  // 32x32 MFMA tiles per wave along M
@@ -304,30 +320,33 @@ __global__ __launch_bounds__(GEMM_THREADS, GEMM_MIN_WAVES) void rfn_gemm_kernel(
     const float* pa[StA::NV];
     const float* pb[StB::NV];
     long stepA = 0, stepB = 0;
-    if constexpr (FAST) {
-        stA.init_ptrs(pa, segA, seg_lda, row0, tid);
-        stB.init_ptrs(pb, segB, seg_ldb, col0, tid);
+    auto setup_fast = [&]() {  // per-thread source pointers of the tile at (seg, k0)
+        stA.init_ptrs(pa, segA + (AK ? (long)k0 : (long)k0 * seg_lda), seg_lda, row0, tid);
+        stB.init_ptrs(pb, segB + (BKF ? (long)k0 : (long)k0 * seg_ldb), seg_ldb, col0, tid);
         stepA = AK ? BK : (long)BK * seg_lda;
         stepB = BKF ? BK : (long)BK * seg_ldb;
+    };
+    if constexpr (FAST) {
+        if (seg < P.nseg) setup_fast();
     }
     auto issue_load = [&]() {
         if constexpr (FAST) {
             stA.load_fast(pa, stepA);
             stB.load_fast(pb, stepB);
-            if constexpr (!AK) {
-                if (do_colsum) stA.add_rowsum(ps);
-            }
         } else {
             stA.load(segA, seg_lda, row0, M, k0, segK, tid);
             stB.load(segB, seg_ldb, col0, N, k0, segK, tid);
-            if constexpr (!AK) {
-                if (do_colsum) stA.add_rowsum(ps);
-            }
-            k0 += BK;
-            if (k0 >= segK) {
-                k0 = 0;
-                ++seg;
-                fetch_seg();
+        }
+        if constexpr (!AK) {
+            if (do_colsum) stA.add_rowsum(ps);
+        }
+        k0 += BK;
+        if (k0 >= segK) {  // next K segment (rare): refresh the register-resident descriptor
+            k0 = 0;
+            ++seg;
+            fetch_seg();
+            if constexpr (FAST) {
+                if (seg < P.nseg) setup_fast();
             }
         }
     };
@@ -517,14 +536,35 @@ static int launch_tile(GemmArgs& a, hipStream_t st) {
     // big tile when it still fills the chip (>= 2 blocks per CU), else 64x64 for the skinny
     // per-step GEMMs (M = batch) so that more CUs get a tile.
     const long big = (long)rfn_cdiv(a.M, 128) * rfn_cdiv(a.N, 128) * a.ngroups;
-    if (big >= 384) {
+    bool colsum = false;
+    int iters32 = 0;
+    double flops = 0;
+    for (int g = 0; g < a.ngroups; ++g) colsum = colsum || (a.g[g].a_colsum != nullptr);
+    for (int s = 0; s < a.g[0].nseg; ++s) {
+        iters32 += rfn_cdiv(a.g[0].seg[s].K, GEMM_BIG_BK);
+        flops += 2.0 * a.M * a.N * a.g[0].seg[s].K * a.ngroups;
+    }
+    // Medium problems (the heavier per-step GEMMs: M = batch, a few GF): the 128x128 tile is ~1.5x more efficient
+    // than 64x64 but yields too few tiles, so cut K across blocks to reach ~2 blocks per CU.
+    int big_split = 1;
+    if (big < 384 && a.part && !colsum && big >= 16 && flops >= GEMM_MEDIUM_MIN_FLOPS) {
+        long want = (512 + big - 1) / big;
+        if (want > iters32 / 8) want = iters32 / 8;
+        if (want > 16) want = 16;
+        const long cap = (long)a.pad_ * (1 << 18) / ((long)a.M * a.N * a.ngroups);
+        if (want > cap) want = cap;
+        if (want >= 2) big_split = (int)want;
+    }
+    if (big >= 384 || big_split > 1) {
+        a.splitk = big_split;
         a.tiles_m = rfn_cdiv(a.M, GEMM_BIG_BM);
         a.tiles_n = rfn_cdiv(a.N, GEMM_BIG_BN);
 #if GEMM_FAST_PATH
         if constexpr (VEC) {
             bool fast = (a.M % GEMM_BIG_BM == 0) && (a.N % GEMM_BIG_BN == 0);
             for (int g = 0; g < a.ngroups; ++g)
-                fast = fast && a.g[g].nseg == 1 && a.g[g].seg[0].K > 0 && (a.g[g].seg[0].K % GEMM_BIG_BK == 0);
+                for (int s = 0; s < a.g[g].nseg; ++s)
+                    fast = fast && a.g[g].seg[s].K > 0 && (a.g[g].seg[s].K % GEMM_BIG_BK == 0);
             if (fast)
                 return launch_cfg<GEMM_BIG_BM, GEMM_BIG_BN, AK, BKF, true, (AK && BKF) ? GEMM_NT_STAGES : GEMM_XX_STAGES,
                                   GEMM_BIG_BK, true>(a, st);
@@ -539,17 +579,15 @@ static int launch_tile(GemmArgs& a, hipStream_t st) {
     if (a.part) {
         const long tiles = (long)a.tiles_m * a.tiles_n * a.ngroups;
         int iters = 0;
-        bool colsum = false;
-        for (int s = 0; s < a.g[0].nseg; ++s) iters += rfn_cdiv(a.g[0].seg[s].K, 32);
-        for (int g = 0; g < a.ngroups; ++g) colsum = colsum || (a.g[g].a_colsum != nullptr);
-        long want = tiles > 0 ? 768 / tiles : 1;
-        if (want > iters / 4) want = iters / 4;
+        for (int s = 0; s < a.g[0].nseg; ++s) iters += rfn_cdiv(a.g[0].seg[s].K, GEMM_SMALL_BK);
+        long want = tiles > 0 ? GEMM_SPLIT_TARGET / tiles : 1;
+        if (want > iters / GEMM_SPLIT_MIN_ITERS) want = iters / GEMM_SPLIT_MIN_ITERS;
         if (want > 16) want = 16;
         const long cap = (long)(a.pad_ /* ws MiB */) * (1 << 18) / ((long)a.M * a.N * a.ngroups);  // floats
         if (want > cap) want = cap;
         a.splitk = (!colsum && want >= 2) ? (int)want : 1;
     }
-    return launch_cfg<64, 64, AK, BKF, VEC, 2, 32>(a, st);
+    return launch_cfg<64, 64, AK, BKF, VEC, GEMM_SMALL_STAGES, GEMM_SMALL_BK>(a, st);
 }
 
 extern "C" int rfn_gemm_f32(int M, int N, int ngroups, const rfn_gemm_problem* problems, int accumulate,
