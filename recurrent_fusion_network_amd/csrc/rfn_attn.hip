@@ -162,9 +162,9 @@ extern "C" int rfn_attn_context_fwd(const float* att_seq, int64_t sb, int64_t sl
 }
 
 // ---- backward of the context: dalpha[b,l] = <dz[b,:], x[b,l,:]> ---------------------------------
-#define DAL_ROWS 16 /* rows of L per block: B * ceil(L/16) blocks keep every CU streaming */
-// Each wave owns 4 rows and walks them TOGETHER along d, so 4 (x2 with the unroll) independent 16-B loads are
-// in flight per lane instead of one row's dependent stream.
+#define DAL_ROWS 64 /* rows of L per block (16 per wave): ~0.5 MB streamed per block, B * ceil(L/64) blocks */
+// Each wave owns 16 rows in groups of 4 that it walks TOGETHER along d, so 4 (x2 with the unroll) independent
+// 16-B loads are in flight per lane instead of one row's dependent stream.
 template <bool VEC>
 __global__ __launch_bounds__(ATT_THREADS) void attn_dalpha_k(const float* __restrict__ x, long sb, long sl,
                                                             const float* __restrict__ dz, long lddz, int L, int D,
@@ -173,31 +173,33 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_dalpha_k(const float* __rest
     const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int d = tid; d < D; d += ATT_THREADS) dz_s[d] = dz[b * lddz + d];
     __syncthreads();
-    const int l0 = blockIdx.x * DAL_ROWS + wave * 4;   // rows l0 .. l0+3 of this wave
-    const float* p0 = x + b * sb + (long)l0 * sl;
-    const int nr = min(4, L - l0);
-    if (nr <= 0) return;
-    float part[4] = {0.f, 0.f, 0.f, 0.f};
-    if constexpr (VEC) {
+    for (int grp = 0; grp < DAL_ROWS / (4 * ATT_WAVES); ++grp) {
+        const int l0 = blockIdx.x * DAL_ROWS + (grp * ATT_WAVES + wave) * 4;   // rows l0 .. l0+3 of this wave
+        const int nr = min(4, L - l0);
+        if (nr <= 0) break;
+        const float* p0 = x + b * sb + (long)l0 * sl;
+        float part[4] = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (VEC) {
 #pragma unroll 2
-        for (int d = lane * 4; d < D; d += 256) {
-            const f32x4 gv = *reinterpret_cast<const f32x4*>(dz_s + d);
-            f32x4 xv[4];
+            for (int d = lane * 4; d < D; d += 256) {
+                const f32x4 gv = *reinterpret_cast<const f32x4*>(dz_s + d);
+                f32x4 xv[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                xv[r] = (r < nr) ? *reinterpret_cast<const f32x4*>(p0 + r * sl + d) : f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int r = 0; r < 4; ++r)   // rows past the end re-read the last valid row (result discarded):
+                    xv[r] = *reinterpret_cast<const f32x4*>(p0 + min(r, nr - 1) * sl + d);  // no branch per load
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                part[r] += xv[r][0] * gv[0] + xv[r][1] * gv[1] + xv[r][2] * gv[2] + xv[r][3] * gv[3];
+                for (int r = 0; r < 4; ++r)
+                    part[r] += xv[r][0] * gv[0] + xv[r][1] * gv[1] + xv[r][2] * gv[2] + xv[r][3] * gv[3];
+            }
+        } else {
+            for (int d = lane; d < D; d += 64)
+                for (int r = 0; r < nr; ++r) part[r] += p0[r * sl + d] * dz_s[d];
         }
-    } else {
-        for (int d = lane; d < D; d += 64)
-            for (int r = 0; r < nr; ++r) part[r] += p0[r * sl + d] * dz_s[d];
-    }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const float t = rfn_wave_sum(part[r]);
-        if (lane == 0 && r < nr) dalpha[(long)b * L + l0 + r] = t;
+        for (int r = 0; r < 4; ++r) {
+            const float t = rfn_wave_sum(part[r]);
+            if (lane == 0 && r < nr) dalpha[(long)b * L + l0 + r] = t;
+        }
     }
 }
 
