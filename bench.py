@@ -36,10 +36,16 @@ WORKLOADS = {
 
 
 def make_cfg(w):
-    from oracle import rfn_oracle as O   # only for the shared seeded-weight / synthetic-input streams
+    """The `opt` Namespace fields the model and the criteria read (reference opts.py defaults).
+    Built here, not taken from oracle/: the oracle is only touched by the cpu_baseline leg."""
+    from types import SimpleNamespace
     info = [dict(att_num=w['L'], att_feat_size=w['D'], fc_feat_size=w['D']) for _ in range(w['M'])]
-    return O.make_cfg(info, vocab_size=9487, rnn_size=512, input_encoding_size=512, att_hid_size=512,
-                      num_review_steps_0=8, num_review_steps=8, top_words_count=1000, seq_length=16)
+    return SimpleNamespace(
+        caption_model='recurrent_fusion_model', vocab_size=9487, input_encoding_size=512, rnn_type='lstm',
+        rnn_size=512, num_layers=1, drop_prob_lm=0.0, drop_prob_reason=0.0, drop_prob_fusion=0.0, seq_length=16,
+        num_review_steps=8, num_review_steps_0=8, top_words_count=1000, att_hid_size=512, review_maxout=0,
+        maxout=0, fusion_maxout=0, use_cuda=1, feat_array_info=info, use_label_smoothing=0,
+        label_smoothing_epsilon=0.1, use_ppo=0, ppo_clip=0.2)
 
 
 def synthetic_inputs(cfg, B, seed, dev):
@@ -112,7 +118,7 @@ def main():
     ap.add_argument('--workload', default='c3', choices=sorted(WORKLOADS))
     ap.add_argument('--batch', type=int, default=0, help='captions per GPU (default: the workload value)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-sample', type=int, default=4)
+    ap.add_argument('--cpu-sample', type=int, default=16, help='captions in the CPU-baseline sample (~10 s of CPU work)')
     args = ap.parse_args()
 
     import recurrent_fusion_network_amd as R
@@ -178,15 +184,18 @@ def main():
         # roofline of the dominant kernel, timed live with HIP events on the launch stream
         secs, flops = time_dominant_kernel(model, att, reps=5)
         achieved = flops / secs / 1e12
-        traffic = None
-        tfile = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')   # written from the rocprofv3 --pmc passes
+        traffic = None               # HBM-side bytes per launch of that kernel, from the rocprofv3 --pmc passes
+        tfile = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
         if os.path.exists(tfile):
             try:
-                traffic = json.load(open(tfile)).get(args.workload)
+                gb = json.load(open(tfile)).get(args.workload)
+                traffic = None if gb is None else int(gb * 1e9)
             except Exception:
                 traffic = None
         out['roofline'] = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': FP32_MFMA_PEAK_TFLOPS,
                            'unit': 'TFLOP/s', 'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': traffic,
+                           'traffic_unit': 'bytes per launch (2*FETCH_SIZE + WRITE_SIZE)',
+                           'algorithmic_bytes': int(4 * (B * w['L'] * w['D'] + 8 * 512 * w['D'] + B * w['L'] * 8 * 512)),
                            'kernel': 'rfn_gemm_kernel<128,128,kfast,kfast,vec> (grouped att_2_att_h projection, '
                                      '%.3f TFLOP per launch, %.3f ms per launch)' % (flops / 1e12, secs * 1e3)}
         # whole-step view against the same peak (SURVEY.md 8d algorithmic FLOP of one step)
