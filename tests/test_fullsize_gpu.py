@@ -1,0 +1,119 @@
+"""Full-size (BASELINE config C3: B=256, M=4, L=196, D=2048) checks through size-independent properties, and
+edge-case shapes against the oracle."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _c3(dev, B, seed=100):
+    import bench as HB
+    import recurrent_fusion_network_amd as R
+    cfg = HB.make_cfg(HB.WORKLOADS['c3'])
+    model = R.RecurrentFusionModel(cfg).to(dev)
+    HB.seeded_weights_(model, seed)
+    model.eval()
+    batch = HB.synthetic_inputs(cfg, B, seed, dev)
+    return cfg, model, batch
+
+
+def test_c3_full_batch_properties(dev):
+    import recurrent_fusion_network_amd as R
+    B = 256
+    cfg, model, (fc, att, labels, masks, top) = _c3(dev, B)
+    crit = R.ReviewNetEnsembleCriterion(cfg)
+
+    def run(rows):
+        sl = lambda t: t[rows].contiguous()  # noqa: E731
+        model.zero_grad(set_to_none=True)
+        lp, reason = model([sl(f) for f in fc], [sl(a) for a in att], sl(labels))
+        loss = crit(lp, sl(labels)[:, 1:], sl(masks)[:, 1:], reason, sl(top), 1.0)
+        loss.backward()
+        grads = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+        return lp.detach(), [r.detach() for r in reason], loss.detach(), grads
+
+    allrows = torch.arange(B, device=dev)
+    lp, reason, loss, g_full = run(allrows)
+    assert tuple(lp.shape) == (B, 17, 9488)
+    # every distribution is normalised
+    assert float(torch.logsumexp(lp, 2).abs().max()) < 1e-4
+    # determinism: a second run gives the same bits (no float atomics anywhere on the path)
+    lp2, _, loss2, g2 = run(allrows)
+    assert torch.equal(lp, lp2) and torch.equal(loss, loss2)
+    k = 'review_steps_individual.3.lstm.1.att_model.att_2_att_h.weight'
+    assert torch.equal(g_full[k], g2[k])
+    # batch rows are independent: a 6-row sub-batch reproduces those rows of the full batch
+    rows = torch.tensor([0, 1, 77, 128, 200, 255], device=dev)
+    lp_s, reason_s, _, _ = run(rows)
+    assert float((lp_s - lp[rows]).abs().max()) < 2e-5
+    for a, b in zip(reason_s, reason):
+        assert float((a - b[rows]).abs().max()) < 2e-5
+    # gradients are additive over rows: B * g(full) = B/2 * g(first half) + B/2 * g(second half)
+    _, _, l1, g1 = run(allrows[:B // 2])
+    _, _, l2, g2h = run(allrows[B // 2:])
+    assert abs(float(loss) - 0.5 * (float(l1) + float(l2))) < 1e-3 * abs(float(loss))
+    for name in (k, 'decoder.h2h.weight', 'review_steps.0.z_2_h.1.weight', 'fc2h.0.weight', 'embed.weight',
+                 'logit.bias', 'review_steps_individual.0.lstm.3.H2h.weight'):
+        want = 0.5 * (g1[name] + g2h[name])
+        err = float((g_full[name] - want).abs().max())
+        assert err <= 1e-6 + 2e-3 * float(want.abs().max()), (name, err)
+
+
+def test_c3_greedy_decode_is_deterministic_and_consistent_with_forward(dev):
+    cfg, model, (fc, att, labels, masks, top) = _c3(dev, 64, seed=7)
+    with torch.no_grad():
+        seq, seq_lp, lp_all, _ = model.sample(fc, att, {'sample_max': 1})
+        seq2 = model.sample(fc, att, {'sample_max': 1})[0]
+        assert torch.equal(seq, seq2)
+        # teacher-forcing the greedy ids reproduces the free-running log-probs wherever the row was alive
+        ids = torch.zeros(64, seq.size(1) + 1, dtype=torch.long, device=dev)
+        ids[:, 1:] = seq
+        lp_tf, _ = model(fc, att, torch.cat([ids, torch.zeros(64, 1, dtype=torch.long, device=dev)], 1))
+    T = min(lp_tf.size(1), lp_all.size(1))
+    alive = torch.cat([torch.ones(64, 1, dtype=torch.bool, device=dev), seq > 0], 1)[:, :T]
+    assert float(((lp_tf[:, :T] - lp_all[:, :T]).abs().amax(2) * alive).max()) < 1e-4
+    # greedy picks are the arg-max of the previous step's distribution
+    assert torch.equal((lp_all[:, :seq.size(1)].argmax(2) * (seq > 0)), seq)
+
+
+@pytest.mark.parametrize('case', ['batch_of_one', 'single_encoder_single_region', 'five_shipped_encoders'])
+def test_edge_shapes_against_oracle(dev, case):
+    """B = 1 (the reference's .squeeze() breaks there, AttentionModelCore.py:47), M = 1 with L = 1, and the
+    reference's five heterogeneous encoders (feat_array.py:240-244: D in {2048, 1536, 1280, 2208}, L in {196, 64, 49},
+    fc != D for Inception-v3)."""
+    import recurrent_fusion_network_amd as R
+    from oracle import rfn_oracle as O
+    if case == 'batch_of_one':
+        info = [dict(att_num=5, att_feat_size=24, fc_feat_size=24), dict(att_num=7, att_feat_size=40, fc_feat_size=32)]
+        B, R_ = 1, 16
+    elif case == 'single_encoder_single_region':
+        info = [dict(att_num=1, att_feat_size=20, fc_feat_size=12)]
+        B, R_ = 3, 16
+    else:
+        info = [dict(att_num=196, att_feat_size=2048, fc_feat_size=2048), dict(att_num=64, att_feat_size=1536, fc_feat_size=1536),
+                dict(att_num=64, att_feat_size=1280, fc_feat_size=2048), dict(att_num=49, att_feat_size=2208, fc_feat_size=2208),
+                dict(att_num=64, att_feat_size=1536, fc_feat_size=1536)]
+        B, R_ = 3, 64
+    cfg = O.make_cfg(info, vocab_size=60, rnn_size=R_, input_encoding_size=R_, att_hid_size=R_, num_review_steps_0=2,
+                     num_review_steps=2, top_words_count=12, seq_length=4)
+    P = O.seeded_params(cfg, 5, scale=0.05)
+    fc, att, labels, masks, top = O.synthetic_batch(cfg, B, seed=9)
+    model = R.RecurrentFusionModel(cfg)
+    model.load_state_dict(P)
+    model = model.to(dev).eval()
+    d = lambda ts: [t.to(dev) for t in ts]  # noqa: E731
+    lp, reason = model(d(fc), d(att), labels.to(dev))
+    crit = R.ReviewNetEnsembleCriterion(cfg)
+    loss = crit(lp, labels.to(dev)[:, 1:], masks.to(dev)[:, 1:], reason, top.to(dev), 1.0)
+    loss.backward()
+    o_lp, o_reason = O.forward(cfg, P, fc, att, labels)
+    o_loss, o_grads = O.train_step_loss_and_grads(cfg, P, fc, att, labels, masks, top, 1.0)
+    assert float((lp.detach().cpu() - o_lp).abs().max()) < 1e-3
+    assert abs(float(loss.detach()) - float(o_loss)) < 1e-3 * max(1.0, abs(float(o_loss)))
+    named = dict(model.named_parameters())
+    for k, g in o_grads.items():
+        err = float((named[k].grad.cpu() - g).abs().max())
+        assert err <= 1e-5 + 2e-3 * float(g.abs().max()), (k, err)
+    with torch.no_grad():
+        seq = model.sample(d(fc), d(att), {'sample_max': 1})[0]
+    assert torch.equal(seq.cpu(), O.sample_greedy(cfg, P, fc, att)[0])
