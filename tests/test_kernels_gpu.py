@@ -498,3 +498,61 @@ def test_beam_step_kernel_matches_python_bookkeeping(dev, W, V1, S):
             assert np.array_equal(dseq[k, j].cpu().numpy(), rs)
             assert np.allclose(dlp[k, j].cpu().numpy(), rl, atol=1e-6)
             assert abs(float(dp[k, j]) - rp) < 1e-5
+
+
+def test_gemm_randomized_shapes_layouts_segments_groups(dev):
+    """60 random problems: all operand layouts, ragged / tiny / large dims, 1-4 K segments of different lengths
+    (different per group), 1-5 groups, bias on some segments, accumulate, padded ldc/lda/ldb, split-K scratch on
+    and off -- every dispatch branch of rfn_gemm_f32_ws against fp64."""
+    import random
+    n = N()
+    rng = random.Random(1234)
+    ws = torch.empty(48 << 20, dtype=torch.uint8, device=dev)
+    g = torch.Generator().manual_seed(99)
+    dims_m = [1, 3, 64, 100, 128, 256, 300, 1024]
+    dims_n = [1, 20, 51, 64, 128, 130, 512, 2048]
+    dims_k = [1, 7, 16, 32, 40, 96, 256, 1000, 2048]
+    for case in range(60):
+        M, Nn = rng.choice(dims_m), rng.choice(dims_n)
+        ak, bk = rng.randint(0, 1), rng.randint(0, 1)
+        ngroups, nseg = rng.randint(1, 5), rng.randint(1, 4)
+        acc, use_ws = rng.random() < 0.4, rng.random() < 0.6
+        pad = rng.choice([0, 0, 4, 5])
+        problems, refs, keep = [], [], []
+        for _ in range(ngroups):
+            ldc = Nn + pad
+            Cfull = torch.randn(M, ldc, generator=g)
+            ref = Cfull[:, :Nn].double().clone() if acc else torch.zeros(M, Nn, dtype=torch.float64)
+            segs = []
+            for _ in range(nseg):
+                K = rng.choice(dims_k)
+                A, Bm = torch.randn(M, K, generator=g), torch.randn(Nn, K, generator=g)
+                ref += A.double() @ Bm.double().t()
+                bias = None
+                if rng.random() < 0.5:
+                    bias = torch.randn(Nn, generator=g)
+                    ref += bias.double()
+                # storage with padded leading dimensions
+                if ak:
+                    Ast = torch.zeros(M, K + pad); Ast[:, :K] = A; lda = K + pad
+                else:
+                    Ast = torch.zeros(K, M + pad); Ast[:, :M] = A.t(); lda = M + pad
+                if bk:
+                    Bst = torch.zeros(Nn, K + pad); Bst[:, :K] = Bm; ldb = K + pad
+                else:
+                    Bst = torch.zeros(K, Nn + pad); Bst[:, :Nn] = Bm.t(); ldb = Nn + pad
+                Ad, Bd = Ast.to(dev), Bst.to(dev)
+                bd = None if bias is None else bias.to(dev)
+                keep += [Ad, Bd, bd]
+                segs.append((Ad, lda, ak, Bd, ldb, bk, K, bd))
+            Cd = Cfull.to(dev)
+            problems.append((Cd, ldc, segs))
+            refs.append((ref, Cfull))
+        n.gemm(M, Nn, problems, accumulate=acc, ws=ws if use_ws else None)
+        for (Cd, ldc, segs), (ref, Cfull) in zip(problems, refs):
+            ktot = sum(s_[6] for s_ in segs)
+            tol = 1e-5 + 3e-6 * ktot * 3.0
+            err = maxerr(Cd[:, :Nn], ref)
+            assert err < tol, (case, M, Nn, ak, bk, ngroups, nseg, acc, use_ws, pad, err, tol)
+            if pad:
+                assert torch.equal(Cd[:, Nn:].cpu(), Cfull[:, Nn:]), 'wrote outside the N columns'
