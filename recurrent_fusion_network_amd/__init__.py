@@ -8,6 +8,7 @@ from .fusion_model import RecurrentFusionModel  # noqa: F401
 from .criteria import ReviewNetEnsembleCriterion, ReviewNetRewardCriterion, clip_gradient  # noqa: F401
 from .optim import FusedClampAdam  # noqa: F401
 from .models import setup  # noqa: F401
+from .feeder import FeatureFeeder, read_image_features  # noqa: F401
 
 __all__ = ['RecurrentFusionModel', 'ReviewNetEnsembleCriterion', 'ReviewNetRewardCriterion', 'clip_gradient',
-           'FusedClampAdam', 'setup']
+           'FusedClampAdam', 'setup', 'FeatureFeeder', 'read_image_features']

@@ -1,0 +1,95 @@
+"""Feature input pipeline for the recurrent-fusion path.
+
+The reference's loader reads, per image and per encoder, `<dir>/<id>.npy` (fc vector) and `<dir>/<id>.npz['feat']`
+(attention map, reshaped to (L, D); dataloader.py:15-29, 247-252), then REPLICATES every image's features
+`seq_per_img` times on the host and ships the replicated batch over PCIe (train.py:116-133: 1.64 GB per 256 captions
+at the headline config).  Here:
+
+  * only the UNIQUE images are staged, into pinned host slots (double buffered), and copied with one asynchronous
+    H2D per tensor on a side stream -- 1/seq_per_img of the reference's PCIe bytes, overlapped with the previous
+    step's compute;
+  * the expansion to caption rows happens on the device (`repeat_interleave`), or not at all: with
+    `model.dedup_seq_per_img = seq_per_img` the fusion stages consume the unique rows directly and only the decoder
+    sees caption rows.
+
+Plumbing only (files, pinned memory, streams); no arithmetic.
+"""
+import numpy as np
+import torch
+
+
+def read_image_features(fc_files, att_files):
+    """get_npy_feat_array (dataloader.py:21-29) incl. the (h, w, D) -> (h*w, D) reshape of :248-249."""
+    fc, att = [], []
+    for f, a in zip(fc_files, att_files):
+        fc.append(np.asarray(np.load(f), dtype=np.float32).reshape(-1))
+        x = np.asarray(np.load(a)['feat'], dtype=np.float32)
+        att.append(x.reshape(-1, x.shape[-1]))
+    return fc, att
+
+
+class FeatureFeeder:
+    def __init__(self, feat_array_info, images_per_batch, seq_per_img=5, device='cuda', depth=2):
+        self.info = feat_array_info
+        self.n_img, self.spi, self.depth = images_per_batch, seq_per_img, depth
+        self.device = torch.device(device)
+        self.cuda = self.device.type == 'cuda'
+        pin = self.cuda
+        self.host, self.dev, self.events, self.count = [], [], [], []
+        for _ in range(depth):
+            self.host.append((
+                [torch.empty(images_per_batch, f['fc_feat_size'], pin_memory=pin) for f in feat_array_info],
+                [torch.empty(images_per_batch, f['att_num'], f['att_feat_size'], pin_memory=pin) for f in feat_array_info]))
+            self.dev.append((
+                [torch.empty(images_per_batch, f['fc_feat_size'], device=self.device) for f in feat_array_info],
+                [torch.empty(images_per_batch, f['att_num'], f['att_feat_size'], device=self.device)
+                 for f in feat_array_info]))
+            self.events.append(torch.cuda.Event() if self.cuda else None)
+            self.count.append(0)
+        self.copy_stream = torch.cuda.Stream(device=self.device) if self.cuda else None
+
+    def stage(self, slot, images):
+        """images: list (<= images_per_batch) of (fc_list, att_list) as read_image_features returns.  Writes the
+        pinned slot; the caller must not restage a slot before the batch() that consumed it was issued."""
+        if len(images) > self.n_img:
+            raise ValueError('more images than the feeder was sized for')
+        fc_h, att_h = self.host[slot]
+        for k, (fc, att) in enumerate(images):
+            for i, f in enumerate(self.info):
+                if fc[i].shape != (f['fc_feat_size'],) or att[i].shape != (f['att_num'], f['att_feat_size']):
+                    raise ValueError('image %d encoder %d: got fc %s att %s, expected (%d,) (%d, %d)' % (
+                        k, i, fc[i].shape, att[i].shape, f['fc_feat_size'], f['att_num'], f['att_feat_size']))
+                fc_h[i][k].copy_(torch.from_numpy(fc[i]))
+                att_h[i][k].copy_(torch.from_numpy(att[i]))
+        self.count[slot] = len(images)
+
+    def upload(self, slot):
+        """Asynchronous H2D of the unique images of `slot` on the copy stream."""
+        n = self.count[slot]
+        if not self.cuda:
+            for src, dst in zip(self.host[slot][0] + self.host[slot][1], self.dev[slot][0] + self.dev[slot][1]):
+                dst[:n].copy_(src[:n])
+            return
+        # the copy must not overwrite device buffers a previous batch() is still being read from
+        self.copy_stream.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(self.copy_stream):
+            for src, dst in zip(self.host[slot][0] + self.host[slot][1], self.dev[slot][0] + self.dev[slot][1]):
+                dst[:n].copy_(src[:n], non_blocking=True)
+            self.events[slot].record(self.copy_stream)
+
+    def batch(self, slot, expand=True):
+        """(fc_feats, att_feats) lists on the device.  expand=True: caption rows (each image seq_per_img times, the
+        reference's batch layout); expand=False: unique images, for a model with dedup_seq_per_img set."""
+        if self.cuda:
+            torch.cuda.current_stream(self.device).wait_event(self.events[slot])
+        n = self.count[slot]
+        fc = [t[:n] for t in self.dev[slot][0]]
+        att = [t[:n] for t in self.dev[slot][1]]
+        if expand:
+            fc = [t.repeat_interleave(self.spi, dim=0) for t in fc]
+            att = [t.repeat_interleave(self.spi, dim=0) for t in att]
+        return fc, att
+
+    def pcie_bytes(self, slot):
+        n = self.count[slot]
+        return 4 * n * sum(f['fc_feat_size'] + f['att_num'] * f['att_feat_size'] for f in self.info)

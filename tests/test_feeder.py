@@ -1,0 +1,65 @@
+"""Feature input pipeline (recurrent_fusion_network_amd/feeder.py) against the reference loader's batch layout
+(dataloader.py:15-29, 247-252, 337-340)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+INFO = [dict(att_num=6, att_feat_size=8, fc_feat_size=8), dict(att_num=4, att_feat_size=12, fc_feat_size=10)]
+
+
+def _write_images(tmp, n_img, rng):
+    files = []
+    for k in range(n_img):
+        fcs, atts = [], []
+        for i, f in enumerate(INFO):
+            d = os.path.join(tmp, 'enc%d' % i)
+            os.makedirs(d, exist_ok=True)
+            fc = rng.standard_normal(f['fc_feat_size']).astype(np.float32)
+            h = 2 if f['att_num'] % 2 == 0 else 1            # stored as (h, w, D) like the extractors do
+            att = rng.standard_normal((h, f['att_num'] // h, f['att_feat_size'])).astype(np.float32)
+            np.save(os.path.join(d, '%d.npy' % k), fc)
+            np.savez(os.path.join(d, '%d.npz' % k), feat=att)
+            fcs.append(os.path.join(d, '%d.npy' % k))
+            atts.append(os.path.join(d, '%d.npz' % k))
+        files.append((fcs, atts))
+    return files
+
+
+def _reference_batch(files, spi):
+    """What DataLoader.get_batch builds on the host: every image's features repeated seq_per_img times, stacked."""
+    fc_b, att_b = [[] for _ in INFO], [[] for _ in INFO]
+    for fcs, atts in files:
+        for i in range(len(INFO)):
+            fc_b[i] += [np.load(fcs[i])] * spi
+            a = np.load(atts[i])['feat']
+            att_b[i] += [a.reshape(-1, a.shape[2])] * spi
+    return [np.stack(x) for x in fc_b], [np.stack(x) for x in att_b]
+
+
+@pytest.mark.parametrize('device', ['cpu', pytest.param('cuda', marks=pytest.mark.gpu)])
+def test_feeder_matches_reference_batch_layout(tmp_path, device):
+    from recurrent_fusion_network_amd.feeder import FeatureFeeder, read_image_features
+    rng = np.random.default_rng(0)
+    files = _write_images(str(tmp_path), 5, rng)
+    feeder = FeatureFeeder(INFO, images_per_batch=4, seq_per_img=3, device=device)
+    for slot, chunk in enumerate((files[:4], files[4:])):            # a full and a ragged batch, two slots
+        feeder.stage(slot, [read_image_features(*f) for f in chunk])
+        feeder.upload(slot)
+    for slot, chunk in enumerate((files[:4], files[4:])):
+        fc, att = feeder.batch(slot, expand=True)
+        ref_fc, ref_att = _reference_batch(chunk, 3)
+        for i in range(len(INFO)):
+            assert np.array_equal(fc[i].cpu().numpy(), ref_fc[i]) and np.array_equal(att[i].cpu().numpy(), ref_att[i])
+        ufc, uatt = feeder.batch(slot, expand=False)
+        assert ufc[0].shape[0] == len(chunk) and np.array_equal(uatt[1].cpu().numpy(), ref_att[1][::3])
+        # the unique-image upload moves 1/seq_per_img of the reference's PCIe bytes
+        ref_bytes = sum(x.nbytes for x in ref_fc + ref_att)
+        assert feeder.pcie_bytes(slot) * 3 == ref_bytes
+    with pytest.raises(ValueError):
+        feeder.stage(0, [read_image_features(*f) for f in files])    # 5 images > images_per_batch
+    bad = read_image_features(*files[0])
+    bad[1][0] = bad[1][0][:-1]
+    with pytest.raises(ValueError):
+        feeder.stage(0, [bad])
