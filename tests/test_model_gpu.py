@@ -276,6 +276,55 @@ def test_inference_hooks(dev):
     assert maxerr(logit, o_logit) < 1e-4 and maxerr(st2[1][0], oc2) < 1e-4
 
 
+def test_ensemble_decode_matches_oracle(dev):
+    """eval_utils.py:268-290: mean of the members' logits, log_softmax, shared greedy token."""
+    from oracle import rfn_oracle as O
+    from recurrent_fusion_network_amd.ensemble import EnsembleDecoder
+    cfg, spec, P, batch, gold = load_case('mid')
+    Ps = [P, O.seeded_params(cfg, 41), O.seeded_params(cfg, 42)]
+    models = [build(cfg, p, dev) for p in Ps]
+    fc, att, labels, masks, top = to_dev(batch, dev)
+    seq, seq_lp, lp_all = EnsembleDecoder(models).sample(fc, att)
+    # oracle ensemble, free running
+    B = batch[0][0].size(0)
+    states = []
+    for p in Ps:
+        hs, cs = O.init_state(cfg, p, batch[0])
+        comb, _, (h, c) = O.thought_vectors(cfg, p, batch[1], hs, cs)
+        states.append([comb, h, c])
+    it = torch.zeros(B, dtype=torch.long)
+    o_seq, o_lp, unfinished = [], [], None
+    for t in range(cfg.seq_length + 1):
+        if t >= 1:
+            val, it = torch.max(logprobs, 1)
+            unfinished = (it > 0) if t == 1 else unfinished & (it > 0)
+            if int(unfinished.sum()) == 0:
+                break
+            o_seq.append(it * unfinished.long())
+            o_lp.append(val)
+        logits = []
+        for p, s_ in zip(Ps, states):
+            lg, s_[1], s_[2] = O.one_time_step(cfg, p, p['embed.weight'][it], s_[0], s_[1], s_[2])
+            logits.append(lg)
+        logprobs = torch.log_softmax(sum(logits) / len(Ps), 1)
+    assert torch.equal(seq.cpu(), torch.stack(o_seq, 1))
+    assert maxerr(seq_lp, torch.stack(o_lp, 1)) < LOGP_TOL
+    # members spread over ranks: the logit sum goes through one RCCL all-reduce per step (1-rank group here)
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        dist.init_process_group('nccl', init_method='tcp://127.0.0.1:29533', rank=0, world_size=1,
+                                device_id=dev)
+        try:
+            seq_pg = EnsembleDecoder(models, process_group=dist.group.WORLD).sample(fc, att)[0]
+            assert torch.equal(seq_pg, seq)
+        finally:
+            dist.destroy_process_group()
+    # a one-member "ensemble" is the plain greedy sample
+    s1 = EnsembleDecoder(models[:1]).sample(fc, att)[0]
+    with torch.no_grad():
+        assert torch.equal(s1, models[0].sample(fc, att, {'sample_max': 1})[0])
+
+
 def test_cpu_inputs_fail_loudly():
     import recurrent_fusion_network_amd as R
     cfg, spec, P, batch, gold = load_case('tiny0')
