@@ -276,6 +276,86 @@ def test_inference_hooks(dev):
     assert maxerr(logit, o_logit) < 1e-4 and maxerr(st2[1][0], oc2) < 1e-4
 
 
+def test_unchanged_trainer_route_torch_adam_and_clip_gradient(dev):
+    """train.py:143-163 unchanged: zero_grad -> forward -> crit -> backward -> utils.clip_gradient -> optim.Adam.step.
+    `.grad` must be populated for every parameter and the update must equal the fused optimizer's."""
+    import recurrent_fusion_network_amd as R
+    cfg, spec, P, batch, gold = load_case('mid')
+    fc, att, labels, masks, top = to_dev(batch, dev)
+    crit = R.ReviewNetEnsembleCriterion(cfg)
+    m1 = build(cfg, P, dev, train=True)
+    opt1 = torch.optim.Adam(m1.parameters(), lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5)
+    m2 = build(cfg, P, dev, train=True)
+    opt2 = R.FusedClampAdam(m2, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5, grad_clip=0.05)
+    for step in range(2):
+        opt1.zero_grad()
+        lp, reason = m1(fc, att, labels)
+        crit(lp, labels[:, 1:], masks[:, 1:], reason, top, 1.0).backward()
+        assert all(p.grad is not None for p in m1.parameters())
+        R.clip_gradient(opt1, 0.05)                       # small clip so the clamp really bites
+        opt1.step()
+        opt2.zero_grad()
+        lp2, reason2 = m2(fc, att, labels)
+        crit(lp2, labels[:, 1:], masks[:, 1:], reason2, top, 1.0).backward()
+        opt2.step()
+    p2 = dict(m2.named_parameters())
+    for k, p in m1.named_parameters():
+        assert maxerr(p, p2[k].detach().cpu()) < 3e-6, k
+    # a second backward before zero_grad accumulates, like autograd
+    opt1.zero_grad()
+    for _ in range(2):
+        lp, reason = m1(fc, att, labels)
+        crit(lp, labels[:, 1:], masks[:, 1:], reason, top, 1.0).backward()
+    g2 = m1.logit.weight.grad.clone()
+    opt1.zero_grad()
+    lp, reason = m1(fc, att, labels)
+    crit(lp, labels[:, 1:], masks[:, 1:], reason, top, 1.0).backward()
+    assert maxerr(g2, (2 * m1.logit.weight.grad).cpu()) < 1e-6 + 1e-5 * float(g2.abs().max())
+
+
+def test_checkpoint_round_trip_and_models_setup(dev, tmp_path):
+    """models.setup(opt) with start_from / load_model_id (models.py:26-36): a saved state_dict reloads to the same
+    outputs."""
+    import pickle
+    import recurrent_fusion_network_amd as R
+    cfg, spec, P, batch, gold = load_case('tiny1')
+    fc, att, labels, masks, top = to_dev(batch, dev)
+    model = build(cfg, P, dev)
+    with torch.no_grad():
+        ref, _ = model(fc, att, labels)
+    torch.save(model.state_dict(), str(tmp_path / 'model_best.pth'))
+    with open(str(tmp_path / 'infos_best.pkl'), 'wb') as f:
+        pickle.dump({'iter': 0}, f)
+    cfg.start_from, cfg.load_model_id = str(tmp_path), 'best'
+    m2 = R.setup(cfg).to(dev).eval()
+    with torch.no_grad():
+        out, _ = m2(fc, att, labels)
+    assert torch.equal(out, ref)
+
+
+def test_scheduled_sampling(dev):
+    """misc/RecurrentFusionModel.py:260-270: ss_prob -> 0 is teacher forcing; ss_prob = 1 feeds sampled tokens from
+    the model's previous distribution (steps >= 1), so later log-probs change while step 0 cannot."""
+    cfg, spec, P, batch, gold = load_case('mid')
+    model = build(cfg, P, dev, train=True)
+    fc, att, labels, masks, top = to_dev(batch, dev)
+    base, _ = model(fc, att, labels)
+    model.ss_prob = 1e-12
+    almost, _ = model(fc, att, labels)
+    assert torch.equal(base, almost)
+    model.ss_prob = 1.0
+    torch.manual_seed(3)
+    ss, _ = model(fc, att, labels)
+    assert tuple(ss.shape) == tuple(base.shape)
+    assert torch.equal(ss[:, :1], base[:, :1])           # step 0 is fed BOS; from step 1 on the input is a sample
+    assert not torch.equal(ss[:, 1:], base[:, 1:])
+    ss.sum().backward()                                    # gradients flow through the sampled-token pass
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters())
+    torch.manual_seed(3)
+    again, _ = model(fc, att, labels)
+    assert torch.equal(ss, again)
+
+
 def test_ensemble_decode_matches_oracle(dev):
     """eval_utils.py:268-290: mean of the members' logits, log_softmax, shared greedy token."""
     from oracle import rfn_oracle as O
