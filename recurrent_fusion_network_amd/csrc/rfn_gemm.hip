@@ -47,6 +47,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef GEMM_SPLIT_TARGET
 #define GEMM_SPLIT_TARGET 768 /* blocks a split-K launch aims for */
 #endif
+#ifndef GEMM_ONE_WAVE
+#define GEMM_ONE_WAVE 0
+#endif
+#ifndef GEMM_ONE_WAVE_STAGES
+#define GEMM_ONE_WAVE_STAGES 1
+#endif
 #ifndef GEMM_BAND_ROWS
 #define GEMM_BAND_ROWS 8    /* row tiles per band of the block order (B-operand panels are re-fetched once per band) */
 #endif
@@ -87,18 +93,18 @@ struct GemmArgs {
 // ---- staging of one ROWS x BK operand tile ---------------------------------------------------
 // [row][k] tiles have BK+4 floats per row: 36 and 68 both put the 16 rows of a ds_read_b128 lane group on 16
 // distinct 16-B bank slots (row*36 mod 64 and row*68 mod 64 = 4*row mod 64 are all different for 16 rows).
-template <int ROWS, bool KFAST, bool VEC, int BK>
+template <int ROWS, bool KFAST, bool VEC, int BK, int THREADS = GEMM_THREADS>
 struct Stage {
-    static constexpr int NV = ROWS * BK / 4 / GEMM_THREADS;  // float4 per thread
+    static constexpr int NV = ROWS * BK / 4 / THREADS;  // float4 per thread
     static constexpr int LDK = BK + 4;                       // [row][k] row length
     static constexpr int LDR = ROWS + 4;                     // [k][row] row length
     static constexpr int LDS_FLOATS = KFAST ? ROWS * LDK : BK * LDR;
     static constexpr int KQ = BK / 4;                        // float4 per [row][k] row
-    static constexpr int RPASS = GEMM_THREADS / KQ;          // rows covered per pass (kfast, vec)
+    static constexpr int RPASS = THREADS / KQ;          // rows covered per pass (kfast, vec)
     static constexpr int RQ = ROWS / 4;                      // float4 per [k][row] row
-    static constexpr int KPASS = GEMM_THREADS / RQ;          // k rows covered per pass (rowfast, vec)
-    static constexpr int RPASS_S = GEMM_THREADS / BK;        // rows per pass (kfast, scalar)
-    static constexpr int KPASS_S = GEMM_THREADS / ROWS;      // k rows per pass (rowfast, scalar)
+    static constexpr int KPASS = THREADS / RQ;          // k rows covered per pass (rowfast, vec)
+    static constexpr int RPASS_S = THREADS / BK;        // rows per pass (kfast, scalar)
+    static constexpr int KPASS_S = THREADS / ROWS;      // k rows per pass (rowfast, scalar)
     f32x4 v[NV];
 
     // rows [row0, row0+ROWS) x k [k0, k0+BK) of an operand with `nrows` valid rows and K valid k.
@@ -221,12 +227,14 @@ struct Stage {
 // STAGES = 2: double-buffered LDS, one barrier per K step (2 blocks/CU at 128x128).
 // STAGES = 1: single buffer, two barriers per K step, half the LDS -> 3 blocks/CU cover each other's stalls.
 // FAST: every tile is interior (M % BM == N % BN == 0 and every segment's K % BK == 0).
-template <int BM, int BN, bool AK, bool BKF, bool VEC, int STAGES, int BK, bool FAST>
-__global__ __launch_bounds__(GEMM_THREADS, GEMM_MIN_WAVES) void rfn_gemm_kernel(const GemmArgs args) {
-    constexpr int MT = BM / 64;  // 32x32 MFMA tiles per wave along M
-    constexpr int NT = BN / 64;
-    using StA = Stage<BM, AK, VEC, BK>;
-    using StB = Stage<BN, BKF, VEC, BK>;
+template <int BM, int BN, bool AK, bool BKF, bool VEC, int STAGES, int BK, bool FAST, int THREADS = GEMM_THREADS>
+__global__ __launch_bounds__(THREADS, (THREADS == 64) ? 1 : GEMM_MIN_WAVES) void rfn_gemm_kernel(const GemmArgs args) {
+    constexpr int WGM = (THREADS == 256) ? 2 : 1;  // waves along M / N: 2x2 (256 threads) or one wave per block
+    constexpr int WGN = WGM;
+    constexpr int MT = BM / (32 * WGM);  // 32x32 MFMA tiles per wave along M
+    constexpr int NT = BN / (32 * WGN);
+    using StA = Stage<BM, AK, VEC, BK, THREADS>;
+    using StB = Stage<BN, BKF, VEC, BK, THREADS>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // LDS: [A buf0 | A buf1 | B buf0 | B buf1]; pointers are computed, not tabulated
     float* const sA0 = smem;
@@ -235,7 +243,7 @@ __global__ __launch_bounds__(GEMM_THREADS, GEMM_MIN_WAVES) void rfn_gemm_kernel(
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WGN, wn = wave % WGN;
     const int l31 = lane & 31, h = lane >> 5;
 
     // ---- block -> (group, tile_m, tile_n): bijective XCD remap, then 8-row bands ------------
@@ -374,17 +382,17 @@ __global__ __launch_bounds__(GEMM_THREADS, GEMM_MIN_WAVES) void rfn_gemm_kernel(
         // latency hides under a full 16-MFMA group instead of the last two MFMAs
         f32x4 af[2][MT], bf[2][NT];
 #pragma unroll
-        for (int i = 0; i < MT; ++i) af[0][i] = StA::frag(a_l, wm * (BM / 2) + i * 32 + l31, 0, h);
+        for (int i = 0; i < MT; ++i) af[0][i] = StA::frag(a_l, wm * (BM / WGM) + i * 32 + l31, 0, h);
 #pragma unroll
-        for (int j = 0; j < NT; ++j) bf[0][j] = StB::frag(b_l, wn * (BN / 2) + j * 32 + l31, 0, h);
+        for (int j = 0; j < NT; ++j) bf[0][j] = StB::frag(b_l, wn * (BN / WGN) + j * 32 + l31, 0, h);
 #pragma unroll
         for (int q = 0; q < BK / 8; ++q) {
             const int cb = q & 1, nb = cb ^ 1;
             if (q + 1 < BK / 8) {
 #pragma unroll
-                for (int i = 0; i < MT; ++i) af[nb][i] = StA::frag(a_l, wm * (BM / 2) + i * 32 + l31, q + 1, h);
+                for (int i = 0; i < MT; ++i) af[nb][i] = StA::frag(a_l, wm * (BM / WGM) + i * 32 + l31, q + 1, h);
 #pragma unroll
-                for (int j = 0; j < NT; ++j) bf[nb][j] = StB::frag(b_l, wn * (BN / 2) + j * 32 + l31, q + 1, h);
+                for (int j = 0; j < NT; ++j) bf[nb][j] = StB::frag(b_l, wn * (BN / WGN) + j * 32 + l31, q + 1, h);
             }
 #pragma unroll
             for (int c = 0; c < 4; ++c)
@@ -399,9 +407,9 @@ __global__ __launch_bounds__(GEMM_THREADS, GEMM_MIN_WAVES) void rfn_gemm_kernel(
         for (int q = 0; q < BK / 8; ++q) {
             f32x4 af[MT], bf[NT];
 #pragma unroll
-            for (int i = 0; i < MT; ++i) af[i] = StA::frag(a_l, wm * (BM / 2) + i * 32 + l31, q, h);
+            for (int i = 0; i < MT; ++i) af[i] = StA::frag(a_l, wm * (BM / WGM) + i * 32 + l31, q, h);
 #pragma unroll
-            for (int j = 0; j < NT; ++j) bf[j] = StB::frag(b_l, wn * (BN / 2) + j * 32 + l31, q, h);
+            for (int j = 0; j < NT; ++j) bf[j] = StB::frag(b_l, wn * (BN / WGN) + j * 32 + l31, q, h);
 #pragma unroll
             for (int c = 0; c < 4; ++c)
 #pragma unroll
@@ -430,7 +438,7 @@ __global__ __launch_bounds__(GEMM_THREADS, GEMM_MIN_WAVES) void rfn_gemm_kernel(
 
     if constexpr (!AK) {
         if (do_colsum) {  // block-uniform; the K loop's last barrier has retired every LDS read
-            constexpr int PARTS = VEC ? GEMM_THREADS / (BM / 4) : GEMM_THREADS / BM;
+            constexpr int PARTS = VEC ? THREADS / (BM / 4) : THREADS / BM;
             if constexpr (VEC) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) smem[(tid / (BM / 4)) * BM + 4 * (tid % (BM / 4)) + e] = ps[e];
@@ -452,13 +460,13 @@ __global__ __launch_bounds__(GEMM_THREADS, GEMM_MIN_WAVES) void rfn_gemm_kernel(
         float* part = args.part + ((long)grp * splitk + ks) * (long)M * N;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-            const int col = col0 + wn * (BN / 2) + j * 32 + l31;
+            const int col = col0 + wn * (BN / WGN) + j * 32 + l31;
             if (col >= N) continue;
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int row = row0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const int row = row0 + wm * (BM / WGM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                     if (row < M) part[(long)row * N + col] = acc[i][j][r];
                 }
         }
@@ -468,7 +476,7 @@ __global__ __launch_bounds__(GEMM_THREADS, GEMM_MIN_WAVES) void rfn_gemm_kernel(
     // ---- epilogue: bias, optional accumulate, bounds-checked store --------------------------
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-        const int col = col0 + wn * (BN / 2) + j * 32 + l31;
+        const int col = col0 + wn * (BN / WGN) + j * 32 + l31;
         if (col >= N) continue;
         float bsum = 0.f;
         for (int s = 0; s < P.nseg; ++s)
@@ -477,7 +485,7 @@ __global__ __launch_bounds__(GEMM_THREADS, GEMM_MIN_WAVES) void rfn_gemm_kernel(
         for (int i = 0; i < MT; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = row0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int row = row0 + wm * (BM / WGM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
 #if GEMM_ABLATE == 2
                 if (row < M && acc[i][j][r] == 123.456f) {
 #else
@@ -510,19 +518,19 @@ __global__ __launch_bounds__(256) void rfn_gemm_reduce_k(const GemmArgs args) {
     *c = args.accumulate ? *c + s : s;
 }
 
-template <int BM, int BN, bool AK, bool BKF, bool VEC, int STAGES, int BK, bool FAST = false>
+template <int BM, int BN, bool AK, bool BKF, bool VEC, int STAGES, int BK, bool FAST = false, int THREADS = GEMM_THREADS>
 static int launch_cfg(const GemmArgs& a, hipStream_t st) {
-    using StA = Stage<BM, AK, VEC, BK>;
-    using StB = Stage<BN, BKF, VEC, BK>;
+    using StA = Stage<BM, AK, VEC, BK, THREADS>;
+    using StB = Stage<BN, BKF, VEC, BK, THREADS>;
     const size_t lds = STAGES * (StA::LDS_FLOATS + StB::LDS_FLOATS) * sizeof(float);
     const int nblk = a.ngroups * a.tiles_m * a.tiles_n * a.splitk;
-    auto k = rfn_gemm_kernel<BM, BN, AK, BKF, VEC, STAGES, BK, FAST>;
+    auto k = rfn_gemm_kernel<BM, BN, AK, BKF, VEC, STAGES, BK, FAST, THREADS>;
     static bool attr_set = false;  // idempotent; a race only repeats the same call
     if (!attr_set) {
         hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL(k, dim3(nblk), dim3(GEMM_THREADS), lds, st, a);
+    hipLaunchKernelGGL(k, dim3(nblk), dim3(THREADS), lds, st, a);
     RFN_CHECK_LAUNCH();
     if (a.splitk > 1) {
         hipLaunchKernelGGL(rfn_gemm_reduce_k, dim3(rfn_cdiv((long)a.M * a.N, 256), a.ngroups), dim3(256), 0, st, a);
@@ -565,6 +573,13 @@ static int launch_tile(GemmArgs& a, hipStream_t st) {
             for (int g = 0; g < a.ngroups; ++g)
                 for (int s = 0; s < a.g[g].nseg; ++s)
                     fast = fast && a.g[g].seg[s].K > 0 && (a.g[g].seg[s].K % GEMM_BIG_BK == 0);
+#if GEMM_ONE_WAVE
+            if (fast && (a.M % 64 == 0) && (a.N % 64 == 0)) {   // experiment: barrier-free single-wave 64x64 blocks
+                a.tiles_m = a.M / 64;
+                a.tiles_n = a.N / 64;
+                return launch_cfg<64, 64, AK, BKF, true, GEMM_ONE_WAVE_STAGES, GEMM_BIG_BK, true, 64>(a, st);
+            }
+#endif
             if (fast)
                 return launch_cfg<GEMM_BIG_BM, GEMM_BIG_BN, AK, BKF, true, (AK && BKF) ? GEMM_NT_STAGES : GEMM_XX_STAGES,
                                   GEMM_BIG_BK, true>(a, st);

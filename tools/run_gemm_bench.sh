@@ -5,8 +5,6 @@ cd "$(dirname "$0")/.."
 mkdir -p /tmp/gb
 build() { hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-unused-value -Wno-unused-result -DVARIANT="\"$1\"" $2 tools/gemm_bench.hip -o /tmp/gb/$1; }
 build default ""
-build band4 "-DGEMM_BAND_ROWS=4"
-build band16 "-DGEMM_BAND_ROWS=16"
-build band32 "-DGEMM_BAND_ROWS=32"
-build band64 "-DGEMM_BAND_ROWS=64"
-for v in default band4 band16 band32 band64; do /tmp/gb/$v; done
+build onewave_s1 "-DGEMM_ONE_WAVE=1 -DGEMM_ONE_WAVE_STAGES=1"
+build onewave_s2 "-DGEMM_ONE_WAVE=1 -DGEMM_ONE_WAVE_STAGES=2"
+for v in default onewave_s1 onewave_s2; do /tmp/gb/$v; done
