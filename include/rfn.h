@@ -115,6 +115,9 @@ int rfn_colsum_f32(const float* X, int64_t ldx, int rows, int cols, float* out, 
 int rfn_colsum_grouped_f32(const float* X, int64_t group_stride, int64_t ldx, int rows, int cols,
                            float* const* outs_host, int ngroups, void* stream);
 
+/* outs_host[g][0..n) = value for `ngroups` small device buffers in one launch */
+int rfn_fill_small_f32(float* const* outs_host, int ngroups, int n, float value, void* stream);
+
 /* Additive soft attention, AttentionModelCore.forward (misc/AttentionModelCore.py:31-48; inlined
  * copy misc/LSTMSoftAttentionCore.py:64-79), split at the GEMM boundary:
  *   proj[b,l,:] = att_2_att_h(att_seq[b,l,:])  (hoisted GEMM, :32-34)

@@ -85,6 +85,27 @@ extern "C" int rfn_colsum_grouped_f32(const float* X, int64_t group_stride, int6
     return RFN_OK;
 }
 
+// out[g][0..n) = value for up to 64 small buffers per launch (the exactly-zero att_h_2_out.bias gradients)
+__global__ __launch_bounds__(64) void fill_small_k(const ColsumOuts outs, int n, float value) {
+    float* o = outs.out[blockIdx.x];
+    for (int i = threadIdx.x; i < n; i += 64) o[i] = value;
+}
+extern "C" int rfn_fill_small_f32(float* const* outs, int ngroups, int n, float value, void* stream) {
+    if (ngroups < 1 || n < 1) return RFN_ERR_SHAPE;
+    if (!outs) return RFN_ERR_ARG;
+    for (int g0 = 0; g0 < ngroups; g0 += 64) {
+        ColsumOuts o;
+        const int ng = ngroups - g0 < 64 ? ngroups - g0 : 64;
+        for (int g = 0; g < ng; ++g) {
+            if (!outs[g0 + g]) return RFN_ERR_ARG;
+            o.out[g] = outs[g0 + g];
+        }
+        hipLaunchKernelGGL(fill_small_k, dim3(ng), dim3(64), 0, (hipStream_t)stream, o, n, value);
+        RFN_CHECK_LAUNCH();
+    }
+    return RFN_OK;
+}
+
 // ---- embedding ----------------------------------------------------------------------------------
 __global__ __launch_bounds__(128) void embed_fwd_k(const float* __restrict__ W, int E, long V1,
                                                    const int64_t* __restrict__ ids, int inner, long si, long so,

@@ -592,7 +592,6 @@ extern "C" int rfn_prefix_bwd(const rfn_dims* d, int B, const float* const* prm,
             RFN_TRY(rfn_attn_scores_bwd(p2, (long)T2 * A, (long)B * T2 * A, hp + i * BA, prm[P.s2(t, i, 6)],
                                         al + (long)i * B * T1, dal, B, T1, A, p2, (long)T2 * A, (long)B * T2 * A, 0,
                                         dhp + i * BA, dwp + ((long)t * M + i) * BA, st));
-            RFN_TRY(zero_f32(grd[P.s2(t, i, 7)], 1, st));
             segs[i] = seg_dx(dhp + i * BA, A, prm[P.s2(t, i, 4)], R, A);
         }
         RFN_TRY(gemm_segs(B, R, M, segs, dhrec, R, 1, gx));
@@ -605,6 +604,10 @@ extern "C" int rfn_prefix_bwd(const rfn_dims* d, int B, const float* const* prm,
             for (int i = 0; i < M; ++i) outs[t * M + i] = grd[P.s2(t, i, 6)];
         if (T2 * M > 64) return RFN_ERR_SHAPE;
         RFN_TRY(rfn_colsum_grouped_f32(dwp, BA, A, B, A, outs, T2 * M, st));
+        // att_h_2_out.bias shifts all scores of a softmax equally: its gradient is exactly 0
+        for (int t = 0; t < T2; ++t)
+            for (int i = 0; i < M; ++i) outs[t * M + i] = grd[P.s2(t, i, 7)];
+        RFN_TRY(rfn_fill_small_f32(outs, T2 * M, 1, 0.f, st));
     }
     for (int t = 0; t < T2; ++t)
         pr[t] = prob_dw(grd[P.s2_hh_w(t)], R, grd[P.s2_hh_b(t)], W + Lo.g2 + (long)t * B * 4 * R, 4 * R, h2 + t * BR, R, B);
@@ -664,7 +667,6 @@ extern "C" int rfn_prefix_bwd(const rfn_dims* d, int B, const float* const* prm,
             RFN_TRY(rfn_attn_scores_bwd(p1, Li * T1 * A, (long)T1 * A, hp + i * BA, prm[P.s1(t, i, 4)],
                                         W + Lo.al1[i] + (long)t * B * Li, dali, B, (int)Li, A, p1, Li * T1 * A,
                                         (long)T1 * A, 0, dhp + i * BA, dwp + ((long)t * M + i) * BA, st));
-            RFN_TRY(zero_f32(grd[P.s1(t, i, 5)], 1, st));
             pr[i] = prob1(dHc + i * R, MR, seg_dx(dhp + i * BA, A, prm[P.s1(t, i, 2)], R, A));
         }
         RFN_TRY(gemm_groups(B, R, M, pr, 1, gx));
@@ -679,6 +681,9 @@ extern "C" int rfn_prefix_bwd(const rfn_dims* d, int B, const float* const* prm,
         for (int t = 0; t < T1; ++t)
             for (int i = 0; i < M; ++i) outs[t * M + i] = grd[P.s1(t, i, 4)];
         RFN_TRY(rfn_colsum_grouped_f32(dwp, BA, A, B, A, outs, T1 * M, st));
+        for (int t = 0; t < T1; ++t)
+            for (int i = 0; i < M; ++i) outs[t * M + i] = grd[P.s1(t, i, 5)];
+        RFN_TRY(rfn_fill_small_f32(outs, T1 * M, 1, 0.f, st));
     }
     // weight gradients of stage I (per encoder; see rfn_prefix_bwd_wgrad) unless the caller defers them
     if (!defer_wgrad)
