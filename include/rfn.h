@@ -278,10 +278,12 @@ int rfn_prefix_bwd(const rfn_dims* d, int B, const float* const* params,
                    uint64_t seed, int defer_wgrad, void* stream);
 /* With defer_wgrad != 0, rfn_prefix_bwd leaves out the stage-I weight gradients of the encoders
  * (review_steps_individual.{t}.lstm.{enc}.{att_model.att_2_att_h, att_model.h_2_att_h, H2h, z2h}.{weight,bias}
- * for all t); this call produces them for one encoder from the same workspace.  A data-parallel host
- * all-reduces encoder i's gradient bucket while encoder i+1's GEMMs (the largest of backward) run. */
+ * for all t); this call produces them for one encoder from the same workspace.  `parts` bit 0: H2h, z2h,
+ * h_2_att_h (0.27 GB of gradients, short GEMMs); bit 1: att_2_att_h (34 MB, the longest GEMM of backward).
+ * A data-parallel host issues part 1, all-reduces that bucket under part 2's GEMM, and so on: only the last
+ * encoder's 34 MB bucket remains exposed at the end of backward. */
 int rfn_prefix_bwd_wgrad(const rfn_dims* d, int B, const float* const* att_feats, float* const* grads,
-                         void* ws, size_t ws_bytes, int enc, void* stream);
+                         void* ws, size_t ws_bytes, int enc, int parts, void* stream);
 
 /* Phase 2 = the teacher-forced decoder loop of forward() (misc/RecurrentFusionModel.py:257-281):
  * for s < S: xt = embed(ids[b,s]); decoder cell (misc/LSTMSoftAttentionCore.py:60-102);

@@ -687,7 +687,7 @@ extern "C" int rfn_prefix_bwd(const rfn_dims* d, int B, const float* const* prm,
     }
     // weight gradients of stage I (per encoder; see rfn_prefix_bwd_wgrad) unless the caller defers them
     if (!defer_wgrad)
-        for (int i = 0; i < M; ++i) RFN_TRY(rfn_prefix_bwd_wgrad(d, B, att, grd, ws, ws_bytes, i, st));
+        for (int i = 0; i < M; ++i) RFN_TRY(rfn_prefix_bwd_wgrad(d, B, att, grd, ws, ws_bytes, i, 3, st));
     return RFN_OK;
 }
 
@@ -696,9 +696,9 @@ extern "C" int rfn_prefix_bwd(const rfn_dims* d, int B, const float* const* prm,
 // Reads only the workspace rfn_prefix_bwd left behind, so a data-parallel host can all-reduce encoder i's
 // gradient bucket while encoder i+1's GEMMs run.
 extern "C" int rfn_prefix_bwd_wgrad(const rfn_dims* d, int B, const float* const* att, float* const* grd, void* ws,
-                                    size_t ws_bytes, int enc, void* st) {
+                                    size_t ws_bytes, int enc, int parts, void* st) {
     RFN_TRY(check_dims(d));
-    if (B < 1 || enc < 0 || enc >= d->M) return RFN_ERR_SHAPE;
+    if (B < 1 || enc < 0 || enc >= d->M || (parts & ~3) || !parts) return RFN_ERR_SHAPE;
     if (!att || !grd || !ws) return RFN_ERR_ARG;
     const PrefixLayout Lo = prefix_layout(d, B, 1);
     if (ws_bytes < Lo.total * sizeof(float)) return RFN_ERR_WORKSPACE;
@@ -711,6 +711,13 @@ extern "C" int rfn_prefix_bwd_wgrad(const rfn_dims* d, int B, const float* const
     const float* Hs = W + Lo.Hs;
     rfn_gemm_problem pr[64];
     const long Li = d->L[i], Di = d->D[i];
+    if (parts & 2) {  // part B: the dominant att_2_att_h gradient (small bucket, long GEMM)
+        for (int t = 0; t < T1; ++t)
+            pr[t] = prob_dw(grd[P.s1(t, i, 0)], Di, grd[P.s1(t, i, 1)], W + Lo.P1[i] + (long)t * A, (long)T1 * A, att[i], Di,
+                            (int)(B * Li));
+        if (!(parts & 1)) return gemm_groups(A, (int)Di, T1, pr, 0, gx);
+    }
+    // part A: H2h, z2h, h_2_att_h (large bucket, short GEMMs)
     for (int t = 0; t < T1; ++t)
         pr[t] = prob_dw(grd[P.s1(t, i, 6)], MR, grd[P.s1(t, i, 7)], W + Lo.g1 + ((long)t * M + i) * B * 4 * R, 4 * R,
                         Hs + t * BMR, MR, B);
@@ -723,10 +730,12 @@ extern "C" int rfn_prefix_bwd_wgrad(const rfn_dims* d, int B, const float* const
         pr[t] = prob_dw(grd[P.s1(t, i, 2)], R, grd[P.s1(t, i, 3)], W + Lo.dhp1 + ((long)t * M + i) * BA, A,
                         Hs + t * BMR + i * R, MR, B);
     RFN_TRY(gemm_groups(A, R, T1, pr, 0, gx));
-    for (int t = 0; t < T1; ++t)
-        pr[t] = prob_dw(grd[P.s1(t, i, 0)], Di, grd[P.s1(t, i, 1)], W + Lo.P1[i] + (long)t * A, (long)T1 * A, att[i], Di,
-                        (int)(B * Li));
-    RFN_TRY(gemm_groups(A, (int)Di, T1, pr, 0, gx));
+    if (parts & 2) {
+        for (int t = 0; t < T1; ++t)
+            pr[t] = prob_dw(grd[P.s1(t, i, 0)], Di, grd[P.s1(t, i, 1)], W + Lo.P1[i] + (long)t * A, (long)T1 * A, att[i], Di,
+                            (int)(B * Li));
+        RFN_TRY(gemm_groups(A, (int)Di, T1, pr, 0, gx));
+    }
     return RFN_OK;
 }
 

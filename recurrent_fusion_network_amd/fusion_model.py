@@ -139,9 +139,10 @@ class _PrefixFn(torch.autograd.Function):
         # ... then one encoder at a time, so a data-parallel host overlaps bucket i's all-reduce with the
         # GEMMs of encoder i+1 (the largest of backward)
         for i in range(M):
-            N.check(N.lib.rfn_prefix_bwd_wgrad(C.byref(d), B, att_ptrs, gtable, ctx.ws.data_ptr(), ws_bytes, i,
-                                               N.stream_ptr()), 'rfn_prefix_bwd_wgrad')
-            model._bucket_done('enc%d' % i, flats['enc%d' % i])
+            for part, tag in ((1, 'a'), (2, 'b')):
+                N.check(N.lib.rfn_prefix_bwd_wgrad(C.byref(d), B, att_ptrs, gtable, ctx.ws.data_ptr(), ws_bytes, i,
+                                                   part, N.stream_ptr()), 'rfn_prefix_bwd_wgrad')
+                model._bucket_done('enc%d%s' % (i, tag), flats['enc%d%s' % (i, tag)])
         ctx.ws = None
         model._deliver_grads(ctx.params, [by_slot[sl] for sl in model._prefix_slots])
         return (None, None, None, None, None) + (None,) * (2 * M) + (None,) * len(ctx.params)
@@ -247,16 +248,20 @@ class RecurrentFusionModel(nn.Module):
         self._prefix_slots = [i for i, n in enumerate(self._slot_names) if not is_dec(n)]
         self._decoder_slots = [i for i, n in enumerate(self._slot_names) if is_dec(n)]
         # gradient buckets, in the order their gradients become final during backward: the decoder, the
-        # fusion "core" (everything of phase 1 except the per-encoder stage-I weights) and one bucket per
-        # encoder (rfn_prefix_bwd_wgrad).  Each bucket is one flat buffer = one all-reduce = one Adam launch.
+        # fusion "core" (everything of phase 1 except the per-encoder stage-I weights) and two buckets per
+        # encoder (rfn_prefix_bwd_wgrad parts 1 and 2).  Each bucket is one flat buffer = one all-reduce = one Adam launch.
         enc_re = re.compile(r'^review_steps_individual\.\d+\.lstm\.(\d+)\.(att_model\.att_2_att_h|att_model\.h_2_att_h|H2h|z2h)\.')
         self._bucket_slots = {'decoder': list(self._decoder_slots), 'core': []}
         for i in range(M):
-            self._bucket_slots['enc%d' % i] = []
+            self._bucket_slots['enc%da' % i] = []    # H2h, z2h, h_2_att_h of encoder i (rfn_prefix_bwd_wgrad part 1)
+            self._bucket_slots['enc%db' % i] = []    # att_2_att_h of encoder i            (part 2)
         for idx in self._prefix_slots:
             m = enc_re.match(self._slot_names[idx])
-            self._bucket_slots['enc%s' % m.group(1) if m else 'core'].append(idx)
-        self._prefix_buckets = ['core'] + ['enc%d' % i for i in range(M)]
+            if not m:
+                self._bucket_slots['core'].append(idx)
+            else:
+                self._bucket_slots['enc%s%s' % (m.group(1), 'b' if 'att_2_att_h' in m.group(2) else 'a')].append(idx)
+        self._prefix_buckets = ['core'] + [b for i in range(M) for b in ('enc%da' % i, 'enc%db' % i)]
         self.grad_ready_hook = None      # callable(bucket_name, flat_grad_tensor), see parallel.GradSync
         # Opt-in: real batches hold each image's features `seq_per_img` times in a row (dataloader.py:251-252).
         # With this set to that count, stages I/II run once per image and their outputs are fanned out to the
