@@ -217,6 +217,16 @@ int rfn_xe_loss(const float* logp, int B, int T, int V1, const int64_t* target, 
                 const float* mask, int64_t ld_mask, float eps, float gscale,
                 float* scratch /* B*T floats, needed when loss_out != NULL */, float* loss_out,
                 int accumulate_loss, float* dlogp, void* stream);
+/* ReviewNetRewardCriterion policy + entropy terms (misc/utils.py:50-72):
+ * loss_out[0] (+)= [ -sum pol(b,t)*mask(b,t) + entropy_reg * sum mask0(b,t) * sum_v lp*exp(lp) ] / B with
+ * mask0 = seq > 0, mask = [1, mask0[:, :-1]], pol = input*reward or the reference's PPO-clip surrogate.
+ * d_input (B,T) and d_logprobs_all rows t < T (same strides convention) are overwritten when non-NULL. */
+int rfn_rl_loss(const float* input, int64_t ld_in, const int64_t* seq, int64_t ld_seq, const float* reward,
+                int64_t ld_rw, const float* logprobs_all, int64_t lp_sb, int64_t lp_st, int B, int T, int V1,
+                float entropy_reg, const float* old_logprobs, int64_t ld_old, int use_ppo, float ppo_clip,
+                float* scratch /* B*T floats when loss_out != NULL */, float* loss_out, int accumulate_loss,
+                float* d_input, int64_t ld_din, float* d_logprobs_all, int64_t dlp_sb, int64_t dlp_st,
+                void* stream);
 /* nn.MultiLabelMarginLoss, mean reduction (misc/utils.py:186-190), scaled by `scale`:
  * loss_out[0] (+)= scale * MLM(pred, target); dpred (overwritten) = scale * gscale * dMLM/dpred. */
 int rfn_multilabel_margin(const float* pred, int B, int K, const int64_t* target, float scale,

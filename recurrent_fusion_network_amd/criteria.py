@@ -3,9 +3,8 @@
 * ReviewNetEnsembleCriterion (misc/utils.py:153-192): masked NLL (optionally label-smoothed) / batch
   + reason_weight / (M+1) * sum_j MultiLabelMarginLoss(top_pred[j], top_true)  -> rfn_xe_loss +
   rfn_multilabel_margin, fixed summation order.
-* ReviewNetRewardCriterion (misc/utils.py:44-84): REINFORCE / PPO-clip term + entropy regulariser + the
-  same reason loss.  The (B,T) element-wise policy term is host glue on torch tensors (it is not on the
-  timed path); the reason loss uses the HIP kernel.
+* ReviewNetRewardCriterion (misc/utils.py:44-84): REINFORCE / PPO-clip term + entropy regulariser
+  (rfn_rl_loss) + the same reason loss (rfn_multilabel_margin).
 * clip_gradient (misc/utils.py:292-296): element-wise clamp; FusedClampAdam fuses it into the update.
 """
 import torch
@@ -109,6 +108,45 @@ class _MLMFn(torch.autograd.Function):
         return (None, None) + tuple(out)
 
 
+class _RLFn(torch.autograd.Function):
+    """Policy + entropy terms of ReviewNetRewardCriterion (misc/utils.py:50-72): rfn_rl_loss."""
+
+    @staticmethod
+    def forward(ctx, seq, reward, entropy_reg, old_lp, use_ppo, ppo_clip, inp, logprobs_all):
+        inp = N.require_cuda_f32(inp, 'input')
+        lp = N.require_cuda_f32(logprobs_all, 'logprobs_all')
+        B, T = inp.shape
+        V1 = lp.size(2)
+        if lp.size(1) < T:
+            raise N.RfnError('logprobs_all has fewer steps than the sampled sequence')
+        dev = inp.device
+        seq = seq.to(dev).long().contiguous()
+        reward = reward.to(dev).float().contiguous()
+        old = None if old_lp is None else old_lp.to(dev).float().contiguous()
+        loss = torch.zeros(1, device=dev)
+        scratch = torch.empty(B * T, device=dev)
+        N.check(N.lib.rfn_rl_loss(inp.data_ptr(), T, seq.data_ptr(), seq.stride(0), reward.data_ptr(), reward.stride(0),
+                                  lp.data_ptr(), lp.stride(0), lp.stride(1), B, T, V1, float(entropy_reg), N.ptr(old),
+                                  T, int(bool(use_ppo)), float(ppo_clip), scratch.data_ptr(), loss.data_ptr(), 0, None,
+                                  0, None, 0, 0, N.stream_ptr()), 'rfn_rl_loss')
+        ctx.args = (float(entropy_reg), int(bool(use_ppo)), float(ppo_clip), B, T, V1)
+        ctx.save_for_backward(inp, lp, seq, reward, *(() if old is None else (old,)))
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        inp, lp, seq, reward, *rest = ctx.saved_tensors
+        old = rest[0] if rest else None
+        ent, ppo, clip, B, T, V1 = ctx.args
+        d_inp = torch.empty_like(inp)
+        d_lp = torch.zeros_like(lp)                      # rows t >= T do not enter the loss
+        N.check(N.lib.rfn_rl_loss(inp.data_ptr(), T, seq.data_ptr(), seq.stride(0), reward.data_ptr(), reward.stride(0),
+                                  lp.data_ptr(), lp.stride(0), lp.stride(1), B, T, V1, ent, N.ptr(old), T, ppo, clip,
+                                  None, None, 0, d_inp.data_ptr(), T, d_lp.data_ptr(), d_lp.stride(0), d_lp.stride(1),
+                                  N.stream_ptr()), 'rfn_rl_loss (grad)')
+        return None, None, None, None, None, None, d_inp.mul_(g), d_lp.mul_(g)
+
+
 class ReviewNetRewardCriterion(nn.Module):
     def __init__(self, opt):
         super().__init__()
@@ -117,21 +155,9 @@ class ReviewNetRewardCriterion(nn.Module):
 
     def forward(self, input, seq, reward, logprobs_all, entropy_reg, top_pred, top_true, reason_weight,
                 sample_logprobs_old, opt):
-        B, T = input.shape
-        inp = input.contiguous().view(-1)
-        reward = reward.to(inp.device).contiguous().view(-1)
-        mask_0 = (seq > 0).float()
-        mask = torch.cat([mask_0.new_ones(B, 1), mask_0[:, :-1]], 1).view(-1)
-        lp = logprobs_all[:, :T, :]
-        entropy_minus = (lp * torch.exp(lp)).sum(2) * mask_0
-        if getattr(opt, 'use_ppo', 0):
-            ratio = torch.exp(inp) / (1e-5 + torch.exp(sample_logprobs_old.contiguous().view(-1)))
-            surr1 = ratio * reward
-            surr2 = surr1.clamp(1 - opt.ppo_clip, 1 + opt.ppo_clip) * reward
-            out = -torch.min(surr1, surr2) * mask
-        else:
-            out = -inp * reward * mask
-        out = out.sum() / B + entropy_reg * entropy_minus.sum() / B
+        use_ppo = getattr(opt, 'use_ppo', 0)
+        out = _RLFn.apply(seq, reward, entropy_reg, sample_logprobs_old if use_ppo else None, use_ppo,
+                          getattr(opt, 'ppo_clip', 0.2), input, logprobs_all)
         preds = top_pred if isinstance(top_pred, (list, tuple)) else [top_pred]
         return out + _MLMFn.apply(float(reason_weight) / len(preds), top_true, *preds)
 

@@ -367,6 +367,85 @@ extern "C" int rfn_xe_loss(const float* logp, int B, int T, int V1, const int64_
     return RFN_OK;
 }
 
+// ---- RL reward criterion, policy + entropy terms (misc/utils.py:50-72) ------------------------------------
+// One block per (b, t) row:  term = -pol(b,t) * mask(b,t) + entropy_reg * mask0(b,t) * sum_v lp*exp(lp),
+// mask0 = seq > 0, mask = [1, mask0[:, :-1]] (the step AFTER an END still counts), pol = input*reward or the
+// PPO-clip surrogate min(surr1, clamp(surr1, 1-c, 1+c)*reward) with surr1 = exp(input)/(1e-5+exp(old))*reward
+// (written as in the reference: it clamps surr1, not the ratio).  Gradients w.r.t. input and logprobs_all.
+__global__ __launch_bounds__(256) void rl_loss_k(const float* __restrict__ inp, long ld_in, const int64_t* __restrict__ seq,
+                                                 long ld_seq, const float* __restrict__ reward, long ld_rw,
+                                                 const float* __restrict__ lp_all, long lp_sb, long lp_st, int T, int V1,
+                                                 float entropy_reg, const float* __restrict__ old_lp, long ld_old,
+                                                 int use_ppo, float ppo_clip, float inv_B, float* __restrict__ row_loss,
+                                                 float* __restrict__ d_inp, long ld_din, float* __restrict__ d_lp,
+                                                 long dlp_sb, long dlp_st) {
+    __shared__ float red[4];
+    const int r = blockIdx.x, b = r / T, t = r - b * T;
+    const float m0 = (seq[b * ld_seq + t] > 0) ? 1.f : 0.f;
+    const float mk = (t == 0) ? 1.f : ((seq[b * ld_seq + t - 1] > 0) ? 1.f : 0.f);
+    const float* lp = lp_all + b * lp_sb + t * lp_st;
+    if (row_loss) {
+        float e = 0.f;
+        if (m0 != 0.f && entropy_reg != 0.f)
+            for (int v = threadIdx.x; v < V1; v += 256) e += lp[v] * expf(lp[v]);
+        e = block_sum_256(e, red);
+        if (threadIdx.x == 0) {
+            const float x = inp[b * ld_in + t], rw = reward[b * ld_rw + t];
+            float pol;
+            if (use_ppo) {
+                const float ratio = expf(x) / (1e-5f + expf(old_lp[b * ld_old + t]));
+                const float s1 = ratio * rw;
+                const float s2 = fminf(fmaxf(s1, 1.f - ppo_clip), 1.f + ppo_clip) * rw;
+                pol = fminf(s1, s2);
+            } else {
+                pol = x * rw;
+            }
+            row_loss[r] = -pol * mk + entropy_reg * m0 * e;
+        }
+    }
+    if (d_lp) {
+        float* d = d_lp + b * dlp_sb + t * dlp_st;
+        const float c = entropy_reg * m0 * inv_B;
+        for (int v = threadIdx.x; v < V1; v += 256) d[v] = (c != 0.f) ? c * expf(lp[v]) * (1.f + lp[v]) : 0.f;
+    }
+    if (d_inp && threadIdx.x == 0) {
+        const float x = inp[b * ld_in + t], rw = reward[b * ld_rw + t];
+        float g;
+        if (use_ppo) {
+            const float ratio = expf(x) / (1e-5f + expf(old_lp[b * ld_old + t]));
+            const float s1 = ratio * rw;
+            const float cl = fminf(fmaxf(s1, 1.f - ppo_clip), 1.f + ppo_clip);
+            const float s2 = cl * rw;
+            const float ds1 = ratio * rw;                                        // d surr1 / d input
+            const float ds2 = (s1 > 1.f - ppo_clip && s1 < 1.f + ppo_clip) ? ds1 * rw : 0.f;
+            g = (s1 <= s2) ? ds1 : ds2;
+        } else {
+            g = rw;
+        }
+        d_inp[b * ld_din + t] = -g * mk * inv_B;
+    }
+}
+extern "C" int rfn_rl_loss(const float* input, int64_t ld_in, const int64_t* seq, int64_t ld_seq, const float* reward,
+                           int64_t ld_rw, const float* logprobs_all, int64_t lp_sb, int64_t lp_st, int B, int T, int V1,
+                           float entropy_reg, const float* old_logprobs, int64_t ld_old, int use_ppo, float ppo_clip,
+                           float* scratch, float* loss_out, int accumulate_loss, float* d_input, int64_t ld_din,
+                           float* d_logprobs_all, int64_t dlp_sb, int64_t dlp_st, void* stream) {
+    if (B <= 0 || T <= 0 || V1 <= 0) return RFN_ERR_SHAPE;
+    if (!input || !seq || !reward || !logprobs_all || (loss_out && !scratch) || (use_ppo && !old_logprobs))
+        return RFN_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(rl_loss_k, dim3(B * T), dim3(256), 0, st, input, (long)ld_in, seq, (long)ld_seq, reward,
+                       (long)ld_rw, logprobs_all, (long)lp_sb, (long)lp_st, T, V1, entropy_reg, old_logprobs,
+                       (long)ld_old, use_ppo, ppo_clip, 1.0f / (float)B, loss_out ? scratch : nullptr, d_input,
+                       (long)ld_din, d_logprobs_all, (long)dlp_sb, (long)dlp_st);
+    RFN_CHECK_LAUNCH();
+    if (loss_out) {
+        hipLaunchKernelGGL(sum_k, dim3(1), dim3(256), 0, st, scratch, B * T, 1.0f / (float)B, loss_out, accumulate_loss);
+        RFN_CHECK_LAUNCH();
+    }
+    return RFN_OK;
+}
+
 // ---- nn.MultiLabelMarginLoss (mean) -----------------------------------------------------------------
 // Row b: targets = ids before the first -1; loss_b = sum_{j in targets} sum_{i not target}
 // max(0, 1 - x[j] + x[i]) / K.  One block per row; hit counts per target through LDS integer atomics.

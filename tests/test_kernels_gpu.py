@@ -556,3 +556,40 @@ def test_gemm_randomized_shapes_layouts_segments_groups(dev):
             assert err < tol, (case, M, Nn, ak, bk, ngroups, nseg, acc, use_ws, pad, err, tol)
             if pad:
                 assert torch.equal(Cd[:, Nn:].cpu(), Cfull[:, Nn:]), 'wrote outside the N columns'
+
+
+@pytest.mark.parametrize('use_ppo', [0, 1])
+def test_rl_reward_criterion_matches_oracle(dev, use_ppo):
+    """ReviewNetRewardCriterion (misc/utils.py:50-84) incl. the PPO-clip surrogate, finished rows (seq == 0) and a
+    logprobs_all that holds one more step than the sampled sequence."""
+    from types import SimpleNamespace
+    import recurrent_fusion_network_amd as R
+    from oracle import rfn_oracle as O
+    B, T, V1, K = 6, 5, 301, 40
+    g = torch.Generator().manual_seed(5 + use_ppo)
+    lp_all = torch.log_softmax(torch.randn(B, T + 1, V1, generator=g), 2)
+    seq = torch.randint(1, V1, (B, T), generator=g)
+    seq[1, 2:] = 0
+    seq[4, 0:] = 0
+    inp = lp_all[:, :T].gather(2, seq.unsqueeze(2)).squeeze(2).clone()
+    old = inp + 0.3 * torch.randn(B, T, generator=g)
+    reward = torch.randn(B, 1, generator=g).expand(B, T).contiguous() * 2.0
+    preds = [torch.randn(B, K, generator=g) for _ in range(2)]
+    top = -torch.ones(B, K, dtype=torch.long)
+    top[:, :3] = torch.stack([torch.randperm(K, generator=g)[:3] for _ in range(B)])
+    cfg = SimpleNamespace(use_ppo=use_ppo, ppo_clip=0.2, use_label_smoothing=0, label_smoothing_epsilon=0.1)
+    # oracle (fp64 autograd)
+    ir, lr = inp.double().requires_grad_(True), lp_all.double().requires_grad_(True)
+    pr = [p.double().requires_grad_(True) for p in preds]
+    ref = O.rl_criterion(cfg, ir, seq, reward.double(), lr, 0.01, pr, top, 1.0, old.double())
+    ref.backward()
+    crit = R.ReviewNetRewardCriterion(cfg)
+    idv, ldv = inp.to(dev).requires_grad_(True), lp_all.to(dev).requires_grad_(True)
+    pdv = [p.to(dev).requires_grad_(True) for p in preds]
+    loss = crit(idv, seq.to(dev), reward.to(dev), ldv, 0.01, pdv, top.to(dev), 1.0, old.to(dev), cfg)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(ref.detach())) < 1e-5 * max(1.0, abs(float(ref.detach())))
+    assert maxerr(idv.grad, ir.grad) < 1e-6
+    assert maxerr(ldv.grad, lr.grad) < 1e-7
+    for a, b in zip(pdv, pr):
+        assert maxerr(a.grad, b.grad) < 1e-7
