@@ -33,7 +33,7 @@ extern "C" {
 #define RFN_ERR_ARG (-5)         /* null / misaligned pointer */
 
 #define RFN_MAX_ENC 8
-#define RFN_ABI_VERSION 1
+#define RFN_ABI_VERSION 2
 
 /* Model dimensions: the fields RecurrentFusionModel.__init__ reads from `opt`
  * (misc/RecurrentFusionModel.py:118-151). */
@@ -49,8 +49,8 @@ typedef struct rfn_dims {
     int32_t L[RFN_MAX_ENC];    /* feat_array_info[i]['att_num']                           */
     int32_t D[RFN_MAX_ENC];    /* feat_array_info[i]['att_feat_size']                     */
     int32_t F[RFN_MAX_ENC];    /* feat_array_info[i]['fc_feat_size']                      */
-    int32_t review_maxout;     /* opt.review_maxout: must be 0 (RFN_ERR_UNSUPPORTED)      */
-    int32_t decoder_maxout;    /* opt.maxout:        must be 0 (RFN_ERR_UNSUPPORTED)      */
+    int32_t review_maxout;     /* opt.review_maxout (stage II gates are 5R wide)          */
+    int32_t decoder_maxout;    /* opt.maxout        (decoder gates are 5R wide)           */
     float drop_fusion;         /* opt.drop_prob_fusion (stage I)                          */
     float drop_reason;         /* opt.drop_prob_reason (stage II)                         */
     float drop_lm;             /* opt.drop_prob_lm     (decoder)                          */
@@ -148,29 +148,31 @@ int rfn_attn_scores_bwd(const float* proj, int64_t proj_sb, int64_t proj_sl, con
 /* LSTM gate epilogue shared by the three cells (misc/RecurrentFusionModel.py:55-73,
  * misc/LSTMSoftMultiAttentionFeatArrayNoInputCore.py:54-72, misc/LSTMSoftAttentionCore.py:83-101):
  * gates[b, 0:4R] = [in | forget | out | g] pre-activations on entry, activations on exit;
- * c_next = f*c_prev + i*g; h_next = dropout(o*tanh(c_next)).  drop_p > 0 draws a Philox mask from
+ * c_next = f*c_prev + i*g; h_next = dropout(o*tanh(c_next)).  maxout != 0: gates are 5R wide,
+ * g = max(chunk 3, chunk 4) without tanh (LSTMSoftMultiAttention...py:60-62, LSTMSoftAttentionCore.py:89-91).  drop_p > 0 draws a Philox mask from
  * (seed, offset) that rfn_lstm_bwd regenerates. */
 int rfn_lstm_fwd(float* gates, int64_t ldg, const float* c_prev, int64_t ldcp, float* c_next,
-                 int64_t ldcn, float* h_next, int64_t ldh, int B, int R, float drop_p,
+                 int64_t ldcn, float* h_next, int64_t ldh, int B, int R, int maxout, float drop_p,
                  uint64_t seed, uint64_t offset, void* stream);
 /* G independent cells in one launch (the M encoders of a stage-I step): group g uses gates + g*gs_gates,
  * c_prev + g*gs_cprev, c_next + g*gs_cnext, h_next + g*gs_h and dropout stream offset + g. */
 int rfn_lstm_fwd_grouped(float* gates, int64_t ldg, const float* c_prev, int64_t ldcp, float* c_next,
-                         int64_t ldcn, float* h_next, int64_t ldh, int B, int R, float drop_p,
+                         int64_t ldcn, float* h_next, int64_t ldh, int B, int R, int maxout, float drop_p,
                          uint64_t seed, uint64_t offset, int G, int64_t gs_gates, int64_t gs_cprev,
                          int64_t gs_cnext, int64_t gs_h, void* stream);
 /* dgates (in place over the activations), dc_prev = dc_next_total * f.
  * dh / dc_next are the TOTAL incoming gradients of h_next / c_next (dc_next may be NULL). */
 int rfn_lstm_bwd(float* gates, int64_t ldg, const float* c_prev, int64_t ldcp, const float* c_next,
                  int64_t ldcn, const float* dh, int64_t lddh, const float* dc_next, int64_t lddcn,
-                 float* dc_prev, int64_t lddcp, int B, int R, float drop_p, uint64_t seed,
+                 float* dc_prev, int64_t lddcp, int B, int R, int maxout, float drop_p, uint64_t seed,
                  uint64_t offset, void* stream);
 
 /* grouped backward: c_prev and c_next share gs_c; dc_next and dc_prev share gs_dc */
 int rfn_lstm_bwd_grouped(float* gates, int64_t ldg, const float* c_prev, int64_t ldcp, const float* c_next,
                          int64_t ldcn, const float* dh, int64_t lddh, const float* dc_next, int64_t lddcn,
-                         float* dc_prev, int64_t lddcp, int B, int R, float drop_p, uint64_t seed,
-                         uint64_t offset, int G, int64_t gs_gates, int64_t gs_c, int64_t gs_dh, int64_t gs_dc,
+                         float* dc_prev, int64_t lddcp, int B, int R, int maxout, float drop_p,
+                         uint64_t seed, uint64_t offset, int G, int64_t gs_gates, int64_t gs_c, int64_t gs_dh,
+                         int64_t gs_dc,
                          void* stream);
 
 /* nn.Embedding gather (misc/RecurrentFusionModel.py:276): out[r,:] = W[id(r), :] with

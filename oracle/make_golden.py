@@ -31,6 +31,9 @@ CONFIGS = {
     # name: (feat specs (L, D, fc), R/A/E, V, K, T1, T2, B, seq_length, seed, ragged max words)
     'tiny0': dict(feats=[(5, 24, 24), (7, 40, 32)], R=16, V=50, K=20, T1=3, T2=3, B=3, S=5, seed=0, max_words=3),
     'tiny1': dict(feats=[(5, 24, 24), (7, 40, 32)], R=16, V=50, K=20, T1=3, T2=3, B=3, S=5, seed=1, max_words=5),
+    # maxout variants of the stage-II and decoder cells (opts.py:180-185); fusion_maxout is set too and must be ignored
+    'tinymax': dict(feats=[(5, 24, 24), (7, 40, 32)], R=16, V=50, K=20, T1=3, T2=3, B=3, S=5, seed=5, max_words=5,
+                    extra=dict(review_maxout=1, maxout=1, fusion_maxout=1)),
     'mid': dict(feats=[(196, 96, 96), (64, 80, 128), (49, 72, 72)], R=64, V=300, K=50, T1=8, T2=8, B=6, S=16,
                 seed=2, max_words=16),
     'c2': dict(feats=[(49, 512, 512)] * 2, R=512, V=9487, K=1000, T1=8, T2=8, B=8, S=16, seed=3, max_words=16),
@@ -42,7 +45,7 @@ def cfg_of(spec):
     info = [dict(att_num=L, att_feat_size=D, fc_feat_size=F) for (L, D, F) in spec['feats']]
     return O.make_cfg(info, vocab_size=spec['V'], rnn_size=spec['R'], input_encoding_size=spec['R'],
                       att_hid_size=spec['R'], num_review_steps_0=spec['T1'], num_review_steps=spec['T2'],
-                      top_words_count=spec['K'], seq_length=spec['S'])
+                      top_words_count=spec['K'], seq_length=spec['S'], **spec.get('extra', {}))
 
 
 def batch_of(cfg, spec):
@@ -221,7 +224,7 @@ def generate(name, RefModel, ref_utils, outdir):
         out['greedy_top5_idx'] = t5.indices.numpy()
 
     # ---- RL: multinomial sample with grad + reward criterion (train_rl.py:160-191) -------------
-    if name in ('tiny0', 'tiny1', 'mid', 'c2'):
+    if name in ('tiny0', 'tiny1', 'tinymax', 'mid', 'c2'):
         torch.manual_seed(77 + spec['seed'])
         model.zero_grad()
         s_seq, s_lp, s_all, s_rp = model.sample(fc, att, {'sample_max': 0, 'beam_size': 1, 'temperature': 1.0})
@@ -275,7 +278,7 @@ def generate(name, RefModel, ref_utils, outdir):
         model.zero_grad()
 
     # ---- beam search (misc/RecurrentFusionModel.py:352-543) -----------------------------------
-    if name in ('tiny0', 'mid', 'c2'):
+    if name in ('tiny0', 'tinymax', 'mid', 'c2'):
         beam = 3
         nb = min(spec['B'], 3)
         fcb = [f[:nb] for f in fc]
@@ -316,7 +319,7 @@ def generate(name, RefModel, ref_utils, outdir):
             # a4: stage-II cell (t=2)
             th = [rnd(B, spec['T1'], R) for _ in range(M)]
             o4, (nh4, nc4) = model.review_steps[2](th, (h.unsqueeze(0), c.unsqueeze(0)))
-            oh4, oc4, _ = O.review_cell(th, h, c, P, 2, R)
+            oh4, oc4, _ = O.review_cell(th, h, c, P, 2, R, cfg.review_maxout)
             close(oh4, o4, 1e-5, 'a4 h')
             for i in range(M):
                 out['cell_a4_thoughts_%d' % i] = th[i].numpy()
@@ -324,7 +327,7 @@ def generate(name, RefModel, ref_utils, outdir):
             # a5: decoder cell
             xt, comb = rnd(B, R), rnd(B, spec['T2'], R)
             o5, (nh5, nc5) = model.decoder(xt, comb, (h.unsqueeze(0), c.unsqueeze(0)))
-            oh5, oc5, _ = O.decoder_cell(xt, comb, h, c, P, R)
+            oh5, oc5, _ = O.decoder_cell(xt, comb, h, c, P, R, cfg.maxout)
             close(oh5, o5, 1e-5, 'a5 h')
             out['cell_a5_xt'], out['cell_a5_comb'] = xt.numpy(), comb.numpy()
             out['cell_a5_out_h'], out['cell_a5_out_c'] = o5.numpy(), nc5[0].numpy()

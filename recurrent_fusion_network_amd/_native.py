@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, 'librfn_hip.so')
 RFN_MAX_ENC = 8
 RFN_GEMM_MAXSEG = 8
 RFN_GEMM_MAXGROUP = 8
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class RfnError(RuntimeError):
@@ -67,10 +67,10 @@ def _load():
         'rfn_attn_context_bwd_dalpha': (C.c_int, [P, L, L, P, L, I, I, I, P, P]),
         'rfn_attn_context_bwd_dseq': (C.c_int, [P, P, L, I, I, I, P, L, L, P]),
         'rfn_attn_scores_bwd': (C.c_int, [P, L, L, P, P, P, P, I, I, I, P, L, L, I, P, P, P]),
-        'rfn_lstm_fwd': (C.c_int, [P, L, P, L, P, L, P, L, I, I, F, U64, U64, P]),
-        'rfn_lstm_bwd': (C.c_int, [P, L, P, L, P, L, P, L, P, L, P, L, I, I, F, U64, U64, P]),
-        'rfn_lstm_fwd_grouped': (C.c_int, [P, L, P, L, P, L, P, L, I, I, F, U64, U64, I, L, L, L, L, P]),
-        'rfn_lstm_bwd_grouped': (C.c_int, [P, L, P, L, P, L, P, L, P, L, P, L, I, I, F, U64, U64, I, L, L, L, L, P]),
+        'rfn_lstm_fwd': (C.c_int, [P, L, P, L, P, L, P, L, I, I, I, F, U64, U64, P]),
+        'rfn_lstm_bwd': (C.c_int, [P, L, P, L, P, L, P, L, P, L, P, L, I, I, I, F, U64, U64, P]),
+        'rfn_lstm_fwd_grouped': (C.c_int, [P, L, P, L, P, L, P, L, I, I, I, F, U64, U64, I, L, L, L, L, P]),
+        'rfn_lstm_bwd_grouped': (C.c_int, [P, L, P, L, P, L, P, L, P, L, P, L, I, I, I, F, U64, U64, I, L, L, L, L, P]),
         'rfn_embed_fwd': (C.c_int, [P, I, L, P, I, L, L, I, P, L, P]),
         'rfn_embed_bwd': (C.c_int, [P, L, P, I, L, L, I, I, L, P, P]),
         'rfn_log_softmax_fwd': (C.c_int, [P, L, I, I, I, L, L, P, P]),

@@ -27,9 +27,9 @@ __device__ __forceinline__ float rfn_philox_uniform(uint64_t seed, uint64_t offs
 
 __global__ __launch_bounds__(256) void lstm_fwd_k(float* __restrict__ gates, long ldg, const float* c_prev /* may alias c_next */,
                                                   long ldcp, float* c_next, long ldcn,
-                                                  float* __restrict__ h_next, long ldh, int B, int R, float drop_p,
-                                                  uint64_t seed, uint64_t offset, long gs_g, long gs_cp, long gs_cn,
-                                                  long gs_h) {
+                                                  float* __restrict__ h_next, long ldh, int B, int R, int maxout,
+                                                  float drop_p, uint64_t seed, uint64_t offset, long gs_g, long gs_cp,
+                                                  long gs_cn, long gs_h) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (long)B * R) return;
     const int grp = blockIdx.y;   // independent cells of one step (the M encoders of stage I)
@@ -40,7 +40,14 @@ __global__ __launch_bounds__(256) void lstm_fwd_k(float* __restrict__ gates, lon
     const float ig = rfn_sigmoid(g[j]);
     const float fg = rfn_sigmoid(g[R + j]);
     const float og = rfn_sigmoid(g[2 * R + j]);
-    const float gg = tanhf(g[3 * R + j]);
+    float gg;
+    if (maxout) {  // in_transform = max of the two candidate chunks, no tanh; chunk 4 keeps the selector
+        const float a = g[3 * R + j], b2 = g[4 * R + j];
+        gg = fmaxf(a, b2);
+        g[4 * R + j] = (a >= b2) ? 1.f : 0.f;
+    } else {
+        gg = tanhf(g[3 * R + j]);
+    }
     g[j] = ig;
     g[R + j] = fg;
     g[2 * R + j] = og;
@@ -56,29 +63,29 @@ __global__ __launch_bounds__(256) void lstm_fwd_k(float* __restrict__ gates, lon
 }
 
 extern "C" int rfn_lstm_fwd_grouped(float* gates, int64_t ldg, const float* c_prev, int64_t ldcp, float* c_next,
-                                    int64_t ldcn, float* h_next, int64_t ldh, int B, int R, float drop_p,
+                                    int64_t ldcn, float* h_next, int64_t ldh, int B, int R, int maxout, float drop_p,
                                     uint64_t seed, uint64_t offset, int G, int64_t gs_gates, int64_t gs_cprev,
                                     int64_t gs_cnext, int64_t gs_h, void* stream) {
     if (B <= 0 || R <= 0 || G < 1 || drop_p < 0.f || drop_p >= 1.f) return RFN_ERR_SHAPE;
     if (!gates || !c_prev || !c_next || !h_next) return RFN_ERR_ARG;
     hipLaunchKernelGGL(lstm_fwd_k, dim3(rfn_cdiv((long)B * R, 256), G), dim3(256), 0, (hipStream_t)stream, gates,
-                       (long)ldg, c_prev, (long)ldcp, c_next, (long)ldcn, h_next, (long)ldh, B, R, drop_p, seed,
-                       offset, (long)gs_gates, (long)gs_cprev, (long)gs_cnext, (long)gs_h);
+                       (long)ldg, c_prev, (long)ldcp, c_next, (long)ldcn, h_next, (long)ldh, B, R, maxout ? 1 : 0, drop_p,
+                       seed, offset, (long)gs_gates, (long)gs_cprev, (long)gs_cnext, (long)gs_h);
     RFN_CHECK_LAUNCH();
     return RFN_OK;
 }
 extern "C" int rfn_lstm_fwd(float* gates, int64_t ldg, const float* c_prev, int64_t ldcp, float* c_next,
-                            int64_t ldcn, float* h_next, int64_t ldh, int B, int R, float drop_p, uint64_t seed,
-                            uint64_t offset, void* stream) {
-    return rfn_lstm_fwd_grouped(gates, ldg, c_prev, ldcp, c_next, ldcn, h_next, ldh, B, R, drop_p, seed, offset, 1, 0,
-                                0, 0, 0, stream);
+                            int64_t ldcn, float* h_next, int64_t ldh, int B, int R, int maxout, float drop_p,
+                            uint64_t seed, uint64_t offset, void* stream) {
+    return rfn_lstm_fwd_grouped(gates, ldg, c_prev, ldcp, c_next, ldcn, h_next, ldh, B, R, maxout, drop_p, seed, offset,
+                                1, 0, 0, 0, 0, stream);
 }
 
 __global__ __launch_bounds__(256) void lstm_bwd_k(float* __restrict__ gates, long ldg, const float* __restrict__ c_prev,
                                                   long ldcp, const float* __restrict__ c_next, long ldcn,
                                                   const float* __restrict__ dh, long lddh,
                                                   const float* dc_next /* may alias dc_prev */, long lddcn,
-                                                  float* dc_prev, long lddcp, int B, int R, float drop_p,
+                                                  float* dc_prev, long lddcp, int B, int R, int maxout, float drop_p,
                                                   uint64_t seed, uint64_t offset, long gs_g, long gs_c, long gs_dh,
                                                   long gs_dc) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
@@ -106,28 +113,34 @@ __global__ __launch_bounds__(256) void lstm_bwd_k(float* __restrict__ gates, lon
     g[j] = d_i * ig * (1.0f - ig);
     g[R + j] = d_f * fg * (1.0f - fg);
     g[2 * R + j] = d_o * og * (1.0f - og);
-    g[3 * R + j] = d_g * (1.0f - gg * gg);
+    if (maxout) {  // the gradient goes to the chunk that won the max
+        const float sel = g[4 * R + j];
+        g[3 * R + j] = d_g * sel;
+        g[4 * R + j] = d_g * (1.0f - sel);
+    } else {
+        g[3 * R + j] = d_g * (1.0f - gg * gg);
+    }
     dc_prev[b * lddcp + j] = dc * fg;
 }
 
 extern "C" int rfn_lstm_bwd_grouped(float* gates, int64_t ldg, const float* c_prev, int64_t ldcp,
                                     const float* c_next, int64_t ldcn, const float* dh, int64_t lddh,
                                     const float* dc_next, int64_t lddcn, float* dc_prev, int64_t lddcp, int B, int R,
-                                    float drop_p, uint64_t seed, uint64_t offset, int G, int64_t gs_gates,
+                                    int maxout, float drop_p, uint64_t seed, uint64_t offset, int G, int64_t gs_gates,
                                     int64_t gs_c, int64_t gs_dh, int64_t gs_dc, void* stream) {
     if (B <= 0 || R <= 0 || G < 1 || drop_p < 0.f || drop_p >= 1.f) return RFN_ERR_SHAPE;
     if (!gates || !c_prev || !c_next || !dh || !dc_prev) return RFN_ERR_ARG;
     hipLaunchKernelGGL(lstm_bwd_k, dim3(rfn_cdiv((long)B * R, 256), G), dim3(256), 0, (hipStream_t)stream, gates,
                        (long)ldg, c_prev, (long)ldcp, c_next, (long)ldcn, dh, (long)lddh, dc_next, (long)lddcn,
-                       dc_prev, (long)lddcp, B, R, drop_p, seed, offset, (long)gs_gates, (long)gs_c, (long)gs_dh,
+                       dc_prev, (long)lddcp, B, R, maxout ? 1 : 0, drop_p, seed, offset, (long)gs_gates, (long)gs_c, (long)gs_dh,
                        (long)gs_dc);
     RFN_CHECK_LAUNCH();
     return RFN_OK;
 }
 extern "C" int rfn_lstm_bwd(float* gates, int64_t ldg, const float* c_prev, int64_t ldcp, const float* c_next,
                             int64_t ldcn, const float* dh, int64_t lddh, const float* dc_next, int64_t lddcn,
-                            float* dc_prev, int64_t lddcp, int B, int R, float drop_p, uint64_t seed, uint64_t offset,
-                            void* stream) {
+                            float* dc_prev, int64_t lddcp, int B, int R, int maxout, float drop_p, uint64_t seed,
+                            uint64_t offset, void* stream) {
     return rfn_lstm_bwd_grouped(gates, ldg, c_prev, ldcp, c_next, ldcn, dh, lddh, dc_next, lddcn, dc_prev, lddcp, B, R,
-                                drop_p, seed, offset, 1, 0, 0, 0, 0, stream);
+                                maxout, drop_p, seed, offset, 1, 0, 0, 0, 0, stream);
 }

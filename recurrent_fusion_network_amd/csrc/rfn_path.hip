@@ -61,7 +61,6 @@ int check_dims(const rfn_dims* d) {
         return RFN_ERR_SHAPE;
     for (int i = 0; i < d->M; ++i)
         if (d->L[i] < 1 || d->D[i] < 1 || d->F[i] < 1) return RFN_ERR_SHAPE;
-    if (d->review_maxout || d->decoder_maxout) return RFN_ERR_UNSUPPORTED;
     if (d->drop_fusion < 0 || d->drop_fusion >= 1 || d->drop_reason < 0 || d->drop_reason >= 1 || d->drop_lm < 0 ||
         d->drop_lm >= 1)
         return RFN_ERR_SHAPE;
@@ -159,6 +158,10 @@ int zero_f32(float* dst, size_t n, void* st) {
 // ---------------------------------------------------------------------------------------------
 // workspace layouts (offsets in floats, 256-B aligned)
 // ---------------------------------------------------------------------------------------------
+// LSTM gate width: [in | forget | out | g] or, with maxout, [in | forget | out | g1 | g2] (max of the last two,
+// misc/LSTMSoftMultiAttentionFeatArrayNoInputCore.py:25-27,60-62; misc/LSTMSoftAttentionCore.py:25-28,89-91)
+inline int gate_width(int maxout, int R) { return (maxout ? 5 : 4) * R; }
+
 struct Bump {
     size_t off = 0;
     size_t take(size_t n) {
@@ -178,6 +181,7 @@ struct PrefixLayout {
     size_t total;
 };
 PrefixLayout prefix_layout(const rfn_dims* d, int B, int train) {
+    const size_t G2 = (size_t)gate_width(d->review_maxout, d->R);
     PrefixLayout L;
     memset(&L, 0, sizeof(L));
     Bump b;
@@ -201,7 +205,7 @@ PrefixLayout prefix_layout(const rfn_dims* d, int B, int train) {
     L.hp2 = b.take(T2 * M * Bz * A);
     L.al2 = b.take(T2 * M * Bz * T1);
     L.z2 = b.take(T2 * M * Bz * R);
-    L.g2 = b.take(T2 * Bz * 4 * R);
+    L.g2 = b.take(T2 * Bz * G2);
     L.gws = b.take(GEMM_WS_FLOATS);
     if (train) {
         for (int i = 0; i < d->M; ++i) L.dz1[i] = b.take(Bz * d->D[i]);
@@ -227,13 +231,14 @@ struct DecoderLayout {
     size_t total;
 };
 DecoderLayout decoder_layout(const rfn_dims* d, int B, int S, int train) {
+    const size_t GD = (size_t)gate_width(d->decoder_maxout, d->R);
     DecoderLayout L;
     memset(&L, 0, sizeof(L));
     Bump b;
     const size_t R = d->R, A = d->A, E = d->E, T2 = d->T2, V1 = d->V1, Bz = B, Sz = S;
     L.Pd = b.take(T2 * Bz * A);
     L.xs = b.take(Sz * Bz * E);
-    L.gd = b.take(Sz * Bz * 4 * R);
+    L.gd = b.take(Sz * Bz * GD);
     L.hd = b.take((Sz + 1) * Bz * R);
     L.cd = b.take((Sz + 1) * Bz * R);
     L.hpd = b.take(Sz * Bz * A);
@@ -343,6 +348,7 @@ extern "C" int rfn_param_shape(const rfn_dims* d, int idx, int64_t* rows, int64_
     if (!rows || !cols) return RFN_ERR_ARG;
     const PIdx P(d);
     const int M = d->M, R = d->R, A = d->A;
+    const int G2 = gate_width(d->review_maxout, R), GD = gate_width(d->decoder_maxout, R);
     if (idx < 0 || idx >= P.count()) return RFN_ERR_SHAPE;
     auto att_shape = [&](int k, int feat, int64_t* r, int64_t* c) {
         const int64_t rr[6] = {A, A, A, A, 1, 1};
@@ -367,10 +373,10 @@ extern "C" int rfn_param_shape(const rfn_dims* d, int idx, int64_t* rows, int64_
         *rows = d->K; *cols = ((idx - P.rind_w(0)) & 1) ? 1 : R;
     } else if (idx < P.r_w()) {
         const int per = 2 + 8 * M, k = (idx - P.s2base(0)) % per;
-        if (k < 2) { *rows = 4 * R; *cols = k ? 1 : R; }
+        if (k < 2) { *rows = G2; *cols = k ? 1 : R; }
         else {
             const int kk = (k - 2) % 8;
-            if (kk < 2) { *rows = 4 * R; *cols = kk ? 1 : R; }
+            if (kk < 2) { *rows = G2; *cols = kk ? 1 : R; }
             else att_shape(kk - 2, R, rows, cols);
         }
     } else if (idx == P.r_w()) {
@@ -379,7 +385,7 @@ extern "C" int rfn_param_shape(const rfn_dims* d, int idx, int64_t* rows, int64_
         *rows = d->K; *cols = 1;
     } else {
         const int k = idx - P.dec(0);
-        if (k < 6) { *rows = 4 * R; *cols = (k & 1) ? 1 : (k < 2 ? d->E : R); }
+        if (k < 6) { *rows = GD; *cols = (k & 1) ? 1 : (k < 2 ? d->E : R); }
         else att_shape(k - 6, R, rows, cols);
     }
     return RFN_OK;
@@ -403,6 +409,7 @@ extern "C" int rfn_prefix_fwd(const rfn_dims* d, int B, const float* const* prm,
     if (ws_bytes < Lo.total * sizeof(float)) return RFN_ERR_WORKSPACE;
     const PIdx P(d);
     const int M = d->M, R = d->R, A = d->A, T1 = d->T1, T2 = d->T2, K = d->K;
+    const int G2 = gate_width(d->review_maxout, R);
     const long MR = (long)M * R, BMR = (long)B * MR, BR = (long)B * R;
     float* W = (float*)ws;
     const GemmCtx gx{st, W + Lo.gws, GEMM_WS_FLOATS * sizeof(float)};
@@ -455,7 +462,7 @@ extern "C" int rfn_prefix_fwd(const rfn_dims* d, int B, const float* const* prm,
         }
         RFN_TRY(gemm_groups(B, 4 * R, M, pr, 0, gx));
         // the M cells of this step in one launch: encoder i's state is column block i of the (B, M*R) rows
-        RFN_TRY(rfn_lstm_fwd_grouped(g, 4 * R, Cc, MR, Cn, MR, Hn, MR, B, R, train ? d->drop_fusion : 0.f, seed,
+        RFN_TRY(rfn_lstm_fwd_grouped(g, 4 * R, Cc, MR, Cn, MR, Hn, MR, B, R, 0, train ? d->drop_fusion : 0.f, seed,
                                      (uint64_t)(t * M), M, (long)B * 4 * R, R, R, R, st));
     }
 
@@ -495,7 +502,7 @@ extern "C" int rfn_prefix_fwd(const rfn_dims* d, int B, const float* const* prm,
         float* hp = W + Lo.hp2 + (long)t * M * B * A;
         float* al = W + Lo.al2 + (long)t * M * B * T1;
         float* z = W + Lo.z2 + (long)t * M * BR;
-        float* g = W + Lo.g2 + (long)t * B * 4 * R;
+        float* g = W + Lo.g2 + (long)t * B * G2;
         for (int i = 0; i < M; ++i)
             pr[i] = prob1(hp + (long)i * B * A, A, seg_lin(hc, R, prm[P.s2(t, i, 4)], R, R, prm[P.s2(t, i, 5)]));
         RFN_TRY(gemm_groups(B, A, M, pr, 0, gx));
@@ -508,8 +515,8 @@ extern "C" int rfn_prefix_fwd(const rfn_dims* d, int B, const float* const* prm,
                                          st));
             segs[1 + i] = seg_lin(z + i * BR, R, prm[P.s2(t, i, 0)], R, R, prm[P.s2(t, i, 1)]);
         }
-        RFN_TRY(gemm_segs(B, 4 * R, M + 1, segs, g, 4 * R, 0, gx));
-        RFN_TRY(rfn_lstm_fwd(g, 4 * R, cc, R, cn, R, hn, R, B, R, train ? d->drop_reason : 0.f, seed,
+        RFN_TRY(gemm_segs(B, G2, M + 1, segs, g, G2, 0, gx));
+        RFN_TRY(rfn_lstm_fwd(g, G2, cc, R, cn, R, hn, R, B, R, d->review_maxout, train ? d->drop_reason : 0.f, seed,
                              OFF_STAGE2 + (uint64_t)t, st));
     }
     RFN_TRY(gemm1(T2 * B, K, seg_lin(h2 + BR, R, prm[P.r_w()], R, R, prm[P.r_b()]), rmat, K, 0, gx));
@@ -532,6 +539,7 @@ extern "C" int rfn_prefix_bwd(const rfn_dims* d, int B, const float* const* prm,
     if (ws_bytes < Lo.total * sizeof(float)) return RFN_ERR_WORKSPACE;
     const PIdx P(d);
     const int M = d->M, R = d->R, A = d->A, T1 = d->T1, T2 = d->T2, K = d->K;
+    const int G2 = gate_width(d->review_maxout, R);
     const long MR = (long)M * R, BMR = (long)B * MR, BR = (long)B * R, BA = (long)B * A;
     float* W = (float*)ws;
     const GemmCtx gx{st, W + Lo.gws, GEMM_WS_FLOATS * sizeof(float)};
@@ -569,7 +577,7 @@ extern "C" int rfn_prefix_bwd(const rfn_dims* d, int B, const float* const* prm,
         float* hp = W + Lo.hp2 + (long)t * M * BA;
         float* dhp = W + Lo.dhp2 + (long)t * M * BA;
         float* al = W + Lo.al2 + (long)t * M * B * T1;
-        float* g = W + Lo.g2 + (long)t * B * 4 * R;
+        float* g = W + Lo.g2 + (long)t * B * G2;
         float* dht = dh2e + t * BR;  // total dh of h2[t+1]
         if (t == T2 - 1) {
             if (d_h) RFN_TRY(rfn_axpby_2d(1.f, d_h, R, 1.f, dht, R, B, R, st));
@@ -577,11 +585,11 @@ extern "C" int rfn_prefix_bwd(const rfn_dims* d, int B, const float* const* prm,
             RFN_TRY(rfn_axpby_2d(1.f, dhrec, R, 1.f, dht, R, B, R, st));
         }
         const float* dcn = (t == T2 - 1) ? d_c : dc2;
-        RFN_TRY(rfn_lstm_bwd(g, 4 * R, c2 + t * BR, R, c2 + (t + 1) * BR, R, dht, R, dcn, R, dc2, R, B, R,
+        RFN_TRY(rfn_lstm_bwd(g, G2, c2 + t * BR, R, c2 + (t + 1) * BR, R, dht, R, dcn, R, dc2, R, B, R, d->review_maxout,
                              d->drop_reason, seed, OFF_STAGE2 + (uint64_t)t, st));
         // dh_rec = dgates . W_hh ; dz_i = dgates . W_z_i   (same shape: one grouped launch)
-        pr[0] = prob1(dhrec, R, seg_dx(g, 4 * R, prm[P.s2_hh_w(t)], R, 4 * R));
-        for (int i = 0; i < M; ++i) pr[1 + i] = prob1(dz2 + i * BR, R, seg_dx(g, 4 * R, prm[P.s2(t, i, 0)], R, 4 * R));
+        pr[0] = prob1(dhrec, R, seg_dx(g, G2, prm[P.s2_hh_w(t)], R, G2));
+        for (int i = 0; i < M; ++i) pr[1 + i] = prob1(dz2 + i * BR, R, seg_dx(g, G2, prm[P.s2(t, i, 0)], R, G2));
         RFN_TRY(gemm_groups(B, R, M + 1, pr, 0, gx));
         for (int i = 0; i < M; ++i) {
             const float* th = Hs + BMR + i * R;  // thoughts_i[b, l] = Hs[1 + l][b, iR:]
@@ -610,13 +618,13 @@ extern "C" int rfn_prefix_bwd(const rfn_dims* d, int B, const float* const* prm,
         RFN_TRY(rfn_fill_small_f32(outs, T2 * M, 1, 0.f, st));
     }
     for (int t = 0; t < T2; ++t)
-        pr[t] = prob_dw(grd[P.s2_hh_w(t)], R, grd[P.s2_hh_b(t)], W + Lo.g2 + (long)t * B * 4 * R, 4 * R, h2 + t * BR, R, B);
-    RFN_TRY(gemm_groups(4 * R, R, T2, pr, 0, gx));
+        pr[t] = prob_dw(grd[P.s2_hh_w(t)], R, grd[P.s2_hh_b(t)], W + Lo.g2 + (long)t * B * G2, G2, h2 + t * BR, R, B);
+    RFN_TRY(gemm_groups(G2, R, T2, pr, 0, gx));
     for (int i = 0; i < M; ++i) {
         for (int t = 0; t < T2; ++t)
-            pr[t] = prob_dw(grd[P.s2(t, i, 0)], R, grd[P.s2(t, i, 1)], W + Lo.g2 + (long)t * B * 4 * R, 4 * R,
+            pr[t] = prob_dw(grd[P.s2(t, i, 0)], R, grd[P.s2(t, i, 1)], W + Lo.g2 + (long)t * B * G2, G2,
                             W + Lo.z2 + ((long)t * M + i) * BR, R, B);
-        RFN_TRY(gemm_groups(4 * R, R, T2, pr, 0, gx));
+        RFN_TRY(gemm_groups(G2, R, T2, pr, 0, gx));
         for (int t = 0; t < T2; ++t)
             pr[t] = prob_dw(grd[P.s2(t, i, 4)], R, grd[P.s2(t, i, 5)], W + Lo.dhp2 + ((long)t * M + i) * BA, A,
                             h2 + t * BR, R, B);
@@ -652,7 +660,7 @@ extern "C" int rfn_prefix_bwd(const rfn_dims* d, int B, const float* const* prm,
         float* g = W + Lo.g1 + (long)t * M * B * 4 * R;
         float* hp = W + Lo.hp1 + (long)t * M * BA;
         float* dhp = W + Lo.dhp1 + (long)t * M * BA;
-        RFN_TRY(rfn_lstm_bwd_grouped(g, 4 * R, Cs + t * BMR, MR, Cs + (t + 1) * BMR, MR, dHn, MR, dC, MR, dC, MR, B, R,
+        RFN_TRY(rfn_lstm_bwd_grouped(g, 4 * R, Cs + t * BMR, MR, Cs + (t + 1) * BMR, MR, dHn, MR, dC, MR, dC, MR, B, R, 0,
                                      d->drop_fusion, seed, (uint64_t)(t * M), M, (long)B * 4 * R, R, R, R, st));
         // dH_t += sum_i dgates_i . W_H[t,i]   (every cell reads the whole concatenated H, :53)
         for (int i = 0; i < M; ++i) segs[i] = seg_dx(g + (long)i * B * 4 * R, 4 * R, prm[P.s1(t, i, 6)], MR, 4 * R);
@@ -757,6 +765,7 @@ extern "C" int rfn_decoder_fwd(const rfn_dims* d, int B, int S, const float* con
     if (ws_bytes < Lo.total * sizeof(float)) return RFN_ERR_WORKSPACE;
     const PIdx P(d);
     const int R = d->R, A = d->A, E = d->E, T2 = d->T2, V1 = d->V1;
+    const int GD = gate_width(d->decoder_maxout, R);
     const long BR = (long)B * R, BA = (long)B * A;
     float* W = (float*)ws;
     const GemmCtx gx{st, W + Lo.gws, GEMM_WS_FLOATS * sizeof(float)};
@@ -767,7 +776,7 @@ extern "C" int rfn_decoder_fwd(const rfn_dims* d, int B, int S, const float* con
     RFN_TRY(gemm1(T2 * B, A, seg_lin(comb, R, prm[P.dec(6)], R, R, prm[P.dec(7)]), W + Lo.Pd, A, 0, gx));
     // all token embeddings and their i2h projections in one go (teacher forcing: ids are known)
     RFN_TRY(rfn_embed_fwd(prm[P.embed()], E, V1, ids, B, ld_ids, 1, S * B, W + Lo.xs, E, st));
-    RFN_TRY(gemm1(S * B, 4 * R, seg_lin(W + Lo.xs, E, prm[P.dec(0)], E, E, prm[P.dec(1)]), gd, 4 * R, 0, gx));
+    RFN_TRY(gemm1(S * B, GD, seg_lin(W + Lo.xs, E, prm[P.dec(0)], E, E, prm[P.dec(1)]), gd, GD, 0, gx));
     RFN_TRY(copy_f32(hd, h0, BR, st));
     RFN_TRY(copy_f32(cd, c0, BR, st));
     rfn_gemm_seg segs[2];
@@ -776,14 +785,14 @@ extern "C" int rfn_decoder_fwd(const rfn_dims* d, int B, int S, const float* con
         float* hp = W + Lo.hpd + s * BA;
         float* al = W + Lo.ald + (long)s * B * T2;
         float* z = W + Lo.zd + s * BR;
-        float* g = gd + (long)s * B * 4 * R;
+        float* g = gd + (long)s * B * GD;
         RFN_TRY(gemm1(B, A, seg_lin(hc, R, prm[P.dec(8)], R, R, prm[P.dec(9)]), hp, A, 0, gx));
         RFN_TRY(rfn_attn_scores_fwd(W + Lo.Pd, A, BA, hp, prm[P.dec(10)], prm[P.dec(11)], B, T2, A, al, st));
         RFN_TRY(rfn_attn_context_fwd(comb, R, BR, al, B, T2, R, z, R, st));
         segs[0] = seg_lin(hc, R, prm[P.dec(2)], R, R, prm[P.dec(3)]);
         segs[1] = seg_lin(z, R, prm[P.dec(4)], R, R, prm[P.dec(5)]);
-        RFN_TRY(gemm_segs(B, 4 * R, 2, segs, g, 4 * R, 1, gx));
-        RFN_TRY(rfn_lstm_fwd(g, 4 * R, cd + s * BR, R, cd + (s + 1) * BR, R, hd + (s + 1) * BR, R, B, R,
+        RFN_TRY(gemm_segs(B, GD, 2, segs, g, GD, 1, gx));
+        RFN_TRY(rfn_lstm_fwd(g, GD, cd + s * BR, R, cd + (s + 1) * BR, R, hd + (s + 1) * BR, R, B, R, d->decoder_maxout,
                              train ? d->drop_lm : 0.f, seed, OFF_DECODER + (uint64_t)s, st));
     }
     // logits of all steps, then log-softmax written in the reference's (B, S, V+1) layout
@@ -805,6 +814,7 @@ extern "C" int rfn_decoder_bwd(const rfn_dims* d, int B, int S, const float* con
     if (ws_bytes < Lo.total * sizeof(float)) return RFN_ERR_WORKSPACE;
     const PIdx P(d);
     const int R = d->R, A = d->A, E = d->E, T2 = d->T2, V1 = d->V1;
+    const int GD = gate_width(d->decoder_maxout, R);
     const long BR = (long)B * R, BA = (long)B * A;
     float* W = (float*)ws;
     const GemmCtx gx{st, W + Lo.gws, GEMM_WS_FLOATS * sizeof(float)};
@@ -825,13 +835,13 @@ extern "C" int rfn_decoder_bwd(const rfn_dims* d, int B, int S, const float* con
     RFN_TRY(zero_f32(dPd, (size_t)T2 * BA, st));
     rfn_gemm_problem pr[2];
     for (int s = S - 1; s >= 0; --s) {
-        float* g = gd + (long)s * B * 4 * R;
+        float* g = gd + (long)s * B * GD;
         float* dht = dhe + s * BR;
         if (s < S - 1) RFN_TRY(rfn_axpby_2d(1.f, dhrec, R, 1.f, dht, R, B, R, st));
-        RFN_TRY(rfn_lstm_bwd(g, 4 * R, cd + s * BR, R, cd + (s + 1) * BR, R, dht, R, (s < S - 1) ? dc : nullptr, R, dc,
-                             R, B, R, d->drop_lm, seed, OFF_DECODER + (uint64_t)s, st));
-        pr[0] = prob1(dhrec, R, seg_dx(g, 4 * R, prm[P.dec(2)], R, 4 * R));
-        pr[1] = prob1(dz, R, seg_dx(g, 4 * R, prm[P.dec(4)], R, 4 * R));
+        RFN_TRY(rfn_lstm_bwd(g, GD, cd + s * BR, R, cd + (s + 1) * BR, R, dht, R, (s < S - 1) ? dc : nullptr, R, dc,
+                             R, B, R, d->decoder_maxout, d->drop_lm, seed, OFF_DECODER + (uint64_t)s, st));
+        pr[0] = prob1(dhrec, R, seg_dx(g, GD, prm[P.dec(2)], R, GD));
+        pr[1] = prob1(dz, R, seg_dx(g, GD, prm[P.dec(4)], R, GD));
         RFN_TRY(gemm_groups(B, R, 2, pr, 0, gx));
         float* al = W + Lo.ald + (long)s * B * T2;
         RFN_TRY(rfn_attn_context_bwd_dalpha(comb, R, BR, dz, R, B, T2, R, W + Lo.dal, st));
@@ -850,11 +860,11 @@ extern "C" int rfn_decoder_bwd(const rfn_dims* d, int B, int S, const float* con
     // weights shared across steps: one GEMM over (S*B) time-major rows each, bias gradients ride along
     RFN_TRY(rfn_colsum_f32(W + Lo.dwp, A, S * B, A, grd[P.dec(10)], 0, st));
     RFN_TRY(gemm_dw(A, R, grd[P.dec(8)], R, grd[P.dec(9)], W + Lo.dhpd, A, hd, R, S * B, gx));
-    RFN_TRY(gemm_dw(4 * R, R, grd[P.dec(2)], R, grd[P.dec(3)], gd, 4 * R, hd, R, S * B, gx));
-    RFN_TRY(gemm_dw(4 * R, R, grd[P.dec(4)], R, grd[P.dec(5)], gd, 4 * R, W + Lo.zd, R, S * B, gx));
-    RFN_TRY(gemm_dw(4 * R, E, grd[P.dec(0)], E, grd[P.dec(1)], gd, 4 * R, W + Lo.xs, E, S * B, gx));
+    RFN_TRY(gemm_dw(GD, R, grd[P.dec(2)], R, grd[P.dec(3)], gd, GD, hd, R, S * B, gx));
+    RFN_TRY(gemm_dw(GD, R, grd[P.dec(4)], R, grd[P.dec(5)], gd, GD, W + Lo.zd, R, S * B, gx));
+    RFN_TRY(gemm_dw(GD, E, grd[P.dec(0)], E, grd[P.dec(1)], gd, GD, W + Lo.xs, E, S * B, gx));
     // embedding: dx = dgates . W_i2h, then the fixed-order scatter
-    RFN_TRY(gemm1(S * B, E, seg_dx(gd, 4 * R, prm[P.dec(0)], E, 4 * R), W + Lo.dxs, E, 0, gx));
+    RFN_TRY(gemm1(S * B, E, seg_dx(gd, GD, prm[P.dec(0)], E, GD), W + Lo.dxs, E, 0, gx));
     RFN_TRY(rfn_embed_bwd(W + Lo.dxs, E, ids, B, ld_ids, 1, S * B, E, V1, grd[P.embed()], st));
     return RFN_OK;
 }
@@ -869,7 +879,7 @@ extern "C" size_t rfn_decoder_step_ws_bytes(const rfn_dims* d, int B) {
     b.take((size_t)B * d->A);
     b.take((size_t)B * d->T2);
     b.take((size_t)B * d->R);
-    b.take((size_t)B * 4 * d->R);
+    b.take((size_t)B * gate_width(d->decoder_maxout, d->R));
     b.take((size_t)B * d->V1);
     return b.off * sizeof(float);
 }
@@ -893,6 +903,7 @@ extern "C" int rfn_decoder_step(const rfn_dims* d, int B, const float* const* pr
     if (ws_bytes < rfn_decoder_step_ws_bytes(d, B)) return RFN_ERR_WORKSPACE;
     const PIdx P(d);
     const int R = d->R, A = d->A, E = d->E, T2 = d->T2, V1 = d->V1;
+    const int GD = gate_width(d->decoder_maxout, R);
     const long BR = (long)B * R, BA = (long)B * A;
     Bump b;
     float* W = (float*)ws;
@@ -901,7 +912,7 @@ extern "C" int rfn_decoder_step(const rfn_dims* d, int B, const float* const* pr
     float* hp = W + b.take((size_t)B * A);
     float* al = W + b.take((size_t)B * T2);
     float* z = W + b.take((size_t)B * R);
-    float* g = W + b.take((size_t)B * 4 * R);
+    float* g = W + b.take((size_t)B * GD);
     float* lg = logits ? logits : W + b.take((size_t)B * V1);
     RFN_TRY(rfn_embed_fwd(prm[P.embed()], E, V1, ids, B, 1, 0, B, x, E, st));
     RFN_TRY(gemm1(B, A, seg_lin(h, R, prm[P.dec(8)], R, R, prm[P.dec(9)]), hp, A, 0, gx));
@@ -911,8 +922,8 @@ extern "C" int rfn_decoder_step(const rfn_dims* d, int B, const float* const* pr
     segs[0] = seg_lin(x, E, prm[P.dec(0)], E, E, prm[P.dec(1)]);
     segs[1] = seg_lin(h, R, prm[P.dec(2)], R, R, prm[P.dec(3)]);
     segs[2] = seg_lin(z, R, prm[P.dec(4)], R, R, prm[P.dec(5)]);
-    RFN_TRY(gemm_segs(B, 4 * R, 3, segs, g, 4 * R, 0, gx));
-    RFN_TRY(rfn_lstm_fwd(g, 4 * R, c, R, c, R, h, R, B, R, 0.f, 0, 0, st));  // eval: no dropout
+    RFN_TRY(gemm_segs(B, GD, 3, segs, g, GD, 0, gx));
+    RFN_TRY(rfn_lstm_fwd(g, GD, c, R, c, R, h, R, B, R, d->decoder_maxout, 0.f, 0, 0, st));  // eval: no dropout
     if (logits || logp) {
         RFN_TRY(gemm1(B, V1, seg_lin(h, R, prm[P.logit_w()], R, R, prm[P.logit_b()]), lg, V1, 0, gx));
         if (logp) {

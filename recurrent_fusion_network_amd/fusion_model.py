@@ -63,10 +63,11 @@ class _FusionStepParams(nn.Module):
 class _ReviewStepParams(nn.Module):
     """LSTMSoftMultiAttentionFeatArrayNoInputCore (misc/LSTMSoftMultiAttentionFeatArrayNoInputCore.py:24-38)."""
 
-    def __init__(self, M, rnn_size, att_hid):
+    def __init__(self, M, rnn_size, att_hid, maxout=0):
         super().__init__()
-        self.h2h = nn.Linear(rnn_size, 4 * rnn_size)
-        self.z_2_h = nn.ModuleList([nn.Linear(rnn_size, 4 * rnn_size) for _ in range(M)])
+        gw = (5 if maxout else 4) * rnn_size
+        self.h2h = nn.Linear(rnn_size, gw)
+        self.z_2_h = nn.ModuleList([nn.Linear(rnn_size, gw) for _ in range(M)])
         self.att_model = nn.ModuleList([_AttParams(rnn_size, rnn_size, att_hid) for _ in range(M)])
         _uniform(self.h2h.weight, self.h2h.bias)
 
@@ -74,11 +75,12 @@ class _ReviewStepParams(nn.Module):
 class _DecoderParams(nn.Module):
     """LSTMSoftAttentionCore (misc/LSTMSoftAttentionCore.py:24-58)."""
 
-    def __init__(self, enc_size, rnn_size, att_hid):
+    def __init__(self, enc_size, rnn_size, att_hid, maxout=0):
         super().__init__()
-        self.i2h = nn.Linear(enc_size, 4 * rnn_size)
-        self.h2h = nn.Linear(rnn_size, 4 * rnn_size)
-        self.z2h = nn.Linear(rnn_size, 4 * rnn_size)
+        gw = (5 if maxout else 4) * rnn_size
+        self.i2h = nn.Linear(enc_size, gw)
+        self.h2h = nn.Linear(rnn_size, gw)
+        self.z2h = nn.Linear(rnn_size, gw)
         self.att_2_att_h = nn.Linear(rnn_size, att_hid)
         self.h_2_att_h = nn.Linear(rnn_size, att_hid)
         self.att_h_2_out = nn.Linear(att_hid, 1)
@@ -217,8 +219,6 @@ class RecurrentFusionModel(nn.Module):
         self.decoder_maxout = opt.maxout
         self.fusion_maxout = opt.fusion_maxout  # accepted and ignored, exactly like the reference (:94-96)
         self.use_cuda = getattr(opt, 'use_cuda', 1)
-        if self.review_maxout or self.decoder_maxout:
-            raise N.RfnError('review_maxout / maxout are not implemented by the HIP path')
         self.feat_array_info = opt.feat_array_info
         M = self.num_feat_array = len(self.feat_array_info)
         self.fc_feat_size = [f['fc_feat_size'] for f in self.feat_array_info]
@@ -232,9 +232,10 @@ class RecurrentFusionModel(nn.Module):
         self.review_steps_individual = nn.ModuleList(
             [_FusionStepParams(M, R, self.att_feat_size, A) for _ in range(self.num_review_steps_0)])
         self.reason_linear_individual = nn.ModuleList([nn.Linear(R, self.top_words_count) for _ in range(M)])
-        self.review_steps = nn.ModuleList([_ReviewStepParams(M, R, A) for _ in range(self.num_review_steps)])
+        self.review_steps = nn.ModuleList([_ReviewStepParams(M, R, A, self.review_maxout)
+                                           for _ in range(self.num_review_steps)])
         self.reason_linear = nn.Linear(R, self.top_words_count)
-        self.decoder = _DecoderParams(E, R, A)
+        self.decoder = _DecoderParams(E, R, A, self.decoder_maxout)
         self.init_weights()
 
         self._dims = {}
@@ -287,6 +288,7 @@ class RecurrentFusionModel(nn.Module):
                 self.num_feat_array, self.rnn_size, self.att_hid_size, self.input_encoding_size,
                 self.num_review_steps_0, self.num_review_steps, self.top_words_count, self.vocab_size + 1,
                 self.att_num, self.att_feat_size, self.fc_feat_size,
+                review_maxout=self.review_maxout, decoder_maxout=self.decoder_maxout,
                 drop_fusion=self.drop_prob_fusion if train else 0.0,
                 drop_reason=self.drop_prob_reason if train else 0.0,
                 drop_lm=self.drop_prob_lm if train else 0.0)

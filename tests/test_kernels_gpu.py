@@ -252,12 +252,38 @@ def test_lstm_forward_backward(dev):
     c1d, h1d = torch.empty(B, R, device=dev), torch.empty(B, R, device=dev)
     st = n.stream_ptr()
     n.check(n.lib.rfn_lstm_fwd(gd.data_ptr(), 4 * R, c0d.data_ptr(), R, c1d.data_ptr(), R, h1d.data_ptr(), R, B, R,
-                               0.0, 0, 0, st))
+                               0, 0.0, 0, 0, st))
     assert maxerr(h1d, h1) < 1e-6 and maxerr(c1d, c1) < 1e-6
     dcp = torch.empty(B, R, device=dev)
     dhd, dcnd = dh.to(dev), dcn.to(dev)
     n.check(n.lib.rfn_lstm_bwd(gd.data_ptr(), 4 * R, c0d.data_ptr(), R, c1d.data_ptr(), R, dhd.data_ptr(), R,
-                               dcnd.data_ptr(), R, dcp.data_ptr(), R, B, R, 0.0, 0, 0, st))
+                               dcnd.data_ptr(), R, dcp.data_ptr(), R, B, R, 0, 0.0, 0, 0, st))
+    assert maxerr(gd, sr.grad) < 2e-6 and maxerr(dcp, cr.grad) < 2e-6
+
+
+def test_lstm_maxout_forward_backward(dev):
+    """maxout cells (LSTMSoftMultiAttentionFeatArrayNoInputCore.py:60-62, LSTMSoftAttentionCore.py:89-91): 5R gates,
+    in_transform = max(chunk 3, chunk 4) without tanh."""
+    n = N()
+    B, R = 5, 40
+    sums, c0 = rnd(B, 5 * R, seed=1), rnd(B, R, seed=2)
+    dh, dcn = rnd(B, R, seed=3), rnd(B, R, seed=4)
+    sr, cr = sums.double().requires_grad_(True), c0.double().requires_grad_(True)
+    sig = torch.sigmoid(sr[:, :3 * R])
+    g = torch.max(sr[:, 3 * R:4 * R], sr[:, 4 * R:])
+    c1 = sig[:, R:2 * R] * cr + sig[:, :R] * g
+    h1 = sig[:, 2 * R:] * torch.tanh(c1)
+    (h1 * dh.double()).sum().add((c1 * dcn.double()).sum()).backward()
+    gd, c0d = sums.to(dev), c0.to(dev)
+    c1d, h1d = torch.empty(B, R, device=dev), torch.empty(B, R, device=dev)
+    st = n.stream_ptr()
+    n.check(n.lib.rfn_lstm_fwd(gd.data_ptr(), 5 * R, c0d.data_ptr(), R, c1d.data_ptr(), R, h1d.data_ptr(), R, B, R,
+                               1, 0.0, 0, 0, st))
+    assert maxerr(h1d, h1) < 1e-6 and maxerr(c1d, c1) < 1e-6
+    dcp = torch.empty(B, R, device=dev)
+    dhd, dcnd = dh.to(dev), dcn.to(dev)
+    n.check(n.lib.rfn_lstm_bwd(gd.data_ptr(), 5 * R, c0d.data_ptr(), R, c1d.data_ptr(), R, dhd.data_ptr(), R,
+                               dcnd.data_ptr(), R, dcp.data_ptr(), R, B, R, 1, 0.0, 0, 0, st))
     assert maxerr(gd, sr.grad) < 2e-6 and maxerr(dcp, cr.grad) < 2e-6
 
 
@@ -271,7 +297,7 @@ def test_lstm_dropout_mask_is_regenerated(dev):
         gd = sums.to(dev).clone()
         c1d, h1d = torch.empty(B, R, device=dev), torch.empty(B, R, device=dev)
         n.check(n.lib.rfn_lstm_fwd(gd.data_ptr(), 4 * R, c0d.data_ptr(), R, c1d.data_ptr(), R, h1d.data_ptr(),
-                                   R, B, R, p, seed, 5, n.stream_ptr()))
+                                   R, B, R, 0, p, seed, 5, n.stream_ptr()))
         outs.append((gd, c1d, h1d))
     assert torch.equal(outs[0][2], outs[1][2]) and not torch.equal(outs[0][2], outs[2][2])
     keep = (outs[0][2] != 0).float().mean().item()
@@ -282,7 +308,7 @@ def test_lstm_dropout_mask_is_regenerated(dev):
     dcp = torch.empty(B, R, device=dev)
     act = gd.clone()
     n.check(n.lib.rfn_lstm_bwd(gd.data_ptr(), 4 * R, c0d.data_ptr(), R, c1d.data_ptr(), R, dh.data_ptr(), R,
-                               None, R, dcp.data_ptr(), R, B, R, p, 11, 5, n.stream_ptr()))
+                               None, R, dcp.data_ptr(), R, B, R, 0, p, 11, 5, n.stream_ptr()))
     dropped = (h1d == 0) & (act[:, 2 * R:3 * R] * torch.tanh(c1d) != 0)
     assert float(gd[:, 2 * R:3 * R][dropped].abs().max()) == 0.0
 

@@ -66,7 +66,12 @@ def test_bad_configurations_are_rejected_without_launching():
         if kw['M'] == 0:
             kw['L'], kw['D'], kw['Fc'] = [], [], []
         assert N.lib.rfn_param_count(C.byref(N.make_dims(**kw))) == -1
-    assert N.lib.rfn_param_count(C.byref(N.make_dims(review_maxout=1, **ok))) == -2      # RFN_ERR_UNSUPPORTED
+    assert N.lib.rfn_param_count(C.byref(N.make_dims(review_maxout=1, decoder_maxout=1, **ok))) > 0
+    d5 = N.make_dims(review_maxout=1, decoder_maxout=1, **ok)
+    names5 = N.param_names(d5)
+    assert N.param_shape(d5, names5.index('review_steps.0.h2h.weight')) == (5 * 16, 16)
+    assert N.param_shape(d5, names5.index('decoder.i2h.bias')) == (5 * 16, 1)
+    assert N.param_shape(d5, names5.index('review_steps_individual.0.lstm.0.H2h.weight')) == (4 * 16, 2 * 16)   # fusion_maxout is ignored
     assert N.lib.rfn_param_count(C.byref(N.make_dims(drop_lm=1.0, **ok))) == -1
     assert N.lib.rfn_prefix_ws_bytes(C.byref(N.make_dims(**ok)), 0, 1) == 0
     with pytest.raises(N.RfnError):
@@ -108,6 +113,8 @@ def test_model_shell_schema_and_loud_failure_on_cpu():
     with pytest.raises(Exception):
         R.setup(cfg)
     cfg.caption_model = 'recurrent_fusion_model'
-    cfg.maxout = 1
-    with pytest.raises(R._native.RfnError):
-        R.RecurrentFusionModel(cfg)
+    cfg.maxout, cfg.review_maxout, cfg.fusion_maxout = 1, 1, 1
+    m5 = R.RecurrentFusionModel(cfg)
+    shapes5 = O.param_shapes(cfg)
+    assert all(tuple(v.shape) == shapes5[k] for k, v in m5.state_dict().items())
+    assert m5.decoder.h2h.weight.shape[0] == 5 * 16 and m5.review_steps_individual[0].lstm[0].H2h.weight.shape[0] == 4 * 16
