@@ -121,6 +121,10 @@ def main():
     ap.add_argument('--cpu-sample', type=int, default=16, help='captions in the CPU-baseline sample (~10 s of CPU work)')
     args = ap.parse_args()
 
+    if int(os.environ.get('WORLD_SIZE', '1')) > 1:
+        # data parallel: keep the big GEMM tiles single-buffered (<= 110 KB LDS per CU) so RCCL's kernels can run
+        # beside the long weight-gradient GEMMs instead of waiting for them (read once by librfn_hip.so)
+        os.environ.setdefault('RFN_GEMM_LDS_LEAN', '1')
     import recurrent_fusion_network_amd as R
     from recurrent_fusion_network_amd import parallel as DP
 

@@ -19,6 +19,8 @@
 //     one barrier per K step; 2 blocks/CU co-reside so the partner's MFMAs cover staging.
 //   * 1-D grid with a bijective XCD remap + 8-row bands so the blocks sharing an A row-panel and a
 //     B column-panel run on one XCD's L2 at the same time.
+#include <stdlib.h>
+
 #include "rfn_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -567,6 +569,13 @@ static int launch_tile(GemmArgs& a, hipStream_t st) {
         a.splitk = big_split;
         a.tiles_m = rfn_cdiv(a.M, GEMM_BIG_BM);
         a.tiles_n = rfn_cdiv(a.N, GEMM_BIG_BN);
+        // RFN_GEMM_LDS_LEAN=1 (set by data-parallel hosts): single-buffered big tiles, <= 110 KB of LDS per CU, so
+        // that RCCL's kernels can co-reside with the long weight-gradient GEMMs instead of waiting them out.
+        static const bool lean = [] {
+            const char* e = getenv("RFN_GEMM_LDS_LEAN");
+            return e && e[0] == '1';
+        }();
+        constexpr int ST = (AK && BKF) ? GEMM_NT_STAGES : GEMM_XX_STAGES;
 #if GEMM_FAST_PATH
         if constexpr (VEC) {
             bool fast = (a.M % GEMM_BIG_BM == 0) && (a.N % GEMM_BIG_BN == 0);
@@ -580,12 +589,14 @@ static int launch_tile(GemmArgs& a, hipStream_t st) {
                 return launch_cfg<64, 64, AK, BKF, true, GEMM_ONE_WAVE_STAGES, GEMM_BIG_BK, true, 64>(a, st);
             }
 #endif
-            if (fast)
-                return launch_cfg<GEMM_BIG_BM, GEMM_BIG_BN, AK, BKF, true, (AK && BKF) ? GEMM_NT_STAGES : GEMM_XX_STAGES,
-                                  GEMM_BIG_BK, true>(a, st);
+            if (fast) {
+                if (lean) return launch_cfg<GEMM_BIG_BM, GEMM_BIG_BN, AK, BKF, true, 1, GEMM_BIG_BK, true>(a, st);
+                return launch_cfg<GEMM_BIG_BM, GEMM_BIG_BN, AK, BKF, true, ST, GEMM_BIG_BK, true>(a, st);
+            }
         }
 #endif
-        return launch_cfg<GEMM_BIG_BM, GEMM_BIG_BN, AK, BKF, VEC, (AK && BKF) ? GEMM_NT_STAGES : GEMM_XX_STAGES, GEMM_BIG_BK>(a, st);
+        if (lean) return launch_cfg<GEMM_BIG_BM, GEMM_BIG_BN, AK, BKF, VEC, 1, GEMM_BIG_BK>(a, st);
+        return launch_cfg<GEMM_BIG_BM, GEMM_BIG_BN, AK, BKF, VEC, ST, GEMM_BIG_BK>(a, st);
     }
     a.tiles_m = rfn_cdiv(a.M, 64);
     a.tiles_n = rfn_cdiv(a.N, 64);
