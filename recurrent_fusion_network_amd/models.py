@@ -1,8 +1,9 @@
-"""Model factory: the drop-in boundary of the reference (models.py:14-38).
+"""Model factory: the drop-in boundary of the reference (its models.py, lines 14-38).
 
-``setup(opt)`` returns the HIP-backed module for ``caption_model == 'recurrent_fusion_model'`` and resumes
-from ``model_<id>.pth`` exactly like the reference (same state_dict keys).  Other caption models are outside
-the accelerated path and raise.
+``setup(opt)`` keeps the reference's contract -- build the captioner named by ``opt.caption_model`` and, when
+``opt.start_from`` is set, resume from ``<start_from>/model_<load_model_id>.pth`` (same state_dict keys, so
+checkpoints written by the reference load unchanged).  Only ``recurrent_fusion_model`` is on the accelerated path
+(SURVEY.md section 2); every other name raises.
 """
 import os
 
@@ -10,15 +11,31 @@ import torch
 
 from .fusion_model import RecurrentFusionModel
 
+_REGISTRY = {'recurrent_fusion_model': RecurrentFusionModel}
+
+
+def _resume_paths(opt):
+    """(checkpoint, infos) paths of a run to continue, or None.  The reference insists that the infos pickle
+    exists next to the checkpoint even though the factory only reads the weights."""
+    root = getattr(opt, 'start_from', None)
+    if root is None:
+        return None
+    tag = opt.load_model_id
+    return os.path.join(root, 'model_%s.pth' % tag), os.path.join(root, 'infos_%s.pkl' % tag)
+
 
 def setup(opt):
-    if opt.caption_model != 'recurrent_fusion_model':
-        raise Exception("Caption model not supported by the MI355X path: {}".format(opt.caption_model))
-    model = RecurrentFusionModel(opt)
-    if vars(opt).get('start_from', None) is not None:
-        assert os.path.isdir(opt.start_from), " %s must be a a path" % opt.start_from
-        infos = os.path.join(opt.start_from, "infos_" + opt.load_model_id + ".pkl")
-        assert os.path.isfile(infos), "infos.pkl file does not exist in path %s" % opt.start_from
-        state = torch.load(os.path.join(opt.start_from, 'model_' + opt.load_model_id + '.pth'), map_location='cpu')
-        model.load_state_dict(state)
+    try:
+        cls = _REGISTRY[opt.caption_model]
+    except KeyError:
+        raise Exception('Caption model not supported by the MI355X path: {}'.format(opt.caption_model))
+    model = cls(opt)
+    resume = _resume_paths(opt)
+    if resume is not None:
+        ckpt, infos = resume
+        if not os.path.isdir(opt.start_from):
+            raise AssertionError('%s must be a path' % opt.start_from)
+        if not os.path.isfile(infos):
+            raise AssertionError('infos pickle does not exist in path %s' % opt.start_from)
+        model.load_state_dict(torch.load(ckpt, map_location='cpu'))
     return model
