@@ -145,6 +145,23 @@ int rfn_attn_scores_bwd(const float* proj, int64_t proj_sb, int64_t proj_sl, con
                         int A, float* dproj, int64_t dproj_sb, int64_t dproj_sl,
                         int accumulate_dproj, float* dhproj, float* dw_part, void* stream);
 
+/* Fused small-L (L <= 32) attention of up to RFN_MAX_ENC encoders in one launch: scores + softmax + context
+ * (forward) and dalpha + softmax/tanh backward + d att_seq (backward), one block per (batch row, encoder).
+ * Used by stage II and the decoder, which attend over the T1 / T2 thought vectors.  Arrays are host arrays of
+ * device pointers, one entry per encoder; all encoders share strides and (L, A, D). */
+int rfn_attn_small_fwd(int ngroups, const float* const* proj, int64_t proj_sb, int64_t proj_sl,
+                       const float* const* hproj, const float* const* w_out, const float* const* b_out,
+                       const float* const* att_seq, int64_t sb, int64_t sl, int B, int L, int A, int D,
+                       float* const* alpha, float* const* z, int64_t ldz, void* stream);
+/* datt_seq (may be NULL) is ACCUMULATED into: datt_seq[g][b,l,:] += alpha*dz; dproj/dhproj/dw_part as in
+ * rfn_attn_scores_bwd. */
+int rfn_attn_small_bwd(int ngroups, const float* const* proj, int64_t proj_sb, int64_t proj_sl,
+                       const float* const* hproj, const float* const* w_out, const float* const* alpha,
+                       const float* const* att_seq, int64_t sb, int64_t sl, const float* const* dz,
+                       int64_t lddz, int B, int L, int A, int D, float* const* dproj, int64_t dproj_sb,
+                       int64_t dproj_sl, int accumulate_dproj, float* const* dhproj, float* const* dw_part,
+                       float* const* datt_seq, void* stream);
+
 /* LSTM gate epilogue shared by the three cells (misc/RecurrentFusionModel.py:55-73,
  * misc/LSTMSoftMultiAttentionFeatArrayNoInputCore.py:54-72, misc/LSTMSoftAttentionCore.py:83-101):
  * gates[b, 0:4R] = [in | forget | out | g] pre-activations on entry, activations on exit;

@@ -10,6 +10,8 @@
 //   context : z[b,:] = sum_l alpha[b,l] att_seq[b,l,:]   -- one coalesced pass over the features.
 // Layout: lanes run along the contiguous feature/hidden index with 16-B loads, a wave owns whole
 // (b,l) rows, softmax reductions are 64-lane shuffles (L <= a few hundred: SURVEY.md section 5).
+#include <string.h>
+
 #include "rfn_common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -364,6 +366,182 @@ extern "C" int rfn_attn_scores_bwd(const float* proj, int64_t proj_sb, int64_t p
                            alpha, dalpha, L, A, dproj, (long)dproj_sb, (long)dproj_sl, accumulate_dproj, dhproj,
                            dw_part);
     }
+    RFN_CHECK_LAUNCH();
+    return RFN_OK;
+}
+
+// =====================================================================================================
+// Fused small-L attention (stage II and the decoder attend over L = T1 / T2 = 8 thought vectors): the whole
+// AttentionModelCore.forward of up to RFN_MAX_ENC encoders in ONE launch, and its whole backward in one.
+// One block per (batch row, encoder): everything of a row fits in LDS / registers, so scores, softmax and
+// context (resp. dalpha, softmax/tanh backward, d att_seq) never leave the CU.  Replaces 3 + 3 launches per
+// encoder per cell step of the split kernels above, which remain for the large-L stage-I maps.
+// =====================================================================================================
+struct AttnSmallArgs {
+    const float* proj[RFN_MAX_ENC];    // (b, l, :) at proj + b*psb + l*psl
+    const float* hproj[RFN_MAX_ENC];   // (B, A)
+    const float* w_out[RFN_MAX_ENC];   // (A)
+    const float* b_out[RFN_MAX_ENC];   // (1) or NULL
+    const float* x[RFN_MAX_ENC];       // att_seq: (b, l, :) at x + b*xsb + l*xsl
+    float* alpha[RFN_MAX_ENC];         // (B, L)
+    float* z[RFN_MAX_ENC];             // (B, D) with row stride ldz          (forward out / backward: dz in)
+    float* dproj[RFN_MAX_ENC];         // backward out (may alias proj)
+    float* dhproj[RFN_MAX_ENC];        // (B, A)
+    float* dw_part[RFN_MAX_ENC];       // (B, A)
+    float* dx[RFN_MAX_ENC];            // accumulated: dx[b,l,:] += ...   (same strides as x)
+    long psb, psl, xsb, xsl, ldz, dpsb, dpsl;
+    int L, A, D, accumulate_dproj;
+};
+#define ATS_MAX_L 32
+
+__global__ __launch_bounds__(ATT_THREADS) void attn_small_fwd_k(const AttnSmallArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int A = a.A, L = a.L, D = a.D, Ap = (A + 3) & ~3;
+    float* hp_s = sm;
+    float* w_s = sm + Ap;
+    float* s_s = sm + 2 * Ap;   // [ATS_MAX_L] scores, then alpha
+    const int b = blockIdx.x, g = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* proj = a.proj[g] + b * a.psb;
+    for (int i = tid; i < A; i += ATT_THREADS) {
+        hp_s[i] = a.hproj[g][(long)b * A + i];
+        w_s[i] = a.w_out[g][i];
+    }
+    __syncthreads();
+    const float bo = a.b_out[g] ? a.b_out[g][0] : 0.f;
+    const bool vecA = (A % 4 == 0) && ((a.psb | a.psl) % 4 == 0) && ((((uintptr_t)a.proj[g]) & 15) == 0);
+    for (int l = wave; l < L; l += ATT_WAVES) {
+        const float s = (vecA ? row_tanh_dot<true>(proj + l * a.psl, hp_s, w_s, A, lane)
+                              : row_tanh_dot<false>(proj + l * a.psl, hp_s, w_s, A, lane)) + bo;
+        if (lane == 0) s_s[l] = s;
+    }
+    __syncthreads();
+    float m = -INFINITY, sum = 0.f;
+    for (int l = 0; l < L; ++l) m = fmaxf(m, s_s[l]);
+    for (int l = 0; l < L; ++l) sum += expf(s_s[l] - m);
+    const float inv = 1.0f / sum;
+    __syncthreads();
+    if (tid < L) {
+        const float al = expf(s_s[tid] - m) * inv;
+        s_s[tid] = al;
+        a.alpha[g][(long)b * L + tid] = al;
+    }
+    __syncthreads();
+    const float* x = a.x[g] + b * a.xsb;
+    float* z = a.z[g] + b * a.ldz;
+    for (int d = tid; d < D; d += ATT_THREADS) {
+        float acc = 0.f;
+        for (int l = 0; l < L; ++l) acc += s_s[l] * x[l * a.xsl + d];
+        z[d] = acc;
+    }
+}
+
+__global__ __launch_bounds__(ATT_THREADS) void attn_small_bwd_k(const AttnSmallArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int A = a.A, L = a.L, D = a.D, Ap = (A + 3) & ~3, Dp = (D + 3) & ~3;
+    float* hp_s = sm;                 // [Ap]
+    float* w_s = sm + Ap;             // [Ap]
+    float* dz_s = sm + 2 * Ap;        // [Dp]
+    float* al_s = dz_s + Dp;          // [ATS_MAX_L]
+    float* ds_s = al_s + ATS_MAX_L;   // [ATS_MAX_L]
+    const int b = blockIdx.x, g = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* dz = a.z[g] + b * a.ldz;
+    for (int i = tid; i < A; i += ATT_THREADS) {
+        hp_s[i] = a.hproj[g][(long)b * A + i];
+        w_s[i] = a.w_out[g][i];
+    }
+    for (int d = tid; d < D; d += ATT_THREADS) dz_s[d] = dz[d];
+    if (tid < L) al_s[tid] = a.alpha[g][(long)b * L + tid];
+    __syncthreads();
+    const float* x = a.x[g] + b * a.xsb;
+    // dalpha[l] = <dz, x[l]> : one wave per row
+    for (int l = wave; l < L; l += ATT_WAVES) {
+        float part = 0.f;
+        for (int d = lane; d < D; d += 64) part += x[l * a.xsl + d] * dz_s[d];
+        part = rfn_wave_sum(part);
+        if (lane == 0) ds_s[l] = part;
+    }
+    __syncthreads();
+    float dot = 0.f;
+    for (int l = 0; l < L; ++l) dot += al_s[l] * ds_s[l];
+    __syncthreads();
+    if (tid < L) ds_s[tid] = al_s[tid] * (ds_s[tid] - dot);   // softmax backward
+    __syncthreads();
+    // d att_seq through the context: dx[l, :] += alpha[l] * dz
+    if (a.dx[g]) {
+        float* dx = a.dx[g] + b * a.xsb;
+        for (int i = tid; i < L * D; i += ATT_THREADS) {
+            const int l = i / D, d = i - l * D;
+            dx[l * a.xsl + d] += al_s[l] * dz_s[d];
+        }
+    }
+    // tanh backward over the (L, A) slice: one thread per hidden unit, rows in order (deterministic sums)
+    const float* proj = a.proj[g] + b * a.psb;
+    float* dproj = a.dproj[g] + b * a.dpsb;
+    for (int i = tid; i < A; i += ATT_THREADS) {
+        const float hh = hp_s[i], ww = w_s[i];
+        float ah = 0.f, aw = 0.f;
+        for (int l = 0; l < L; ++l) {
+            const float t = rfn_tanh_fast(proj[l * a.psl + i] + hh);
+            const float dpre = ds_s[l] * ww * (1.0f - t * t);
+            float* o = dproj + l * a.dpsl + i;
+            *o = a.accumulate_dproj ? *o + dpre : dpre;
+            ah += dpre;
+            aw += ds_s[l] * t;
+        }
+        a.dhproj[g][(long)b * A + i] = ah;
+        a.dw_part[g][(long)b * A + i] = aw;
+    }
+}
+
+extern "C" int rfn_attn_small_fwd(int ngroups, const float* const* proj, int64_t proj_sb, int64_t proj_sl,
+                                  const float* const* hproj, const float* const* w_out, const float* const* b_out,
+                                  const float* const* att_seq, int64_t sb, int64_t sl, int B, int L, int A, int D,
+                                  float* const* alpha, float* const* z, int64_t ldz, void* stream) {
+    if (ngroups < 1 || ngroups > RFN_MAX_ENC || B <= 0 || L <= 0 || L > ATS_MAX_L || A <= 0 || D <= 0)
+        return RFN_ERR_SHAPE;
+    if (!proj || !hproj || !w_out || !att_seq || !alpha || !z) return RFN_ERR_ARG;
+    AttnSmallArgs a;
+    memset(&a, 0, sizeof(a));
+    for (int g = 0; g < ngroups; ++g) {
+        if (!proj[g] || !hproj[g] || !w_out[g] || !att_seq[g] || !alpha[g] || !z[g]) return RFN_ERR_ARG;
+        a.proj[g] = proj[g]; a.hproj[g] = hproj[g]; a.w_out[g] = w_out[g];
+        a.b_out[g] = b_out ? b_out[g] : nullptr;
+        a.x[g] = att_seq[g]; a.alpha[g] = alpha[g]; a.z[g] = z[g];
+    }
+    a.psb = proj_sb; a.psl = proj_sl; a.xsb = sb; a.xsl = sl; a.ldz = ldz;
+    a.L = L; a.A = A; a.D = D;
+    const size_t lds = (size_t)(2 * ((A + 3) & ~3) + ATS_MAX_L) * sizeof(float);
+    if (lds > 64 * 1024) return RFN_ERR_SHAPE;
+    hipLaunchKernelGGL(attn_small_fwd_k, dim3(B, ngroups), dim3(ATT_THREADS), lds, (hipStream_t)stream, a);
+    RFN_CHECK_LAUNCH();
+    return RFN_OK;
+}
+
+extern "C" int rfn_attn_small_bwd(int ngroups, const float* const* proj, int64_t proj_sb, int64_t proj_sl,
+                                  const float* const* hproj, const float* const* w_out, const float* const* alpha,
+                                  const float* const* att_seq, int64_t sb, int64_t sl, const float* const* dz,
+                                  int64_t lddz, int B, int L, int A, int D, float* const* dproj, int64_t dproj_sb,
+                                  int64_t dproj_sl, int accumulate_dproj, float* const* dhproj, float* const* dw_part,
+                                  float* const* datt_seq, void* stream) {
+    if (ngroups < 1 || ngroups > RFN_MAX_ENC || B <= 0 || L <= 0 || L > ATS_MAX_L || A <= 0 || D <= 0)
+        return RFN_ERR_SHAPE;
+    if (!proj || !hproj || !w_out || !alpha || !att_seq || !dz || !dproj || !dhproj || !dw_part) return RFN_ERR_ARG;
+    AttnSmallArgs a;
+    memset(&a, 0, sizeof(a));
+    for (int g = 0; g < ngroups; ++g) {
+        if (!proj[g] || !hproj[g] || !w_out[g] || !alpha[g] || !att_seq[g] || !dz[g] || !dproj[g] || !dhproj[g] ||
+            !dw_part[g])
+            return RFN_ERR_ARG;
+        a.proj[g] = proj[g]; a.hproj[g] = hproj[g]; a.w_out[g] = w_out[g];
+        a.x[g] = att_seq[g]; a.alpha[g] = const_cast<float*>(alpha[g]); a.z[g] = const_cast<float*>(dz[g]);
+        a.dproj[g] = dproj[g]; a.dhproj[g] = dhproj[g]; a.dw_part[g] = dw_part[g];
+        a.dx[g] = datt_seq ? datt_seq[g] : nullptr;
+    }
+    a.psb = proj_sb; a.psl = proj_sl; a.xsb = sb; a.xsl = sl; a.ldz = lddz; a.dpsb = dproj_sb; a.dpsl = dproj_sl;
+    a.L = L; a.A = A; a.D = D; a.accumulate_dproj = accumulate_dproj;
+    const size_t lds = (size_t)(2 * ((A + 3) & ~3) + ((D + 3) & ~3) + 2 * ATS_MAX_L) * sizeof(float);
+    if (lds > 64 * 1024) return RFN_ERR_SHAPE;
+    hipLaunchKernelGGL(attn_small_bwd_k, dim3(B, ngroups), dim3(ATT_THREADS), lds, (hipStream_t)stream, a);
     RFN_CHECK_LAUNCH();
     return RFN_OK;
 }

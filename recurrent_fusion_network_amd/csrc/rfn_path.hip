@@ -507,13 +507,21 @@ extern "C" int rfn_prefix_fwd(const rfn_dims* d, int B, const float* const* prm,
             pr[i] = prob1(hp + (long)i * B * A, A, seg_lin(hc, R, prm[P.s2(t, i, 4)], R, R, prm[P.s2(t, i, 5)]));
         RFN_TRY(gemm_groups(B, A, M, pr, 0, gx));
         segs[0] = seg_lin(hc, R, prm[P.s2_hh_w(t)], R, R, prm[P.s2_hh_b(t)]);
-        for (int i = 0; i < M; ++i) {
-            RFN_TRY(rfn_attn_scores_fwd(W + Lo.P2[i] + (long)t * A, (long)T2 * A, (long)B * T2 * A,
-                                        hp + (long)i * B * A, prm[P.s2(t, i, 6)], prm[P.s2(t, i, 7)], B, T1, A,
-                                        al + (long)i * B * T1, st));
-            RFN_TRY(rfn_attn_context_fwd(Hs + BMR + i * R, MR, BMR, al + (long)i * B * T1, B, T1, R, z + i * BR, R,
-                                         st));
-            segs[1 + i] = seg_lin(z + i * BR, R, prm[P.s2(t, i, 0)], R, R, prm[P.s2(t, i, 1)]);
+        {   // attention of all M encoders over the T1 thoughts: one fused launch
+            const float *a_p[RFN_MAX_ENC], *a_hp[RFN_MAX_ENC], *a_w[RFN_MAX_ENC], *a_b[RFN_MAX_ENC], *a_x[RFN_MAX_ENC];
+            float *a_al[RFN_MAX_ENC], *a_z[RFN_MAX_ENC];
+            for (int i = 0; i < M; ++i) {
+                a_p[i] = W + Lo.P2[i] + (long)t * A;
+                a_hp[i] = hp + (long)i * B * A;
+                a_w[i] = prm[P.s2(t, i, 6)];
+                a_b[i] = prm[P.s2(t, i, 7)];
+                a_x[i] = Hs + BMR + i * R;
+                a_al[i] = al + (long)i * B * T1;
+                a_z[i] = z + i * BR;
+                segs[1 + i] = seg_lin(z + i * BR, R, prm[P.s2(t, i, 0)], R, R, prm[P.s2(t, i, 1)]);
+            }
+            RFN_TRY(rfn_attn_small_fwd(M, a_p, (long)T2 * A, (long)B * T2 * A, a_hp, a_w, a_b, a_x, MR, BMR, B, T1, A,
+                                       R, a_al, a_z, R, st));
         }
         RFN_TRY(gemm_segs(B, G2, M + 1, segs, g, G2, 0, gx));
         RFN_TRY(rfn_lstm_fwd(g, G2, cc, R, cn, R, hn, R, B, R, d->review_maxout, train ? d->drop_reason : 0.f, seed,
@@ -591,16 +599,25 @@ extern "C" int rfn_prefix_bwd(const rfn_dims* d, int B, const float* const* prm,
         pr[0] = prob1(dhrec, R, seg_dx(g, G2, prm[P.s2_hh_w(t)], R, G2));
         for (int i = 0; i < M; ++i) pr[1 + i] = prob1(dz2 + i * BR, R, seg_dx(g, G2, prm[P.s2(t, i, 0)], R, G2));
         RFN_TRY(gemm_groups(B, R, M + 1, pr, 0, gx));
-        for (int i = 0; i < M; ++i) {
-            const float* th = Hs + BMR + i * R;  // thoughts_i[b, l] = Hs[1 + l][b, iR:]
-            RFN_TRY(rfn_attn_context_bwd_dalpha(th, MR, BMR, dz2 + i * BR, R, B, T1, R, dal, st));
-            RFN_TRY(rfn_attn_context_bwd_dseq(al + (long)i * B * T1, dz2 + i * BR, R, B, T1, R, dHs + BMR + i * R, MR,
-                                              BMR, st));
-            float* p2 = W + Lo.P2[i] + (long)t * A;
-            RFN_TRY(rfn_attn_scores_bwd(p2, (long)T2 * A, (long)B * T2 * A, hp + i * BA, prm[P.s2(t, i, 6)],
-                                        al + (long)i * B * T1, dal, B, T1, A, p2, (long)T2 * A, (long)B * T2 * A, 0,
-                                        dhp + i * BA, dwp + ((long)t * M + i) * BA, st));
-            segs[i] = seg_dx(dhp + i * BA, A, prm[P.s2(t, i, 4)], R, A);
+        {   // whole attention backward of the M encoders in one fused launch (dP overwrites P in place)
+            const float *a_p[RFN_MAX_ENC], *a_hp[RFN_MAX_ENC], *a_w[RFN_MAX_ENC], *a_al[RFN_MAX_ENC], *a_x[RFN_MAX_ENC],
+                *a_dz[RFN_MAX_ENC];
+            float *a_dp[RFN_MAX_ENC], *a_dhp[RFN_MAX_ENC], *a_dw[RFN_MAX_ENC], *a_dx[RFN_MAX_ENC];
+            for (int i = 0; i < M; ++i) {
+                a_dp[i] = W + Lo.P2[i] + (long)t * A;
+                a_p[i] = a_dp[i];
+                a_hp[i] = hp + i * BA;
+                a_w[i] = prm[P.s2(t, i, 6)];
+                a_al[i] = al + (long)i * B * T1;
+                a_x[i] = Hs + BMR + i * R;  // thoughts_i[b, l] = Hs[1 + l][b, iR:]
+                a_dz[i] = dz2 + i * BR;
+                a_dhp[i] = dhp + i * BA;
+                a_dw[i] = dwp + ((long)t * M + i) * BA;
+                a_dx[i] = dHs + BMR + i * R;
+                segs[i] = seg_dx(dhp + i * BA, A, prm[P.s2(t, i, 4)], R, A);
+            }
+            RFN_TRY(rfn_attn_small_bwd(M, a_p, (long)T2 * A, (long)B * T2 * A, a_hp, a_w, a_al, a_x, MR, BMR, a_dz, R,
+                                       B, T1, A, R, a_dp, (long)T2 * A, (long)B * T2 * A, 0, a_dhp, a_dw, a_dx, st));
         }
         RFN_TRY(gemm_segs(B, R, M, segs, dhrec, R, 1, gx));
     }
@@ -750,6 +767,19 @@ extern "C" int rfn_prefix_bwd_wgrad(const rfn_dims* d, int B, const float* const
 // =============================================================================================
 // phase 2: teacher-forced decoder
 // =============================================================================================
+// single-encoder forms of the fused small-L attention (decoder: one attention over the T2 fused thoughts)
+static int attn1_fwd(const float* proj, long psb, long psl, const float* hp, const float* w, const float* bo,
+                     const float* x, long sb, long sl, int B, int L, int A, int D, float* al, float* z, long ldz,
+                     void* st) {
+    return rfn_attn_small_fwd(1, &proj, psb, psl, &hp, &w, &bo, &x, sb, sl, B, L, A, D, &al, &z, ldz, st);
+}
+static int attn1_bwd(const float* proj, long psb, long psl, const float* hp, const float* w, const float* al,
+                     const float* x, long sb, long sl, const float* dz, long lddz, int B, int L, int A, int D,
+                     float* dproj, long dpsb, long dpsl, int acc, float* dhp, float* dwp, float* dx, void* st) {
+    return rfn_attn_small_bwd(1, &proj, psb, psl, &hp, &w, &al, &x, sb, sl, &dz, lddz, B, L, A, D, &dproj, dpsb, dpsl,
+                              acc, &dhp, &dwp, &dx, st);
+}
+
 extern "C" size_t rfn_decoder_ws_bytes(const rfn_dims* d, int B, int S, int train) {
     if (check_dims(d) != RFN_OK || B < 1 || S < 1) return 0;
     return decoder_layout(d, B, S, train).total * sizeof(float);
@@ -787,8 +817,7 @@ extern "C" int rfn_decoder_fwd(const rfn_dims* d, int B, int S, const float* con
         float* z = W + Lo.zd + s * BR;
         float* g = gd + (long)s * B * GD;
         RFN_TRY(gemm1(B, A, seg_lin(hc, R, prm[P.dec(8)], R, R, prm[P.dec(9)]), hp, A, 0, gx));
-        RFN_TRY(rfn_attn_scores_fwd(W + Lo.Pd, A, BA, hp, prm[P.dec(10)], prm[P.dec(11)], B, T2, A, al, st));
-        RFN_TRY(rfn_attn_context_fwd(comb, R, BR, al, B, T2, R, z, R, st));
+        RFN_TRY(attn1_fwd(W + Lo.Pd, A, BA, hp, prm[P.dec(10)], prm[P.dec(11)], comb, R, BR, B, T2, A, R, al, z, R, st));
         segs[0] = seg_lin(hc, R, prm[P.dec(2)], R, R, prm[P.dec(3)]);
         segs[1] = seg_lin(z, R, prm[P.dec(4)], R, R, prm[P.dec(5)]);
         RFN_TRY(gemm_segs(B, GD, 2, segs, g, GD, 1, gx));
@@ -844,11 +873,9 @@ extern "C" int rfn_decoder_bwd(const rfn_dims* d, int B, int S, const float* con
         pr[1] = prob1(dz, R, seg_dx(g, GD, prm[P.dec(4)], R, GD));
         RFN_TRY(gemm_groups(B, R, 2, pr, 0, gx));
         float* al = W + Lo.ald + (long)s * B * T2;
-        RFN_TRY(rfn_attn_context_bwd_dalpha(comb, R, BR, dz, R, B, T2, R, W + Lo.dal, st));
-        RFN_TRY(rfn_attn_context_bwd_dseq(al, dz, R, B, T2, R, d_comb, R, BR, st));
         float* dhp = W + Lo.dhpd + s * BA;
-        RFN_TRY(rfn_attn_scores_bwd(W + Lo.Pd, A, BA, W + Lo.hpd + s * BA, prm[P.dec(10)], al, W + Lo.dal, B, T2, A,
-                                    dPd, A, BA, 1, dhp, W + Lo.dwp + s * BA, st));
+        RFN_TRY(attn1_bwd(W + Lo.Pd, A, BA, W + Lo.hpd + s * BA, prm[P.dec(10)], al, comb, R, BR, dz, R, B, T2, A, R,
+                          dPd, A, BA, 1, dhp, W + Lo.dwp + s * BA, d_comb, st));
         RFN_TRY(gemm1(B, R, seg_dx(dhp, A, prm[P.dec(8)], R, A), dhrec, R, 1, gx));
     }
     RFN_TRY(copy_f32(d_h0, dhrec, BR, st));
@@ -916,8 +943,7 @@ extern "C" int rfn_decoder_step(const rfn_dims* d, int B, const float* const* pr
     float* lg = logits ? logits : W + b.take((size_t)B * V1);
     RFN_TRY(rfn_embed_fwd(prm[P.embed()], E, V1, ids, B, 1, 0, B, x, E, st));
     RFN_TRY(gemm1(B, A, seg_lin(h, R, prm[P.dec(8)], R, R, prm[P.dec(9)]), hp, A, 0, gx));
-    RFN_TRY(rfn_attn_scores_fwd(cproj, A, BA, hp, prm[P.dec(10)], prm[P.dec(11)], B, T2, A, al, st));
-    RFN_TRY(rfn_attn_context_fwd(comb, R, BR, al, B, T2, R, z, R, st));
+    RFN_TRY(attn1_fwd(cproj, A, BA, hp, prm[P.dec(10)], prm[P.dec(11)], comb, R, BR, B, T2, A, R, al, z, R, st));
     rfn_gemm_seg segs[3];
     segs[0] = seg_lin(x, E, prm[P.dec(0)], E, E, prm[P.dec(1)]);
     segs[1] = seg_lin(h, R, prm[P.dec(2)], R, R, prm[P.dec(3)]);

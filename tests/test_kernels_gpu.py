@@ -234,6 +234,68 @@ def test_attention_time_major_strides(dev):
     assert maxerr(alpha, al_ref) < 2e-6 and maxerr(z, z_ref) < 1e-5
 
 
+@pytest.mark.parametrize('G,B,L,A,D', [(4, 6, 8, 512, 512), (1, 5, 8, 64, 96), (3, 4, 5, 30, 18), (2, 3, 32, 17, 7)])
+def test_fused_small_attention_groups_match_fp64(dev, G, B, L, A, D):
+    """rfn_attn_small_fwd/bwd: G encoders in one launch over time-major (step, batch, G*feature) thoughts, as
+    stage II lays them out; backward overwrites the projections in place and accumulates d thoughts."""
+    n = N()
+    proj = [rnd(B, L, A, seed=10 + g) for g in range(G)]           # (b, l) addressed with strides like P2
+    hp = [rnd(B, A, seed=20 + g) for g in range(G)]
+    w = [rnd(A, seed=30 + g, scale=0.3) for g in range(G)]
+    bo = [rnd(1, seed=40 + g) for g in range(G)]
+    x_tm = rnd(L, B, G * D, seed=50)                                # thoughts: Hs[1 + l][b, g*D:(g+1)*D]
+    dz = rnd(B, G * D, seed=51)
+    pd = [t.to(dev) for t in proj]
+    hpd = [t.to(dev) for t in hp]
+    wd = [t.to(dev) for t in w]
+    bod = [t.to(dev) for t in bo]
+    xd, dzd = x_tm.to(dev), dz.to(dev)
+    alpha = torch.empty(G, B, L, device=dev)
+    z = torch.empty(B, G * D, device=dev)
+    st = n.stream_ptr()
+    arr = lambda ts: n.ptr_array(ts)
+    xs = [xd[:, :, g * D:] for g in range(G)]
+    a_p, a_hp, a_w, a_b, a_x = arr(pd), arr(hpd), arr(wd), arr(bod), arr(xs)
+    a_al, a_z = arr([alpha[g] for g in range(G)]), arr([z[:, g * D:] for g in range(G)])
+    n.check(n.lib.rfn_attn_small_fwd(G, a_p, L * A, A, a_hp, a_w, a_b, a_x, G * D, B * G * D, B, L, A, D, a_al, a_z,
+                                     G * D, st))
+    refs = []
+    for g in range(G):
+        pr, hr, wr = [t.double().requires_grad_(True) for t in (proj[g], hp[g], w[g])]
+        xr = x_tm[:, :, g * D:(g + 1) * D].transpose(0, 1).double().requires_grad_(True)
+        al_ref, z_ref = attn_ref(pr, hr, wr, bo[g], xr)
+        assert maxerr(alpha[g], al_ref) < 2e-6
+        assert maxerr(z[:, g * D:(g + 1) * D], z_ref) < 1e-5
+        z_ref.backward(dz[:, g * D:(g + 1) * D].double())
+        refs.append((pr.grad, hr.grad, wr.grad, xr.grad))
+    dx = torch.ones(L, B, G * D, device=dev)                        # accumulated into
+    dhp = torch.empty(G, B, A, device=dev)
+    dwp = torch.empty(G, B, A, device=dev)
+    inpl = [t.clone() for t in pd]
+    a_pi = arr(inpl)
+    a_dz = arr([dzd[:, g * D:] for g in range(G)])
+    a_dhp, a_dwp = arr([dhp[g] for g in range(G)]), arr([dwp[g] for g in range(G)])
+    a_dx = arr([dx[:, :, g * D:] for g in range(G)])
+    n.check(n.lib.rfn_attn_small_bwd(G, a_pi, L * A, A, a_hp, a_w, a_al, a_x, G * D, B * G * D, a_dz, G * D, B, L, A, D,
+                                     a_pi, L * A, A, 0, a_dhp, a_dwp, a_dx, st))
+    for g in range(G):
+        gp, gh, gw, gx = refs[g]
+        assert maxerr(inpl[g], gp) < 2e-5
+        assert maxerr(dhp[g], gh) < 1e-4
+        assert maxerr(dwp[g].sum(0), gw) < 1e-4 * max(1.0, float(gw.abs().max()))
+        assert maxerr(dx[:, :, g * D:(g + 1) * D].transpose(0, 1), gx + 1.0) < 1e-5
+    # separate, accumulated dproj (decoder form) and no d att_seq
+    acc = [torch.ones(B, L, A, device=dev) for _ in range(G)]
+    a_acc = arr(acc)
+    n.check(n.lib.rfn_attn_small_bwd(G, a_p, L * A, A, a_hp, a_w, a_al, a_x, G * D, B * G * D, a_dz, G * D, B, L, A, D,
+                                     a_acc, L * A, A, 1, a_dhp, a_dwp, None, st))
+    for g in range(G):
+        assert maxerr(acc[g], refs[g][0] + 1.0) < 2e-5
+    # rejects L beyond the fused kernel's bound
+    assert n.lib.rfn_attn_small_fwd(G, a_p, L * A, A, a_hp, a_w, a_b, a_x, G * D, B * G * D, B, 33, A, D, a_al, a_z,
+                                    G * D, st) != 0
+
+
 # ------------------------------------------------------------------------------------------------
 # LSTM epilogue
 # ------------------------------------------------------------------------------------------------
