@@ -10,6 +10,7 @@
 //   context : z[b,:] = sum_l alpha[b,l] att_seq[b,l,:]   -- one coalesced pass over the features.
 // Layout: lanes run along the contiguous feature/hidden index with 16-B loads, a wave owns whole
 // (b,l) rows, softmax reductions are 64-lane shuffles (L <= a few hundred: SURVEY.md section 5).
+#include <stdlib.h>
 #include <string.h>
 
 #include "rfn_common.h"
@@ -164,10 +165,9 @@ extern "C" int rfn_attn_context_fwd(const float* att_seq, int64_t sb, int64_t sl
 }
 
 // ---- backward of the context: dalpha[b,l] = <dz[b,:], x[b,l,:]> ---------------------------------
-#define DAL_ROWS 64 /* rows of L per block (16 per wave): ~0.5 MB streamed per block, B * ceil(L/64) blocks */
-// Each wave owns 16 rows in groups of 4 that it walks TOGETHER along d, so 4 (x2 with the unroll) independent
-// 16-B loads are in flight per lane instead of one row's dependent stream.
-template <bool VEC>
+// Each wave owns ROWS/4 rows in groups of RG that it walks TOGETHER along d, so RG (x2 with the unroll)
+// independent 16-B loads are in flight per lane instead of one row's dependent stream.
+template <bool VEC, int RG, int ROWS>
 __global__ __launch_bounds__(ATT_THREADS) void attn_dalpha_k(const float* __restrict__ x, long sb, long sl,
                                                             const float* __restrict__ dz, long lddz, int L, int D,
                                                             float* __restrict__ dalpha) {
@@ -175,22 +175,24 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_dalpha_k(const float* __rest
     const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int d = tid; d < D; d += ATT_THREADS) dz_s[d] = dz[b * lddz + d];
     __syncthreads();
-    for (int grp = 0; grp < DAL_ROWS / (4 * ATT_WAVES); ++grp) {
-        const int l0 = blockIdx.x * DAL_ROWS + (grp * ATT_WAVES + wave) * 4;   // rows l0 .. l0+3 of this wave
-        const int nr = min(4, L - l0);
+    for (int grp = 0; grp < ROWS / (RG * ATT_WAVES); ++grp) {
+        const int l0 = blockIdx.x * ROWS + (grp * ATT_WAVES + wave) * RG;   // rows l0 .. l0+RG-1 of this wave
+        const int nr = min(RG, L - l0);
         if (nr <= 0) break;
         const float* p0 = x + b * sb + (long)l0 * sl;
-        float part[4] = {0.f, 0.f, 0.f, 0.f};
+        float part[RG];
+#pragma unroll
+        for (int r = 0; r < RG; ++r) part[r] = 0.f;
         if constexpr (VEC) {
 #pragma unroll 2
             for (int d = lane * 4; d < D; d += 256) {
                 const f32x4 gv = *reinterpret_cast<const f32x4*>(dz_s + d);
-                f32x4 xv[4];
+                f32x4 xv[RG];
 #pragma unroll
-                for (int r = 0; r < 4; ++r)   // rows past the end re-read the last valid row (result discarded):
+                for (int r = 0; r < RG; ++r)   // rows past the end re-read the last valid row (result discarded):
                     xv[r] = *reinterpret_cast<const f32x4*>(p0 + min(r, nr - 1) * sl + d);  // no branch per load
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
+                for (int r = 0; r < RG; ++r)
                     part[r] += xv[r][0] * gv[0] + xv[r][1] * gv[1] + xv[r][2] * gv[2] + xv[r][3] * gv[3];
             }
         } else {
@@ -198,11 +200,18 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_dalpha_k(const float* __rest
                 for (int r = 0; r < nr; ++r) part[r] += p0[r * sl + d] * dz_s[d];
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < RG; ++r) {
             const float t = rfn_wave_sum(part[r]);
             if (lane == 0 && r < nr) dalpha[(long)b * L + l0 + r] = t;
         }
     }
+}
+
+template <bool VEC, int RG, int ROWS>
+static void launch_dalpha(const float* att_seq, long sb, long sl, const float* dz, long lddz, int B, int L, int D,
+                          float* dalpha, size_t lds, hipStream_t st) {
+    hipLaunchKernelGGL((attn_dalpha_k<VEC, RG, ROWS>), dim3(rfn_cdiv(L, ROWS), B), dim3(ATT_THREADS), lds, st, att_seq,
+                       sb, sl, dz, lddz, L, D, dalpha);
 }
 
 extern "C" int rfn_attn_context_bwd_dalpha(const float* att_seq, int64_t sb, int64_t sl, const float* dz,
@@ -213,13 +222,8 @@ extern "C" int rfn_attn_context_bwd_dalpha(const float* att_seq, int64_t sb, int
     if (lds > 64 * 1024) return RFN_ERR_SHAPE;
     const bool vec = (D % 4 == 0) && rfn_aligned16(att_seq) && (sb % 4 == 0) && (sl % 4 == 0);
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid(rfn_cdiv(L, DAL_ROWS), B);
-    if (vec)
-        hipLaunchKernelGGL(attn_dalpha_k<true>, grid, dim3(ATT_THREADS), lds, st, att_seq, (long)sb, (long)sl, dz,
-                           (long)lddz, L, D, dalpha);
-    else
-        hipLaunchKernelGGL(attn_dalpha_k<false>, grid, dim3(ATT_THREADS), lds, st, att_seq, (long)sb, (long)sl, dz,
-                           (long)lddz, L, D, dalpha);
+    if (vec) launch_dalpha<true, 4, 64>(att_seq, sb, sl, dz, lddz, B, L, D, dalpha, lds, st);
+    else launch_dalpha<false, 4, 64>(att_seq, sb, sl, dz, lddz, B, L, D, dalpha, lds, st);
     RFN_CHECK_LAUNCH();
     return RFN_OK;
 }

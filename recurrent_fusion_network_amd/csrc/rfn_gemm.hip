@@ -294,7 +294,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == 64) ? 1 : GEMM_MIN_WAVES) void
 
     // bias gradient riding on the weight-gradient GEMM: column sums of the [k][row] A operand, taken from
     // the staging registers by the blocks of the first column tile
-    const bool do_colsum = !AK && (tn == 0) && (P.a_colsum != nullptr) && (splitk == 1);
+    const bool do_colsum = !AK && (tn == 0) && (P.a_colsum != nullptr);
     float ps[4] = {0.f, 0.f, 0.f, 0.f};
 
     // split-K: this block owns iterations [it_begin, it_end) of the flattened (segment, k) space
@@ -452,8 +452,12 @@ __global__ __launch_bounds__(THREADS, (THREADS == 64) ? 1 : GEMM_MIN_WAVES) void
                 float t = 0.f;
 #pragma unroll
                 for (int p2 = 0; p2 < PARTS; ++p2) t += smem[p2 * BM + tid];
-                float* o = P.a_colsum + row0 + tid;
-                *o = args.accumulate ? *o + t : t;
+                if (splitk > 1) {  // partial column sum of this K range: [ngroups][splitk][M] behind the partial tiles
+                    args.part[(long)args.ngroups * splitk * M * N + ((long)grp * splitk + ks) * M + row0 + tid] = t;
+                } else {
+                    float* o = P.a_colsum + row0 + tid;
+                    *o = args.accumulate ? *o + t : t;
+                }
             }
         }
     }
@@ -503,13 +507,25 @@ __global__ __launch_bounds__(THREADS, (THREADS == 64) ? 1 : GEMM_MIN_WAVES) void
     }
 }
 
-// C = sum_ks part[g][ks] + sum_s bias_s (+ C): fixed summation order, one thread per output element
+// C = sum_ks part[g][ks] + sum_s bias_s (+ C): fixed summation order, one thread per output element.  The blocks
+// past the C range finish the a_colsum rider the same way (partial column sums of every K range, in order).
 __global__ __launch_bounds__(256) void rfn_gemm_reduce_k(const GemmArgs args) {
     const long MN = (long)args.M * args.N;
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= MN) return;
     const int grp = blockIdx.y;
     const rfn_gemm_problem& P = args.g[grp];
+    const int c_blocks = (int)((MN + 255) / 256);
+    if ((int)blockIdx.x >= c_blocks) {
+        const int row = ((int)blockIdx.x - c_blocks) * 256 + threadIdx.x;
+        if (row >= args.M || !P.a_colsum) return;
+        const float* cs = args.part + (long)args.ngroups * args.splitk * MN + (long)grp * args.splitk * args.M + row;
+        float s = 0.f;
+        for (int k = 0; k < args.splitk; ++k) s += cs[(long)k * args.M];
+        float* o = P.a_colsum + row;
+        *o = args.accumulate ? *o + s : s;
+        return;
+    }
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= MN) return;
     const int row = (int)(i / args.N), col = (int)(i - (long)row * args.N);
     const float* part = args.part + (long)grp * args.splitk * MN + i;
     float s = 0.f;
@@ -535,7 +551,11 @@ static int launch_cfg(const GemmArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(k, dim3(nblk), dim3(THREADS), lds, st, a);
     RFN_CHECK_LAUNCH();
     if (a.splitk > 1) {
-        hipLaunchKernelGGL(rfn_gemm_reduce_k, dim3(rfn_cdiv((long)a.M * a.N, 256), a.ngroups), dim3(256), 0, st, a);
+        bool colsum = false;
+        for (int g = 0; g < a.ngroups; ++g) colsum = colsum || (a.g[g].a_colsum != nullptr);
+        const int cs_blocks = (colsum && !AK) ? rfn_cdiv(a.M, 256) : 0;
+        hipLaunchKernelGGL(rfn_gemm_reduce_k, dim3(rfn_cdiv((long)a.M * a.N, 256) + cs_blocks, a.ngroups), dim3(256), 0,
+                           st, a);
         RFN_CHECK_LAUNCH();
     }
     return RFN_OK;
@@ -557,11 +577,11 @@ static int launch_tile(GemmArgs& a, hipStream_t st) {
     // Medium problems (the heavier per-step GEMMs: M = batch, a few GF): the 128x128 tile is ~1.5x more efficient
     // than 64x64 but yields too few tiles, so cut K across blocks to reach ~2 blocks per CU.
     int big_split = 1;
-    if (big < 384 && a.part && !colsum && big >= 16 && flops >= GEMM_MEDIUM_MIN_FLOPS) {
+    if (big < 384 && a.part && big >= 16 && flops >= GEMM_MEDIUM_MIN_FLOPS) {
         long want = (512 + big - 1) / big;
         if (want > iters32 / 8) want = iters32 / 8;
         if (want > 16) want = 16;
-        const long cap = (long)a.pad_ * (1 << 18) / ((long)a.M * a.N * a.ngroups);
+        const long cap = (long)a.pad_ * (1 << 18) / (((long)a.M * a.N + a.M) * a.ngroups);
         if (want > cap) want = cap;
         if (want >= 2) big_split = (int)want;
     }
@@ -609,9 +629,9 @@ static int launch_tile(GemmArgs& a, hipStream_t st) {
         long want = tiles > 0 ? GEMM_SPLIT_TARGET / tiles : 1;
         if (want > iters / GEMM_SPLIT_MIN_ITERS) want = iters / GEMM_SPLIT_MIN_ITERS;
         if (want > 16) want = 16;
-        const long cap = (long)(a.pad_ /* ws MiB */) * (1 << 18) / ((long)a.M * a.N * a.ngroups);  // floats
+        const long cap = (long)(a.pad_ /* ws MiB */) * (1 << 18) / (((long)a.M * a.N + a.M) * a.ngroups);  // floats
         if (want > cap) want = cap;
-        a.splitk = (!colsum && want >= 2) ? (int)want : 1;
+        a.splitk = (want >= 2) ? (int)want : 1;
     }
     return launch_cfg<64, 64, AK, BKF, VEC, GEMM_SMALL_STAGES, GEMM_SMALL_BK>(a, st);
 }

@@ -139,6 +139,36 @@ def test_gemm_weight_gradient_emits_bias_gradient(dev):
         assert maxerr(db, dY.double().sum(0)) < 1e-4
 
 
+@pytest.mark.parametrize('rows,Nn,K,groups', [(4352, 512, 512, 1), (4352, 2048, 512, 1), (1000, 70, 36, 2),
+                                               (4352, 300, 130, 3), (256, 2048, 512, 2)])
+def test_gemm_weight_gradient_split_k_keeps_the_bias_rider(dev, rows, Nn, K, groups):
+    """Weight gradients of the step-shared weights reduce over S*B rows with few output tiles: they are cut
+    along the reduction, and the a_colsum rider is finished by the same fixed-order reduce (deterministic,
+    accumulate honoured for both outputs)."""
+    n = N()
+    ws = torch.empty(48 << 20, dtype=torch.uint8, device=dev)
+    keep, probs, refs = [], [], []
+    for g in range(groups):
+        dY, X = rnd(rows, Nn, seed=1 + g), rnd(rows, K, seed=20 + g)
+        dYd, Xd = dY.to(dev), X.to(dev)
+        keep += [dYd, Xd]
+        dW = torch.full((Nn, K), 0.5, device=dev)
+        db = torch.full((Nn,), -2.0, device=dev)
+        probs.append((dW, K, [(dYd, Nn, 0, Xd, K, 0, rows, None)], db))
+        refs.append((dY.double().t() @ X.double(), dY.double().sum(0)))
+    n.gemm(Nn, K, probs, accumulate=True, ws=ws)
+    first = [(p[0].clone(), p[3].clone()) for p in probs]
+    for (dW, db), (rW, rb) in zip(first, refs):
+        assert maxerr(dW, rW + 0.5) < 3e-3
+        assert maxerr(db, rb - 2.0) < 1e-3
+    for p in probs:
+        p[0].fill_(0.5)
+        p[3].fill_(-2.0)
+    n.gemm(Nn, K, probs, accumulate=True, ws=ws)
+    for p, (dW, db) in zip(probs, first):
+        assert torch.equal(p[0], dW) and torch.equal(p[3], db)
+
+
 def test_gemm_strided_views_like_the_path(dev):
     """The path feeds column blocks of wider buffers (lda > K, ldc > N): e.g. encoder i's slice of H."""
     n = N()
