@@ -439,6 +439,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_small_fwd_k(const AttnSmallA
     }
 }
 
+template <bool VEC>
 __global__ __launch_bounds__(ATT_THREADS) void attn_small_bwd_k(const AttnSmallArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int A = a.A, L = a.L, D = a.D, Ap = (A + 3) & ~3, Dp = (D + 3) & ~3;
@@ -457,12 +458,33 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_small_bwd_k(const AttnSmallA
     if (tid < L) al_s[tid] = a.alpha[g][(long)b * L + tid];
     __syncthreads();
     const float* x = a.x[g] + b * a.xsb;
-    // dalpha[l] = <dz, x[l]> : one wave per row
-    for (int l = wave; l < L; l += ATT_WAVES) {
-        float part = 0.f;
-        for (int d = lane; d < D; d += 64) part += x[l * a.xsl + d] * dz_s[d];
-        part = rfn_wave_sum(part);
-        if (lane == 0) ds_s[l] = part;
+    // dalpha[l] = <dz, x[l]> : each wave takes rows l, l + 4 together (independent load streams)
+    for (int l = wave; l < L; l += 2 * ATT_WAVES) {
+        const int l2 = l + ATT_WAVES;
+        const bool two = l2 < L;
+        const float* x0 = x + l * a.xsl;
+        const float* x1 = x + (two ? l2 : l) * a.xsl;
+        float p0 = 0.f, p1 = 0.f;
+        if constexpr (VEC) {
+            for (int d = lane * 4; d < D; d += 256) {
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(x0 + d);
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(x1 + d);
+                const f32x4 gv = *reinterpret_cast<const f32x4*>(dz_s + d);
+                p0 += v0[0] * gv[0] + v0[1] * gv[1] + v0[2] * gv[2] + v0[3] * gv[3];
+                p1 += v1[0] * gv[0] + v1[1] * gv[1] + v1[2] * gv[2] + v1[3] * gv[3];
+            }
+        } else {
+            for (int d = lane; d < D; d += 64) {
+                p0 += x0[d] * dz_s[d];
+                p1 += x1[d] * dz_s[d];
+            }
+        }
+        p0 = rfn_wave_sum(p0);
+        p1 = rfn_wave_sum(p1);
+        if (lane == 0) {
+            ds_s[l] = p0;
+            if (two) ds_s[l2] = p1;
+        }
     }
     __syncthreads();
     float dot = 0.f;
@@ -473,27 +495,85 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_small_bwd_k(const AttnSmallA
     // d att_seq through the context: dx[l, :] += alpha[l] * dz
     if (a.dx[g]) {
         float* dx = a.dx[g] + b * a.xsb;
-        for (int i = tid; i < L * D; i += ATT_THREADS) {
-            const int l = i / D, d = i - l * D;
-            dx[l * a.xsl + d] += al_s[l] * dz_s[d];
+        if constexpr (VEC) {
+            const int D4 = D >> 2, n4 = L * D4;
+            for (int i0 = tid; i0 < n4; i0 += 4 * ATT_THREADS) {
+                f32x4 v[4];
+                float* o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int i = min(i0 + j * ATT_THREADS, n4 - 1);
+                    const int l = i / D4;
+                    o[j] = dx + l * a.xsl + 4 * (i - l * D4);
+                    v[j] = *reinterpret_cast<const f32x4*>(o[j]);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int i = i0 + j * ATT_THREADS;
+                    if (i >= n4) break;
+                    const int l = i / D4, d = 4 * (i - l * D4);
+                    const f32x4 gv = *reinterpret_cast<const f32x4*>(dz_s + d);
+                    *reinterpret_cast<f32x4*>(o[j]) = v[j] + al_s[l] * gv;
+                }
+            }
+        } else {
+            for (int i = tid; i < L * D; i += ATT_THREADS) {
+                const int l = i / D, d = i - l * D;
+                dx[l * a.xsl + d] += al_s[l] * dz_s[d];
+            }
         }
     }
-    // tanh backward over the (L, A) slice: one thread per hidden unit, rows in order (deterministic sums)
+    // tanh backward over the (L, A) slice: one thread per (4) hidden unit(s), rows in order (deterministic sums),
+    // four rows' loads issued together
     const float* proj = a.proj[g] + b * a.psb;
     float* dproj = a.dproj[g] + b * a.dpsb;
-    for (int i = tid; i < A; i += ATT_THREADS) {
-        const float hh = hp_s[i], ww = w_s[i];
-        float ah = 0.f, aw = 0.f;
-        for (int l = 0; l < L; ++l) {
-            const float t = rfn_tanh_fast(proj[l * a.psl + i] + hh);
-            const float dpre = ds_s[l] * ww * (1.0f - t * t);
-            float* o = dproj + l * a.dpsl + i;
-            *o = a.accumulate_dproj ? *o + dpre : dpre;
-            ah += dpre;
-            aw += ds_s[l] * t;
+    const bool acc = a.accumulate_dproj != 0;
+    if constexpr (VEC) {
+        for (int i = 4 * tid; i < A; i += 4 * ATT_THREADS) {
+            const f32x4 hh = *reinterpret_cast<const f32x4*>(hp_s + i);
+            const f32x4 ww = *reinterpret_cast<const f32x4*>(w_s + i);
+            f32x4 ah = {0.f, 0.f, 0.f, 0.f}, aw = {0.f, 0.f, 0.f, 0.f};
+            for (int l0 = 0; l0 < L; l0 += 4) {
+                f32x4 pv[4], ov[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int l = min(l0 + j, L - 1);
+                    pv[j] = *reinterpret_cast<const f32x4*>(proj + l * a.psl + i);
+                    if (acc) ov[j] = *reinterpret_cast<const f32x4*>(dproj + l * a.dpsl + i);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int l = l0 + j;
+                    if (l >= L) break;
+                    f32x4 dpre;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float t = rfn_tanh_fast(pv[j][e] + hh[e]);
+                        dpre[e] = ds_s[l] * ww[e] * (1.0f - t * t);
+                        ah[e] += dpre[e];
+                        aw[e] += ds_s[l] * t;
+                    }
+                    *reinterpret_cast<f32x4*>(dproj + l * a.dpsl + i) = acc ? ov[j] + dpre : dpre;
+                }
+            }
+            *reinterpret_cast<f32x4*>(a.dhproj[g] + (long)b * A + i) = ah;
+            *reinterpret_cast<f32x4*>(a.dw_part[g] + (long)b * A + i) = aw;
         }
-        a.dhproj[g][(long)b * A + i] = ah;
-        a.dw_part[g][(long)b * A + i] = aw;
+    } else {
+        for (int i = tid; i < A; i += ATT_THREADS) {
+            const float hh = hp_s[i], ww = w_s[i];
+            float ah = 0.f, aw = 0.f;
+            for (int l = 0; l < L; ++l) {
+                const float t = rfn_tanh_fast(proj[l * a.psl + i] + hh);
+                const float dpre = ds_s[l] * ww * (1.0f - t * t);
+                float* o = dproj + l * a.dpsl + i;
+                *o = acc ? *o + dpre : dpre;
+                ah += dpre;
+                aw += ds_s[l] * t;
+            }
+            a.dhproj[g][(long)b * A + i] = ah;
+            a.dw_part[g][(long)b * A + i] = aw;
+        }
     }
 }
 
@@ -545,7 +625,14 @@ extern "C" int rfn_attn_small_bwd(int ngroups, const float* const* proj, int64_t
     a.L = L; a.A = A; a.D = D; a.accumulate_dproj = accumulate_dproj;
     const size_t lds = (size_t)(2 * ((A + 3) & ~3) + ((D + 3) & ~3) + 2 * ATS_MAX_L) * sizeof(float);
     if (lds > 64 * 1024) return RFN_ERR_SHAPE;
-    hipLaunchKernelGGL(attn_small_bwd_k, dim3(B, ngroups), dim3(ATT_THREADS), lds, (hipStream_t)stream, a);
+    bool vec = (A % 4 == 0) && (D % 4 == 0) && ((proj_sb | proj_sl | sb | sl | lddz | dproj_sb | dproj_sl) % 4 == 0);
+    for (int g = 0; g < ngroups; ++g)
+        vec = vec && rfn_aligned16(proj[g]) && rfn_aligned16(att_seq[g]) && rfn_aligned16(dproj[g]) &&
+              rfn_aligned16(dhproj[g]) && rfn_aligned16(dw_part[g]) && (!datt_seq || rfn_aligned16(datt_seq[g]));
+    if (vec)
+        hipLaunchKernelGGL(attn_small_bwd_k<true>, dim3(B, ngroups), dim3(ATT_THREADS), lds, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(attn_small_bwd_k<false>, dim3(B, ngroups), dim3(ATT_THREADS), lds, (hipStream_t)stream, a);
     RFN_CHECK_LAUNCH();
     return RFN_OK;
 }

@@ -577,7 +577,11 @@ static int launch_tile(GemmArgs& a, hipStream_t st) {
     // Medium problems (the heavier per-step GEMMs: M = batch, a few GF): the 128x128 tile is ~1.5x more efficient
     // than 64x64 but yields too few tiles, so cut K across blocks to reach ~2 blocks per CU.
     int big_split = 1;
-    if (big < 384 && a.part && big >= 16 && flops >= GEMM_MEDIUM_MIN_FLOPS) {
+    static const long medium_max = [] {
+        const char* e = getenv("RFN_GEMM_MEDIUM_MAX");
+        return e ? atol(e) : 256L;   // 256 < big < 384: 64x64 tiles fill the chip better than a 2-way split
+    }();
+    if (big <= medium_max && a.part && big >= 16 && flops >= GEMM_MEDIUM_MIN_FLOPS) {
         long want = (512 + big - 1) / big;
         if (want > iters32 / 8) want = iters32 / 8;
         if (want > 16) want = 16;

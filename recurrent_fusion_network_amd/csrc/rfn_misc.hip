@@ -25,19 +25,34 @@ __device__ __forceinline__ float block_max_256(float v, float* red) {
 }
 
 // ---- out[n] (+)= sum_r X[r, n] ----------------------------------------------------------------
-// block = 64 columns x 4 row lanes; each wave reads 256 contiguous bytes per row.
-__global__ __launch_bounds__(256) void colsum_k(const float* __restrict__ X, long ldx, int rows, int cols,
-                                                float* __restrict__ out, int accumulate) {
-    __shared__ float red[4][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
-    float acc = 0.f;
-    if (c < cols)
-        for (int r = rl; r < rows; r += 4) acc += X[r * ldx + c];
-    red[rl][threadIdx.x & 63] = acc;
+// block = CW columns x (1024 / CW) row lanes, 4 independent row streams per thread; the lanes' partial sums are
+// combined through LDS in a fixed order.  Narrow matrices (the (S*B, A) attention partials) take CW = 16 so that
+// 4x more blocks share the rows; wide ones keep 256-B row segments per wave.
+template <int CW>
+__global__ __launch_bounds__(1024) void colsum_k(const float* __restrict__ X, long ldx, int rows, int cols,
+                                                 float* __restrict__ out, int accumulate) {
+    constexpr int RL = 1024 / CW;
+    __shared__ float red[RL][CW];
+    const int cl = threadIdx.x % CW, rl = threadIdx.x / CW;
+    const int c = blockIdx.x * CW + cl;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (c < cols) {
+        const float* p = X + c;
+        int r = rl;
+        for (; r + 3 * RL < rows; r += 4 * RL) {
+            a0 += p[(long)r * ldx];
+            a1 += p[(long)(r + RL) * ldx];
+            a2 += p[(long)(r + 2 * RL) * ldx];
+            a3 += p[(long)(r + 3 * RL) * ldx];
+        }
+        for (; r < rows; r += RL) a0 += p[(long)r * ldx];
+    }
+    red[rl][cl] = (a0 + a1) + (a2 + a3);
     __syncthreads();
     if (rl == 0 && c < cols) {
-        const int l = threadIdx.x & 63;
-        const float s = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < RL; ++k) s += red[k][cl];
         out[c] = accumulate ? out[c] + s : s;
     }
 }
@@ -45,8 +60,12 @@ extern "C" int rfn_colsum_f32(const float* X, int64_t ldx, int rows, int cols, f
                               void* stream) {
     if (rows < 0 || cols <= 0) return RFN_ERR_SHAPE;
     if (!X || !out) return RFN_ERR_ARG;
-    hipLaunchKernelGGL(colsum_k, dim3(rfn_cdiv(cols, 64)), dim3(256), 0, (hipStream_t)stream, X, (long)ldx, rows,
-                       cols, out, accumulate);
+    if (cols >= 64 * 128)
+        hipLaunchKernelGGL(colsum_k<64>, dim3(rfn_cdiv(cols, 64)), dim3(1024), 0, (hipStream_t)stream, X, (long)ldx,
+                           rows, cols, out, accumulate);
+    else
+        hipLaunchKernelGGL(colsum_k<16>, dim3(rfn_cdiv(cols, 16)), dim3(1024), 0, (hipStream_t)stream, X, (long)ldx,
+                           rows, cols, out, accumulate);
     RFN_CHECK_LAUNCH();
     return RFN_OK;
 }
