@@ -33,7 +33,7 @@ extern "C" {
 #define RFN_ERR_ARG (-5)         /* null / misaligned pointer */
 
 #define RFN_MAX_ENC 8
-#define RFN_ABI_VERSION 2
+#define RFN_ABI_VERSION 3
 
 /* Model dimensions: the fields RecurrentFusionModel.__init__ reads from `opt`
  * (misc/RecurrentFusionModel.py:118-151). */
@@ -130,6 +130,11 @@ int rfn_attn_scores_fwd(const float* proj, int64_t proj_sb, int64_t proj_sl, con
                         void* stream);
 int rfn_attn_context_fwd(const float* att_seq, int64_t sb, int64_t sl, const float* alpha, int B,
                          int L, int D, float* z, int64_t ldz, void* stream);
+/* rfn_attn_scores_fwd + rfn_attn_context_fwd in two launches instead of three: the context kernel normalises the
+ * raw scores itself.  scores_scratch: B*L floats, must not alias alpha.  Results are bit-identical to the pair. */
+int rfn_attn_fwd(const float* proj, int64_t proj_sb, int64_t proj_sl, const float* hproj, const float* w_out,
+                 const float* b_out, const float* att_seq, int64_t sb, int64_t sl, int B, int L, int A, int D,
+                 float* scores_scratch, float* alpha, float* z, int64_t ldz, void* stream);
 /* dalpha[b,l] = <dz[b,:], att_seq[b,l,:]> */
 int rfn_attn_context_bwd_dalpha(const float* att_seq, int64_t sb, int64_t sl, const float* dz,
                                 int64_t lddz, int B, int L, int D, float* dalpha, void* stream);
@@ -227,6 +232,14 @@ int rfn_axpby_2d(float alpha, const float* x, int64_t ldx, float beta, float* y,
 
 /* y[r,c] = y[r,c] / divisor (IEEE division, as `sum / num_feat_array` in the reference) */
 int rfn_div_2d(float* y, int64_t ldy, int rows, int cols, float divisor, void* stream);
+/* State mean over the M encoder slices of a concatenated (rows, G*gstride) state (misc/RecurrentFusionModel.py:233-235):
+ * y_p[r,c] = (x_p[r,c] + x_p[r,gstride+c] + ...) / G, summed in slice order then divided; up to two (x, y) pairs
+ * (h and c) per launch.  Arrays are host arrays of device pointers. */
+int rfn_mean_over_groups(int npairs, const float* const* x, int64_t ldx, int64_t gstride, int G, float* const* y,
+                         int64_t ldy, int rows, int cols, void* stream);
+/* Its backward: y_p[r, g*gstride + c] = alpha*x_p[r,c] + beta[p]*y_p[r, g*gstride + c] for every slice g. */
+int rfn_bcast_to_groups(int npairs, float alpha, const float* const* x, int64_t ldx, const float* beta,
+                        float* const* y, int64_t ldy, int64_t gstride, int G, int rows, int cols, void* stream);
 
 /* ---- criteria (misc/utils.py) --------------------------------------------------------------- */
 /* ReviewNetEnsembleCriterion language term (misc/utils.py:163-184): loss_out[0] (+)=
@@ -236,6 +249,11 @@ int rfn_xe_loss(const float* logp, int B, int T, int V1, const int64_t* target, 
                 const float* mask, int64_t ld_mask, float eps, float gscale,
                 float* scratch /* B*T floats, needed when loss_out != NULL */, float* loss_out,
                 int accumulate_loss, float* dlogp, void* stream);
+/* Same, with the upstream gradient also read from a device scalar (autograd hands d loss as a 0-dim tensor):
+ * dlogp is scaled by gscale * gscale_dev[0]; gscale_dev may be NULL. */
+int rfn_xe_loss_ex(const float* logp, int B, int T, int V1, const int64_t* target, int64_t ld_target,
+                   const float* mask, int64_t ld_mask, float eps, float gscale, const float* gscale_dev,
+                   float* scratch, float* loss_out, int accumulate_loss, float* dlogp, void* stream);
 /* ReviewNetRewardCriterion policy + entropy terms (misc/utils.py:50-72):
  * loss_out[0] (+)= [ -sum pol(b,t)*mask(b,t) + entropy_reg * sum mask0(b,t) * sum_v lp*exp(lp) ] / B with
  * mask0 = seq > 0, mask = [1, mask0[:, :-1]], pol = input*reward or the reference's PPO-clip surrogate.
@@ -251,6 +269,13 @@ int rfn_rl_loss(const float* input, int64_t ld_in, const int64_t* seq, int64_t l
 int rfn_multilabel_margin(const float* pred, int B, int K, const int64_t* target, float scale,
                           float gscale, float* scratch /* B floats when loss_out != NULL */,
                           float* loss_out, int accumulate_loss, float* dpred, void* stream);
+
+/* All M+1 reasoning heads of ReviewNetEnsembleCriterion in one launch (misc/utils.py:186-190: the per-head
+ * losses are added one after the other, which the fixed-order finish reproduces).  preds / dpreds: host arrays of
+ * nheads device pointers ((B,K) each; dpreds or its entries may be NULL); scratch: nheads*B floats when loss_out. */
+int rfn_multilabel_margin_grouped(int nheads, const float* const* preds, int B, int K, const int64_t* target,
+                                  float scale, float gscale, const float* gscale_dev, float* scratch,
+                                  float* loss_out, int accumulate_loss, float* const* dpreds, void* stream);
 
 /* clip_gradient + Adam with L2 weight decay (misc/utils.py:292-296, train.py:69-71,162-163),
  * one pass: g = clamp(g, +-clip) + wd*p; m,v update; p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps).

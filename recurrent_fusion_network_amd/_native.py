@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, 'librfn_hip.so')
 RFN_MAX_ENC = 8
 RFN_GEMM_MAXSEG = 8
 RFN_GEMM_MAXGROUP = 8
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class RfnError(RuntimeError):
@@ -67,6 +67,7 @@ def _load():
         'rfn_attn_context_bwd_dalpha': (C.c_int, [P, L, L, P, L, I, I, I, P, P]),
         'rfn_attn_context_bwd_dseq': (C.c_int, [P, P, L, I, I, I, P, L, L, P]),
         'rfn_attn_scores_bwd': (C.c_int, [P, L, L, P, P, P, P, I, I, I, P, L, L, I, P, P, P]),
+        'rfn_attn_fwd': (C.c_int, [P, L, L, P, P, P, P, L, L, I, I, I, I, P, P, P, L, P]),
         'rfn_attn_small_fwd': (C.c_int, [I, P, L, L, P, P, P, P, L, L, I, I, I, I, P, P, L, P]),
         'rfn_attn_small_bwd': (C.c_int, [I, P, L, L, P, P, P, P, L, L, P, L, I, I, I, I, P, L, L, I, P, P, P, P]),
         'rfn_lstm_fwd': (C.c_int, [P, L, P, L, P, L, P, L, I, I, I, F, U64, U64, P]),
@@ -81,8 +82,12 @@ def _load():
         'rfn_max_over_steps_bwd': (C.c_int, [P, P, I, I, I, P, P]),
         'rfn_axpby_2d': (C.c_int, [F, P, L, F, P, L, I, I, P]),
         'rfn_div_2d': (C.c_int, [P, L, I, I, F, P]),
+        'rfn_mean_over_groups': (C.c_int, [I, P, L, L, I, P, L, I, I, P]),
+        'rfn_bcast_to_groups': (C.c_int, [I, F, P, L, P, P, L, L, I, I, I, P]),
         'rfn_xe_loss': (C.c_int, [P, I, I, I, P, L, P, L, F, F, P, P, I, P, P]),
         'rfn_multilabel_margin': (C.c_int, [P, I, I, P, F, F, P, P, I, P, P]),
+        'rfn_xe_loss_ex': (C.c_int, [P, I, I, I, P, L, P, L, F, F, P, P, P, I, P, P]),
+        'rfn_multilabel_margin_grouped': (C.c_int, [I, P, I, I, P, F, F, P, P, P, I, P, P]),
         'rfn_rl_loss': (C.c_int, [P, L, P, L, P, L, P, L, L, I, I, I, F, P, L, I, F, P, P, I, P, L, P, L, L, P]),
         'rfn_adam_step': (C.c_int, [P, P, P, P, L, F, F, F, F, F, F, F, I, P]),
         'rfn_greedy_pick': (C.c_int, [P, L, I, I, I, P, P, L, P, L, P, P, P]),

@@ -33,16 +33,16 @@ class _XEFn(torch.autograd.Function):
         preds = [N.require_cuda_f32(p, 'top_pred') for p in top_pred]
         K = preds[0].size(1)
         loss = torch.zeros(1, device=dev)
-        scratch = torch.empty(max(B * T, B), device=dev)
+        scratch = torch.empty(max(B * T, len(preds) * B), device=dev)
         st = N.stream_ptr()
         N.check(N.lib.rfn_xe_loss(log_prob.data_ptr(), B, T, V1, target.data_ptr(), target.stride(0),
                                   mask.data_ptr(), mask.stride(0), eps, 1.0, scratch.data_ptr(), loss.data_ptr(), 0,
                                   None, st), 'rfn_xe_loss')
         scale = reason_weight / len(preds)
-        for p in preds:
-            N.check(N.lib.rfn_multilabel_margin(p.data_ptr(), B, K, top_true.data_ptr(), scale, 1.0,
-                                                scratch.data_ptr(), loss.data_ptr(), 1, None, st),
-                    'rfn_multilabel_margin')
+        # the M+1 reasoning heads in one launch; their losses are added to the language loss head by head
+        N.check(N.lib.rfn_multilabel_margin_grouped(len(preds), N.ptr_array(preds), B, K, top_true.data_ptr(), scale, 1.0,
+                                                    None, scratch.data_ptr(), loss.data_ptr(), 1, None, st),
+                'rfn_multilabel_margin_grouped')
         ctx.eps, ctx.scale, ctx.shape = eps, scale, (B, T, V1, K)
         ctx.save_for_backward(log_prob, target, mask, top_true, *preds)
         return loss[0]
@@ -52,17 +52,15 @@ class _XEFn(torch.autograd.Function):
         log_prob, target, mask, top_true, *preds = ctx.saved_tensors
         B, T, V1, K = ctx.shape
         st = N.stream_ptr()
+        g = g.contiguous().float()                       # d loss stays on the device: the kernels read it there
         dlogp = torch.empty_like(log_prob)
-        N.check(N.lib.rfn_xe_loss(log_prob.data_ptr(), B, T, V1, target.data_ptr(), target.stride(0),
-                                  mask.data_ptr(), mask.stride(0), ctx.eps, 1.0, None, None, 0, dlogp.data_ptr(),
-                                  st), 'rfn_xe_loss (grad)')
-        dlogp.mul_(g)
-        dpreds = []
-        for p in preds:
-            dp = torch.empty_like(p)
-            N.check(N.lib.rfn_multilabel_margin(p.data_ptr(), B, K, top_true.data_ptr(), ctx.scale, 1.0, None, None,
-                                                0, dp.data_ptr(), st), 'rfn_multilabel_margin (grad)')
-            dpreds.append(dp.mul_(g))
+        N.check(N.lib.rfn_xe_loss_ex(log_prob.data_ptr(), B, T, V1, target.data_ptr(), target.stride(0),
+                                     mask.data_ptr(), mask.stride(0), ctx.eps, 1.0, g.data_ptr(), None, None, 0,
+                                     dlogp.data_ptr(), st), 'rfn_xe_loss_ex (grad)')
+        dpreds = [torch.empty_like(p) for p in preds]
+        N.check(N.lib.rfn_multilabel_margin_grouped(len(preds), N.ptr_array(preds), B, K, top_true.data_ptr(),
+                                                    ctx.scale, 1.0, g.data_ptr(), None, None, 0, N.ptr_array(dpreds),
+                                                    st), 'rfn_multilabel_margin_grouped (grad)')
         return (None, None, None, None, None, dlogp) + tuple(dpreds)
 
 
@@ -86,11 +84,10 @@ class _MLMFn(torch.autograd.Function):
         dev = preds[0].device
         top_true = top_true.to(dev).long().contiguous()
         loss = torch.zeros(1, device=dev)
-        scratch = torch.empty(B, device=dev)
-        for j, p in enumerate(preds):
-            N.check(N.lib.rfn_multilabel_margin(p.data_ptr(), B, K, top_true.data_ptr(), scale, 1.0,
-                                                scratch.data_ptr(), loss.data_ptr(), int(j > 0), None,
-                                                N.stream_ptr()), 'rfn_multilabel_margin')
+        scratch = torch.empty(len(preds) * B, device=dev)
+        N.check(N.lib.rfn_multilabel_margin_grouped(len(preds), N.ptr_array(preds), B, K, top_true.data_ptr(), scale, 1.0,
+                                                    None, scratch.data_ptr(), loss.data_ptr(), 0, None,
+                                                    N.stream_ptr()), 'rfn_multilabel_margin_grouped')
         ctx.scale = scale
         ctx.save_for_backward(top_true, *preds)
         return loss[0]
@@ -98,13 +95,12 @@ class _MLMFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         top_true, *preds = ctx.saved_tensors
-        out = []
-        for p in preds:
-            B, K = p.shape
-            dp = torch.empty_like(p)
-            N.check(N.lib.rfn_multilabel_margin(p.data_ptr(), B, K, top_true.data_ptr(), ctx.scale, 1.0, None, None,
-                                                0, dp.data_ptr(), N.stream_ptr()), 'rfn_multilabel_margin (grad)')
-            out.append(dp.mul_(g))
+        B, K = preds[0].shape
+        g = g.contiguous().float()
+        out = [torch.empty_like(p) for p in preds]
+        N.check(N.lib.rfn_multilabel_margin_grouped(len(preds), N.ptr_array(preds), B, K, top_true.data_ptr(),
+                                                    ctx.scale, 1.0, g.data_ptr(), None, None, 0, N.ptr_array(out),
+                                                    N.stream_ptr()), 'rfn_multilabel_margin_grouped (grad)')
         return (None, None) + tuple(out)
 
 

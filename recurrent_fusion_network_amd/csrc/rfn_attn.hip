@@ -88,36 +88,54 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_softmax_k(float* __restrict_
     for (int l = tid; l < L; l += ATT_THREADS) a[l] = expf(a[l] - m) * inv;
 }
 
+static int launch_scores_raw(const float* proj, int64_t proj_sb, int64_t proj_sl, const float* hproj,
+                             const float* w_out, const float* b_out, int B, int L, int A, float* scores,
+                             hipStream_t st);
+
 extern "C" int rfn_attn_scores_fwd(const float* proj, int64_t proj_sb, int64_t proj_sl, const float* hproj,
                                    const float* w_out, const float* b_out, int B, int L, int A, float* alpha,
                                    void* stream) {
-    if (B <= 0 || L <= 0 || A <= 0) return RFN_ERR_SHAPE;
-    if (!proj || !hproj || !w_out || !alpha) return RFN_ERR_ARG;
-    const size_t lds = (2 * ((A + 3) & ~3)) * sizeof(float);
-    if (lds > 64 * 1024) return RFN_ERR_SHAPE;
-    const bool vec = (A % 4 == 0) && rfn_aligned16(proj) && (proj_sb % 4 == 0) && (proj_sl % 4 == 0);
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid(rfn_cdiv(L, SC_ROWS), B);
-    if (vec)
-        hipLaunchKernelGGL(attn_scores_raw_k<true>, grid, dim3(ATT_THREADS), lds, st, proj, (long)proj_sb,
-                           (long)proj_sl, hproj, w_out, b_out, L, A, alpha);
-    else
-        hipLaunchKernelGGL(attn_scores_raw_k<false>, grid, dim3(ATT_THREADS), lds, st, proj, (long)proj_sb,
-                           (long)proj_sl, hproj, w_out, b_out, L, A, alpha);
-    RFN_CHECK_LAUNCH();
+    RFN_TRY(launch_scores_raw(proj, proj_sb, proj_sl, hproj, w_out, b_out, B, L, A, alpha, st));
     hipLaunchKernelGGL(attn_softmax_k, dim3(B), dim3(ATT_THREADS), 0, st, alpha, L);
     RFN_CHECK_LAUNCH();
     return RFN_OK;
 }
 
 // ---- context: z[b,d] = sum_l alpha[b,l] x[b,l,d] ------------------------------------------------
-template <bool VEC>
+// SOFTMAX: `alpha` holds RAW scores; every block of a batch row normalises them itself in LDS (L values: trivial,
+// same reduction order as attn_softmax_k so the weights are bit-identical) and the first block publishes them
+// to alpha_out -- the separate softmax launch of the split path disappears.
+template <bool VEC, bool SOFTMAX>
 __global__ __launch_bounds__(ATT_THREADS) void attn_context_fwd_k(const float* __restrict__ x, long sb, long sl,
                                                                  const float* __restrict__ alpha, int L, int D,
-                                                                 float* __restrict__ z, long ldz) {
+                                                                 float* __restrict__ z, long ldz,
+                                                                 float* __restrict__ alpha_out) {
     extern __shared__ __attribute__((aligned(16))) float al_s[];
     const int b = blockIdx.y, tid = threadIdx.x;
     for (int l = tid; l < L; l += ATT_THREADS) al_s[l] = alpha[(long)b * L + l];
+    if constexpr (SOFTMAX) {
+        __shared__ float red[ATT_WAVES];
+        const int lane = tid & 63, wave = tid >> 6;
+        float m = -INFINITY;   // each thread re-reads exactly the entries it wrote: no barrier needed yet
+        for (int l = tid; l < L; l += ATT_THREADS) m = fmaxf(m, al_s[l]);
+        m = rfn_wave_max(m);
+        if (lane == 0) red[wave] = m;
+        __syncthreads();
+        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        __syncthreads();
+        float sum = 0.f;
+        for (int l = tid; l < L; l += ATT_THREADS) sum += expf(al_s[l] - m);
+        sum = rfn_wave_sum(sum);
+        if (lane == 0) red[wave] = sum;
+        __syncthreads();
+        const float inv = 1.0f / ((red[0] + red[1]) + (red[2] + red[3]));
+        for (int l = tid; l < L; l += ATT_THREADS) {
+            const float a = expf(al_s[l] - m) * inv;
+            al_s[l] = a;
+            if (blockIdx.x == 0) alpha_out[(long)b * L + l] = a;
+        }
+    }
     __syncthreads();
     const float* xb = x + b * sb;
     if constexpr (VEC) {
@@ -146,22 +164,58 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_context_fwd_k(const float* _
     }
 }
 
-extern "C" int rfn_attn_context_fwd(const float* att_seq, int64_t sb, int64_t sl, const float* alpha, int B, int L,
-                                    int D, float* z, int64_t ldz, void* stream) {
+template <bool SOFTMAX>
+static int launch_context(const float* att_seq, int64_t sb, int64_t sl, const float* alpha, int B, int L, int D,
+                          float* z, int64_t ldz, float* alpha_out, hipStream_t st) {
     if (B <= 0 || L <= 0 || D <= 0) return RFN_ERR_SHAPE;
     if (!att_seq || !alpha || !z) return RFN_ERR_ARG;
     if ((size_t)L * sizeof(float) > 64 * 1024) return RFN_ERR_SHAPE;
     const bool vec = (D % 4 == 0) && rfn_aligned16(att_seq) && rfn_aligned16(z) && (sb % 4 == 0) && (sl % 4 == 0) &&
                      (ldz % 4 == 0);
-    hipStream_t st = (hipStream_t)stream;
     if (vec)
-        hipLaunchKernelGGL(attn_context_fwd_k<true>, dim3(rfn_cdiv(D, 4 * ATT_THREADS), B), dim3(ATT_THREADS),
-                           L * sizeof(float), st, att_seq, (long)sb, (long)sl, alpha, L, D, z, (long)ldz);
+        hipLaunchKernelGGL((attn_context_fwd_k<true, SOFTMAX>), dim3(rfn_cdiv(D, 4 * ATT_THREADS), B),
+                           dim3(ATT_THREADS), L * sizeof(float), st, att_seq, (long)sb, (long)sl, alpha, L, D, z,
+                           (long)ldz, alpha_out);
     else
-        hipLaunchKernelGGL(attn_context_fwd_k<false>, dim3(rfn_cdiv(D, ATT_THREADS), B), dim3(ATT_THREADS),
-                           L * sizeof(float), st, att_seq, (long)sb, (long)sl, alpha, L, D, z, (long)ldz);
+        hipLaunchKernelGGL((attn_context_fwd_k<false, SOFTMAX>), dim3(rfn_cdiv(D, ATT_THREADS), B), dim3(ATT_THREADS),
+                           L * sizeof(float), st, att_seq, (long)sb, (long)sl, alpha, L, D, z, (long)ldz, alpha_out);
     RFN_CHECK_LAUNCH();
     return RFN_OK;
+}
+
+extern "C" int rfn_attn_context_fwd(const float* att_seq, int64_t sb, int64_t sl, const float* alpha, int B, int L,
+                                    int D, float* z, int64_t ldz, void* stream) {
+    return launch_context<false>(att_seq, sb, sl, alpha, B, L, D, z, ldz, nullptr, (hipStream_t)stream);
+}
+
+static int launch_scores_raw(const float* proj, int64_t proj_sb, int64_t proj_sl, const float* hproj,
+                             const float* w_out, const float* b_out, int B, int L, int A, float* scores,
+                             hipStream_t st) {
+    if (B <= 0 || L <= 0 || A <= 0) return RFN_ERR_SHAPE;
+    if (!proj || !hproj || !w_out || !scores) return RFN_ERR_ARG;
+    const size_t lds = (2 * ((A + 3) & ~3)) * sizeof(float);
+    if (lds > 64 * 1024) return RFN_ERR_SHAPE;
+    const bool vec = (A % 4 == 0) && rfn_aligned16(proj) && (proj_sb % 4 == 0) && (proj_sl % 4 == 0);
+    dim3 grid(rfn_cdiv(L, SC_ROWS), B);
+    if (vec)
+        hipLaunchKernelGGL(attn_scores_raw_k<true>, grid, dim3(ATT_THREADS), lds, st, proj, (long)proj_sb,
+                           (long)proj_sl, hproj, w_out, b_out, L, A, scores);
+    else
+        hipLaunchKernelGGL(attn_scores_raw_k<false>, grid, dim3(ATT_THREADS), lds, st, proj, (long)proj_sb,
+                           (long)proj_sl, hproj, w_out, b_out, L, A, scores);
+    RFN_CHECK_LAUNCH();
+    return RFN_OK;
+}
+
+// AttentionModelCore.forward in two launches: raw scores, then softmax + context (see attn_context_fwd_k).
+extern "C" int rfn_attn_fwd(const float* proj, int64_t proj_sb, int64_t proj_sl, const float* hproj,
+                            const float* w_out, const float* b_out, const float* att_seq, int64_t sb, int64_t sl,
+                            int B, int L, int A, int D, float* scores_scratch, float* alpha, float* z, int64_t ldz,
+                            void* stream) {
+    if (!scores_scratch || !alpha || scores_scratch == alpha) return RFN_ERR_ARG;
+    RFN_TRY(launch_scores_raw(proj, proj_sb, proj_sl, hproj, w_out, b_out, B, L, A, scores_scratch,
+                              (hipStream_t)stream));
+    return launch_context<true>(att_seq, sb, sl, scores_scratch, B, L, D, z, ldz, alpha, (hipStream_t)stream);
 }
 
 // ---- backward of the context: dalpha[b,l] = <dz[b,:], x[b,l,:]> ---------------------------------

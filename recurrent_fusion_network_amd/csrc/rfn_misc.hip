@@ -3,6 +3,8 @@
 // criteria of misc/utils.py, the clamp+Adam update and the greedy pick of sample().
 // All are HBM/L2-bound byte movers: coalesced 16-B accesses where alignment allows, wave shuffles for
 // reductions, fixed summation orders (no float atomics) so results are bitwise reproducible.
+#include <string.h>
+
 #include "rfn_common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -328,6 +330,73 @@ extern "C" int rfn_div_2d(float* y, int64_t ldy, int rows, int cols, float divis
     return RFN_OK;
 }
 
+// ---- mean over the M encoder slices of a concatenated state and its backward (misc/RecurrentFusionModel.py:233-235)
+// y[r, c] = (((x[r, c] + x[r, G1 + c]) + x[r, 2*G1 + c]) + ...) / G   -- summed first, then divided, like the
+// reference; blockIdx.y selects one of up to two (x, y) pairs (h and c share the launch).
+struct MeanArgs {
+    const float* x[2];
+    float* y[2];
+    float beta[2];   // backward only: y = alpha*x + beta*y per pair
+};
+__global__ __launch_bounds__(256) void mean_groups_k(const MeanArgs a, long ldx, long gstride, int G, long ldy,
+                                                     int rows, int cols) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)rows * cols) return;
+    const int r = (int)(i / cols), c = (int)(i - (long)r * cols);
+    const float* x = a.x[blockIdx.y] + r * ldx + c;
+    float s = x[0];
+    for (int g = 1; g < G; ++g) s += x[g * gstride];
+    a.y[blockIdx.y][r * ldy + c] = s / (float)G;
+}
+extern "C" int rfn_mean_over_groups(int npairs, const float* const* x, int64_t ldx, int64_t gstride, int G,
+                                    float* const* y, int64_t ldy, int rows, int cols, void* stream) {
+    if (npairs < 1 || npairs > 2 || G < 1 || rows <= 0 || cols <= 0) return RFN_ERR_SHAPE;
+    if (!x || !y) return RFN_ERR_ARG;
+    MeanArgs a;
+    memset(&a, 0, sizeof(a));
+    for (int p = 0; p < npairs; ++p) {
+        if (!x[p] || !y[p]) return RFN_ERR_ARG;
+        a.x[p] = x[p];
+        a.y[p] = y[p];
+    }
+    hipLaunchKernelGGL(mean_groups_k, dim3(rfn_cdiv((long)rows * cols, 256), npairs), dim3(256), 0,
+                       (hipStream_t)stream, a, (long)ldx, (long)gstride, G, (long)ldy, rows, cols);
+    RFN_CHECK_LAUNCH();
+    return RFN_OK;
+}
+// y[r, g*gstride + c] = alpha * x[r, c] + beta_p * y[r, g*gstride + c]  for every group g (the mean's backward)
+__global__ __launch_bounds__(256) void bcast_groups_k(const MeanArgs a, float alpha, long ldx, long gstride, int G,
+                                                      long ldy, int rows, int cols) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)rows * cols) return;
+    const int r = (int)(i / cols), c = (int)(i - (long)r * cols);
+    const float xv = alpha * a.x[blockIdx.y][r * ldx + c];
+    const float beta = a.beta[blockIdx.y];
+    float* y = a.y[blockIdx.y] + r * ldy + c;
+    for (int g = 0; g < G; ++g) {
+        float* p = y + g * gstride;
+        *p = (beta == 0.f) ? xv : xv + beta * *p;
+    }
+}
+extern "C" int rfn_bcast_to_groups(int npairs, float alpha, const float* const* x, int64_t ldx, const float* beta,
+                                   float* const* y, int64_t ldy, int64_t gstride, int G, int rows, int cols,
+                                   void* stream) {
+    if (npairs < 1 || npairs > 2 || G < 1 || rows <= 0 || cols <= 0) return RFN_ERR_SHAPE;
+    if (!x || !y || !beta) return RFN_ERR_ARG;
+    MeanArgs a;
+    memset(&a, 0, sizeof(a));
+    for (int p = 0; p < npairs; ++p) {
+        if (!x[p] || !y[p]) return RFN_ERR_ARG;
+        a.x[p] = x[p];
+        a.y[p] = y[p];
+        a.beta[p] = beta[p];
+    }
+    hipLaunchKernelGGL(bcast_groups_k, dim3(rfn_cdiv((long)rows * cols, 256), npairs), dim3(256), 0,
+                       (hipStream_t)stream, a, alpha, (long)ldx, (long)gstride, G, (long)ldy, rows, cols);
+    RFN_CHECK_LAUNCH();
+    return RFN_OK;
+}
+
 // ---- fixed-order sum of n floats -> out[0] ---------------------------------------------------------
 __global__ __launch_bounds__(256) void sum_k(const float* __restrict__ x, int n, float scale, float* __restrict__ out,
                                              int accumulate) {
@@ -342,7 +411,8 @@ __global__ __launch_bounds__(256) void sum_k(const float* __restrict__ x, int n,
 __global__ __launch_bounds__(256) void xe_loss_k(const float* __restrict__ logp, int T, int V1,
                                                  const int64_t* __restrict__ target, long ld_t,
                                                  const float* __restrict__ mask, long ld_m, float eps, float gcoef,
-                                                 float* __restrict__ row_loss, float* __restrict__ dlogp) {
+                                                 const float* __restrict__ gdev, float* __restrict__ row_loss,
+                                                 float* __restrict__ dlogp) {
     __shared__ float red[4];
     const int r = blockIdx.x, b = r / T, t = r - b * T;
     const float* lp = logp + (long)r * V1;
@@ -364,19 +434,20 @@ __global__ __launch_bounds__(256) void xe_loss_k(const float* __restrict__ logp,
     }
     if (dlogp) {
         float* d = dlogp + (long)r * V1;
-        const float base = -mk * gcoef * uni;           // 0 when eps == 0
-        const float hot = -mk * gcoef * (1.0f - eps);
+        const float gc = gdev ? gcoef * gdev[0] : gcoef;  // upstream d loss, read on the device (no host sync)
+        const float base = -mk * gc * uni;              // 0 when eps == 0
+        const float hot = -mk * gc * (1.0f - eps);
         for (int v = threadIdx.x; v < V1; v += 256) d[v] = (v == tg) ? base + hot : base;
     }
 }
-extern "C" int rfn_xe_loss(const float* logp, int B, int T, int V1, const int64_t* target, int64_t ld_target,
-                           const float* mask, int64_t ld_mask, float eps, float gscale, float* scratch,
-                           float* loss_out, int accumulate_loss, float* dlogp, void* stream) {
+extern "C" int rfn_xe_loss_ex(const float* logp, int B, int T, int V1, const int64_t* target, int64_t ld_target,
+                              const float* mask, int64_t ld_mask, float eps, float gscale, const float* gscale_dev,
+                              float* scratch, float* loss_out, int accumulate_loss, float* dlogp, void* stream) {
     if (B <= 0 || T <= 0 || V1 <= 0) return RFN_ERR_SHAPE;
     if (!logp || !target || !mask || (loss_out && !scratch)) return RFN_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(xe_loss_k, dim3(B * T), dim3(256), 0, st, logp, T, V1, target, (long)ld_target, mask,
-                       (long)ld_mask, eps, gscale / (float)B, loss_out ? scratch : nullptr, dlogp);
+                       (long)ld_mask, eps, gscale / (float)B, gscale_dev, loss_out ? scratch : nullptr, dlogp);
     RFN_CHECK_LAUNCH();
     if (loss_out) {
         hipLaunchKernelGGL(sum_k, dim3(1), dim3(256), 0, st, scratch, B * T, 1.0f / (float)B, loss_out,
@@ -384,6 +455,12 @@ extern "C" int rfn_xe_loss(const float* logp, int B, int T, int V1, const int64_
         RFN_CHECK_LAUNCH();
     }
     return RFN_OK;
+}
+extern "C" int rfn_xe_loss(const float* logp, int B, int T, int V1, const int64_t* target, int64_t ld_target,
+                           const float* mask, int64_t ld_mask, float eps, float gscale, float* scratch,
+                           float* loss_out, int accumulate_loss, float* dlogp, void* stream) {
+    return rfn_xe_loss_ex(logp, B, T, V1, target, ld_target, mask, ld_mask, eps, gscale, nullptr, scratch, loss_out,
+                          accumulate_loss, dlogp, stream);
 }
 
 // ---- RL reward criterion, policy + entropy terms (misc/utils.py:50-72) ------------------------------------
@@ -468,9 +545,12 @@ extern "C" int rfn_rl_loss(const float* input, int64_t ld_in, const int64_t* seq
 // ---- nn.MultiLabelMarginLoss (mean) -----------------------------------------------------------------
 // Row b: targets = ids before the first -1; loss_b = sum_{j in targets} sum_{i not target}
 // max(0, 1 - x[j] + x[i]) / K.  One block per row; hit counts per target through LDS integer atomics.
-__global__ __launch_bounds__(256) void mlm_k(const float* __restrict__ pred, int K, const int64_t* __restrict__ target,
-                                             float scale_over_B, float gcoef, float* __restrict__ row_loss,
-                                             float* __restrict__ dpred) {
+struct MlmHeads {
+    const float* pred[RFN_MAX_ENC + 1];
+    float* dpred[RFN_MAX_ENC + 1];
+};
+__global__ __launch_bounds__(256) void mlm_k(const MlmHeads hd, int K, const int64_t* __restrict__ target, float gcoef,
+                                             const float* __restrict__ gdev, float* __restrict__ row_loss) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* x = sm;                                   // [K]
     int* tg = reinterpret_cast<int*>(sm + K);        // [K] target list
@@ -478,7 +558,10 @@ __global__ __launch_bounds__(256) void mlm_k(const float* __restrict__ pred, int
     unsigned char* is_t = reinterpret_cast<unsigned char*>(cnt + K);  // [K]
     __shared__ int nt_s;
     __shared__ float red[4];
-    const int b = blockIdx.x;
+    const int b = blockIdx.x, head = blockIdx.y;
+    const float* pred = hd.pred[head];
+    float* dpred = hd.dpred[head];
+    if (gdev) gcoef *= gdev[0];
     for (int i = threadIdx.x; i < K; i += 256) {
         x[i] = pred[(long)b * K + i];
         is_t[i] = 0;
@@ -514,31 +597,60 @@ __global__ __launch_bounds__(256) void mlm_k(const float* __restrict__ pred, int
         if (dpred) dpred[(long)b * K + i] = gi * invK * gcoef;  // targets fixed up below
     }
     loss = block_sum_256(loss, red);  // also orders the dpred writes above before the fix-up
-    if (row_loss && threadIdx.x == 0) row_loss[b] = loss * invK;
+    if (row_loss && threadIdx.x == 0) row_loss[(long)head * gridDim.x + b] = loss * invK;
     if (dpred && threadIdx.x == 0) {
         // a duplicated target id receives the hits of every slot that names it
         for (int n = 0; n < nt; ++n) dpred[(long)b * K + tg[n]] = 0.f;
         for (int n = 0; n < nt; ++n) dpred[(long)b * K + tg[n]] -= (float)cnt[n] * invK * gcoef;
     }
-    (void)scale_over_B;
 }
-extern "C" int rfn_multilabel_margin(const float* pred, int B, int K, const int64_t* target, float scale, float gscale,
-                                     float* scratch, float* loss_out, int accumulate_loss, float* dpred,
-                                     void* stream) {
-    if (B <= 0 || K <= 0) return RFN_ERR_SHAPE;
-    if (!pred || !target || (loss_out && !scratch)) return RFN_ERR_ARG;
+// out[0] (+)= scale * sum(x[g*n .. g*n+n)) for g = 0..G-1 in order: the per-head sums are added one after the other,
+// exactly as G calls of sum_k would
+__global__ __launch_bounds__(256) void sum_groups_k(const float* __restrict__ x, int n, int G, float scale,
+                                                    float* __restrict__ out, int accumulate) {
+    __shared__ float red[4];
+    float total = accumulate ? out[0] : 0.f;
+    for (int g = 0; g < G; ++g) {
+        float s = 0.f;
+        for (int i = threadIdx.x; i < n; i += 256) s += x[(long)g * n + i];
+        s = block_sum_256(s, red);
+        total = (g == 0 && !accumulate) ? s * scale : total + s * scale;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = total;
+}
+extern "C" int rfn_multilabel_margin_grouped(int nheads, const float* const* preds, int B, int K, const int64_t* target,
+                                             float scale, float gscale, const float* gscale_dev, float* scratch,
+                                             float* loss_out, int accumulate_loss, float* const* dpreds,
+                                             void* stream) {
+    if (nheads < 1 || nheads > RFN_MAX_ENC + 1 || B <= 0 || K <= 0) return RFN_ERR_SHAPE;
+    if (!preds || !target || (loss_out && !scratch)) return RFN_ERR_ARG;
     const size_t lds = (size_t)K * (sizeof(float) + 2 * sizeof(int) + 1) + 16;
     if (lds > 60 * 1024) return RFN_ERR_SHAPE;
+    MlmHeads hd;
+    memset(&hd, 0, sizeof(hd));
+    for (int h = 0; h < nheads; ++h) {
+        if (!preds[h]) return RFN_ERR_ARG;
+        hd.pred[h] = preds[h];
+        hd.dpred[h] = dpreds ? dpreds[h] : nullptr;
+    }
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(mlm_k, dim3(B), dim3(256), lds, st, pred, K, target, scale / (float)B,
-                       scale * gscale / (float)B, loss_out ? scratch : nullptr, dpred);
+    hipLaunchKernelGGL(mlm_k, dim3(B, nheads), dim3(256), lds, st, hd, K, target, scale * gscale / (float)B, gscale_dev,
+                       loss_out ? scratch : nullptr);
     RFN_CHECK_LAUNCH();
     if (loss_out) {
-        hipLaunchKernelGGL(sum_k, dim3(1), dim3(256), 0, st, scratch, B, scale / (float)B, loss_out,
+        hipLaunchKernelGGL(sum_groups_k, dim3(1), dim3(256), 0, st, scratch, B, nheads, scale / (float)B, loss_out,
                            accumulate_loss);
         RFN_CHECK_LAUNCH();
     }
     return RFN_OK;
+}
+extern "C" int rfn_multilabel_margin(const float* pred, int B, int K, const int64_t* target, float scale, float gscale,
+                                     float* scratch, float* loss_out, int accumulate_loss, float* dpred,
+                                     void* stream) {
+    if (!pred) return RFN_ERR_ARG;
+    return rfn_multilabel_margin_grouped(1, &pred, B, K, target, scale, gscale, nullptr, scratch, loss_out,
+                                         accumulate_loss, dpred ? &dpred : nullptr, stream);
 }
 
 // ---- clip_gradient + Adam (misc/utils.py:292-296, train.py:69-71) -----------------------------------

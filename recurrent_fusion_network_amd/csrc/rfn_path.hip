@@ -449,9 +449,11 @@ extern "C" int rfn_prefix_fwd(const rfn_dims* d, int B, const float* const* prm,
             const long Li = d->L[i], Di = d->D[i];
             float* al = W + Lo.al1[i] + (long)t * B * Li;
             float* z = W + Lo.z1[i] + (long)t * B * Di;
-            RFN_TRY(rfn_attn_scores_fwd(W + Lo.P1[i] + (long)t * A, Li * T1 * A, (long)T1 * A, hp + (long)i * B * A,
-                                        prm[P.s1(t, i, 4)], prm[P.s1(t, i, 5)], B, (int)Li, A, al, st));
-            RFN_TRY(rfn_attn_context_fwd(att[i], Li * Di, Di, al, B, (int)Li, (int)Di, z, Di, st));
+            // raw scores land in the (idle) split-K scratch; the context kernel normalises them on the fly
+            if ((size_t)B * Li > GEMM_WS_FLOATS) return RFN_ERR_SHAPE;
+            RFN_TRY(rfn_attn_fwd(W + Lo.P1[i] + (long)t * A, Li * T1 * A, (long)T1 * A, hp + (long)i * B * A,
+                                 prm[P.s1(t, i, 4)], prm[P.s1(t, i, 5)], att[i], Li * Di, Di, B, (int)Li, A, (int)Di,
+                                 W + Lo.gws, al, z, Di, st));
             rfn_gemm_problem& p = pr[i];
             memset(&p, 0, sizeof(p));
             p.C = g + (long)i * B * 4 * R;
@@ -476,12 +478,11 @@ extern "C" int rfn_prefix_fwd(const rfn_dims* d, int B, const float* const* prm,
     // state mean over encoders (:233-235): sum first, then divide, as the reference does
     float* h2 = W + Lo.h2;
     float* c2 = W + Lo.c2;
-    for (int i = 0; i < M; ++i) {
-        RFN_TRY(rfn_axpby_2d(1.f, Hs + T1 * BMR + i * R, MR, i ? 1.f : 0.f, h2, R, B, R, st));
-        RFN_TRY(rfn_axpby_2d(1.f, Cs + T1 * BMR + i * R, MR, i ? 1.f : 0.f, c2, R, B, R, st));
+    {
+        const float* mx[2] = {Hs + T1 * BMR, Cs + T1 * BMR};
+        float* my[2] = {h2, c2};
+        RFN_TRY(rfn_mean_over_groups(2, mx, MR, R, M, my, R, B, R, st));
     }
-    RFN_TRY(rfn_div_2d(h2, R, B, R, (float)M, st));
-    RFN_TRY(rfn_div_2d(c2, R, B, R, (float)M, st));
 
     // hoisted thought projections of stage II: rows (t', b) of encoder i's thoughts = Hs[1:]
     for (int i = 0; i < M; ++i) {
@@ -658,9 +659,11 @@ extern "C" int rfn_prefix_bwd(const rfn_dims* d, int B, const float* const* prm,
 
     // ---- state mean backward (:233-235): every encoder's final (h, c) gets d / M --------------------
     const float invM = 1.0f / (float)M;
-    for (int i = 0; i < M; ++i) {
-        RFN_TRY(rfn_axpby_2d(invM, dhrec, R, 1.f, dHs + T1 * BMR + i * R, MR, B, R, st));
-        RFN_TRY(rfn_axpby_2d(invM, dc2, R, 0.f, dC + i * R, MR, B, R, st));
+    {
+        const float* bx[2] = {dhrec, dc2};
+        float* by[2] = {dHs + T1 * BMR, dC};
+        const float bb[2] = {1.f, 0.f};
+        RFN_TRY(rfn_bcast_to_groups(2, invM, bx, R, bb, by, MR, R, M, B, R, st));
     }
     // ---- reason heads of stage I ----------------------------------------------------------------------
     for (int i = 0; i < M; ++i) {

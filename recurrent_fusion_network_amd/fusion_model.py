@@ -403,7 +403,7 @@ class RecurrentFusionModel(nn.Module):
         if self.ss_prob > 0.0 and S > 1:
             ids = self._scheduled_sampling_ids(ids, comb.detach(), h.detach(), c.detach())
         log_prob = self._decode_teacher_forced(ids, comb, h, c, train, seed)
-        return log_prob, [reason[j] for j in range(self.num_feat_array + 1)]
+        return log_prob, list(reason.unbind(0))
 
     def _decoder_steps(self, seq):
         """Number of decoder steps: the reference breaks at the first all-zero column i >= 1 (:274).  The
@@ -455,7 +455,7 @@ class RecurrentFusionModel(nn.Module):
         The initial state is recomputed from fc_feats (it is what get_init_state returns)."""
         with torch.no_grad():
             comb, h, c, reason = self._prefix(fc_feats, att_feats, False, 0)
-        return (comb.transpose(0, 1).contiguous(), [reason[j] for j in range(self.num_feat_array + 1)],
+        return (comb.transpose(0, 1).contiguous(), list(reason.unbind(0)),
                 (h.unsqueeze(0), c.unsqueeze(0)))
 
     def one_time_step(self, xt_ids, fc_feats, thought_vectors_comb, state_decode):
@@ -481,7 +481,7 @@ class RecurrentFusionModel(nn.Module):
             comb, h, c, reason = self._prefix(fc_feats, att_feats, train, seed)
         B, S, V1 = fc_feats[0].size(0), self.seq_length, self.vocab_size + 1
         dev = comb.device
-        reason_pred = [reason[j] for j in range(self.num_feat_array + 1)]
+        reason_pred = list(reason.unbind(0))
         force = opt.get('force_ids', None)
         with torch.no_grad():
             stepper = _Stepper(self, comb.detach(), h.detach().clone(), c.detach().clone())

@@ -213,6 +213,15 @@ def test_attention_forward_backward(dev, B, L, A, D):
     n.check(n.lib.rfn_attn_scores_fwd(projd.data_ptr(), L * A, A, hpd.data_ptr(), wd.data_ptr(), bod.data_ptr(), B, L,
                                       A, alpha.data_ptr(), st))
     n.check(n.lib.rfn_attn_context_fwd(xd.data_ptr(), L * D, D, alpha.data_ptr(), B, L, D, z.data_ptr(), D, st))
+    # the two-launch form (softmax inside the context kernel) gives the same bits
+    raw, alpha2, z2 = torch.empty(B, L, device=dev), torch.empty(B, L, device=dev), torch.empty(B, D, device=dev)
+    n.check(n.lib.rfn_attn_fwd(projd.data_ptr(), L * A, A, hpd.data_ptr(), wd.data_ptr(), bod.data_ptr(),
+                               xd.data_ptr(), L * D, D, B, L, A, D, raw.data_ptr(), alpha2.data_ptr(), z2.data_ptr(), D,
+                               st))
+    assert torch.equal(alpha2, alpha) and torch.equal(z2, z)
+    assert n.lib.rfn_attn_fwd(projd.data_ptr(), L * A, A, hpd.data_ptr(), wd.data_ptr(), bod.data_ptr(),
+                              xd.data_ptr(), L * D, D, B, L, A, D, alpha2.data_ptr(), alpha2.data_ptr(),
+                              z2.data_ptr(), D, st) != 0   # scratch must not alias alpha
     # fp64 autograd reference
     pr, hr, wr, xr = [t.double().requires_grad_(True) for t in (proj, hp, w, x)]
     al_ref, z_ref = attn_ref(pr, hr, wr, bo, xr)
@@ -324,6 +333,33 @@ def test_fused_small_attention_groups_match_fp64(dev, G, B, L, A, D):
     # rejects L beyond the fused kernel's bound
     assert n.lib.rfn_attn_small_fwd(G, a_p, L * A, A, a_hp, a_w, a_b, a_x, G * D, B * G * D, B, 33, A, D, a_al, a_z,
                                     G * D, st) != 0
+
+
+def test_state_mean_over_encoders_and_backward(dev):
+    """(h, c) mean over the M encoder slices in one launch (sum in slice order, then true division) and the
+    broadcast of its gradient back to every slice."""
+    n = N()
+    B, R, M = 7, 24, 3
+    H, Cc = rnd(B, M * R, seed=1), rnd(B, M * R, seed=2)
+    Hd, Cd = H.to(dev), Cc.to(dev)
+    h, c = torch.empty(B, R, device=dev), torch.empty(B, R, device=dev)
+    n.check(n.lib.rfn_mean_over_groups(2, n.ptr_array([Hd, Cd]), M * R, R, M, n.ptr_array([h, c]), R, B, R,
+                                       n.stream_ptr()))
+    for out, src in ((h, H), (c, Cc)):
+        ref = src[:, :R].clone()
+        for i in range(1, M):
+            ref = ref + src[:, i * R:(i + 1) * R]
+        assert torch.equal(out.cpu(), ref / float(M))
+    dh, dc = rnd(B, R, seed=3), rnd(B, R, seed=4)
+    dhd, dcd = dh.to(dev), dc.to(dev)
+    dH, dC = torch.ones(B, M * R, device=dev), torch.full((B, M * R), float('nan'), device=dev)
+    beta = (C.c_float * 2)(1.0, 0.0)
+    inv = 1.0 / M
+    n.check(n.lib.rfn_bcast_to_groups(2, inv, n.ptr_array([dhd, dcd]), R, beta, n.ptr_array([dH, dC]), M * R, R, M, B,
+                                      R, n.stream_ptr()))
+    inv32 = torch.tensor(inv, dtype=torch.float32)
+    assert torch.equal(dH.cpu(), (inv32 * dh).repeat(1, M) + 1.0)
+    assert torch.equal(dC.cpu(), (inv32 * dc).repeat(1, M))
 
 
 # ------------------------------------------------------------------------------------------------
