@@ -98,14 +98,22 @@ def time_dominant_kernel(model, att, reps):
 def cpu_baseline(cfg, sample_B, seed):
     """The CPU oracle (kind "port": a PyTorch-CPU restatement validated against the reference, see oracle/)
     timed on this host on a bounded sample of the same workload: one XE train step (forward + criterion +
-    backward) at the full model size but `sample_B` captions; cost is linear in B."""
+    backward) at the full model size on a few captions; cost is linear in B.  sample_B = 0 sizes the sample from
+    a B=8 probe so that the timed step is about 15 s of CPU work whatever the host."""
     from oracle import rfn_oracle as O
     P = O.seeded_params(cfg, seed)
-    fc, att, labels, masks, top = O.synthetic_batch(cfg, sample_B, seed=seed + 1)
-    O.train_step_loss_and_grads(cfg, P, [f[:1] for f in fc], [a[:1] for a in att], labels[:1], masks[:1], top[:1])
-    t0 = time.perf_counter()
-    O.train_step_loss_and_grads(cfg, P, fc, att, labels, masks, top)
-    dt = time.perf_counter() - t0
+
+    def run(nb):
+        fc, att, labels, masks, top = O.synthetic_batch(cfg, nb, seed=seed + 1)
+        t0 = time.perf_counter()
+        O.train_step_loss_and_grads(cfg, P, fc, att, labels, masks, top)
+        return time.perf_counter() - t0
+
+    run(1)                                              # warm the allocator and the thread pool
+    if sample_B <= 0:
+        probe = run(8)
+        sample_B = int(min(64, max(8, round(8 * 15.0 / max(probe, 1e-3) / 8) * 8)))
+    dt = run(sample_B)
     return dict(value=round(sample_B / dt, 4), unit='captions/s', cores=torch.get_num_threads(), kind='port',
                 sample='1 XE train step (fwd+loss+bwd) of the same model at B=%d captions, %.1f s' % (sample_B, dt))
 
@@ -118,7 +126,8 @@ def main():
     ap.add_argument('--workload', default='c3', choices=sorted(WORKLOADS))
     ap.add_argument('--batch', type=int, default=0, help='captions per GPU (default: the workload value)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-sample', type=int, default=16, help='captions in the CPU-baseline sample (~10 s of CPU work)')
+    ap.add_argument('--cpu-sample', type=int, default=0,
+                    help='captions in the CPU-baseline sample (0: sized for ~15 s of CPU work from a B=8 probe)')
     args = ap.parse_args()
 
     if int(os.environ.get('WORLD_SIZE', '1')) > 1:
