@@ -15,6 +15,7 @@ from __future__ import annotations
 import ctypes as C
 import re
 
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -575,25 +576,28 @@ class RecurrentFusionModel(nn.Module):
                     stepper.h, h_alt = h_alt, stepper.h
                     stepper.c, c_alt = c_alt, stepper.c
                 stepper.step(ids, out=logp)
-            n_done = done_n.cpu().tolist()
-            d_seq, d_lp, d_p = done_seq.cpu(), done_lp.cpu(), done_p.cpu()
-        seq = torch.zeros(S, B, dtype=torch.long)
-        seq_lp = torch.zeros(S, B)
-        top_seq, top_prob, reason_batch = [], [[] for _ in range(B)], []
-        self.done_beams = [[] for _ in range(B)]
+            n_done = done_n.cpu().numpy()
+            d_seq, d_lp, d_p = done_seq.cpu().numpy(), done_lp.cpu().numpy(), done_p.cpu().numpy()
+        # done beams sorted by -p, stably, as the reference's sorted(..., key=-p) (:529) -- for all images at once
+        key = np.where(np.arange(max_done)[None, :] < n_done[:, None], -d_p, np.inf)
+        rank = np.argsort(key, axis=1, kind='stable')
+        s_all = torch.from_numpy(np.take_along_axis(d_seq, rank[:, :, None], axis=1))
+        l_all = torch.from_numpy(np.take_along_axis(d_lp, rank[:, :, None], axis=1))
+        p_all = np.take_along_axis(d_p, rank, axis=1)
+        seq, seq_lp = s_all[:, 0].contiguous(), l_all[:, 0].contiguous()          # (B, S): best done beam per image
+        top_seq, top_prob, reason_batch = [], [], []
+        self.done_beams = []
+        heads = reason.unsqueeze(2).expand(-1, -1, W, -1)                          # (M+1, B, W, K) broadcast view
         for k in range(B):
-            reason_batch.append([reason[j, k:k + 1].expand(W, -1).contiguous() for j in range(self.num_feat_array + 1)])
-            beams = [{'seq': d_seq[k, n].clone(), 'logps': d_lp[k, n].clone(), 'p': float(d_p[k, n])}
-                     for n in range(n_done[k])]
-            self.done_beams[k] = sorted(beams, key=lambda x: -x['p'])          # stable, as the reference (:529)
-            seq[:, k] = self.done_beams[k][0]['seq']
-            seq_lp[:, k] = self.done_beams[k][0]['logps']
-            cur = torch.zeros(len(beams), S, dtype=torch.long)
-            for j, db in enumerate(self.done_beams[k]):
-                cur[j] = db['seq']
-                top_prob[k].append(db['p'])
-            top_seq.append(cur)
-        return seq.t().to(dev), seq_lp.t().to(dev), top_seq, top_prob, reason_batch
+            n = int(n_done[k])
+            s_k, l_k, p_k = s_all[k, :n], l_all[k, :n], p_all[k, :n].tolist()
+            self.done_beams.append([{'seq': a, 'logps': b_, 'p': c_}
+                                    for a, b_, c_ in zip(s_k.unbind(0), l_k.unbind(0), p_k)])
+            top_seq.append(s_k)
+            top_prob.append(p_k)
+            reason_batch.append([heads[j, k] for j in range(self.num_feat_array + 1)])
+        return seq.to(dev), seq_lp.to(dev), top_seq, top_prob, reason_batch
+
 
 
 class _Stepper:

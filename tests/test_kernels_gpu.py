@@ -616,14 +616,19 @@ def _beam_reference(logps, W, S):
     return done
 
 
-@pytest.mark.parametrize('W,V1,S', [(3, 7, 5), (5, 40, 6), (4, 3, 4)])
-def test_beam_step_kernel_matches_python_bookkeeping(dev, W, V1, S):
+@pytest.mark.parametrize('W,V1,S,ties', [(3, 7, 5, False), (5, 40, 6, False), (4, 3, 4, False), (8, 500, 6, False),
+                                         (16, 2000, 4, False), (1, 50, 4, False), (2, 100, 5, True),
+                                         (5, 9488, 6, True), (9, 700, 5, True)])
+def test_beam_step_kernel_matches_python_bookkeeping(dev, W, V1, S, ties):
     """rfn_beam_step against the reference's bookkeeping with END tokens frequent enough to finish beams early
-    (and, for the tiny vocabulary, to exhaust every candidate -> the early break)."""
+    (and, for the tiny vocabulary, to exhaust every candidate -> the early break); every register-list width of
+    the top-k phase, tied log-probs, the full vocabulary."""
     n = N()
     NB = 4
     g = torch.Generator().manual_seed(W * 100 + V1)
     tables = [torch.log_softmax(torch.randn(NB * W, V1, generator=g) * 2.0, 1) for _ in range(S)]
+    if ties:                                             # many equal log-probs: ties go to the lowest column id
+        tables = [torch.round(tb * 2.0) / 2.0 for tb in tables]
     for tb in tables:
         tb[:, 0] += 1.5                                  # make END (id 0) likely
     st = n.stream_ptr()
