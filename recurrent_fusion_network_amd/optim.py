@@ -38,6 +38,7 @@ class FusedClampAdam:
     def step(self, grad_scale=1.0):
         """grad_scale multiplies the gradient before the clamp (1/world_size after a sum all-reduce)."""
         self.step_count += 1
+        self.model._weights_epoch = getattr(self.model, '_weights_epoch', 0) + 1   # invalidates reuse_prefix entries
         for name, st in self.flat.items():
             g = self.model._last_flat_grads.get(name)
             if g is None:

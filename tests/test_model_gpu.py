@@ -257,6 +257,63 @@ def test_dedup_of_replicated_images_is_exact(dev):
         assert maxerr(outs[1][2][k], ref.cpu()) <= 1e-6 + 1e-4 * float(ref.abs().max()), k
 
 
+def test_reuse_prefix_serves_the_baseline_sample_and_is_invalidated(dev):
+    """model.reuse_prefix: the greedy baseline sample of the self-critical loop (train_rl.py:160-166) reuses the
+    stage-I/II outputs of the multinomial sample on the same input tensors; any change of inputs or weights, a call
+    that needs grad, or new tensor objects recompute."""
+    import recurrent_fusion_network_amd as R
+    import recurrent_fusion_network_amd.fusion_model as FM
+    cfg, spec, P, batch, gold = load_case('mid')
+    fc, att, labels, masks, top = to_dev(batch, dev)
+    model = build(cfg, P, dev, train=True)
+    with torch.no_grad():
+        model.eval()
+        want = model.sample(fc, att, {'sample_max': 1})
+        model.train()
+    calls = []
+    orig = FM._PrefixFn.apply
+
+    def counting(*a):
+        calls.append(1)
+        return orig(*a)
+
+    FM._PrefixFn.apply = counting
+    try:
+        model.reuse_prefix = True
+        seq, lp, lp_all, reason = model.sample(fc, att, {'sample_max': 0})          # with grad: computes, stores
+        assert len(calls) == 1 and lp.requires_grad
+        with torch.no_grad():
+            model.eval()
+            got = model.sample(fc, att, {'sample_max': 1})                          # baseline: served from the cache
+            model.train()
+        assert len(calls) == 1
+        assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]) and torch.equal(got[2], want[2])
+        lp.sum().backward()                                                         # the first graph is intact
+        assert model.logit.weight.grad is not None
+        seq2 = model.sample(fc, att, {'sample_max': 0})                             # needs grad: never served
+        assert len(calls) == 2
+        opt = R.FusedClampAdam(model, lr=1e-3)
+        opt.step()                                                                  # weights moved -> stale
+        with torch.no_grad():
+            model.sample(fc, att, {'sample_max': 1})
+        assert len(calls) == 3
+        with torch.no_grad():
+            model.sample(fc, att, {'sample_max': 1})                                # unchanged again: hit
+            assert len(calls) == 3
+            att[0].mul_(1.0)                                                        # in-place write bumps _version
+            model.sample(fc, att, {'sample_max': 1})
+            assert len(calls) == 4
+            att2 = [a.clone() for a in att]                                         # same values, new objects
+            model.sample(fc, att2, {'sample_max': 1})
+            assert len(calls) == 5
+        model.reuse_prefix = False
+        with torch.no_grad():
+            model.sample(fc, att2, {'sample_max': 1})
+        assert len(calls) == 6
+    finally:
+        FM._PrefixFn.apply = orig
+
+
 def test_inference_hooks(dev):
     """get_init_state / get_thought_vectors / one_time_step (misc/RecurrentFusionModel.py:283-350)."""
     from oracle import rfn_oracle as O

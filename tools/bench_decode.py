@@ -43,7 +43,15 @@ def rl_step():
     loss.backward(); opt.step()
     return loss
 
-for name, fn, reps in (('greedy sample', greedy, 5), ('beam=5 sample_beam', beam, 3), ('RL step (sample+baseline+loss+bwd+Adam)', rl_step, 3)):
+def rl_step_reuse():
+    model.reuse_prefix = True
+    try:
+        return rl_step()
+    finally:
+        model.reuse_prefix = False
+
+for name, fn, reps in (('greedy sample', greedy, 5), ('beam=5 sample_beam', beam, 3), ('RL step (sample+baseline+loss+bwd+Adam)', rl_step, 3),
+                       ('RL step, model.reuse_prefix (baseline sample reuses stages I/II)', rl_step_reuse, 3)):
     dt, out = timed(fn, reps)
     print(json.dumps({'mode': name, 'images_per_s': round(B / dt, 1), 'ms': round(dt * 1e3, 2), 'B': B,
                       'config': 'M=4, L=196, D=2048, R=512, V+1=9488, seq=16'}), flush=True)
