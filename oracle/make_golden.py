@@ -34,6 +34,9 @@ CONFIGS = {
     # maxout variants of the stage-II and decoder cells (opts.py:180-185); fusion_maxout is set too and must be ignored
     'tinymax': dict(feats=[(5, 24, 24), (7, 40, 32)], R=16, V=50, K=20, T1=3, T2=3, B=3, S=5, seed=5, max_words=5,
                     extra=dict(review_maxout=1, maxout=1, fusion_maxout=1)),
+    # R != A != E, every width off the 4-float vector paths, T1 != T2, heterogeneous L / D / fc
+    'odd': dict(feats=[(9, 22, 13), (4, 35, 35), (11, 17, 29)], R=26, A=15, E=19, V=61, K=13, T1=3, T2=4, B=5, S=5,
+                seed=6, max_words=4),
     'mid': dict(feats=[(196, 96, 96), (64, 80, 128), (49, 72, 72)], R=64, V=300, K=50, T1=8, T2=8, B=6, S=16,
                 seed=2, max_words=16),
     'c2': dict(feats=[(49, 512, 512)] * 2, R=512, V=9487, K=1000, T1=8, T2=8, B=8, S=16, seed=3, max_words=16),
@@ -43,8 +46,8 @@ CONFIGS = {
 
 def cfg_of(spec):
     info = [dict(att_num=L, att_feat_size=D, fc_feat_size=F) for (L, D, F) in spec['feats']]
-    return O.make_cfg(info, vocab_size=spec['V'], rnn_size=spec['R'], input_encoding_size=spec['R'],
-                      att_hid_size=spec['R'], num_review_steps_0=spec['T1'], num_review_steps=spec['T2'],
+    return O.make_cfg(info, vocab_size=spec['V'], rnn_size=spec['R'], input_encoding_size=spec.get('E', spec['R']),
+                      att_hid_size=spec.get('A', spec['R']), num_review_steps_0=spec['T1'], num_review_steps=spec['T2'],
                       top_words_count=spec['K'], seq_length=spec['S'], **spec.get('extra', {}))
 
 
@@ -118,7 +121,7 @@ def close(a, b, tol, what):
 def generate(name, RefModel, ref_utils, outdir):
     spec = CONFIGS[name]
     cfg = cfg_of(spec)
-    full = name.startswith('tiny')
+    full = name.startswith('tiny') or name == 'odd'
     torch.manual_seed(0)
     model = RefModel(cfg)
     sd = model.state_dict()
@@ -224,7 +227,7 @@ def generate(name, RefModel, ref_utils, outdir):
         out['greedy_top5_idx'] = t5.indices.numpy()
 
     # ---- RL: multinomial sample with grad + reward criterion (train_rl.py:160-191) -------------
-    if name in ('tiny0', 'tiny1', 'tinymax', 'mid', 'c2'):
+    if name in ('tiny0', 'tiny1', 'tinymax', 'odd', 'mid', 'c2'):
         torch.manual_seed(77 + spec['seed'])
         model.zero_grad()
         s_seq, s_lp, s_all, s_rp = model.sample(fc, att, {'sample_max': 0, 'beam_size': 1, 'temperature': 1.0})
@@ -278,7 +281,7 @@ def generate(name, RefModel, ref_utils, outdir):
         model.zero_grad()
 
     # ---- beam search (misc/RecurrentFusionModel.py:352-543) -----------------------------------
-    if name in ('tiny0', 'tinymax', 'mid', 'c2'):
+    if name in ('tiny0', 'tinymax', 'odd', 'mid', 'c2'):
         beam = 3
         nb = min(spec['B'], 3)
         fcb = [f[:nb] for f in fc]
@@ -325,7 +328,7 @@ def generate(name, RefModel, ref_utils, outdir):
                 out['cell_a4_thoughts_%d' % i] = th[i].numpy()
             out['cell_a4_out_h'], out['cell_a4_out_c'] = o4.numpy(), nc4[0].numpy()
             # a5: decoder cell
-            xt, comb = rnd(B, R), rnd(B, spec['T2'], R)
+            xt, comb = rnd(B, cfg.input_encoding_size), rnd(B, spec['T2'], R)
             o5, (nh5, nc5) = model.decoder(xt, comb, (h.unsqueeze(0), c.unsqueeze(0)))
             oh5, oc5, _ = O.decoder_cell(xt, comb, h, c, P, R, cfg.maxout)
             close(oh5, o5, 1e-5, 'a5 h')
@@ -340,7 +343,7 @@ def generate(name, RefModel, ref_utils, outdir):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--only', default='tiny0,tiny1,mid,c2,c3')
+    ap.add_argument('--only', default='tiny0,tiny1,tinymax,odd,mid,c2,c3')
     ap.add_argument('--out', default=os.path.join(ROOT, 'tests', 'golden'))
     args = ap.parse_args()
     torch.set_num_threads(8)

@@ -76,7 +76,8 @@ def test_c3_greedy_decode_is_deterministic_and_consistent_with_forward(dev):
     assert torch.equal((lp_all[:, :seq.size(1)].argmax(2) * (seq > 0)), seq)
 
 
-@pytest.mark.parametrize('case', ['batch_of_one', 'single_encoder_single_region', 'five_shipped_encoders'])
+@pytest.mark.parametrize('case', ['batch_of_one', 'single_encoder_single_region', 'five_shipped_encoders',
+                                  'unequal_odd_widths'])
 def test_edge_shapes_against_oracle(dev, case):
     """B = 1 (the reference's .squeeze() breaks there, AttentionModelCore.py:47), M = 1 with L = 1, and the
     reference's five heterogeneous encoders (feat_array.py:240-244: D in {2048, 1536, 1280, 2208}, L in {196, 64, 49},
@@ -89,13 +90,22 @@ def test_edge_shapes_against_oracle(dev, case):
     elif case == 'single_encoder_single_region':
         info = [dict(att_num=1, att_feat_size=20, fc_feat_size=12)]
         B, R_ = 3, 16
+    elif case == 'unequal_odd_widths':   # R != A != E, nothing a multiple of 4 (scalar kernel paths), T1 != T2
+        info = [dict(att_num=9, att_feat_size=22, fc_feat_size=13), dict(att_num=4, att_feat_size=35, fc_feat_size=35),
+                dict(att_num=11, att_feat_size=17, fc_feat_size=29)]
+        B, R_ = 5, 26
     else:
         info = [dict(att_num=196, att_feat_size=2048, fc_feat_size=2048), dict(att_num=64, att_feat_size=1536, fc_feat_size=1536),
                 dict(att_num=64, att_feat_size=1280, fc_feat_size=2048), dict(att_num=49, att_feat_size=2208, fc_feat_size=2208),
                 dict(att_num=64, att_feat_size=1536, fc_feat_size=1536)]
         B, R_ = 3, 64
-    cfg = O.make_cfg(info, vocab_size=60, rnn_size=R_, input_encoding_size=R_, att_hid_size=R_, num_review_steps_0=2,
-                     num_review_steps=2, top_words_count=12, seq_length=4)
+    if case == 'unequal_odd_widths':
+        cfg = O.make_cfg(info, vocab_size=61, rnn_size=R_, input_encoding_size=19, att_hid_size=15,
+                         num_review_steps_0=3, num_review_steps=2, top_words_count=13, seq_length=5,
+                         use_label_smoothing=1, label_smoothing_epsilon=0.1)
+    else:
+        cfg = O.make_cfg(info, vocab_size=60, rnn_size=R_, input_encoding_size=R_, att_hid_size=R_,
+                         num_review_steps_0=2, num_review_steps=2, top_words_count=12, seq_length=4)
     P = O.seeded_params(cfg, 5, scale=0.05)
     fc, att, labels, masks, top = O.synthetic_batch(cfg, B, seed=9)
     model = R.RecurrentFusionModel(cfg)

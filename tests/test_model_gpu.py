@@ -33,7 +33,7 @@ def maxerr(a, b):
     return float((a.detach().double().cpu() - torch.as_tensor(b).double()).abs().max())
 
 
-@pytest.mark.parametrize('name', ['tiny0', 'tiny1', 'tinymax', 'mid'])
+@pytest.mark.parametrize('name', ['tiny0', 'tiny1', 'tinymax', 'odd', 'mid'])
 def test_forward_loss_grads_full(dev, name):
     import recurrent_fusion_network_amd as R
     from oracle import rfn_oracle as O
@@ -104,7 +104,7 @@ def test_forward_loss_grads_shape_true(dev, name):
         assert float((sl - ref).abs().max()) <= 1e-6 + 2e-3 * max(float(ref.abs().max()), gn / max(1.0, got.numel() ** 0.5)), k
 
 
-@pytest.mark.parametrize('name', ['tiny0', 'tiny1', 'tinymax', 'mid', 'c2', 'c3'])
+@pytest.mark.parametrize('name', ['tiny0', 'tiny1', 'tinymax', 'odd', 'mid', 'c2', 'c3'])
 def test_greedy_sample_ids_bit_exact(dev, name):
     cfg, spec, P, batch, gold = load_case(name)
     model = build(cfg, P, dev)
@@ -124,7 +124,7 @@ def test_greedy_sample_ids_bit_exact(dev, name):
         assert float((lp_all.cpu().gather(2, idx) - torch.from_numpy(gold['greedy_top5_val'])).abs().max()) < LOGP_TOL
 
 
-@pytest.mark.parametrize('name', ['tiny0', 'mid'])
+@pytest.mark.parametrize('name', ['tiny0', 'odd', 'mid'])
 def test_adam_step_matches_reference(dev, name):
     """One clamp + Adam step (train.py:162-163) through FusedClampAdam on the flat buffers."""
     import recurrent_fusion_network_amd as R
@@ -153,7 +153,7 @@ def test_adam_step_matches_reference(dev, name):
         assert float((got[sel] - want[sel]).abs().max()) < 5e-6, k
 
 
-@pytest.mark.parametrize('name', ['tiny0', 'tiny1', 'tinymax', 'mid', 'c2'])
+@pytest.mark.parametrize('name', ['tiny0', 'tiny1', 'tinymax', 'odd', 'mid', 'c2'])
 def test_rl_sample_replay_and_reward_criterion(dev, name):
     """train_rl.py:160-191: multinomial sample with grad (ids replayed from the reference's draw), reward
     criterion, backward."""
@@ -175,7 +175,7 @@ def test_rl_sample_replay_and_reward_criterion(dev, name):
         assert abs(float(p.grad.double().norm()) - gn) <= 1e-5 + 3e-3 * gn, k
 
 
-@pytest.mark.parametrize('name', ['tiny0', 'tinymax', 'mid', 'c2'])
+@pytest.mark.parametrize('name', ['tiny0', 'tinymax', 'odd', 'mid', 'c2'])
 def test_beam_search_matches_reference(dev, name):
     cfg, spec, P, batch, gold = load_case(name)
     model = build(cfg, P, dev)

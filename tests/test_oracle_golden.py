@@ -11,7 +11,7 @@ def maxerr(a, b):
     return float((torch.as_tensor(a).double() - torch.as_tensor(b).double()).abs().max())
 
 
-@pytest.mark.parametrize('name', ['tiny0', 'tiny1', 'tinymax', 'mid'])
+@pytest.mark.parametrize('name', ['tiny0', 'tiny1', 'tinymax', 'odd', 'mid'])
 def test_forward_loss_and_every_gradient(name):
     from oracle import rfn_oracle as O
     cfg, spec, P, batch, gold = load_case(name)
@@ -54,7 +54,7 @@ def test_adam_step_where_well_conditioned():
             assert maxerr(P2[k][sel], torch.from_numpy(gold['stepped/' + k])[sel]) < 2e-6, k
 
 
-@pytest.mark.parametrize('name', ['tiny0', 'tiny1', 'tinymax', 'mid', 'c2', 'c3'])
+@pytest.mark.parametrize('name', ['tiny0', 'tiny1', 'tinymax', 'odd', 'mid', 'c2', 'c3'])
 def test_greedy_sample(name):
     from oracle import rfn_oracle as O
     cfg, spec, P, batch, gold = load_case(name)
@@ -79,7 +79,7 @@ def test_shape_true_forward(name):
     assert abs(float(loss) - float(gold['xe_loss'])) < 1e-3
 
 
-@pytest.mark.parametrize('name', ['tiny0', 'tinymax', 'mid'])
+@pytest.mark.parametrize('name', ['tiny0', 'tinymax', 'odd', 'mid'])
 def test_rl_replay(name):
     from oracle import rfn_oracle as O
     cfg, spec, P, batch, gold = load_case(name)
@@ -92,7 +92,7 @@ def test_rl_replay(name):
     assert abs(float(loss) - float(gold['rl_loss'])) < 1e-4
 
 
-@pytest.mark.parametrize('name', ['tiny0', 'tinymax', 'mid'])
+@pytest.mark.parametrize('name', ['tiny0', 'tinymax', 'odd', 'mid'])
 def test_beam_search(name):
     from oracle import rfn_oracle as O
     cfg, spec, P, batch, gold = load_case(name)
