@@ -51,7 +51,7 @@ def test_c3_full_batch_properties(dev):
     # gradients are additive over rows: B * g(full) = B/2 * g(first half) + B/2 * g(second half)
     _, _, l1, g1 = run(allrows[:B // 2])
     _, _, l2, g2h = run(allrows[B // 2:])
-    assert abs(float(loss) - 0.5 * (float(l1) + float(l2))) < 1e-3 * abs(float(loss))
+    assert abs(float(loss.detach()) - 0.5 * (float(l1.detach()) + float(l2.detach()))) < 1e-3 * abs(float(loss.detach()))
     for name in (k, 'decoder.h2h.weight', 'review_steps.0.z_2_h.1.weight', 'fc2h.0.weight', 'embed.weight',
                  'logit.bias', 'review_steps_individual.0.lstm.3.H2h.weight'):
         want = 0.5 * (g1[name] + g2h[name])

@@ -22,7 +22,7 @@ def test_forward_loss_and_every_gradient(name):
     for j, r in enumerate(reason):
         assert maxerr(r, gold['reason_pred_%d' % j]) < 2e-5
     loss, grads = O.train_step_loss_and_grads(cfg, P, fc, att, labels, masks, top, 1.0)
-    assert abs(float(loss) - float(gold['xe_loss'])) < 1e-4
+    assert abs(float(loss.detach()) - float(gold['xe_loss'])) < 1e-4
     for k, g in grads.items():
         gn = float(gold['gradnorm/' + k])
         assert abs(float(g.double().norm()) - gn) <= 1e-6 + 1e-3 * gn, k
@@ -76,7 +76,7 @@ def test_shape_true_forward(name):
     idx = torch.from_numpy(gold['log_prob_top5_idx'])
     assert maxerr(lp.gather(2, idx), gold['log_prob_top5_val']) < 2e-5
     loss = O.xe_criterion(cfg, lp, labels[:, 1:], masks[:, 1:], reason, top, 1.0)
-    assert abs(float(loss) - float(gold['xe_loss'])) < 1e-3
+    assert abs(float(loss.detach()) - float(gold['xe_loss'])) < 1e-3
 
 
 @pytest.mark.parametrize('name', ['tiny0', 'tinymax', 'odd', 'mid'])
@@ -89,7 +89,7 @@ def test_rl_replay(name):
         seq, seq_lp, lp_all, reason = O.sample_greedy(cfg, P, fc, att, force_ids=raw)
     assert torch.equal(seq, torch.from_numpy(gold['rl_seq']))
     loss = O.rl_criterion(cfg, seq_lp, seq, torch.from_numpy(gold['rl_reward']), lp_all, 0.01, reason, top, 1.0)
-    assert abs(float(loss) - float(gold['rl_loss'])) < 1e-4
+    assert abs(float(loss.detach()) - float(gold['rl_loss'])) < 1e-4
 
 
 @pytest.mark.parametrize('name', ['tiny0', 'tinymax', 'odd', 'mid'])
