@@ -172,6 +172,7 @@ struct Bump {
 };
 
 const size_t GEMM_WS_FLOATS = (size_t)12 << 20;  // 48 MiB of split-K partial tiles
+const size_t STEP_GEMM_WS_FLOATS = (size_t)8 << 20;  // 32 MiB for the free-running decoder step (rows = B * beam)
 
 struct PrefixLayout {
     size_t P1[RFN_MAX_ENC], al1[RFN_MAX_ENC], z1[RFN_MAX_ENC], P2[RFN_MAX_ENC], dz1[RFN_MAX_ENC];
@@ -911,6 +912,7 @@ extern "C" size_t rfn_decoder_step_ws_bytes(const rfn_dims* d, int B) {
     b.take((size_t)B * d->R);
     b.take((size_t)B * gate_width(d->decoder_maxout, d->R));
     b.take((size_t)B * d->V1);
+    b.take(STEP_GEMM_WS_FLOATS);
     return b.off * sizeof(float);
 }
 
@@ -937,7 +939,7 @@ extern "C" int rfn_decoder_step(const rfn_dims* d, int B, const float* const* pr
     const long BR = (long)B * R, BA = (long)B * A;
     Bump b;
     float* W = (float*)ws;
-    const GemmCtx gx{st, nullptr, 0};
+    const GemmCtx gx{st, W + b.take(STEP_GEMM_WS_FLOATS), STEP_GEMM_WS_FLOATS * sizeof(float)};  // split-K scratch
     float* x = W + b.take((size_t)B * E);
     float* hp = W + b.take((size_t)B * A);
     float* al = W + b.take((size_t)B * T2);
