@@ -61,6 +61,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef GEMM_FAST_PATH
 #define GEMM_FAST_PATH 1   /* unchecked pointer-increment staging for interior single-segment problems */
 #endif
+#ifndef GEMM_SETPRIO
+#define GEMM_SETPRIO 0     /* 1: s_setprio(1) around each K step's MFMA cluster; 2: static per-block priority */
+#endif
 #ifndef GEMM_FRAG_PIPE
 #define GEMM_FRAG_PIPE 0   /* explicit register double-buffering of the LDS fragments */
 #endif
@@ -368,6 +371,13 @@ __global__ __launch_bounds__(THREADS, (THREADS == 64) ? 1 : GEMM_MIN_WAVES) void
     }
     __syncthreads();
 
+#if GEMM_SETPRIO == 2
+    {   // co-resident blocks get different static priorities so that their MFMA clusters do not phase-lock
+        const int pr = __builtin_amdgcn_readfirstlane((int)(blockIdx.x % 3));
+        if (pr == 1) __builtin_amdgcn_s_setprio(1);
+        else if (pr == 2) __builtin_amdgcn_s_setprio(2);
+    }
+#endif
     for (int it = 0; it < total_iters; ++it) {
         const int cur = (STAGES == 2) ? (it & 1) : 0;
         const bool more = (it + 1 < total_iters);
@@ -405,6 +415,9 @@ __global__ __launch_bounds__(THREADS, (THREADS == 64) ? 1 : GEMM_MIN_WAVES) void
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cb][i][c], bf[cb][j][c], acc[i][j], 0, 0, 0);
         }
 #else
+#if GEMM_SETPRIO == 1
+        __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
         for (int q = 0; q < BK / 8; ++q) {
             f32x4 af[MT], bf[NT];
@@ -420,6 +433,9 @@ __global__ __launch_bounds__(THREADS, (THREADS == 64) ? 1 : GEMM_MIN_WAVES) void
                     for (int j = 0; j < NT; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][c], bf[j][c], acc[i][j], 0, 0, 0);
         }
+#if GEMM_SETPRIO == 1
+        __builtin_amdgcn_s_setprio(0);
+#endif
 #endif
 
         if constexpr (STAGES == 2) {
