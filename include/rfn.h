@@ -150,7 +150,7 @@ int rfn_attn_scores_bwd(const float* proj, int64_t proj_sb, int64_t proj_sl, con
                         int A, float* dproj, int64_t dproj_sb, int64_t dproj_sl,
                         int accumulate_dproj, float* dhproj, float* dw_part, void* stream);
 
-/* Fused small-L (L <= 32) attention of up to RFN_MAX_ENC encoders in one launch: scores + softmax + context
+/* Fused small-L (L <= 1024; meant for a handful) attention of up to RFN_MAX_ENC encoders in one launch: scores + softmax + context
  * (forward) and dalpha + softmax/tanh backward + d att_seq (backward), one block per (batch row, encoder).
  * Used by stage II and the decoder, which attend over the T1 / T2 thought vectors.  Arrays are host arrays of
  * device pointers, one entry per encoder; all encoders share strides and (L, A, D). */

@@ -450,14 +450,14 @@ struct AttnSmallArgs {
     long psb, psl, xsb, xsl, ldz, dpsb, dpsl;
     int L, A, D, accumulate_dproj;
 };
-#define ATS_MAX_L 32
+#define ATS_MAX_L 1024   /* every thread walks the L scores of its row: meant for L = T1 / T2, a handful */
 
 __global__ __launch_bounds__(ATT_THREADS) void attn_small_fwd_k(const AttnSmallArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int A = a.A, L = a.L, D = a.D, Ap = (A + 3) & ~3;
     float* hp_s = sm;
     float* w_s = sm + Ap;
-    float* s_s = sm + 2 * Ap;   // [ATS_MAX_L] scores, then alpha
+    float* s_s = sm + 2 * Ap;   // [L] scores, then alpha
     const int b = blockIdx.x, g = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* proj = a.proj[g] + b * a.psb;
     for (int i = tid; i < A; i += ATT_THREADS) {
@@ -478,10 +478,10 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_small_fwd_k(const AttnSmallA
     for (int l = 0; l < L; ++l) sum += expf(s_s[l] - m);
     const float inv = 1.0f / sum;
     __syncthreads();
-    if (tid < L) {
-        const float al = expf(s_s[tid] - m) * inv;
-        s_s[tid] = al;
-        a.alpha[g][(long)b * L + tid] = al;
+    for (int l = tid; l < L; l += ATT_THREADS) {
+        const float al = expf(s_s[l] - m) * inv;
+        s_s[l] = al;
+        a.alpha[g][(long)b * L + l] = al;
     }
     __syncthreads();
     const float* x = a.x[g] + b * a.xsb;
@@ -500,8 +500,9 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_small_bwd_k(const AttnSmallA
     float* hp_s = sm;                 // [Ap]
     float* w_s = sm + Ap;             // [Ap]
     float* dz_s = sm + 2 * Ap;        // [Dp]
-    float* al_s = dz_s + Dp;          // [ATS_MAX_L]
-    float* ds_s = al_s + ATS_MAX_L;   // [ATS_MAX_L]
+    const int Lp = (L + 3) & ~3;
+    float* al_s = dz_s + Dp;          // [Lp]
+    float* ds_s = al_s + Lp;          // [Lp]
     const int b = blockIdx.x, g = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* dz = a.z[g] + b * a.ldz;
     for (int i = tid; i < A; i += ATT_THREADS) {
@@ -509,7 +510,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_small_bwd_k(const AttnSmallA
         w_s[i] = a.w_out[g][i];
     }
     for (int d = tid; d < D; d += ATT_THREADS) dz_s[d] = dz[d];
-    if (tid < L) al_s[tid] = a.alpha[g][(long)b * L + tid];
+    for (int l = tid; l < L; l += ATT_THREADS) al_s[l] = a.alpha[g][(long)b * L + l];
     __syncthreads();
     const float* x = a.x[g] + b * a.xsb;
     // dalpha[l] = <dz, x[l]> : each wave takes rows l, l + 4 together (independent load streams)
@@ -544,7 +545,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_small_bwd_k(const AttnSmallA
     float dot = 0.f;
     for (int l = 0; l < L; ++l) dot += al_s[l] * ds_s[l];
     __syncthreads();
-    if (tid < L) ds_s[tid] = al_s[tid] * (ds_s[tid] - dot);   // softmax backward
+    for (int l = tid; l < L; l += ATT_THREADS) ds_s[l] = al_s[l] * (ds_s[l] - dot);   // softmax backward
     __syncthreads();
     // d att_seq through the context: dx[l, :] += alpha[l] * dz
     if (a.dx[g]) {
@@ -648,7 +649,7 @@ extern "C" int rfn_attn_small_fwd(int ngroups, const float* const* proj, int64_t
     }
     a.psb = proj_sb; a.psl = proj_sl; a.xsb = sb; a.xsl = sl; a.ldz = ldz;
     a.L = L; a.A = A; a.D = D;
-    const size_t lds = (size_t)(2 * ((A + 3) & ~3) + ATS_MAX_L) * sizeof(float);
+    const size_t lds = (size_t)(2 * ((A + 3) & ~3) + L) * sizeof(float);
     if (lds > 64 * 1024) return RFN_ERR_SHAPE;
     hipLaunchKernelGGL(attn_small_fwd_k, dim3(B, ngroups), dim3(ATT_THREADS), lds, (hipStream_t)stream, a);
     RFN_CHECK_LAUNCH();
@@ -677,7 +678,7 @@ extern "C" int rfn_attn_small_bwd(int ngroups, const float* const* proj, int64_t
     }
     a.psb = proj_sb; a.psl = proj_sl; a.xsb = sb; a.xsl = sl; a.ldz = lddz; a.dpsb = dproj_sb; a.dpsl = dproj_sl;
     a.L = L; a.A = A; a.D = D; a.accumulate_dproj = accumulate_dproj;
-    const size_t lds = (size_t)(2 * ((A + 3) & ~3) + ((D + 3) & ~3) + 2 * ATS_MAX_L) * sizeof(float);
+    const size_t lds = (size_t)(2 * ((A + 3) & ~3) + ((D + 3) & ~3) + 2 * ((L + 3) & ~3)) * sizeof(float);
     if (lds > 64 * 1024) return RFN_ERR_SHAPE;
     bool vec = (A % 4 == 0) && (D % 4 == 0) && ((proj_sb | proj_sl | sb | sl | lddz | dproj_sb | dproj_sl) % 4 == 0);
     for (int g = 0; g < ngroups; ++g)

@@ -77,7 +77,7 @@ def test_c3_greedy_decode_is_deterministic_and_consistent_with_forward(dev):
 
 
 @pytest.mark.parametrize('case', ['batch_of_one', 'single_encoder_single_region', 'five_shipped_encoders',
-                                  'unequal_odd_widths'])
+                                  'unequal_odd_widths', 'many_review_steps'])
 def test_edge_shapes_against_oracle(dev, case):
     """B = 1 (the reference's .squeeze() breaks there, AttentionModelCore.py:47), M = 1 with L = 1, and the
     reference's five heterogeneous encoders (feat_array.py:240-244: D in {2048, 1536, 1280, 2208}, L in {196, 64, 49},
@@ -90,6 +90,9 @@ def test_edge_shapes_against_oracle(dev, case):
     elif case == 'single_encoder_single_region':
         info = [dict(att_num=1, att_feat_size=20, fc_feat_size=12)]
         B, R_ = 3, 16
+    elif case == 'many_review_steps':    # T1 = 35, T2 = 33: stage II / decoder attend over more than a wave-row of thoughts
+        info = [dict(att_num=6, att_feat_size=16, fc_feat_size=16)]     # (steps x encoders <= 64 per phase)
+        B, R_ = 3, 16
     elif case == 'unequal_odd_widths':   # R != A != E, nothing a multiple of 4 (scalar kernel paths), T1 != T2
         info = [dict(att_num=9, att_feat_size=22, fc_feat_size=13), dict(att_num=4, att_feat_size=35, fc_feat_size=35),
                 dict(att_num=11, att_feat_size=17, fc_feat_size=29)]
@@ -99,7 +102,10 @@ def test_edge_shapes_against_oracle(dev, case):
                 dict(att_num=64, att_feat_size=1280, fc_feat_size=2048), dict(att_num=49, att_feat_size=2208, fc_feat_size=2208),
                 dict(att_num=64, att_feat_size=1536, fc_feat_size=1536)]
         B, R_ = 3, 64
-    if case == 'unequal_odd_widths':
+    if case == 'many_review_steps':
+        cfg = O.make_cfg(info, vocab_size=40, rnn_size=R_, input_encoding_size=R_, att_hid_size=R_,
+                         num_review_steps_0=35, num_review_steps=33, top_words_count=10, seq_length=4)
+    elif case == 'unequal_odd_widths':
         cfg = O.make_cfg(info, vocab_size=61, rnn_size=R_, input_encoding_size=19, att_hid_size=15,
                          num_review_steps_0=3, num_review_steps=2, top_words_count=13, seq_length=5,
                          use_label_smoothing=1, label_smoothing_epsilon=0.1)

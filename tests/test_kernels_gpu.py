@@ -273,7 +273,7 @@ def test_attention_time_major_strides(dev):
     assert maxerr(alpha, al_ref) < 2e-6 and maxerr(z, z_ref) < 1e-5
 
 
-@pytest.mark.parametrize('G,B,L,A,D', [(4, 6, 8, 512, 512), (1, 5, 8, 64, 96), (3, 4, 5, 30, 18), (2, 3, 32, 17, 7)])
+@pytest.mark.parametrize('G,B,L,A,D', [(4, 6, 8, 512, 512), (1, 5, 8, 64, 96), (3, 4, 5, 30, 18), (2, 3, 32, 17, 7), (2, 3, 300, 24, 20)])
 def test_fused_small_attention_groups_match_fp64(dev, G, B, L, A, D):
     """rfn_attn_small_fwd/bwd: G encoders in one launch over time-major (step, batch, G*feature) thoughts, as
     stage II lays them out; backward overwrites the projections in place and accumulates d thoughts."""
@@ -331,7 +331,7 @@ def test_fused_small_attention_groups_match_fp64(dev, G, B, L, A, D):
     for g in range(G):
         assert maxerr(acc[g], refs[g][0] + 1.0) < 2e-5
     # rejects L beyond the fused kernel's bound
-    assert n.lib.rfn_attn_small_fwd(G, a_p, L * A, A, a_hp, a_w, a_b, a_x, G * D, B * G * D, B, 33, A, D, a_al, a_z,
+    assert n.lib.rfn_attn_small_fwd(G, a_p, L * A, A, a_hp, a_w, a_b, a_x, G * D, B * G * D, B, 1025, A, D, a_al, a_z,
                                     G * D, st) != 0
 
 
