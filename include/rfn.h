@@ -36,7 +36,8 @@ extern "C" {
 #define RFN_ABI_VERSION 3
 
 /* Model dimensions: the fields RecurrentFusionModel.__init__ reads from `opt`
- * (misc/RecurrentFusionModel.py:118-151). */
+ * (misc/RecurrentFusionModel.py:118-151).  Limits (RFN_ERR_SHAPE otherwise): M <= RFN_MAX_ENC,
+ * T1*M <= 64 and T2*M <= 64 (the reference ships T1 = T2 = 8, M <= 5), dropout probabilities in [0, 1). */
 typedef struct rfn_dims {
     int32_t M;                 /* number of encoders, len(opt.feat_array_info)            */
     int32_t R;                 /* opt.rnn_size                                            */

@@ -61,6 +61,8 @@ int check_dims(const rfn_dims* d) {
         return RFN_ERR_SHAPE;
     for (int i = 0; i < d->M; ++i)
         if (d->L[i] < 1 || d->D[i] < 1 || d->F[i] < 1) return RFN_ERR_SHAPE;
+    // the per-phase grouped launches carry at most 64 (step, encoder) pointer slots (rfn.h, rfn_dims)
+    if (d->T1 * d->M > 64 || d->T2 * d->M > 64) return RFN_ERR_SHAPE;
     if (d->drop_fusion < 0 || d->drop_fusion >= 1 || d->drop_reason < 0 || d->drop_reason >= 1 || d->drop_lm < 0 ||
         d->drop_lm >= 1)
         return RFN_ERR_SHAPE;
