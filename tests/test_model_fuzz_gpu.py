@@ -1,0 +1,63 @@
+"""Randomised whole-path parity: two dozen seeded random model configurations (encoder count, every width, step counts,
+maxout, label smoothing, ragged captions, batch size) -- HIP path vs the CPU oracle on forward log-probs, the XE loss,
+EVERY parameter gradient and the greedy token ids (bit-exact).  The oracle itself is pinned by the reference's golden
+vectors on seven fixed tiers (tests/test_oracle_golden.py); this sweeps the shape space between them."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _random_case(seed):
+    from oracle import rfn_oracle as O
+    rng = np.random.default_rng(seed)
+    M = int(rng.integers(1, 5))
+    info = [dict(att_num=int(rng.integers(1, 41)), att_feat_size=int(rng.integers(4, 71)),
+                 fc_feat_size=int(rng.integers(4, 51))) for _ in range(M)]
+    extra = dict(review_maxout=int(rng.integers(0, 2)), maxout=int(rng.integers(0, 2)),
+                 use_label_smoothing=int(rng.integers(0, 2)), label_smoothing_epsilon=0.1)
+    cfg = O.make_cfg(info, vocab_size=int(rng.integers(20, 121)), rnn_size=int(rng.integers(8, 41)),
+                     input_encoding_size=int(rng.integers(8, 41)), att_hid_size=int(rng.integers(8, 41)),
+                     num_review_steps_0=int(rng.integers(1, 7)), num_review_steps=int(rng.integers(1, 7)),
+                     top_words_count=int(rng.integers(5, 31)), seq_length=int(rng.integers(2, 9)), **extra)
+    B = int(rng.integers(1, 7))
+    P = O.seeded_params(cfg, 100 + seed, scale=0.08)
+    fc, att, labels, masks, top = O.synthetic_batch(cfg, B, seed=200 + seed)
+    S = cfg.seq_length
+    n = rng.integers(1, S + 1, size=B)                     # ragged captions: row b keeps n_b words
+    for b in range(B):
+        labels[b, 1 + n[b]:] = 0
+        masks[b, n[b] + 2:] = 0
+    return O, cfg, P, (fc, att, labels, masks, top)
+
+
+@pytest.mark.parametrize('seed', range(24))
+def test_random_configuration_matches_oracle(dev, seed):
+    import recurrent_fusion_network_amd as R
+    O, cfg, P, (fc, att, labels, masks, top) = _random_case(seed)
+    model = R.RecurrentFusionModel(cfg)
+    model.load_state_dict(P)
+    model = model.to(dev).eval()
+    d = lambda ts: [t.to(dev) for t in ts]  # noqa: E731
+    lp, reason = model(d(fc), d(att), labels.to(dev))
+    crit = R.ReviewNetEnsembleCriterion(cfg)
+    loss = crit(lp, labels.to(dev)[:, 1:], masks.to(dev)[:, 1:], reason, top.to(dev), 1.0)
+    loss.backward()
+    o_lp, o_reason = O.forward(cfg, P, fc, att, labels)
+    o_loss, o_grads = O.train_step_loss_and_grads(cfg, P, fc, att, labels, masks, top, 1.0)
+    assert lp.shape == o_lp.shape, (tuple(lp.shape), tuple(o_lp.shape))
+    assert float((lp.detach().cpu() - o_lp).abs().max()) < 1e-3
+    for a, b in zip(reason, o_reason):
+        assert float((a.detach().cpu() - b).abs().max()) < 1e-4
+    assert abs(float(loss.detach()) - float(o_loss)) < 1e-4 * max(1.0, abs(float(o_loss)))
+    named = dict(model.named_parameters())
+    assert set(named) == set(o_grads)
+    for k, g in o_grads.items():
+        err = float((named[k].grad.cpu() - g).abs().max())
+        assert err <= 1e-6 + 1e-3 * float(g.abs().max()), (k, err, float(g.abs().max()))
+    with torch.no_grad():
+        seq, seq_lp, lp_all, _ = model.sample(d(fc), d(att), {'sample_max': 1})
+    o_seq = O.sample_greedy(cfg, P, fc, att)
+    assert torch.equal(seq.cpu(), o_seq[0])
+    assert float((seq_lp.cpu() - o_seq[1]).abs().max()) < 1e-3
