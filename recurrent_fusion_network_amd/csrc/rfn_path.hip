@@ -688,10 +688,20 @@ extern "C" int rfn_prefix_bwd(const rfn_dims* d, int B, const float* const* prm,
         // dH_t += sum_i dgates_i . W_H[t,i]   (every cell reads the whole concatenated H, :53)
         for (int i = 0; i < M; ++i) segs[i] = seg_dx(g + (long)i * B * 4 * R, 4 * R, prm[P.s1(t, i, 6)], MR, 4 * R);
         RFN_TRY(gemm_segs(B, (int)MR, M, segs, dHc, MR, 1, gx));
+        // dz_i = dgates_i . W_z[t,i]: one grouped launch when the encoders share a feature width
+        bool same_d = true;
+        for (int i = 1; i < M; ++i) same_d = same_d && d->D[i] == d->D[0];
+        if (same_d && M > 1) {
+            for (int i = 0; i < M; ++i)
+                pr[i] = prob1(W + Lo.dz1[i], d->D[0],
+                              seg_dx(g + (long)i * B * 4 * R, 4 * R, prm[P.s1(t, i, 8)], d->D[0], 4 * R));
+            RFN_TRY(gemm_groups(B, d->D[0], M, pr, 0, gx));
+        }
         for (int i = 0; i < M; ++i) {
             const long Li = d->L[i], Di = d->D[i];
             float* dz = W + Lo.dz1[i];
-            RFN_TRY(gemm1(B, (int)Di, seg_dx(g + (long)i * B * 4 * R, 4 * R, prm[P.s1(t, i, 8)], Di, 4 * R), dz, Di, 0, gx));
+            if (!(same_d && M > 1))
+                RFN_TRY(gemm1(B, (int)Di, seg_dx(g + (long)i * B * 4 * R, 4 * R, prm[P.s1(t, i, 8)], Di, 4 * R), dz, Di, 0, gx));
             float* dali = dal + (long)i * B * Li;
             RFN_TRY(rfn_attn_context_bwd_dalpha(att[i], Li * Di, Di, dz, Di, B, (int)Li, (int)Di, dali, st));
             float* p1 = W + Lo.P1[i] + (long)t * A;
