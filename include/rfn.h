@@ -225,6 +225,11 @@ int rfn_max_over_steps_fwd(const float* X, int T, int B, int K, float* out, int3
 /* dX[t,b,k] = (arg[b,k]==t) ? dout[b,k] : 0 */
 int rfn_max_over_steps_bwd(const float* dout, const int32_t* arg, int T, int B, int K, float* dX,
                            void* stream);
+/* The same for `ngroups` heads in one launch: X slabs (T,B,K) back to back, out / arg / dout (B,K) back to back. */
+int rfn_max_over_steps_fwd_grouped(const float* X, int T, int B, int K, float* out, int32_t* arg, int ngroups,
+                                   void* stream);
+int rfn_max_over_steps_bwd_grouped(const float* dout, const int32_t* arg, int T, int B, int K, float* dX,
+                                   int ngroups, void* stream);
 
 /* y[r,c] = alpha*x[r,c] + beta*y[r,c]  (state mean misc/RecurrentFusionModel.py:233-235,
  * gradient fan-in) */

@@ -80,6 +80,8 @@ def _load():
         'rfn_log_softmax_bwd': (C.c_int, [P, P, I, I, I, L, L, P, L, P]),
         'rfn_max_over_steps_fwd': (C.c_int, [P, I, I, I, P, P, P]),
         'rfn_max_over_steps_bwd': (C.c_int, [P, P, I, I, I, P, P]),
+        'rfn_max_over_steps_fwd_grouped': (C.c_int, [P, I, I, I, P, P, I, P]),
+        'rfn_max_over_steps_bwd_grouped': (C.c_int, [P, P, I, I, I, P, I, P]),
         'rfn_axpby_2d': (C.c_int, [F, P, L, F, P, L, I, I, P]),
         'rfn_div_2d': (C.c_int, [P, L, I, I, F, P]),
         'rfn_mean_over_groups': (C.c_int, [I, P, L, L, I, P, L, I, I, P]),

@@ -250,10 +250,12 @@ extern "C" int rfn_log_softmax_bwd(const float* g, const float* logp, int rows, 
 }
 
 // ---- reason heads: max over steps ------------------------------------------------------------------
+// blockIdx.y = head: X slabs (T, B*K) lie `T*BK` apart, out / arg / dout (B*K) `BK` apart.
 __global__ __launch_bounds__(256) void max_steps_fwd_k(const float* __restrict__ X, int T, long BK,
                                                        float* __restrict__ out, int32_t* __restrict__ arg) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= BK) return;
+    X += (long)blockIdx.y * T * BK;
     float m = X[i];
     int a = 0;
     for (int t = 1; t < T; ++t) {
@@ -263,35 +265,44 @@ __global__ __launch_bounds__(256) void max_steps_fwd_k(const float* __restrict__
             a = t;
         }
     }
-    out[i] = m;
-    if (arg) arg[i] = a;
+    out[blockIdx.y * BK + i] = m;
+    if (arg) arg[blockIdx.y * BK + i] = a;
 }
-extern "C" int rfn_max_over_steps_fwd(const float* X, int T, int B, int K, float* out, int32_t* arg, void* stream) {
-    if (T <= 0 || B <= 0 || K <= 0) return RFN_ERR_SHAPE;
+extern "C" int rfn_max_over_steps_fwd_grouped(const float* X, int T, int B, int K, float* out, int32_t* arg,
+                                              int ngroups, void* stream) {
+    if (T <= 0 || B <= 0 || K <= 0 || ngroups < 1) return RFN_ERR_SHAPE;
     if (!X || !out) return RFN_ERR_ARG;
     const long BK = (long)B * K;
-    hipLaunchKernelGGL(max_steps_fwd_k, dim3(rfn_cdiv(BK, 256)), dim3(256), 0, (hipStream_t)stream, X, T, BK, out,
-                       arg);
+    hipLaunchKernelGGL(max_steps_fwd_k, dim3(rfn_cdiv(BK, 256), ngroups), dim3(256), 0, (hipStream_t)stream, X, T, BK,
+                       out, arg);
     RFN_CHECK_LAUNCH();
     return RFN_OK;
+}
+extern "C" int rfn_max_over_steps_fwd(const float* X, int T, int B, int K, float* out, int32_t* arg, void* stream) {
+    return rfn_max_over_steps_fwd_grouped(X, T, B, K, out, arg, 1, stream);
 }
 __global__ __launch_bounds__(256) void max_steps_bwd_k(const float* __restrict__ dout, const int32_t* __restrict__ arg,
                                                        int T, long BK, float* __restrict__ dX) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= BK) return;
-    const float g = dout ? dout[i] : 0.f;
-    const int a = arg[i];
+    const float g = dout ? dout[blockIdx.y * BK + i] : 0.f;
+    const int a = arg[blockIdx.y * BK + i];
+    dX += (long)blockIdx.y * T * BK;
     for (int t = 0; t < T; ++t) dX[t * BK + i] = (t == a) ? g : 0.f;
+}
+extern "C" int rfn_max_over_steps_bwd_grouped(const float* dout, const int32_t* arg, int T, int B, int K, float* dX,
+                                              int ngroups, void* stream) {
+    if (T <= 0 || B <= 0 || K <= 0 || ngroups < 1) return RFN_ERR_SHAPE;
+    if (!arg || !dX) return RFN_ERR_ARG;
+    const long BK = (long)B * K;
+    hipLaunchKernelGGL(max_steps_bwd_k, dim3(rfn_cdiv(BK, 256), ngroups), dim3(256), 0, (hipStream_t)stream, dout, arg,
+                       T, BK, dX);
+    RFN_CHECK_LAUNCH();
+    return RFN_OK;
 }
 extern "C" int rfn_max_over_steps_bwd(const float* dout, const int32_t* arg, int T, int B, int K, float* dX,
                                       void* stream) {
-    if (T <= 0 || B <= 0 || K <= 0) return RFN_ERR_SHAPE;
-    if (!arg || !dX) return RFN_ERR_ARG;
-    const long BK = (long)B * K;
-    hipLaunchKernelGGL(max_steps_bwd_k, dim3(rfn_cdiv(BK, 256)), dim3(256), 0, (hipStream_t)stream, dout, arg, T, BK,
-                       dX);
-    RFN_CHECK_LAUNCH();
-    return RFN_OK;
+    return rfn_max_over_steps_bwd_grouped(dout, arg, T, B, K, dX, 1, stream);
 }
 
 // ---- y = alpha*x + beta*y on a strided 2-D view ------------------------------------------------------

@@ -201,7 +201,7 @@ PrefixLayout prefix_layout(const rfn_dims* d, int B, int train) {
     L.Cs = b.take((T1 + 1) * Bz * M * R);
     L.hp1 = b.take(T1 * M * Bz * A);
     L.g1 = b.take(T1 * M * Bz * 4 * R);
-    L.rmat = b.take((T1 > T2 ? T1 : T2) * Bz * K);
+    L.rmat = b.take((T1 * M > T2 ? T1 * M : T2) * Bz * K);   // M slabs (T1,B,K) of the stage-I heads / one (T2,B,K)
     L.rarg = b.take((M + 1) * Bz * K);  // int32, same width
     L.h2 = b.take((T2 + 1) * Bz * R);
     L.c2 = b.take((T2 + 1) * Bz * R);
@@ -473,10 +473,11 @@ extern "C" int rfn_prefix_fwd(const rfn_dims* d, int B, const float* const* prm,
 
     // reason heads of stage I: max over steps of reason_linear_individual (:217, :229)
     float* rmat = W + Lo.rmat;
-    for (int i = 0; i < M; ++i) {
-        RFN_TRY(gemm1(T1 * B, K, seg_lin(Hs + BMR + i * R, MR, prm[P.rind_w(i)], R, R, prm[P.rind_b(i)]), rmat, K, 0, gx));
-        RFN_TRY(rfn_max_over_steps_fwd(rmat, T1, B, K, reason_pred + (long)i * B * K, rarg + (long)i * B * K, st));
-    }
+    for (int i = 0; i < M; ++i)   // all encoders' heads: one grouped GEMM into M slabs, one max-over-steps launch
+        pr[i] = prob1(rmat + (long)i * T1 * B * K, K,
+                      seg_lin(Hs + BMR + i * R, MR, prm[P.rind_w(i)], R, R, prm[P.rind_b(i)]));
+    RFN_TRY(gemm_groups(T1 * B, K, M, pr, 0, gx));
+    RFN_TRY(rfn_max_over_steps_fwd_grouped(rmat, T1, B, K, reason_pred, rarg, M, st));
 
     // state mean over encoders (:233-235): sum first, then divide, as the reference does
     float* h2 = W + Lo.h2;
@@ -669,12 +670,14 @@ extern "C" int rfn_prefix_bwd(const rfn_dims* d, int B, const float* const* prm,
         RFN_TRY(rfn_bcast_to_groups(2, invM, bx, R, bb, by, MR, R, M, B, R, st));
     }
     // ---- reason heads of stage I ----------------------------------------------------------------------
-    for (int i = 0; i < M; ++i) {
-        RFN_TRY(rfn_max_over_steps_bwd(d_reason ? d_reason + (long)i * B * K : nullptr, rarg + (long)i * B * K, T1, B, K,
-                                       rmat, st));
-        RFN_TRY(gemm1(T1 * B, R, seg_dx(rmat, K, prm[P.rind_w(i)], R, K), dHs + BMR + i * R, MR, 1, gx));
-        RFN_TRY(gemm_dw(K, R, grd[P.rind_w(i)], R, grd[P.rind_b(i)], rmat, K, Hs + BMR + i * R, MR, T1 * B, gx));
-    }
+    RFN_TRY(rfn_max_over_steps_bwd_grouped(d_reason, rarg, T1, B, K, rmat, M, st));
+    for (int i = 0; i < M; ++i)
+        pr[i] = prob1(dHs + BMR + i * R, MR, seg_dx(rmat + (long)i * T1 * B * K, K, prm[P.rind_w(i)], R, K));
+    RFN_TRY(gemm_groups(T1 * B, R, M, pr, 1, gx));
+    for (int i = 0; i < M; ++i)
+        pr[i] = prob_dw(grd[P.rind_w(i)], R, grd[P.rind_b(i)], rmat + (long)i * T1 * B * K, K, Hs + BMR + i * R, MR,
+                        T1 * B);
+    RFN_TRY(gemm_groups(K, R, M, pr, 0, gx));
 
     // ---- stage I backward --------------------------------------------------------------------------------
     for (int t = T1 - 1; t >= 0; --t) {
