@@ -145,7 +145,7 @@ def main():
     rank, world, local = DP.init_from_env('nccl')
     if world != args.gpus:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run' % (args.gpus, world))
-    dev = torch.device('cuda', local)
+    dev = torch.device('cuda', int(os.environ.get('RFN_DEVICE_INDEX', local)))   # test hook: ranks sharing one GPU
     torch.cuda.set_device(dev)
     w = dict(WORKLOADS[args.workload])
     B = args.batch or w['B']

@@ -25,10 +25,12 @@ def init_from_env(backend=None):
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend is None:
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        backend = os.environ.get('RFN_DIST_BACKEND', backend)   # test hook: gloo lets two ranks share one GPU
         if backend == 'nccl':
-            torch.cuda.set_device(local)
+            local_dev = int(os.environ.get('RFN_DEVICE_INDEX', local))
+            torch.cuda.set_device(local_dev)
             dist.init_process_group(backend=backend, rank=rank, world_size=world,
-                                    device_id=torch.device('cuda', local))
+                                    device_id=torch.device('cuda', local_dev))
         else:
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
