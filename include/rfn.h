@@ -373,6 +373,13 @@ int rfn_decoder_step(const rfn_dims* d, int B, const float* const* params, const
                      const float* cproj, const int64_t* ids, float* h, float* c, float* logits,
                      float* logp, int64_t ld_logp /* row stride of logp, >= V1 */, void* ws,
                      size_t ws_bytes, void* stream);
+/* The same step fed with an already embedded token xt (B, E) -- the literal signature of the reference's
+ * one_time_step(xt, thought_vectors_comb, state) (misc/RecurrentFusionModel.py:345-350), whose callers do
+ * xt = model.embed(it) themselves (eval_utils.py:368,516,539). */
+int rfn_decoder_step_embedded(const rfn_dims* d, int B, const float* const* params, const float* comb,
+                              const float* cproj, const float* xt, int64_t ld_xt, float* h, float* c,
+                              float* logits, float* logp, int64_t ld_logp, void* ws, size_t ws_bytes,
+                              void* stream);
 
 #ifdef __cplusplus
 }

@@ -105,6 +105,7 @@ def _load():
         'rfn_decoder_step_ws_bytes': (SZ, [DP, I]),
         'rfn_decoder_prepare': (C.c_int, [DP, I, P, P, P, P]),
         'rfn_decoder_step': (C.c_int, [DP, I, P, P, P, P, P, P, P, P, L, P, SZ, P]),
+        'rfn_decoder_step_embedded': (C.c_int, [DP, I, P, P, P, P, L, P, P, P, P, L, P, SZ, P]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol

@@ -941,12 +941,13 @@ extern "C" int rfn_decoder_prepare(const rfn_dims* d, int B, const float* const*
     return gemm1(d->T2 * B, d->A, seg_lin(comb, d->R, prm[P.dec(6)], d->R, d->R, prm[P.dec(7)]), cproj, d->A, 0, gx);
 }
 
-extern "C" int rfn_decoder_step(const rfn_dims* d, int B, const float* const* prm, const float* comb,
-                                const float* cproj, const int64_t* ids, float* h, float* c, float* logits, float* logp,
-                                int64_t ld_logp, void* ws, size_t ws_bytes, void* st) {
+static int decoder_step_impl(const rfn_dims* d, int B, const float* const* prm, const float* comb, const float* cproj,
+                             const int64_t* ids, const float* xt, int64_t ld_xt, float* h, float* c, float* logits,
+                             float* logp, int64_t ld_logp, void* ws, size_t ws_bytes, void* st) {
     RFN_TRY(check_dims(d));
     if (B < 1) return RFN_ERR_SHAPE;
-    if (!prm || !comb || !cproj || !ids || !h || !c || !ws) return RFN_ERR_ARG;
+    if (!prm || !comb || !cproj || (!ids && !xt) || !h || !c || !ws) return RFN_ERR_ARG;
+    if (xt && ld_xt < d->E) return RFN_ERR_SHAPE;
     if (ws_bytes < rfn_decoder_step_ws_bytes(d, B)) return RFN_ERR_WORKSPACE;
     const PIdx P(d);
     const int R = d->R, A = d->A, E = d->E, T2 = d->T2, V1 = d->V1;
@@ -961,11 +962,11 @@ extern "C" int rfn_decoder_step(const rfn_dims* d, int B, const float* const* pr
     float* z = W + b.take((size_t)B * R);
     float* g = W + b.take((size_t)B * GD);
     float* lg = logits ? logits : W + b.take((size_t)B * V1);
-    RFN_TRY(rfn_embed_fwd(prm[P.embed()], E, V1, ids, B, 1, 0, B, x, E, st));
+    if (!xt) RFN_TRY(rfn_embed_fwd(prm[P.embed()], E, V1, ids, B, 1, 0, B, x, E, st));
     RFN_TRY(gemm1(B, A, seg_lin(h, R, prm[P.dec(8)], R, R, prm[P.dec(9)]), hp, A, 0, gx));
     RFN_TRY(attn1_fwd(cproj, A, BA, hp, prm[P.dec(10)], prm[P.dec(11)], comb, R, BR, B, T2, A, R, al, z, R, st));
     rfn_gemm_seg segs[3];
-    segs[0] = seg_lin(x, E, prm[P.dec(0)], E, E, prm[P.dec(1)]);
+    segs[0] = xt ? seg_lin(xt, ld_xt, prm[P.dec(0)], E, E, prm[P.dec(1)]) : seg_lin(x, E, prm[P.dec(0)], E, E, prm[P.dec(1)]);
     segs[1] = seg_lin(h, R, prm[P.dec(2)], R, R, prm[P.dec(3)]);
     segs[2] = seg_lin(z, R, prm[P.dec(4)], R, R, prm[P.dec(5)]);
     RFN_TRY(gemm_segs(B, GD, 3, segs, g, GD, 0, gx));
@@ -978,4 +979,19 @@ extern "C" int rfn_decoder_step(const rfn_dims* d, int B, const float* const* pr
         }
     }
     return RFN_OK;
+}
+
+extern "C" int rfn_decoder_step(const rfn_dims* d, int B, const float* const* prm, const float* comb,
+                                const float* cproj, const int64_t* ids, float* h, float* c, float* logits, float* logp,
+                                int64_t ld_logp, void* ws, size_t ws_bytes, void* st) {
+    if (!ids) return RFN_ERR_ARG;
+    return decoder_step_impl(d, B, prm, comb, cproj, ids, nullptr, 0, h, c, logits, logp, ld_logp, ws, ws_bytes, st);
+}
+// the reference's one_time_step signature: the caller has already embedded the token (xt = model.embed(it))
+extern "C" int rfn_decoder_step_embedded(const rfn_dims* d, int B, const float* const* prm, const float* comb,
+                                         const float* cproj, const float* xt, int64_t ld_xt, float* h, float* c,
+                                         float* logits, float* logp, int64_t ld_logp, void* ws, size_t ws_bytes,
+                                         void* st) {
+    if (!xt) return RFN_ERR_ARG;
+    return decoder_step_impl(d, B, prm, comb, cproj, nullptr, xt, ld_xt, h, c, logits, logp, ld_logp, ws, ws_bytes, st);
 }

@@ -479,13 +479,14 @@ class RecurrentFusionModel(nn.Module):
         return (comb.transpose(0, 1).contiguous(), list(reason.unbind(0)),
                 (h.unsqueeze(0), c.unsqueeze(0)))
 
-    def one_time_step(self, xt_ids, fc_feats, thought_vectors_comb, state_decode):
-        """misc/RecurrentFusionModel.py:345-350 -> (logit (B,V+1) pre-softmax, state).  Takes token ids (the
-        reference takes the embedded xt; embedding is fused into the step here)."""
+    def one_time_step(self, xt, fc_feats, thought_vectors_comb, state_decode):
+        """misc/RecurrentFusionModel.py:345-350 -> (logit (B,V+1) pre-softmax, state).  `xt` is the embedded
+        input (B, E) exactly as in the reference (its callers do xt = model.embed(it), eval_utils.py:368), or int64
+        token ids (B,), in which case the embedding is fused into the step."""
         with torch.no_grad():
             comb = thought_vectors_comb.transpose(0, 1).contiguous()
             stepper = _Stepper(self, comb, state_decode[0][-1].clone(), state_decode[1][-1].clone())
-            logits = stepper.step(xt_ids.contiguous(), want='logits')
+            logits = stepper.step(xt.contiguous(), want='logits')
             return logits, (stepper.h.unsqueeze(0), stepper.c.unsqueeze(0))
 
     def sample(self, fc_feats, att_feats, opt={}):
@@ -638,13 +639,24 @@ class _Stepper:
         self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev)
 
     def step(self, ids, out=None, want='logp'):
+        """ids: int64 token ids (B,) -- or an already embedded float input (B, E), as the reference's one_time_step."""
         V1 = self.d.V1
         if out is None:
             out = torch.empty(self.B, V1, device=self.h.device)
-        if ids.dtype != torch.long or not ids.is_contiguous():
-            ids = ids.long().contiguous()
         logits_ptr = out.data_ptr() if want == 'logits' else None
         logp_ptr = out.data_ptr() if want == 'logp' else None
+        if ids.is_floating_point():
+            xt = N.require_cuda_f32(ids, 'xt')
+            if tuple(xt.shape) != (self.B, self.d.E):
+                raise N.RfnError('embedded xt must be (%d, %d), got %s' % (self.B, self.d.E, tuple(xt.shape)))
+            N.check(N.lib.rfn_decoder_step_embedded(C.byref(self.d), self.B, self.table, self.comb.data_ptr(),
+                                                    self.cproj.data_ptr(), xt.data_ptr(), xt.stride(0),
+                                                    self.h.data_ptr(), self.c.data_ptr(), logits_ptr, logp_ptr,
+                                                    out.stride(0), self.ws.data_ptr(), self.ws_bytes, N.stream_ptr()),
+                    'rfn_decoder_step_embedded')
+            return out
+        if ids.dtype != torch.long or not ids.is_contiguous():
+            ids = ids.long().contiguous()
         N.check(N.lib.rfn_decoder_step(C.byref(self.d), self.B, self.table, self.comb.data_ptr(),
                                        self.cproj.data_ptr(), ids.data_ptr(), self.h.data_ptr(), self.c.data_ptr(),
                                        logits_ptr, logp_ptr, out.stride(0), self.ws.data_ptr(), self.ws_bytes,

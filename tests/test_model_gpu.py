@@ -331,6 +331,16 @@ def test_inference_hooks(dev):
     logit, st2 = model.one_time_step(ids, fc, comb, st)
     o_logit, oh2, oc2 = O.one_time_step(cfg, P, P['embed.weight'][ids.cpu()], o_comb, oh, oc)
     assert maxerr(logit, o_logit) < 1e-4 and maxerr(st2[1][0], oc2) < 1e-4
+    # the reference's literal calling convention: the caller embeds the token itself (eval_utils.py:368)
+    ids2 = torch.arange(1, fc[0].size(0) + 1, device=dev)
+    with torch.no_grad():
+        xt = model.embed(ids2)
+    assert tuple(xt.shape) == (fc[0].size(0), cfg.input_encoding_size)
+    logit_x, st_x = model.one_time_step(xt, fc, comb, st)
+    logit_i, st_i = model.one_time_step(ids2, fc, comb, st)
+    assert torch.equal(logit_x, logit_i) and torch.equal(st_x[0], st_i[0]) and torch.equal(st_x[1], st_i[1])
+    with pytest.raises(Exception):
+        model.one_time_step(xt[:, :-1], fc, comb, st)
 
 
 def test_unchanged_trainer_route_torch_adam_and_clip_gradient(dev):
