@@ -328,6 +328,12 @@ int rfn_prefix_fwd(const rfn_dims* d, int B, const float* const* params,
                    const float* const* fc_feats, const float* const* att_feats, float* comb,
                    float* h_out, float* c_out, float* reason_pred, void* ws, size_t ws_bytes,
                    int train, uint64_t seed, void* stream);
+/* get_thought_vectors(fc_feats, att_feats, state_list) with the caller's stage-I state (:283-331): init_h[i],
+ * init_c[i] are (B,R) contiguous, one pair per encoder; inference only (workspace of train = 0). */
+int rfn_prefix_fwd_from_state(const rfn_dims* d, int B, const float* const* params,
+                              const float* const* init_h, const float* const* init_c,
+                              const float* const* att_feats, float* comb, float* h_out, float* c_out,
+                              float* reason_pred, void* ws, size_t ws_bytes, void* stream);
 /* Gradients of phase 1.  d_comb (T2,B,R), d_h, d_c (B,R), d_reason_pred (M+1,B,K) are the incoming
  * gradients (any may be NULL = zero).  Every slot of grads[] (same table as params) that belongs
  * to phase 1 is OVERWRITTEN exactly once (no zero-fill needed); phase-2 slots are not touched. */

@@ -97,6 +97,7 @@ def _load():
         'rfn_gather_rows': (C.c_int, [P, P, P, I, I, P]),
         'rfn_prefix_ws_bytes': (SZ, [DP, I, I]),
         'rfn_prefix_fwd': (C.c_int, [DP, I, P, P, P, P, P, P, P, P, SZ, I, U64, P]),
+        'rfn_prefix_fwd_from_state': (C.c_int, [DP, I, P, P, P, P, P, P, P, P, P, SZ, P]),
         'rfn_prefix_bwd': (C.c_int, [DP, I, P, P, P, P, P, P, P, P, P, SZ, U64, I, P]),
         'rfn_prefix_bwd_wgrad': (C.c_int, [DP, I, P, P, P, SZ, I, I, P]),
         'rfn_decoder_ws_bytes': (SZ, [DP, I, I, I]),

@@ -402,12 +402,13 @@ extern "C" size_t rfn_prefix_ws_bytes(const rfn_dims* d, int B, int train) {
     return prefix_layout(d, B, train).total * sizeof(float);
 }
 
-extern "C" int rfn_prefix_fwd(const rfn_dims* d, int B, const float* const* prm, const float* const* fc,
-                              const float* const* att, float* comb, float* h_out, float* c_out, float* reason_pred,
-                              void* ws, size_t ws_bytes, int train, uint64_t seed, void* st) {
+static int prefix_fwd_impl(const rfn_dims* d, int B, const float* const* prm, const float* const* fc,
+                           const float* const* init_h, const float* const* init_c, const float* const* att,
+                           float* comb, float* h_out, float* c_out, float* reason_pred, void* ws, size_t ws_bytes,
+                           int train, uint64_t seed, void* st) {
     RFN_TRY(check_dims(d));
     if (B < 1) return RFN_ERR_SHAPE;
-    if (!prm || !fc || !att || !ws) return RFN_ERR_ARG;
+    if (!prm || (!fc && !(init_h && init_c)) || !att || !ws) return RFN_ERR_ARG;
     const PrefixLayout Lo = prefix_layout(d, B, train);
     if (ws_bytes < Lo.total * sizeof(float)) return RFN_ERR_WORKSPACE;
     const PIdx P(d);
@@ -421,10 +422,20 @@ extern "C" int rfn_prefix_fwd(const rfn_dims* d, int B, const float* const* prm,
     int32_t* rarg = (int32_t*)(W + Lo.rarg);
 
     // K0: h0_i = fc2h_i(fc_i) written straight into the concatenated H of step 0; c0 = h0 (:202-208)
-    for (int i = 0; i < M; ++i)
-        RFN_TRY(gemm1(B, R, seg_lin(fc[i], d->F[i], prm[P.fc_w(i)], d->F[i], d->F[i], prm[P.fc_b(i)]), Hs + i * R, MR,
-                      0, gx));
-    RFN_TRY(copy_f32(Cs, Hs, BMR, st));
+    if (init_h) {   // caller-provided stage-I state (get_thought_vectors(fc, att, state_list), :283)
+        for (int i = 0; i < M; ++i) {
+            if (!init_h[i] || !init_c[i]) return RFN_ERR_ARG;
+            RFN_TRY(rfn_axpby_2d(1.f, init_h[i], R, 0.f, Hs + i * R, MR, B, R, st));
+            RFN_TRY(rfn_axpby_2d(1.f, init_c[i], R, 0.f, Cs + i * R, MR, B, R, st));
+        }
+    } else {
+        for (int i = 0; i < M; ++i) {
+            if (!fc[i]) return RFN_ERR_ARG;
+            RFN_TRY(gemm1(B, R, seg_lin(fc[i], d->F[i], prm[P.fc_w(i)], d->F[i], d->F[i], prm[P.fc_b(i)]), Hs + i * R,
+                          MR, 0, gx));
+        }
+        RFN_TRY(copy_f32(Cs, Hs, BMR, st));
+    }
 
     // hoisted feature projections of stage I: P1_i[(b,l), t*A + a], all T1 step weights grouped
     rfn_gemm_problem pr[64];
@@ -539,6 +550,23 @@ extern "C" int rfn_prefix_fwd(const rfn_dims* d, int B, const float* const* prm,
     if (h_out) RFN_TRY(copy_f32(h_out, h2 + (long)T2 * BR, BR, st));
     if (c_out) RFN_TRY(copy_f32(c_out, c2 + (long)T2 * BR, BR, st));
     return RFN_OK;
+}
+
+extern "C" int rfn_prefix_fwd(const rfn_dims* d, int B, const float* const* prm, const float* const* fc,
+                              const float* const* att, float* comb, float* h_out, float* c_out, float* reason_pred,
+                              void* ws, size_t ws_bytes, int train, uint64_t seed, void* st) {
+    if (!fc) return RFN_ERR_ARG;
+    return prefix_fwd_impl(d, B, prm, fc, nullptr, nullptr, att, comb, h_out, c_out, reason_pred, ws, ws_bytes, train,
+                           seed, st);
+}
+// get_thought_vectors with a caller-provided state_list (inference only: no backward through the given state)
+extern "C" int rfn_prefix_fwd_from_state(const rfn_dims* d, int B, const float* const* prm, const float* const* init_h,
+                                         const float* const* init_c, const float* const* att, float* comb,
+                                         float* h_out, float* c_out, float* reason_pred, void* ws, size_t ws_bytes,
+                                         void* st) {
+    if (!init_h || !init_c) return RFN_ERR_ARG;
+    return prefix_fwd_impl(d, B, prm, nullptr, init_h, init_c, att, comb, h_out, c_out, reason_pred, ws, ws_bytes, 0, 0,
+                           st);
 }
 
 extern "C" int rfn_prefix_bwd(const rfn_dims* d, int B, const float* const* prm, const float* const* fc,

@@ -473,11 +473,43 @@ class RecurrentFusionModel(nn.Module):
 
     def get_thought_vectors(self, fc_feats, att_feats, state_list=None):
         """misc/RecurrentFusionModel.py:283-331 -> (thought_vectors_comb (B,T2,R), reason_pred, state_review).
-        The initial state is recomputed from fc_feats (it is what get_init_state returns)."""
+        `state_list`: the M (h, c) pairs of shape (1,B,R) that get_init_state returns -- used as given, like the
+        reference; None recomputes them from fc_feats."""
         with torch.no_grad():
-            comb, h, c, reason = self._prefix(fc_feats, att_feats, False, 0)
+            if state_list is None:
+                comb, h, c, reason = self._prefix(fc_feats, att_feats, False, 0)
+            else:
+                comb, h, c, reason = self._prefix_from_state(att_feats, state_list)
         return (comb.transpose(0, 1).contiguous(), list(reason.unbind(0)),
                 (h.unsqueeze(0), c.unsqueeze(0)))
+
+    def _prefix_from_state(self, att_feats, state_list):
+        M, R = self.num_feat_array, self.rnn_size
+        if len(state_list) != M or len(att_feats) != M:
+            raise N.RfnError('expected %d (h, c) states and att feature tensors' % M)
+        B = att_feats[0].size(0)
+        hs = [N.require_cuda_f32(s_[0].reshape(-1, R), 'state h') for s_ in state_list]
+        cs = [N.require_cuda_f32(s_[1].reshape(-1, R), 'state c') for s_ in state_list]
+        att = [N.require_cuda_f32(a, 'att_feats') for a in att_feats]
+        for i in range(M):
+            if hs[i].size(0) != B or cs[i].size(0) != B:
+                raise N.RfnError('state %d has batch %d, features have %d' % (i, hs[i].size(0), B))
+            if tuple(att[i].shape) != (B, self.att_num[i], self.att_feat_size[i]):
+                raise N.RfnError('att_feats[%d] has shape %s' % (i, tuple(att[i].shape)))
+        d = self._dims_for(False)
+        dev = att[0].device
+        K = self.top_words_count
+        table = self._param_table(self._params_of(self._prefix_slots), self._prefix_slots)
+        ws_bytes = N.lib.rfn_prefix_ws_bytes(C.byref(d), B, 0)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        comb = torch.empty(d.T2, B, R, device=dev)
+        h, c = torch.empty(B, R, device=dev), torch.empty(B, R, device=dev)
+        reason = torch.empty(M + 1, B, K, device=dev)
+        N.check(N.lib.rfn_prefix_fwd_from_state(C.byref(d), B, table, N.ptr_array(hs), N.ptr_array(cs),
+                                                N.ptr_array(att), comb.data_ptr(), h.data_ptr(), c.data_ptr(),
+                                                reason.data_ptr(), ws.data_ptr(), ws_bytes, N.stream_ptr()),
+                'rfn_prefix_fwd_from_state')
+        return comb, h, c, reason
 
     def one_time_step(self, xt, fc_feats, thought_vectors_comb, state_decode):
         """misc/RecurrentFusionModel.py:345-350 -> (logit (B,V+1) pre-softmax, state).  `xt` is the embedded

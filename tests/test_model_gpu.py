@@ -327,6 +327,18 @@ def test_inference_hooks(dev):
     comb, reason, st = model.get_thought_vectors(fc, att, state)
     o_comb, o_reason, (oh, oc) = O.thought_vectors(cfg, P, batch[1], hs, cs)
     assert maxerr(comb, o_comb) < 1e-4 and maxerr(st[0][0], oh) < 1e-4
+    comb0, reason0, st0 = model.get_thought_vectors(fc, att)              # state recomputed from fc_feats: same bits
+    assert torch.equal(comb0, comb) and torch.equal(st0[1], st[1])
+    # a state_list that is NOT what get_init_state returns is honoured (c != h, scaled h), like the reference
+    hs2 = [h * 0.5 for h in hs]
+    cs2 = [c * -0.25 for c in cs]
+    state2 = [(h.unsqueeze(0).to(dev), c.unsqueeze(0).to(dev)) for h, c in zip(hs2, cs2)]
+    comb2, reason2, st2_ = model.get_thought_vectors(fc, att, state2)
+    o_comb2, o_reason2, (oh2_, oc2_) = O.thought_vectors(cfg, P, batch[1], hs2, cs2)
+    assert maxerr(comb2, o_comb2) < 1e-4 and maxerr(st2_[1][0], oc2_) < 1e-4
+    for a, b in zip(reason2, o_reason2):
+        assert maxerr(a, b) < 1e-4
+    assert maxerr(comb2, o_comb) > 1e-3
     ids = torch.zeros(fc[0].size(0), dtype=torch.long, device=dev)
     logit, st2 = model.one_time_step(ids, fc, comb, st)
     o_logit, oh2, oc2 = O.one_time_step(cfg, P, P['embed.weight'][ids.cpu()], o_comb, oh, oc)
