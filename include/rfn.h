@@ -151,6 +151,13 @@ int rfn_attn_scores_bwd(const float* proj, int64_t proj_sb, int64_t proj_sl, con
                         int A, float* dproj, int64_t dproj_sb, int64_t dproj_sl,
                         int accumulate_dproj, float* dhproj, float* dw_part, void* stream);
 
+/* rfn_attn_context_bwd_dalpha + rfn_attn_scores_bwd in one launch, one block per batch row: dalpha never leaves
+ * the CU.  Results are bit-identical to the pair.  (d att_seq is not produced: stage-I features need no gradient.) */
+int rfn_attn_bwd(const float* proj, int64_t proj_sb, int64_t proj_sl, const float* hproj, const float* w_out,
+                 const float* alpha, const float* att_seq, int64_t sb, int64_t sl, const float* dz, int64_t lddz,
+                 int B, int L, int A, int D, float* dproj, int64_t dproj_sb, int64_t dproj_sl,
+                 int accumulate_dproj, float* dhproj, float* dw_part, void* stream);
+
 /* Fused small-L (L <= 1024; meant for a handful) attention of up to RFN_MAX_ENC encoders in one launch: scores + softmax + context
  * (forward) and dalpha + softmax/tanh backward + d att_seq (backward), one block per (batch row, encoder).
  * Used by stage II and the decoder, which attend over the T1 / T2 thought vectors.  Arrays are host arrays of

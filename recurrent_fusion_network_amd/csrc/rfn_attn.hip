@@ -309,11 +309,14 @@ extern "C" int rfn_attn_context_bwd_dseq(const float* alpha, const float* dz, in
 // the four waves' sums are combined through LDS in a fixed order (deterministic).
 #define SB_THREADS 1024
 #define SB_WAVES 16
-template <bool VEC>
+// FUSED: dalpha[l] = <dz, x[l]> is computed here first (into LDS, same per-row arithmetic as attn_dalpha_k), so the
+// context backward and the score backward of one (step, encoder) are a single launch: x is streamed, then P.
+template <bool VEC, bool FUSED>
 __global__ __launch_bounds__(SB_THREADS) void attn_scores_bwd_k(
     const float* proj /* may alias dproj */, long sb, long sl, const float* __restrict__ hproj,
     const float* __restrict__ w_out, const float* __restrict__ alpha, const float* __restrict__ dalpha, int L, int A,
-    float* dproj, long dsb, long dsl, int accumulate, float* __restrict__ dhproj, float* __restrict__ dw_part) {
+    float* dproj, long dsb, long dsl, int accumulate, float* __restrict__ dhproj, float* __restrict__ dw_part,
+    const float* __restrict__ x, long xsb, long xsl, const float* __restrict__ dz, long lddz, int D, int vec_x) {
     constexpr int W = VEC ? 4 : 1;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int Ap = (A + 3) & ~3;
@@ -328,9 +331,44 @@ __global__ __launch_bounds__(SB_THREADS) void attn_scores_bwd_k(
         hp_s[a] = hproj[(long)b * A + a];
         w_s[a] = w_out[a];
     }
+    const float* dal = dalpha + (long)b * L;
+    if constexpr (FUSED) {
+        const int Lp = (L + 3) & ~3;
+        float* dal_s = ds_s + Lp;                  // [Lp]
+        float* dz_s = dal_s + Lp;                  // [D]
+        for (int d = tid; d < D; d += SB_THREADS) dz_s[d] = dz[b * lddz + d];
+        __syncthreads();
+        for (int l0 = wave * 4; l0 < L; l0 += SB_WAVES * 4) {   // 4 rows per wave walked together, as attn_dalpha_k
+            const int nr = min(4, L - l0);
+            const float* p0 = x + b * xsb + (long)l0 * xsl;
+            float pt[4] = {0.f, 0.f, 0.f, 0.f};
+            if (vec_x) {
+#pragma unroll 2
+                for (int d = lane * 4; d < D; d += 256) {
+                    const f32x4 gv = *reinterpret_cast<const f32x4*>(dz_s + d);
+                    f32x4 xv[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) xv[r] = *reinterpret_cast<const f32x4*>(p0 + min(r, nr - 1) * xsl + d);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        pt[r] += xv[r][0] * gv[0] + xv[r][1] * gv[1] + xv[r][2] * gv[2] + xv[r][3] * gv[3];
+                }
+            } else {
+                for (int d = lane; d < D; d += 64)
+                    for (int r = 0; r < nr; ++r) pt[r] += p0[r * xsl + d] * dz_s[d];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float t = rfn_wave_sum(pt[r]);
+                if (lane == 0 && r < nr) dal_s[l0 + r] = t;
+            }
+        }
+        __syncthreads();
+        dal = dal_s;
+    }
     // softmax backward: ds = alpha * (dalpha - <alpha, dalpha>)
     float part = 0.f;
-    for (int l = tid; l < L; l += SB_THREADS) part += alpha[(long)b * L + l] * dalpha[(long)b * L + l];
+    for (int l = tid; l < L; l += SB_THREADS) part += alpha[(long)b * L + l] * dal[l];
     part = rfn_wave_sum(part);
     if (lane == 0) dot_s[wave] = part;
     __syncthreads();
@@ -338,7 +376,7 @@ __global__ __launch_bounds__(SB_THREADS) void attn_scores_bwd_k(
 #pragma unroll
     for (int w2 = 0; w2 < SB_WAVES; ++w2) dot += dot_s[w2];
     for (int l = tid; l < L; l += SB_THREADS)
-        ds_s[l] = alpha[(long)b * L + l] * (dalpha[(long)b * L + l] - dot);
+        ds_s[l] = alpha[(long)b * L + l] * (dal[l] - dot);
     __syncthreads();
 
     for (int a0 = 0; a0 < A; a0 += 64 * W) {
@@ -400,32 +438,57 @@ __global__ __launch_bounds__(SB_THREADS) void attn_scores_bwd_k(
     }
 }
 
+template <bool FUSED>
+static int launch_scores_bwd(const float* proj, int64_t proj_sb, int64_t proj_sl, const float* hproj,
+                             const float* w_out, const float* alpha, const float* dalpha, int B, int L, int A,
+                             float* dproj, int64_t dproj_sb, int64_t dproj_sl, int accumulate_dproj, float* dhproj,
+                             float* dw_part, const float* x, int64_t xsb, int64_t xsl, const float* dz, int64_t lddz,
+                             int D, hipStream_t st) {
+    if (B <= 0 || L <= 0 || A <= 0) return RFN_ERR_SHAPE;
+    if (!proj || !hproj || !w_out || !alpha || !dproj || !dhproj || !dw_part) return RFN_ERR_ARG;
+    size_t fl = (size_t)(2 + 2 * SB_WAVES) * ((A + 3) & ~3) + SB_WAVES + L;
+    if (FUSED) fl = (size_t)(2 + 2 * SB_WAVES) * ((A + 3) & ~3) + SB_WAVES + 2 * ((L + 3) & ~3) + ((D + 3) & ~3);
+    const size_t lds = fl * sizeof(float);
+    if (lds > 150 * 1024) return RFN_ERR_SHAPE;
+    const bool vec = (A % 4 == 0) && rfn_aligned16(proj) && rfn_aligned16(dproj) && (proj_sb % 4 == 0) &&
+                     (proj_sl % 4 == 0) && (dproj_sb % 4 == 0) && (dproj_sl % 4 == 0);
+    const int vec_x = FUSED && (D % 4 == 0) && rfn_aligned16(x) && (xsb % 4 == 0) && (xsl % 4 == 0);
+    if (vec) {
+        auto k = attn_scores_bwd_k<true, FUSED>;
+        if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k, dim3(B), dim3(SB_THREADS), lds, st, proj, (long)proj_sb, (long)proj_sl, hproj, w_out,
+                           alpha, dalpha, L, A, dproj, (long)dproj_sb, (long)dproj_sl, accumulate_dproj, dhproj,
+                           dw_part, x, (long)xsb, (long)xsl, dz, (long)lddz, D, vec_x);
+    } else {
+        auto k = attn_scores_bwd_k<false, FUSED>;
+        if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k, dim3(B), dim3(SB_THREADS), lds, st, proj, (long)proj_sb, (long)proj_sl, hproj, w_out,
+                           alpha, dalpha, L, A, dproj, (long)dproj_sb, (long)dproj_sl, accumulate_dproj, dhproj,
+                           dw_part, x, (long)xsb, (long)xsl, dz, (long)lddz, D, vec_x);
+    }
+    RFN_CHECK_LAUNCH();
+    return RFN_OK;
+}
+
 extern "C" int rfn_attn_scores_bwd(const float* proj, int64_t proj_sb, int64_t proj_sl, const float* hproj,
                                    const float* w_out, const float* alpha, const float* dalpha, int B, int L, int A,
                                    float* dproj, int64_t dproj_sb, int64_t dproj_sl, int accumulate_dproj,
                                    float* dhproj, float* dw_part, void* stream) {
-    if (B <= 0 || L <= 0 || A <= 0) return RFN_ERR_SHAPE;
-    if (!proj || !hproj || !w_out || !alpha || !dalpha || !dproj || !dhproj || !dw_part) return RFN_ERR_ARG;
-    const size_t lds = (size_t)((2 + 2 * SB_WAVES) * ((A + 3) & ~3) + SB_WAVES + L) * sizeof(float);
-    if (lds > 150 * 1024) return RFN_ERR_SHAPE;
-    const bool vec = (A % 4 == 0) && rfn_aligned16(proj) && rfn_aligned16(dproj) && (proj_sb % 4 == 0) &&
-                     (proj_sl % 4 == 0) && (dproj_sb % 4 == 0) && (dproj_sl % 4 == 0);
-    hipStream_t st = (hipStream_t)stream;
-    if (vec) {
-        auto k = attn_scores_bwd_k<true>;
-        if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k, dim3(B), dim3(SB_THREADS), lds, st, proj, (long)proj_sb, (long)proj_sl, hproj, w_out,
-                           alpha, dalpha, L, A, dproj, (long)dproj_sb, (long)dproj_sl, accumulate_dproj, dhproj,
-                           dw_part);
-    } else {
-        auto k = attn_scores_bwd_k<false>;
-        if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k, dim3(B), dim3(SB_THREADS), lds, st, proj, (long)proj_sb, (long)proj_sl, hproj, w_out,
-                           alpha, dalpha, L, A, dproj, (long)dproj_sb, (long)dproj_sl, accumulate_dproj, dhproj,
-                           dw_part);
-    }
-    RFN_CHECK_LAUNCH();
-    return RFN_OK;
+    if (!dalpha) return RFN_ERR_ARG;
+    return launch_scores_bwd<false>(proj, proj_sb, proj_sl, hproj, w_out, alpha, dalpha, B, L, A, dproj, dproj_sb,
+                                    dproj_sl, accumulate_dproj, dhproj, dw_part, nullptr, 0, 0, nullptr, 0, 0,
+                                    (hipStream_t)stream);
+}
+
+// rfn_attn_context_bwd_dalpha + rfn_attn_scores_bwd in one launch (dalpha stays in LDS); bit-identical to the pair.
+extern "C" int rfn_attn_bwd(const float* proj, int64_t proj_sb, int64_t proj_sl, const float* hproj, const float* w_out,
+                            const float* alpha, const float* att_seq, int64_t sb, int64_t sl, const float* dz,
+                            int64_t lddz, int B, int L, int A, int D, float* dproj, int64_t dproj_sb, int64_t dproj_sl,
+                            int accumulate_dproj, float* dhproj, float* dw_part, void* stream) {
+    if (!att_seq || !dz || D <= 0) return RFN_ERR_ARG;
+    return launch_scores_bwd<true>(proj, proj_sb, proj_sl, hproj, w_out, alpha, alpha /* unused */, B, L, A, dproj,
+                                   dproj_sb, dproj_sl, accumulate_dproj, dhproj, dw_part, att_seq, sb, sl, dz, lddz, D,
+                                   (hipStream_t)stream);
 }
 
 // =====================================================================================================

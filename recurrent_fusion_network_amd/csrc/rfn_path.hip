@@ -174,6 +174,7 @@ struct Bump {
 };
 
 const size_t GEMM_WS_FLOATS = (size_t)12 << 20;  // 48 MiB of split-K partial tiles
+const int FUSED_ATTN_BWD_MIN_B = 96;   // below this the (L/64, B) grid of the split dalpha kernel fills the chip better
 const size_t STEP_GEMM_WS_FLOATS = (size_t)8 << 20;  // 32 MiB for the free-running decoder step (rows = B * beam)
 
 struct PrefixLayout {
@@ -734,11 +735,18 @@ extern "C" int rfn_prefix_bwd(const rfn_dims* d, int B, const float* const* prm,
             if (!(same_d && M > 1))
                 RFN_TRY(gemm1(B, (int)Di, seg_dx(g + (long)i * B * 4 * R, 4 * R, prm[P.s1(t, i, 8)], Di, 4 * R), dz, Di, 0, gx));
             float* dali = dal + (long)i * B * Li;
-            RFN_TRY(rfn_attn_context_bwd_dalpha(att[i], Li * Di, Di, dz, Di, B, (int)Li, (int)Di, dali, st));
             float* p1 = W + Lo.P1[i] + (long)t * A;
-            RFN_TRY(rfn_attn_scores_bwd(p1, Li * T1 * A, (long)T1 * A, hp + i * BA, prm[P.s1(t, i, 4)],
-                                        W + Lo.al1[i] + (long)t * B * Li, dali, B, (int)Li, A, p1, Li * T1 * A,
-                                        (long)T1 * A, 0, dhp + i * BA, dwp + ((long)t * M + i) * BA, st));
+            if (B >= FUSED_ATTN_BWD_MIN_B) {   // one block per row fills the chip: dalpha stays in LDS, one launch
+                RFN_TRY(rfn_attn_bwd(p1, Li * T1 * A, (long)T1 * A, hp + i * BA, prm[P.s1(t, i, 4)],
+                                     W + Lo.al1[i] + (long)t * B * Li, att[i], Li * Di, Di, dz, Di, B, (int)Li, A,
+                                     (int)Di, p1, Li * T1 * A, (long)T1 * A, 0, dhp + i * BA,
+                                     dwp + ((long)t * M + i) * BA, st));
+            } else {
+                RFN_TRY(rfn_attn_context_bwd_dalpha(att[i], Li * Di, Di, dz, Di, B, (int)Li, (int)Di, dali, st));
+                RFN_TRY(rfn_attn_scores_bwd(p1, Li * T1 * A, (long)T1 * A, hp + i * BA, prm[P.s1(t, i, 4)],
+                                            W + Lo.al1[i] + (long)t * B * Li, dali, B, (int)Li, A, p1, Li * T1 * A,
+                                            (long)T1 * A, 0, dhp + i * BA, dwp + ((long)t * M + i) * BA, st));
+            }
             pr[i] = prob1(dHc + i * R, MR, seg_dx(dhp + i * BA, A, prm[P.s1(t, i, 2)], R, A));
         }
         RFN_TRY(gemm_groups(B, R, M, pr, 1, gx));

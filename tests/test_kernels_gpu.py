@@ -239,6 +239,17 @@ def test_attention_forward_backward(dev, B, L, A, D):
     assert maxerr(dproj, pr.grad) < 2e-5
     assert maxerr(dhp, hr.grad) < 1e-4
     assert maxerr(dwp.sum(0), wr.grad) < 1e-4 * max(1.0, float(wr.grad.abs().max()))
+    # the one-launch form (dalpha kept in LDS) gives the same bits, in place too
+    dproj_f, dhp_f, dwp_f = torch.empty(B, L, A, device=dev), torch.empty(B, A, device=dev), torch.empty(B, A, device=dev)
+    n.check(n.lib.rfn_attn_bwd(projd.data_ptr(), L * A, A, hpd.data_ptr(), wd.data_ptr(), alpha.data_ptr(),
+                               xd.data_ptr(), L * D, D, dzd.data_ptr(), D, B, L, A, D, dproj_f.data_ptr(), L * A, A, 0,
+                               dhp_f.data_ptr(), dwp_f.data_ptr(), st))
+    assert torch.equal(dproj_f, dproj) and torch.equal(dhp_f, dhp) and torch.equal(dwp_f, dwp)
+    inpl_f = projd.clone()
+    n.check(n.lib.rfn_attn_bwd(inpl_f.data_ptr(), L * A, A, hpd.data_ptr(), wd.data_ptr(), alpha.data_ptr(),
+                               xd.data_ptr(), L * D, D, dzd.data_ptr(), D, B, L, A, D, inpl_f.data_ptr(), L * A, A, 0,
+                               dhp_f.data_ptr(), dwp_f.data_ptr(), st))
+    assert torch.equal(inpl_f, dproj)
     # d att_seq through the context path only (the projection path is a GEMM)
     dx = torch.zeros(B, L, D, device=dev)
     n.check(n.lib.rfn_attn_context_bwd_dseq(alpha.data_ptr(), dzd.data_ptr(), D, B, L, D, dx.data_ptr(), L * D, D, st))

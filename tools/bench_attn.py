@@ -52,8 +52,19 @@ def main():
                                        al.data_ptr(), dal.data_ptr(), B, L, A, proj[i].data_ptr(), L * T1 * A, T1 * A,
                                        0, dhp.data_ptr(), dwp.data_ptr(), st))
 
+    def fused_bwd(i):
+        n.check(L_.rfn_attn_bwd(proj[i].data_ptr(), L * T1 * A, T1 * A, hp.data_ptr(), w.data_ptr(), al.data_ptr(),
+                                x[i].data_ptr(), L * D, D, dz.data_ptr(), D, B, L, A, D, proj[i].data_ptr(),
+                                L * T1 * A, T1 * A, 0, dhp.data_ptr(), dwp.data_ptr(), st))
+
+    def split_bwd(i):
+        dalpha(i)
+        scores_bwd(i)
+
     cases = [('scores_fwd (raw+softmax)', scores, B * L * A * 4), ('context_fwd', context, B * L * D * 4),
-             ('dalpha', dalpha, B * L * D * 4), ('scores_bwd (in place)', scores_bwd, 2 * B * L * A * 4)]
+             ('dalpha', dalpha, B * L * D * 4), ('scores_bwd (in place)', scores_bwd, 2 * B * L * A * 4),
+             ('dalpha + scores_bwd (2 launches)', split_bwd, B * L * D * 4 + 2 * B * L * A * 4),
+             ('rfn_attn_bwd (fused)', fused_bwd, B * L * D * 4 + 2 * B * L * A * 4)]
     for name, fn, nbytes in cases:
         for i in range(M):
             fn(i)
@@ -65,7 +76,7 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / a.reps
-        print(f'{name:28s} {us:8.1f} us   {nbytes / us / 1e3:8.1f} GB/s  ({nbytes / 1e6:.0f} MB algorithmic)')
+        print(f'{name:34s} {us:8.1f} us   {nbytes / us / 1e3:8.1f} GB/s  ({nbytes / 1e6:.0f} MB algorithmic)')
 
 
 if __name__ == '__main__':
