@@ -131,6 +131,7 @@ def main():
     ap.add_argument('--workload', default='c3', choices=sorted(WORKLOADS))
     ap.add_argument('--batch', type=int, default=0, help='captions per GPU (default: the workload value)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--label-smoothing', action='store_true', help='XE criterion with label smoothing 0.1 (SURVEY 8d)')
     ap.add_argument('--cpu-sample', type=int, default=0,
                     help='captions in the CPU-baseline sample (0: sized for ~15 s of CPU work from a B=8 probe)')
     args = ap.parse_args()
@@ -150,6 +151,7 @@ def main():
     w = dict(WORKLOADS[args.workload])
     B = args.batch or w['B']
     cfg = make_cfg(w)
+    cfg.use_label_smoothing = int(args.label_smoothing)
     torch.manual_seed(100 + rank)            # opts.py:178 default seed, + rank (train.py:23)
 
     model = R.RecurrentFusionModel(cfg).to(dev)
