@@ -136,6 +136,13 @@ int rfn_attn_context_fwd(const float* att_seq, int64_t sb, int64_t sl, const flo
 int rfn_attn_fwd(const float* proj, int64_t proj_sb, int64_t proj_sl, const float* hproj, const float* w_out,
                  const float* b_out, const float* att_seq, int64_t sb, int64_t sl, int B, int L, int A, int D,
                  float* scores_scratch, float* alpha, float* z, int64_t ldz, void* stream);
+/* The same for `ngroups` encoders that share (L, A, D) and every stride, two launches in total; arrays are host
+ * arrays of device pointers, one entry per encoder. */
+int rfn_attn_fwd_grouped(int ngroups, const float* const* proj, int64_t proj_sb, int64_t proj_sl,
+                         const float* const* hproj, const float* const* w_out, const float* const* b_out,
+                         const float* const* att_seq, int64_t sb, int64_t sl, int B, int L, int A, int D,
+                         float* const* scores_scratch, float* const* alpha, float* const* z, int64_t ldz,
+                         void* stream);
 /* dalpha[b,l] = <dz[b,:], att_seq[b,l,:]> */
 int rfn_attn_context_bwd_dalpha(const float* att_seq, int64_t sb, int64_t sl, const float* dz,
                                 int64_t lddz, int B, int L, int D, float* dalpha, void* stream);
@@ -157,6 +164,12 @@ int rfn_attn_bwd(const float* proj, int64_t proj_sb, int64_t proj_sl, const floa
                  const float* alpha, const float* att_seq, int64_t sb, int64_t sl, const float* dz, int64_t lddz,
                  int B, int L, int A, int D, float* dproj, int64_t dproj_sb, int64_t dproj_sl,
                  int accumulate_dproj, float* dhproj, float* dw_part, void* stream);
+
+int rfn_attn_bwd_grouped(int ngroups, const float* const* proj, int64_t proj_sb, int64_t proj_sl,
+                         const float* const* hproj, const float* const* w_out, const float* const* alpha,
+                         const float* const* att_seq, int64_t sb, int64_t sl, const float* const* dz, int64_t lddz,
+                         int B, int L, int A, int D, float* const* dproj, int64_t dproj_sb, int64_t dproj_sl,
+                         int accumulate_dproj, float* const* dhproj, float* const* dw_part, void* stream);
 
 /* Fused small-L (L <= 1024; meant for a handful) attention of up to RFN_MAX_ENC encoders in one launch: scores + softmax + context
  * (forward) and dalpha + softmax/tanh backward + d att_seq (backward), one block per (batch row, encoder).

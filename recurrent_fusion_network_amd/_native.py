@@ -69,6 +69,8 @@ def _load():
         'rfn_attn_scores_bwd': (C.c_int, [P, L, L, P, P, P, P, I, I, I, P, L, L, I, P, P, P]),
         'rfn_attn_fwd': (C.c_int, [P, L, L, P, P, P, P, L, L, I, I, I, I, P, P, P, L, P]),
         'rfn_attn_bwd': (C.c_int, [P, L, L, P, P, P, P, L, L, P, L, I, I, I, I, P, L, L, I, P, P, P]),
+        'rfn_attn_fwd_grouped': (C.c_int, [I, P, L, L, P, P, P, P, L, L, I, I, I, I, P, P, P, L, P]),
+        'rfn_attn_bwd_grouped': (C.c_int, [I, P, L, L, P, P, P, P, L, L, P, L, I, I, I, I, P, L, L, I, P, P, P]),
         'rfn_attn_small_fwd': (C.c_int, [I, P, L, L, P, P, P, P, L, L, I, I, I, I, P, P, L, P]),
         'rfn_attn_small_bwd': (C.c_int, [I, P, L, L, P, P, P, P, L, L, P, L, I, I, I, I, P, L, L, I, P, P, P, P]),
         'rfn_lstm_fwd': (C.c_int, [P, L, P, L, P, L, P, L, I, I, I, F, U64, U64, P]),

@@ -41,12 +41,31 @@ __device__ __forceinline__ float row_tanh_dot(const float* __restrict__ p, const
 // Raw scores s[b,l] on a (L-chunk, batch) grid: 16 rows per block, 4 per wave, so B*ceil(L/16) blocks keep every
 // CU full of independent row streams (one block per batch row left 4 waves per CU waiting on their own loads).
 #define SC_ROWS 16
+// Per-encoder pointers of one grouped launch (blockIdx.z = encoder); encoders share every stride and (L, A, D).
+struct AttnEncPtrs {
+    const float* proj[RFN_MAX_ENC];
+    const float* hproj[RFN_MAX_ENC];
+    const float* w_out[RFN_MAX_ENC];
+    const float* b_out[RFN_MAX_ENC];
+    const float* x[RFN_MAX_ENC];
+    const float* alpha_in[RFN_MAX_ENC];   // raw scores (forward) / alpha (backward)
+    const float* dalpha[RFN_MAX_ENC];
+    const float* dz[RFN_MAX_ENC];
+    float* scores[RFN_MAX_ENC];
+    float* alpha_out[RFN_MAX_ENC];
+    float* z[RFN_MAX_ENC];
+    float* dproj[RFN_MAX_ENC];
+    float* dhproj[RFN_MAX_ENC];
+    float* dw_part[RFN_MAX_ENC];
+};
+
 template <bool VEC>
-__global__ __launch_bounds__(ATT_THREADS) void attn_scores_raw_k(const float* __restrict__ proj, long sb, long sl,
-                                                                const float* __restrict__ hproj,
-                                                                const float* __restrict__ w_out,
-                                                                const float* __restrict__ b_out, int L, int A,
-                                                                float* __restrict__ scores) {
+__global__ __launch_bounds__(ATT_THREADS) void attn_scores_raw_k(const AttnEncPtrs E, long sb, long sl, int L, int A) {
+    const float* __restrict__ proj = E.proj[blockIdx.z];
+    const float* __restrict__ hproj = E.hproj[blockIdx.z];
+    const float* __restrict__ w_out = E.w_out[blockIdx.z];
+    const float* __restrict__ b_out = E.b_out[blockIdx.z];
+    float* __restrict__ scores = E.scores[blockIdx.z];
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int Ap = (A + 3) & ~3;
     float* hp_s = sm;
@@ -107,10 +126,12 @@ extern "C" int rfn_attn_scores_fwd(const float* proj, int64_t proj_sb, int64_t p
 // same reduction order as attn_softmax_k so the weights are bit-identical) and the first block publishes them
 // to alpha_out -- the separate softmax launch of the split path disappears.
 template <bool VEC, bool SOFTMAX>
-__global__ __launch_bounds__(ATT_THREADS) void attn_context_fwd_k(const float* __restrict__ x, long sb, long sl,
-                                                                 const float* __restrict__ alpha, int L, int D,
-                                                                 float* __restrict__ z, long ldz,
-                                                                 float* __restrict__ alpha_out) {
+__global__ __launch_bounds__(ATT_THREADS) void attn_context_fwd_k(const AttnEncPtrs E, long sb, long sl, int L, int D,
+                                                                 long ldz) {
+    const float* __restrict__ x = E.x[blockIdx.z];
+    const float* __restrict__ alpha = E.alpha_in[blockIdx.z];
+    float* __restrict__ z = E.z[blockIdx.z];
+    float* __restrict__ alpha_out = E.alpha_out[blockIdx.z];
     extern __shared__ __attribute__((aligned(16))) float al_s[];
     const int b = blockIdx.y, tid = threadIdx.x;
     for (int l = tid; l < L; l += ATT_THREADS) al_s[l] = alpha[(long)b * L + l];
@@ -165,57 +186,100 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_context_fwd_k(const float* _
 }
 
 template <bool SOFTMAX>
-static int launch_context(const float* att_seq, int64_t sb, int64_t sl, const float* alpha, int B, int L, int D,
-                          float* z, int64_t ldz, float* alpha_out, hipStream_t st) {
-    if (B <= 0 || L <= 0 || D <= 0) return RFN_ERR_SHAPE;
-    if (!att_seq || !alpha || !z) return RFN_ERR_ARG;
+static int launch_context(int ng, const AttnEncPtrs& E, int64_t sb, int64_t sl, int B, int L, int D, int64_t ldz,
+                          hipStream_t st) {
+    if (B <= 0 || L <= 0 || D <= 0 || ng < 1 || ng > RFN_MAX_ENC) return RFN_ERR_SHAPE;
     if ((size_t)L * sizeof(float) > 64 * 1024) return RFN_ERR_SHAPE;
-    const bool vec = (D % 4 == 0) && rfn_aligned16(att_seq) && rfn_aligned16(z) && (sb % 4 == 0) && (sl % 4 == 0) &&
-                     (ldz % 4 == 0);
+    bool vec = (D % 4 == 0) && (sb % 4 == 0) && (sl % 4 == 0) && (ldz % 4 == 0);
+    for (int g = 0; g < ng; ++g) {
+        if (!E.x[g] || !E.alpha_in[g] || !E.z[g] || (SOFTMAX && !E.alpha_out[g])) return RFN_ERR_ARG;
+        vec = vec && rfn_aligned16(E.x[g]) && rfn_aligned16(E.z[g]);
+    }
     if (vec)
-        hipLaunchKernelGGL((attn_context_fwd_k<true, SOFTMAX>), dim3(rfn_cdiv(D, 4 * ATT_THREADS), B),
-                           dim3(ATT_THREADS), L * sizeof(float), st, att_seq, (long)sb, (long)sl, alpha, L, D, z,
-                           (long)ldz, alpha_out);
+        hipLaunchKernelGGL((attn_context_fwd_k<true, SOFTMAX>), dim3(rfn_cdiv(D, 4 * ATT_THREADS), B, ng),
+                           dim3(ATT_THREADS), L * sizeof(float), st, E, (long)sb, (long)sl, L, D, (long)ldz);
     else
-        hipLaunchKernelGGL((attn_context_fwd_k<false, SOFTMAX>), dim3(rfn_cdiv(D, ATT_THREADS), B), dim3(ATT_THREADS),
-                           L * sizeof(float), st, att_seq, (long)sb, (long)sl, alpha, L, D, z, (long)ldz, alpha_out);
+        hipLaunchKernelGGL((attn_context_fwd_k<false, SOFTMAX>), dim3(rfn_cdiv(D, ATT_THREADS), B, ng),
+                           dim3(ATT_THREADS), L * sizeof(float), st, E, (long)sb, (long)sl, L, D, (long)ldz);
     RFN_CHECK_LAUNCH();
     return RFN_OK;
 }
 
 extern "C" int rfn_attn_context_fwd(const float* att_seq, int64_t sb, int64_t sl, const float* alpha, int B, int L,
                                     int D, float* z, int64_t ldz, void* stream) {
-    return launch_context<false>(att_seq, sb, sl, alpha, B, L, D, z, ldz, nullptr, (hipStream_t)stream);
+    AttnEncPtrs E;
+    memset(&E, 0, sizeof(E));
+    E.x[0] = att_seq;
+    E.alpha_in[0] = alpha;
+    E.z[0] = z;
+    return launch_context<false>(1, E, sb, sl, B, L, D, ldz, (hipStream_t)stream);
 }
 
-static int launch_scores_raw(const float* proj, int64_t proj_sb, int64_t proj_sl, const float* hproj,
-                             const float* w_out, const float* b_out, int B, int L, int A, float* scores,
-                             hipStream_t st) {
-    if (B <= 0 || L <= 0 || A <= 0) return RFN_ERR_SHAPE;
-    if (!proj || !hproj || !w_out || !scores) return RFN_ERR_ARG;
+static int launch_scores_raw_g(int ng, const AttnEncPtrs& E, int64_t proj_sb, int64_t proj_sl, int B, int L, int A,
+                               hipStream_t st) {
+    if (B <= 0 || L <= 0 || A <= 0 || ng < 1 || ng > RFN_MAX_ENC) return RFN_ERR_SHAPE;
     const size_t lds = (2 * ((A + 3) & ~3)) * sizeof(float);
     if (lds > 64 * 1024) return RFN_ERR_SHAPE;
-    const bool vec = (A % 4 == 0) && rfn_aligned16(proj) && (proj_sb % 4 == 0) && (proj_sl % 4 == 0);
-    dim3 grid(rfn_cdiv(L, SC_ROWS), B);
+    bool vec = (A % 4 == 0) && (proj_sb % 4 == 0) && (proj_sl % 4 == 0);
+    for (int g = 0; g < ng; ++g) {
+        if (!E.proj[g] || !E.hproj[g] || !E.w_out[g] || !E.scores[g]) return RFN_ERR_ARG;
+        vec = vec && rfn_aligned16(E.proj[g]);
+    }
+    dim3 grid(rfn_cdiv(L, SC_ROWS), B, ng);
     if (vec)
-        hipLaunchKernelGGL(attn_scores_raw_k<true>, grid, dim3(ATT_THREADS), lds, st, proj, (long)proj_sb,
-                           (long)proj_sl, hproj, w_out, b_out, L, A, scores);
+        hipLaunchKernelGGL(attn_scores_raw_k<true>, grid, dim3(ATT_THREADS), lds, st, E, (long)proj_sb, (long)proj_sl, L,
+                           A);
     else
-        hipLaunchKernelGGL(attn_scores_raw_k<false>, grid, dim3(ATT_THREADS), lds, st, proj, (long)proj_sb,
-                           (long)proj_sl, hproj, w_out, b_out, L, A, scores);
+        hipLaunchKernelGGL(attn_scores_raw_k<false>, grid, dim3(ATT_THREADS), lds, st, E, (long)proj_sb, (long)proj_sl,
+                           L, A);
     RFN_CHECK_LAUNCH();
     return RFN_OK;
 }
+static int launch_scores_raw(const float* proj, int64_t proj_sb, int64_t proj_sl, const float* hproj,
+                             const float* w_out, const float* b_out, int B, int L, int A, float* scores,
+                             hipStream_t st) {
+    AttnEncPtrs E;
+    memset(&E, 0, sizeof(E));
+    E.proj[0] = proj;
+    E.hproj[0] = hproj;
+    E.w_out[0] = w_out;
+    E.b_out[0] = b_out;
+    E.scores[0] = scores;
+    return launch_scores_raw_g(1, E, proj_sb, proj_sl, B, L, A, st);
+}
 
-// AttentionModelCore.forward in two launches: raw scores, then softmax + context (see attn_context_fwd_k).
+// AttentionModelCore.forward of `ngroups` encoders that share (L, A, D) and strides, in two launches: raw scores,
+// then softmax + context (see attn_context_fwd_k).  Arrays: host arrays of device pointers, one entry per encoder.
+extern "C" int rfn_attn_fwd_grouped(int ngroups, const float* const* proj, int64_t proj_sb, int64_t proj_sl,
+                                    const float* const* hproj, const float* const* w_out, const float* const* b_out,
+                                    const float* const* att_seq, int64_t sb, int64_t sl, int B, int L, int A, int D,
+                                    float* const* scores_scratch, float* const* alpha, float* const* z, int64_t ldz,
+                                    void* stream) {
+    if (ngroups < 1 || ngroups > RFN_MAX_ENC) return RFN_ERR_SHAPE;
+    if (!proj || !hproj || !w_out || !att_seq || !scores_scratch || !alpha || !z) return RFN_ERR_ARG;
+    AttnEncPtrs E;
+    memset(&E, 0, sizeof(E));
+    for (int g = 0; g < ngroups; ++g) {
+        if (!scores_scratch[g] || !alpha[g] || scores_scratch[g] == alpha[g]) return RFN_ERR_ARG;
+        E.proj[g] = proj[g];
+        E.hproj[g] = hproj[g];
+        E.w_out[g] = w_out[g];
+        E.b_out[g] = b_out ? b_out[g] : nullptr;
+        E.scores[g] = scores_scratch[g];
+        E.x[g] = att_seq[g];
+        E.alpha_in[g] = scores_scratch[g];
+        E.alpha_out[g] = alpha[g];
+        E.z[g] = z[g];
+    }
+    RFN_TRY(launch_scores_raw_g(ngroups, E, proj_sb, proj_sl, B, L, A, (hipStream_t)stream));
+    return launch_context<true>(ngroups, E, sb, sl, B, L, D, ldz, (hipStream_t)stream);
+}
 extern "C" int rfn_attn_fwd(const float* proj, int64_t proj_sb, int64_t proj_sl, const float* hproj,
                             const float* w_out, const float* b_out, const float* att_seq, int64_t sb, int64_t sl,
                             int B, int L, int A, int D, float* scores_scratch, float* alpha, float* z, int64_t ldz,
                             void* stream) {
-    if (!scores_scratch || !alpha || scores_scratch == alpha) return RFN_ERR_ARG;
-    RFN_TRY(launch_scores_raw(proj, proj_sb, proj_sl, hproj, w_out, b_out, B, L, A, scores_scratch,
-                              (hipStream_t)stream));
-    return launch_context<true>(att_seq, sb, sl, scores_scratch, B, L, D, z, ldz, alpha, (hipStream_t)stream);
+    return rfn_attn_fwd_grouped(1, &proj, proj_sb, proj_sl, &hproj, &w_out, &b_out, &att_seq, sb, sl, B, L, A, D,
+                                &scores_scratch, &alpha, &z, ldz, stream);
 }
 
 // ---- backward of the context: dalpha[b,l] = <dz[b,:], x[b,l,:]> ---------------------------------
@@ -312,11 +376,19 @@ extern "C" int rfn_attn_context_bwd_dseq(const float* alpha, const float* dz, in
 // FUSED: dalpha[l] = <dz, x[l]> is computed here first (into LDS, same per-row arithmetic as attn_dalpha_k), so the
 // context backward and the score backward of one (step, encoder) are a single launch: x is streamed, then P.
 template <bool VEC, bool FUSED>
-__global__ __launch_bounds__(SB_THREADS) void attn_scores_bwd_k(
-    const float* proj /* may alias dproj */, long sb, long sl, const float* __restrict__ hproj,
-    const float* __restrict__ w_out, const float* __restrict__ alpha, const float* __restrict__ dalpha, int L, int A,
-    float* dproj, long dsb, long dsl, int accumulate, float* __restrict__ dhproj, float* __restrict__ dw_part,
-    const float* __restrict__ x, long xsb, long xsl, const float* __restrict__ dz, long lddz, int D, int vec_x) {
+__global__ __launch_bounds__(SB_THREADS) void attn_scores_bwd_k(const AttnEncPtrs E, long sb, long sl, int L, int A,
+                                                               long dsb, long dsl, int accumulate, long xsb, long xsl,
+                                                               long lddz, int D, int vec_x) {
+    const float* proj = E.proj[blockIdx.y];   // may alias dproj
+    const float* __restrict__ hproj = E.hproj[blockIdx.y];
+    const float* __restrict__ w_out = E.w_out[blockIdx.y];
+    const float* __restrict__ alpha = E.alpha_in[blockIdx.y];
+    const float* __restrict__ dalpha = E.dalpha[blockIdx.y];
+    float* dproj = E.dproj[blockIdx.y];
+    float* __restrict__ dhproj = E.dhproj[blockIdx.y];
+    float* __restrict__ dw_part = E.dw_part[blockIdx.y];
+    const float* __restrict__ x = E.x[blockIdx.y];
+    const float* __restrict__ dz = E.dz[blockIdx.y];
     constexpr int W = VEC ? 4 : 1;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int Ap = (A + 3) & ~3;
@@ -439,32 +511,35 @@ __global__ __launch_bounds__(SB_THREADS) void attn_scores_bwd_k(
 }
 
 template <bool FUSED>
-static int launch_scores_bwd(const float* proj, int64_t proj_sb, int64_t proj_sl, const float* hproj,
-                             const float* w_out, const float* alpha, const float* dalpha, int B, int L, int A,
-                             float* dproj, int64_t dproj_sb, int64_t dproj_sl, int accumulate_dproj, float* dhproj,
-                             float* dw_part, const float* x, int64_t xsb, int64_t xsl, const float* dz, int64_t lddz,
-                             int D, hipStream_t st) {
-    if (B <= 0 || L <= 0 || A <= 0) return RFN_ERR_SHAPE;
-    if (!proj || !hproj || !w_out || !alpha || !dproj || !dhproj || !dw_part) return RFN_ERR_ARG;
+static int launch_scores_bwd(int ng, const AttnEncPtrs& E, int64_t proj_sb, int64_t proj_sl, int B, int L, int A,
+                             int64_t dproj_sb, int64_t dproj_sl, int accumulate_dproj, int64_t xsb, int64_t xsl,
+                             int64_t lddz, int D, hipStream_t st) {
+    if (B <= 0 || L <= 0 || A <= 0 || ng < 1 || ng > RFN_MAX_ENC) return RFN_ERR_SHAPE;
     size_t fl = (size_t)(2 + 2 * SB_WAVES) * ((A + 3) & ~3) + SB_WAVES + L;
     if (FUSED) fl = (size_t)(2 + 2 * SB_WAVES) * ((A + 3) & ~3) + SB_WAVES + 2 * ((L + 3) & ~3) + ((D + 3) & ~3);
     const size_t lds = fl * sizeof(float);
     if (lds > 150 * 1024) return RFN_ERR_SHAPE;
-    const bool vec = (A % 4 == 0) && rfn_aligned16(proj) && rfn_aligned16(dproj) && (proj_sb % 4 == 0) &&
-                     (proj_sl % 4 == 0) && (dproj_sb % 4 == 0) && (dproj_sl % 4 == 0);
-    const int vec_x = FUSED && (D % 4 == 0) && rfn_aligned16(x) && (xsb % 4 == 0) && (xsl % 4 == 0);
+    bool vec = (A % 4 == 0) && (proj_sb % 4 == 0) && (proj_sl % 4 == 0) && (dproj_sb % 4 == 0) && (dproj_sl % 4 == 0);
+    bool vx = FUSED && (D % 4 == 0) && (xsb % 4 == 0) && (xsl % 4 == 0);
+    for (int g = 0; g < ng; ++g) {
+        if (!E.proj[g] || !E.hproj[g] || !E.w_out[g] || !E.alpha_in[g] || !E.dproj[g] || !E.dhproj[g] || !E.dw_part[g])
+            return RFN_ERR_ARG;
+        if (FUSED ? (!E.x[g] || !E.dz[g]) : !E.dalpha[g]) return RFN_ERR_ARG;
+        vec = vec && rfn_aligned16(E.proj[g]) && rfn_aligned16(E.dproj[g]);
+        vx = vx && rfn_aligned16(E.x[g]);
+    }
     if (vec) {
         auto k = attn_scores_bwd_k<true, FUSED>;
         if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k, dim3(B), dim3(SB_THREADS), lds, st, proj, (long)proj_sb, (long)proj_sl, hproj, w_out,
-                           alpha, dalpha, L, A, dproj, (long)dproj_sb, (long)dproj_sl, accumulate_dproj, dhproj,
-                           dw_part, x, (long)xsb, (long)xsl, dz, (long)lddz, D, vec_x);
+        hipLaunchKernelGGL(k, dim3(B, ng), dim3(SB_THREADS), lds, st, E, (long)proj_sb, (long)proj_sl, L, A,
+                           (long)dproj_sb, (long)dproj_sl, accumulate_dproj, (long)xsb, (long)xsl, (long)lddz, D,
+                           (int)vx);
     } else {
         auto k = attn_scores_bwd_k<false, FUSED>;
         if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k, dim3(B), dim3(SB_THREADS), lds, st, proj, (long)proj_sb, (long)proj_sl, hproj, w_out,
-                           alpha, dalpha, L, A, dproj, (long)dproj_sb, (long)dproj_sl, accumulate_dproj, dhproj,
-                           dw_part, x, (long)xsb, (long)xsl, dz, (long)lddz, D, vec_x);
+        hipLaunchKernelGGL(k, dim3(B, ng), dim3(SB_THREADS), lds, st, E, (long)proj_sb, (long)proj_sl, L, A,
+                           (long)dproj_sb, (long)dproj_sl, accumulate_dproj, (long)xsb, (long)xsl, (long)lddz, D,
+                           (int)vx);
     }
     RFN_CHECK_LAUNCH();
     return RFN_OK;
@@ -474,21 +549,40 @@ extern "C" int rfn_attn_scores_bwd(const float* proj, int64_t proj_sb, int64_t p
                                    const float* w_out, const float* alpha, const float* dalpha, int B, int L, int A,
                                    float* dproj, int64_t dproj_sb, int64_t dproj_sl, int accumulate_dproj,
                                    float* dhproj, float* dw_part, void* stream) {
-    if (!dalpha) return RFN_ERR_ARG;
-    return launch_scores_bwd<false>(proj, proj_sb, proj_sl, hproj, w_out, alpha, dalpha, B, L, A, dproj, dproj_sb,
-                                    dproj_sl, accumulate_dproj, dhproj, dw_part, nullptr, 0, 0, nullptr, 0, 0,
+    AttnEncPtrs E;
+    memset(&E, 0, sizeof(E));
+    E.proj[0] = proj; E.hproj[0] = hproj; E.w_out[0] = w_out; E.alpha_in[0] = alpha; E.dalpha[0] = dalpha;
+    E.dproj[0] = dproj; E.dhproj[0] = dhproj; E.dw_part[0] = dw_part;
+    return launch_scores_bwd<false>(1, E, proj_sb, proj_sl, B, L, A, dproj_sb, dproj_sl, accumulate_dproj, 0, 0, 0, 0,
                                     (hipStream_t)stream);
 }
 
-// rfn_attn_context_bwd_dalpha + rfn_attn_scores_bwd in one launch (dalpha stays in LDS); bit-identical to the pair.
+// rfn_attn_context_bwd_dalpha + rfn_attn_scores_bwd of `ngroups` encoders (shared (L, A, D) and strides) in one
+// launch: dalpha stays in LDS; bit-identical to the pairs.
+extern "C" int rfn_attn_bwd_grouped(int ngroups, const float* const* proj, int64_t proj_sb, int64_t proj_sl,
+                                    const float* const* hproj, const float* const* w_out, const float* const* alpha,
+                                    const float* const* att_seq, int64_t sb, int64_t sl, const float* const* dz,
+                                    int64_t lddz, int B, int L, int A, int D, float* const* dproj, int64_t dproj_sb,
+                                    int64_t dproj_sl, int accumulate_dproj, float* const* dhproj,
+                                    float* const* dw_part, void* stream) {
+    if (ngroups < 1 || ngroups > RFN_MAX_ENC || D <= 0) return RFN_ERR_SHAPE;
+    if (!proj || !hproj || !w_out || !alpha || !att_seq || !dz || !dproj || !dhproj || !dw_part) return RFN_ERR_ARG;
+    AttnEncPtrs E;
+    memset(&E, 0, sizeof(E));
+    for (int g = 0; g < ngroups; ++g) {
+        E.proj[g] = proj[g]; E.hproj[g] = hproj[g]; E.w_out[g] = w_out[g]; E.alpha_in[g] = alpha[g];
+        E.x[g] = att_seq[g]; E.dz[g] = dz[g];
+        E.dproj[g] = dproj[g]; E.dhproj[g] = dhproj[g]; E.dw_part[g] = dw_part[g];
+    }
+    return launch_scores_bwd<true>(ngroups, E, proj_sb, proj_sl, B, L, A, dproj_sb, dproj_sl, accumulate_dproj, sb, sl,
+                                   lddz, D, (hipStream_t)stream);
+}
 extern "C" int rfn_attn_bwd(const float* proj, int64_t proj_sb, int64_t proj_sl, const float* hproj, const float* w_out,
                             const float* alpha, const float* att_seq, int64_t sb, int64_t sl, const float* dz,
                             int64_t lddz, int B, int L, int A, int D, float* dproj, int64_t dproj_sb, int64_t dproj_sl,
                             int accumulate_dproj, float* dhproj, float* dw_part, void* stream) {
-    if (!att_seq || !dz || D <= 0) return RFN_ERR_ARG;
-    return launch_scores_bwd<true>(proj, proj_sb, proj_sl, hproj, w_out, alpha, alpha /* unused */, B, L, A, dproj,
-                                   dproj_sb, dproj_sl, accumulate_dproj, dhproj, dw_part, att_seq, sb, sl, dz, lddz, D,
-                                   (hipStream_t)stream);
+    return rfn_attn_bwd_grouped(1, &proj, proj_sb, proj_sl, &hproj, &w_out, &alpha, &att_seq, sb, sl, &dz, lddz, B, L,
+                                A, D, &dproj, dproj_sb, dproj_sl, accumulate_dproj, &dhproj, &dw_part, stream);
 }
 
 // =====================================================================================================

@@ -460,15 +460,37 @@ static int prefix_fwd_impl(const rfn_dims* d, int B, const float* const* prm, co
             pr[i] = prob1(hp + (long)i * B * A, A,
                           seg_lin(Hc + i * R, MR, prm[P.s1(t, i, 2)], R, R, prm[P.s1(t, i, 3)]));
         RFN_TRY(gemm_groups(B, A, M, pr, 0, gx));
+        // attention of the M encoders: one grouped pair of launches when they share (L, D), else one pair each.
+        // Raw scores land in the (idle) split-K scratch; the context kernel normalises them on the fly.
+        bool same_ld = M > 1;
+        for (int i = 1; i < M; ++i) same_ld = same_ld && d->L[i] == d->L[0] && d->D[i] == d->D[0];
+        if (same_ld) {
+            const long L0 = d->L[0], D0 = d->D[0];
+            if ((size_t)M * B * L0 > GEMM_WS_FLOATS) return RFN_ERR_SHAPE;
+            const float *a_p[RFN_MAX_ENC], *a_hp[RFN_MAX_ENC], *a_w[RFN_MAX_ENC], *a_b[RFN_MAX_ENC];
+            float *a_sc[RFN_MAX_ENC], *a_al[RFN_MAX_ENC], *a_z[RFN_MAX_ENC];
+            for (int i = 0; i < M; ++i) {
+                a_p[i] = W + Lo.P1[i] + (long)t * A;
+                a_hp[i] = hp + (long)i * B * A;
+                a_w[i] = prm[P.s1(t, i, 4)];
+                a_b[i] = prm[P.s1(t, i, 5)];
+                a_sc[i] = W + Lo.gws + (long)i * B * L0;
+                a_al[i] = W + Lo.al1[i] + (long)t * B * L0;
+                a_z[i] = W + Lo.z1[i] + (long)t * B * D0;
+            }
+            RFN_TRY(rfn_attn_fwd_grouped(M, a_p, L0 * T1 * A, (long)T1 * A, a_hp, a_w, a_b, att, L0 * D0, D0, B, (int)L0,
+                                         A, (int)D0, a_sc, a_al, a_z, D0, st));
+        }
         for (int i = 0; i < M; ++i) {
             const long Li = d->L[i], Di = d->D[i];
             float* al = W + Lo.al1[i] + (long)t * B * Li;
             float* z = W + Lo.z1[i] + (long)t * B * Di;
-            // raw scores land in the (idle) split-K scratch; the context kernel normalises them on the fly
-            if ((size_t)B * Li > GEMM_WS_FLOATS) return RFN_ERR_SHAPE;
-            RFN_TRY(rfn_attn_fwd(W + Lo.P1[i] + (long)t * A, Li * T1 * A, (long)T1 * A, hp + (long)i * B * A,
-                                 prm[P.s1(t, i, 4)], prm[P.s1(t, i, 5)], att[i], Li * Di, Di, B, (int)Li, A, (int)Di,
-                                 W + Lo.gws, al, z, Di, st));
+            if (!same_ld) {
+                if ((size_t)B * Li > GEMM_WS_FLOATS) return RFN_ERR_SHAPE;
+                RFN_TRY(rfn_attn_fwd(W + Lo.P1[i] + (long)t * A, Li * T1 * A, (long)T1 * A, hp + (long)i * B * A,
+                                     prm[P.s1(t, i, 4)], prm[P.s1(t, i, 5)], att[i], Li * Di, Di, B, (int)Li, A,
+                                     (int)Di, W + Lo.gws, al, z, Di, st));
+            }
             rfn_gemm_problem& p = pr[i];
             memset(&p, 0, sizeof(p));
             p.C = g + (long)i * B * 4 * R;
@@ -729,6 +751,26 @@ extern "C" int rfn_prefix_bwd(const rfn_dims* d, int B, const float* const* prm,
                               seg_dx(g + (long)i * B * 4 * R, 4 * R, prm[P.s1(t, i, 8)], d->D[0], 4 * R));
             RFN_TRY(gemm_groups(B, d->D[0], M, pr, 0, gx));
         }
+        bool same_ld = same_d && M > 1;
+        for (int i = 1; i < M; ++i) same_ld = same_ld && d->L[i] == d->L[0];
+        const bool grouped_bwd = same_ld && B >= FUSED_ATTN_BWD_MIN_B;
+        if (grouped_bwd) {   // all encoders' attention backward of this step: one launch
+            const long L0 = d->L[0], D0 = d->D[0];
+            const float *a_p[RFN_MAX_ENC], *a_hp[RFN_MAX_ENC], *a_w[RFN_MAX_ENC], *a_al[RFN_MAX_ENC], *a_dz[RFN_MAX_ENC];
+            float *a_dp[RFN_MAX_ENC], *a_dhp[RFN_MAX_ENC], *a_dw[RFN_MAX_ENC];
+            for (int i = 0; i < M; ++i) {
+                a_dp[i] = W + Lo.P1[i] + (long)t * A;
+                a_p[i] = a_dp[i];
+                a_hp[i] = hp + i * BA;
+                a_w[i] = prm[P.s1(t, i, 4)];
+                a_al[i] = W + Lo.al1[i] + (long)t * B * L0;
+                a_dz[i] = W + Lo.dz1[i];
+                a_dhp[i] = dhp + i * BA;
+                a_dw[i] = dwp + ((long)t * M + i) * BA;
+            }
+            RFN_TRY(rfn_attn_bwd_grouped(M, a_p, L0 * T1 * A, (long)T1 * A, a_hp, a_w, a_al, att, L0 * D0, D0, a_dz, D0,
+                                         B, (int)L0, A, (int)D0, a_dp, L0 * T1 * A, (long)T1 * A, 0, a_dhp, a_dw, st));
+        }
         for (int i = 0; i < M; ++i) {
             const long Li = d->L[i], Di = d->D[i];
             float* dz = W + Lo.dz1[i];
@@ -736,7 +778,9 @@ extern "C" int rfn_prefix_bwd(const rfn_dims* d, int B, const float* const* prm,
                 RFN_TRY(gemm1(B, (int)Di, seg_dx(g + (long)i * B * 4 * R, 4 * R, prm[P.s1(t, i, 8)], Di, 4 * R), dz, Di, 0, gx));
             float* dali = dal + (long)i * B * Li;
             float* p1 = W + Lo.P1[i] + (long)t * A;
-            if (B >= FUSED_ATTN_BWD_MIN_B) {   // one block per row fills the chip: dalpha stays in LDS, one launch
+            if (grouped_bwd) {
+                // done above
+            } else if (B >= FUSED_ATTN_BWD_MIN_B) {   // one block per row fills the chip: dalpha stays in LDS, one launch
                 RFN_TRY(rfn_attn_bwd(p1, Li * T1 * A, (long)T1 * A, hp + i * BA, prm[P.s1(t, i, 4)],
                                      W + Lo.al1[i] + (long)t * B * Li, att[i], Li * Di, Di, dz, Di, B, (int)Li, A,
                                      (int)Di, p1, Li * T1 * A, (long)T1 * A, 0, dhp + i * BA,

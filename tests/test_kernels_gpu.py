@@ -267,6 +267,41 @@ def test_attention_forward_backward(dev, B, L, A, D):
     assert maxerr(inpl, pr.grad) < 2e-5
 
 
+def test_stage1_attention_grouped_over_encoders_matches_single_calls(dev):
+    """rfn_attn_fwd_grouped / rfn_attn_bwd_grouped (blockIdx.z / .y = encoder) against one call per encoder: same bits."""
+    n = N()
+    G, B, L, A, D = 3, 5, 50, 64, 96
+    st = n.stream_ptr()
+    proj = [rnd(B, L, A, seed=10 + g).to(dev) for g in range(G)]
+    hp = [rnd(B, A, seed=20 + g).to(dev) for g in range(G)]
+    w = [rnd(A, seed=30 + g, scale=0.3).to(dev) for g in range(G)]
+    bo = [rnd(1, seed=40 + g).to(dev) for g in range(G)]
+    x = [rnd(B, L, D, seed=50 + g).to(dev) for g in range(G)]
+    dz = [rnd(B, D, seed=60 + g).to(dev) for g in range(G)]
+    new = lambda *shape: [torch.empty(*shape, device=dev) for _ in range(G)]  # noqa: E731
+    raw, al, z = new(B, L), new(B, L), new(B, D)
+    n.check(n.lib.rfn_attn_fwd_grouped(G, n.ptr_array(proj), L * A, A, n.ptr_array(hp), n.ptr_array(w), n.ptr_array(bo),
+                                       n.ptr_array(x), L * D, D, B, L, A, D, n.ptr_array(raw), n.ptr_array(al),
+                                       n.ptr_array(z), D, st))
+    dp, dhp, dwp = new(B, L, A), new(B, A), new(B, A)
+    n.check(n.lib.rfn_attn_bwd_grouped(G, n.ptr_array(proj), L * A, A, n.ptr_array(hp), n.ptr_array(w), n.ptr_array(al),
+                                       n.ptr_array(x), L * D, D, n.ptr_array(dz), D, B, L, A, D, n.ptr_array(dp), L * A,
+                                       A, 0, n.ptr_array(dhp), n.ptr_array(dwp), st))
+    for g in range(G):
+        raw1, al1, z1 = torch.empty(B, L, device=dev), torch.empty(B, L, device=dev), torch.empty(B, D, device=dev)
+        n.check(n.lib.rfn_attn_fwd(proj[g].data_ptr(), L * A, A, hp[g].data_ptr(), w[g].data_ptr(), bo[g].data_ptr(),
+                                   x[g].data_ptr(), L * D, D, B, L, A, D, raw1.data_ptr(), al1.data_ptr(), z1.data_ptr(),
+                                   D, st))
+        assert torch.equal(al1, al[g]) and torch.equal(z1, z[g])
+        dp1, dhp1, dwp1 = torch.empty(B, L, A, device=dev), torch.empty(B, A, device=dev), torch.empty(B, A, device=dev)
+        n.check(n.lib.rfn_attn_bwd(proj[g].data_ptr(), L * A, A, hp[g].data_ptr(), w[g].data_ptr(), al1.data_ptr(),
+                                   x[g].data_ptr(), L * D, D, dz[g].data_ptr(), D, B, L, A, D, dp1.data_ptr(), L * A, A,
+                                   0, dhp1.data_ptr(), dwp1.data_ptr(), st))
+        assert torch.equal(dp1, dp[g]) and torch.equal(dhp1, dhp[g]) and torch.equal(dwp1, dwp[g])
+        al_ref, z_ref = attn_ref(proj[g].cpu(), hp[g].cpu(), w[g].cpu(), bo[g].cpu(), x[g].cpu())
+        assert maxerr(al[g], al_ref) < 2e-6 and maxerr(z[g], z_ref) < 1e-5
+
+
 def test_attention_time_major_strides(dev):
     """Stage II / decoder read thoughts stored (step, batch, feature): stride_b = R, stride_l = B*R."""
     n = N()
