@@ -12,8 +12,19 @@ if ROOT not in sys.path:
 GOLDEN_DIR = os.path.join(ROOT, 'tests', 'golden')
 
 
+def _ensure_library():
+    """The product library is a build artefact (git-ignored): a fresh checkout builds it once, the same way
+    __graft_entry__.build() does.  A failing build fails the run -- there is no fallback to test instead."""
+    so = os.path.join(ROOT, 'recurrent_fusion_network_amd', 'librfn_hip.so')
+    if not os.path.exists(so):
+        import subprocess
+        subprocess.run(['make', '-C', os.path.join(ROOT, 'recurrent_fusion_network_amd', 'csrc'), '-j4'], check=True,
+                       stdout=subprocess.DEVNULL)
+
+
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    _ensure_library()
 
 
 def pytest_collection_modifyitems(config, items):
