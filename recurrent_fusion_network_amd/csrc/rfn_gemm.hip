@@ -82,6 +82,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef GEMM_NT_STAGES
 #define GEMM_NT_STAGES 1   /* LDS stages of the big NT tile: measured 131 TF single-buffered (3 blocks/CU) vs 125 */
 #endif
+#ifndef GEMM_TAIL_HALF
+#define GEMM_TAIL_HALF 1   /* half-height tiles for the last, partly filled round of a big NT launch */
+#endif
 #ifndef GEMM_ABLATE
 #define GEMM_ABLATE 0      /* 1: skip global loads after the first tile, 2: skip the epilogue stores */
 #endif
@@ -91,6 +94,8 @@ struct GemmArgs {
     int tiles_m, tiles_n;
     int splitk;   // > 1: each tile's K iterations are cut into `splitk` ranges, raw partial tiles go to `part`
     int pad_;
+    int tail_main_blocks;   // > 0: blocks past this id process HALF-height tiles (see rfn_gemm_kernel)
+    int tail_idx_main;      // first per-XCD tile index of the tail round
     float* part;  // [ngroups][splitk][M][N]
     rfn_gemm_problem g[RFN_GEMM_MAXGROUP];
 };
@@ -233,7 +238,8 @@ struct Stage {
 // STAGES = 1: single buffer, two barriers per K step, half the LDS -> 3 blocks/CU cover each other's stalls.
 // FAST: every tile is interior (M % BM == N % BN == 0 and every segment's K % BK == 0).
 template <int BM, int BN, bool AK, bool BKF, bool VEC, int STAGES, int BK, bool FAST, int THREADS = GEMM_THREADS>
-__global__ __launch_bounds__(THREADS, (THREADS == 64) ? 1 : GEMM_MIN_WAVES) void rfn_gemm_kernel(const GemmArgs args) {
+__device__ __forceinline__ void gemm_tile(const GemmArgs& args, const int grp, const int tn, const int ks,
+                                          const int row0, const int col0) {
     constexpr int WGM = (THREADS == 256) ? 2 : 1;  // waves along M / N: 2x2 (256 threads) or one wave per block
     constexpr int WGN = WGM;
     constexpr int MT = BM / (32 * WGM);  // 32x32 MFMA tiles per wave along M
@@ -251,33 +257,8 @@ __global__ __launch_bounds__(THREADS, (THREADS == 64) ? 1 : GEMM_MIN_WAVES) void
     const int wm = wave / WGN, wn = wave % WGN;
     const int l31 = lane & 31, h = lane >> 5;
 
-    // ---- block -> (group, tile_m, tile_n): bijective XCD remap, then 8-row bands ------------
-    const int NC = args.ngroups * args.tiles_n;
     const int splitk = args.splitk;
-    const int nblk = NC * args.tiles_m * splitk;
-    int lid;
-    {
-        const int bid = blockIdx.x;
-#if GEMM_XCD_REMAP
-        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
-        lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-#else
-        lid = bid;
-#endif
-    }
-    const int ks = lid % splitk;  // the K ranges of one tile run next to each other
-    lid /= splitk;
-    const int per_band = GEMM_BAND_ROWS * NC;
-    const int band = lid / per_band;
-    const int rem = lid - band * per_band;
-    const int band_rows = min(GEMM_BAND_ROWS, args.tiles_m - band * GEMM_BAND_ROWS);
-    const int vcol = rem / band_rows;
-    const int tm = band * GEMM_BAND_ROWS + (rem - vcol * band_rows);
-    const int grp = vcol / args.tiles_n;
-    const int tn = vcol - grp * args.tiles_n;
-
     const rfn_gemm_problem& P = args.g[grp];
-    const int row0 = tm * BM, col0 = tn * BN;
     const int M = args.M, N = args.N;
 
     f32x16 acc[MT][NT];
@@ -523,6 +504,54 @@ __global__ __launch_bounds__(THREADS, (THREADS == 64) ? 1 : GEMM_MIN_WAVES) void
     }
 }
 
+// ---- block -> (group, tile_m, tile_n): bijective XCD remap, then 8-row bands --------------------------------------
+// TAIL (big NT launches whose tile count is not a multiple of the resident slots): the blocks of the last, partly
+// filled round each take HALF a tile (BM/2 rows), so that round lasts half as long on twice as many CUs.  Consecutive
+// block ids land on consecutive XCDs, so the tail round is "the last tile indices of every XCD", two blocks per tile.
+template <int BM, int BN, bool AK, bool BKF, bool VEC, int STAGES, int BK, bool FAST, int THREADS = GEMM_THREADS,
+          bool TAIL = false>
+__global__ __launch_bounds__(THREADS, (THREADS == 64) ? 1 : (TAIL ? 3 : GEMM_MIN_WAVES)) void rfn_gemm_kernel(
+    const GemmArgs args) {   // TAIL: 3 waves/SIMD asked for explicitly (the two-body kernel schedules better under it)
+    const int NC = args.ngroups * args.tiles_n;
+    const int splitk = args.splitk;
+    const int nblk = NC * args.tiles_m * splitk;     // whole tiles (x K ranges)
+    int lid, half = -1;
+    {
+        const int bid = blockIdx.x;
+#if GEMM_XCD_REMAP
+        const int q = nblk >> 3, r = nblk & 7;
+        if (TAIL && bid >= args.tail_main_blocks) {   // r == 0, splitk == 1 (host-checked)
+            const int j = bid - args.tail_main_blocks, jdx = j >> 3;
+            lid = (j & 7) * q + args.tail_idx_main + (jdx >> 1);
+            half = jdx & 1;
+        } else {
+            const int xcd = bid & 7, idx = bid >> 3;
+            lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        }
+#else
+        lid = bid;
+#endif
+    }
+    const int ks = lid % splitk;  // the K ranges of one tile run next to each other
+    lid /= splitk;
+    const int per_band = GEMM_BAND_ROWS * NC;
+    const int band = lid / per_band;
+    const int rem = lid - band * per_band;
+    const int band_rows = min(GEMM_BAND_ROWS, args.tiles_m - band * GEMM_BAND_ROWS);
+    const int vcol = rem / band_rows;
+    const int tm = band * GEMM_BAND_ROWS + (rem - vcol * band_rows);
+    const int grp = vcol / args.tiles_n;
+    const int tn = vcol - grp * args.tiles_n;
+    if constexpr (TAIL) {
+        if (half >= 0) {
+            gemm_tile<BM / 2, BN, AK, BKF, VEC, STAGES, BK, FAST, THREADS>(args, grp, tn, ks, tm * BM + half * (BM / 2),
+                                                                          tn * BN);
+            return;
+        }
+    }
+    gemm_tile<BM, BN, AK, BKF, VEC, STAGES, BK, FAST, THREADS>(args, grp, tn, ks, tm * BM, tn * BN);
+}
+
 // C = sum_ks part[g][ks] + sum_s bias_s (+ C): fixed summation order, one thread per output element.  The blocks
 // past the C range finish the a_colsum rider the same way (partial column sums of every K range, in order).
 __global__ __launch_bounds__(256) void rfn_gemm_reduce_k(const GemmArgs args) {
@@ -558,6 +587,34 @@ static int launch_cfg(const GemmArgs& a, hipStream_t st) {
     using StB = Stage<BN, BKF, VEC, BK, THREADS>;
     const size_t lds = STAGES * (StA::LDS_FLOATS + StB::LDS_FLOATS) * sizeof(float);
     const int nblk = a.ngroups * a.tiles_m * a.tiles_n * a.splitk;
+#if GEMM_TAIL_HALF && GEMM_XCD_REMAP
+    // Tile quantisation: with S resident blocks per XCD a launch of 8*q tiles runs ceil(q/S) rounds and the last
+    // one is only (q mod S)/S full.  When that fraction is at most a half (and there are enough rounds for it to
+    // be a tail at all), the last round's tiles are processed as two half-height tiles each.
+    if constexpr (FAST && AK && BKF && VEC && STAGES == 1 && THREADS == 256 && BM == 128) {
+        static const int slots_per_xcd = [] {
+            int dev = 0, cus = 256;
+            if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+            return (cus / 8) * 3;   // three single-buffered NT blocks per CU (VGPR-bound)
+        }();
+        const int q = nblk / 8, tail = slots_per_xcd > 0 ? q % slots_per_xcd : 0;
+        if (a.splitk == 1 && nblk % 8 == 0 && slots_per_xcd > 0 && q / slots_per_xcd >= 4 && tail > 0 &&
+            2 * tail <= slots_per_xcd) {
+            GemmArgs t = a;
+            t.tail_idx_main = q - tail;
+            t.tail_main_blocks = 8 * t.tail_idx_main;
+            auto kt = rfn_gemm_kernel<BM, BN, AK, BKF, VEC, STAGES, BK, FAST, THREADS, true>;
+            static bool attr_set_t = false;
+            if (!attr_set_t) {
+                hipFuncSetAttribute((const void*)kt, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                attr_set_t = true;
+            }
+            hipLaunchKernelGGL(kt, dim3(t.tail_main_blocks + 16 * tail), dim3(THREADS), lds, st, t);
+            RFN_CHECK_LAUNCH();
+            return RFN_OK;
+        }
+    }
+#endif
     auto k = rfn_gemm_kernel<BM, BN, AK, BKF, VEC, STAGES, BK, FAST, THREADS>;
     static bool attr_set = false;  // idempotent; a race only repeats the same call
     if (!attr_set) {
@@ -671,6 +728,8 @@ extern "C" int rfn_gemm_f32_ws(int M, int N, int ngroups, const rfn_gemm_problem
     a.ngroups = ngroups;
     a.accumulate = accumulate;
     a.splitk = 1;
+    a.tail_main_blocks = 0;
+    a.tail_idx_main = 0;
     a.part = (ws && ws_bytes >= (1u << 20) && rfn_aligned16(ws)) ? (float*)ws : nullptr;
     a.pad_ = (int)(ws_bytes >> 20);  // workspace size in MiB (host-side only)
     const int ak = problems[0].seg[0].a_kfast, bk = problems[0].seg[0].b_kfast;

@@ -169,6 +169,32 @@ def test_gemm_weight_gradient_split_k_keeps_the_bias_rider(dev, rows, Nn, K, gro
         assert torch.equal(p[0], dW) and torch.equal(p[3], db)
 
 
+def test_gemm_half_height_tail_round(dev):
+    """Big NT launches whose tile count leaves the last round at most half full process that round as half-height
+    tiles inside the same launch (rfn_gemm.hip, TAIL): 3200 tiles = 400 per XCD = 4 full rounds of 96 + 16, a ragged
+    last band, grouped problems -- every output element against fp64, and bit-identical from call to call."""
+    n = N()
+    M, Nn, K, G = 12800, 2048, 64, 2          # 100 x 16 tiles x 2 groups = 3200
+    A = rnd(M, K, seed=1)
+    Ad = A.to(dev)
+    probs, refs, keep = [], [], []
+    for g in range(G):
+        Bm, b = rnd(Nn, K, seed=10 + g), rnd(Nn, seed=20 + g)
+        Bd, bd = Bm.to(dev), b.to(dev)
+        keep += [Bd, bd]
+        Cg = torch.full((M, Nn), float('nan'), device=dev)
+        probs.append((Cg, Nn, [(Ad, K, 1, Bd, K, 1, K, bd)]))
+        refs.append(A.double() @ Bm.double().t() + b.double())
+    n.gemm(M, Nn, probs)
+    first = [p[0].clone() for p in probs]
+    for Cg, r in zip(first, refs):
+        assert not bool(torch.isnan(Cg).any())
+        assert maxerr(Cg, r) < 2e-4
+    n.gemm(M, Nn, probs)
+    for p, c in zip(probs, first):
+        assert torch.equal(p[0], c)
+
+
 def test_gemm_strided_views_like_the_path(dev):
     """The path feeds column blocks of wider buffers (lda > K, ldc > N): e.g. encoder i's slice of H."""
     n = N()

@@ -5,6 +5,5 @@ cd "$(dirname "$0")/.."
 mkdir -p /tmp/gb
 build() { hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-unused-value -Wno-unused-result -DVARIANT="\"$1\"" $2 tools/gemm_bench.hip -o /tmp/gb/$1; }
 build default ""
-build setprio1 "-DGEMM_SETPRIO=1"
-build setprio2 "-DGEMM_SETPRIO=2"
-for r in 1 2; do for v in default setprio1 setprio2; do /tmp/gb/$v; done; done
+build notail "-DGEMM_TAIL_HALF=0"
+for r in 1 2; do for v in default notail; do /tmp/gb/$v; done; done
