@@ -25,6 +25,8 @@ int main() {
     float* W = dev_rand((size_t)T * A * D, 2);
     float* P;   hipMalloc(&P, (size_t)BL * T * A * 4);
     float* dW;  hipMalloc(&dW, (size_t)T * A * D * 4);
+    const size_t ws_bytes = (size_t)160 << 20;   // split-K scratch, as the path provides one
+    void* ws;   hipMalloc(&ws, ws_bytes);
     hipMemset(P, 0, (size_t)BL * T * A * 4);
     rfn_gemm_problem nt[8], tn[8];
     for (int t = 0; t < T; ++t) {
@@ -43,7 +45,7 @@ int main() {
         const int reps = 6;
         for (int r = 0; r < reps + 1; ++r) {
             hipEventRecord(e0);
-            int rc = which == 0 ? rfn_gemm_f32(BL, A, T, nt, 0, 0) : rfn_gemm_f32(A, D, T, tn, 0, 0);
+            int rc = which == 0 ? rfn_gemm_f32_ws(BL, A, T, nt, 0, ws, ws_bytes, 0) : rfn_gemm_f32_ws(A, D, T, tn, 0, ws, ws_bytes, 0);
             hipEventRecord(e1); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);
             if (rc) { printf("rc %d\n", rc); return 1; }
