@@ -597,19 +597,23 @@ static int launch_cfg(const GemmArgs& a, hipStream_t st) {
             if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
             return (cus / 8) * 3;   // three single-buffered NT blocks per CU (VGPR-bound)
         }();
-        const int q = nblk / 8, tail = slots_per_xcd > 0 ? q % slots_per_xcd : 0;
-        if (a.splitk == 1 && nblk % 8 == 0 && slots_per_xcd > 0 && q / slots_per_xcd >= 4 && tail > 0 &&
-            2 * tail <= slots_per_xcd) {
+        // The two-body kernel is also the better-scheduled one (156 VGPRs = three waves per SIMD, the single-body
+        // instantiation needs 170 = two), so every unsplit launch of this layout goes through it; launches that
+        // do not qualify for a tail simply have no tail blocks.
+        if (a.splitk == 1) {
+            const int q = nblk / 8, tail = slots_per_xcd > 0 ? q % slots_per_xcd : 0;
+            const bool has_tail = nblk % 8 == 0 && slots_per_xcd > 0 && q / slots_per_xcd >= 4 && tail > 0 &&
+                                  2 * tail <= slots_per_xcd;
             GemmArgs t = a;
-            t.tail_idx_main = q - tail;
-            t.tail_main_blocks = 8 * t.tail_idx_main;
+            t.tail_idx_main = has_tail ? q - tail : 0;
+            t.tail_main_blocks = has_tail ? 8 * t.tail_idx_main : 0x7fffffff;
             auto kt = rfn_gemm_kernel<BM, BN, AK, BKF, VEC, STAGES, BK, FAST, THREADS, true>;
             static bool attr_set_t = false;
             if (!attr_set_t) {
                 hipFuncSetAttribute((const void*)kt, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 attr_set_t = true;
             }
-            hipLaunchKernelGGL(kt, dim3(t.tail_main_blocks + 16 * tail), dim3(THREADS), lds, st, t);
+            hipLaunchKernelGGL(kt, dim3(has_tail ? t.tail_main_blocks + 16 * tail : nblk), dim3(THREADS), lds, st, t);
             RFN_CHECK_LAUNCH();
             return RFN_OK;
         }
