@@ -114,7 +114,9 @@ def cpu_baseline(cfg, sample_B, seed):
         probe = run(8)
         sample_B = int(min(64, max(8, round(8 * 15.0 / max(probe, 1e-3) / 8) * 8)))
         dt = run(sample_B)
-        if dt < 10.0 and sample_B < 128:                # fast host: per-caption cost still falls with B, go once more
+        for _ in range(2):                              # fast host: per-caption cost still falls with B, grow the sample
+            if dt >= 10.0 or sample_B >= 128:
+                break
             sample_B = int(min(128, max(sample_B + 8, round(sample_B * 15.0 / dt / 8) * 8)))
             dt = run(sample_B)
     else:
