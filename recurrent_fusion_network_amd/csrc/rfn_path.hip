@@ -126,6 +126,29 @@ int gemm_dw(int N, int K, float* dW, long ldw, float* db, const float* dY, long 
     rfn_gemm_problem p = prob_dw(dW, ldw, db, dY, lddy, X, ldx, rows);
     return rfn_gemm_f32_ws(N, K, 1, &p, 0, gx.ws, gx.ws_bytes, gx.st);
 }
+// The vocabulary (V+1 = 9488 at the headline size) is not a multiple of the 128-wide tile: the three logit-layer GEMMs
+// are issued as an aligned main part that takes the unchecked fast path plus a thin remainder (< 128 columns / rows /
+// reduction elements) on the bounds-checked kernel.  Same sums, same order per output element except the dX split,
+// which adds the remainder's partial product last.
+static inline int aligned_part(int n) { return (n / 128) * 128; }
+int gemm_logits(int rows, int V1, const float* h, int R, const float* Wl, const float* bl, float* C, const GemmCtx& gx) {
+    const int Va = aligned_part(V1);
+    if (Va == V1 || Va == 0) return gemm1(rows, V1, seg_lin(h, R, Wl, R, R, bl), C, V1, 0, gx);
+    RFN_TRY(gemm1(rows, Va, seg_lin(h, R, Wl, R, R, bl), C, V1, 0, gx));
+    return gemm1(rows, V1 - Va, seg_lin(h, R, Wl + (long)Va * R, R, R, bl + Va), C + Va, V1, 0, gx);
+}
+int gemm_logits_dw(int V1, int R, float* dW, float* db, const float* dlg, const float* h, int rows, const GemmCtx& gx) {
+    const int Va = aligned_part(V1);
+    if (Va == V1 || Va == 0) return gemm_dw(V1, R, dW, R, db, dlg, V1, h, R, rows, gx);
+    RFN_TRY(gemm_dw(Va, R, dW, R, db, dlg, V1, h, R, rows, gx));
+    return gemm_dw(V1 - Va, R, dW + (long)Va * R, R, db + Va, dlg + Va, V1, h, R, rows, gx);
+}
+int gemm_logits_dx(int rows, int R, int V1, const float* dlg, const float* Wl, float* dh, const GemmCtx& gx) {
+    const int Va = aligned_part(V1);
+    if (Va == V1 || Va == 0) return gemm1(rows, R, seg_dx(dlg, V1, Wl, R, V1), dh, R, 0, gx);
+    RFN_TRY(gemm1(rows, R, seg_dx(dlg, V1, Wl, R, Va), dh, R, 0, gx));
+    return gemm1(rows, R, seg_dx(dlg + Va, V1, Wl + (long)Va * R, R, V1 - Va), dh, R, 1, gx);
+}
 // any number of K segments into one C (chunks of RFN_GEMM_MAXSEG, later chunks accumulate)
 int gemm_segs(int M, int N, int nseg, const rfn_gemm_seg* segs, float* C, long ldc, int acc, const GemmCtx& gx) {
     for (int s0 = 0; s0 < nseg; s0 += RFN_GEMM_MAXSEG) {
@@ -924,7 +947,7 @@ extern "C" int rfn_decoder_fwd(const rfn_dims* d, int B, int S, const float* con
                              train ? d->drop_lm : 0.f, seed, OFF_DECODER + (uint64_t)s, st));
     }
     // logits of all steps, then log-softmax written in the reference's (B, S, V+1) layout
-    RFN_TRY(gemm1(S * B, V1, seg_lin(hd + BR, R, prm[P.logit_w()], R, R, prm[P.logit_b()]), W + Lo.logits, V1, 0, gx));
+    RFN_TRY(gemm_logits(S * B, V1, hd + BR, R, prm[P.logit_w()], prm[P.logit_b()], W + Lo.logits, gx));
     RFN_TRY(rfn_log_softmax_fwd(W + Lo.logits, V1, S * B, V1, B, (long)S * V1, V1, log_prob, st));
     return RFN_OK;
 }
@@ -957,8 +980,8 @@ extern "C" int rfn_decoder_bwd(const rfn_dims* d, int B, int S, const float* con
     float* dPd = W + Lo.dPd;
     // log-softmax backward into time-major rows, then the batched logit layer
     RFN_TRY(rfn_log_softmax_bwd(d_log_prob, log_prob, S * B, V1, B, (long)S * V1, V1, dlg, V1, st));
-    RFN_TRY(gemm_dw(V1, R, grd[P.logit_w()], R, grd[P.logit_b()], dlg, V1, hd + BR, R, S * B, gx));
-    RFN_TRY(gemm1(S * B, R, seg_dx(dlg, V1, prm[P.logit_w()], R, V1), dhe, R, 0, gx));
+    RFN_TRY(gemm_logits_dw(V1, R, grd[P.logit_w()], grd[P.logit_b()], dlg, hd + BR, S * B, gx));
+    RFN_TRY(gemm_logits_dx(S * B, R, V1, dlg, prm[P.logit_w()], dhe, gx));
     RFN_TRY(zero_f32(d_comb, (size_t)T2 * BR, st));
     RFN_TRY(zero_f32(dPd, (size_t)T2 * BA, st));
     rfn_gemm_problem pr[2];
@@ -1052,7 +1075,7 @@ static int decoder_step_impl(const rfn_dims* d, int B, const float* const* prm, 
     RFN_TRY(gemm_segs(B, GD, 3, segs, g, GD, 0, gx));
     RFN_TRY(rfn_lstm_fwd(g, GD, c, R, c, R, h, R, B, R, d->decoder_maxout, 0.f, 0, 0, st));  // eval: no dropout
     if (logits || logp) {
-        RFN_TRY(gemm1(B, V1, seg_lin(h, R, prm[P.logit_w()], R, R, prm[P.logit_b()]), lg, V1, 0, gx));
+        RFN_TRY(gemm_logits(B, V1, h, R, prm[P.logit_w()], prm[P.logit_b()], lg, gx));
         if (logp) {
             if (ld_logp < V1) return RFN_ERR_SHAPE;
             RFN_TRY(rfn_log_softmax_fwd(lg, V1, B, V1, B, ld_logp, 0, logp, st));
