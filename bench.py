@@ -218,7 +218,7 @@ def main():
                            'unit': 'TFLOP/s', 'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': traffic,
                            'traffic_unit': 'bytes per launch (2*FETCH_SIZE + WRITE_SIZE)',
                            'algorithmic_bytes': int(4 * (B * w['L'] * w['D'] + 8 * 512 * w['D'] + B * w['L'] * 8 * 512)),
-                           'kernel': 'rfn_gemm_kernel<128,128,kfast,kfast,vec> (grouped att_2_att_h projection, '
+                           'kernel': 'rfn_gemm_kernel<128,128,kfast,kfast,vec,...,tail> (grouped att_2_att_h projection, '
                                      '%.3f TFLOP per launch, %.3f ms per launch)' % (flops / 1e12, secs * 1e3)}
         # whole-step view against the same peak (SURVEY.md 8d algorithmic FLOP of one step)
         step_flops = {'c3': 7.667e12, 'c2': 0.1706e12}[args.workload] * (B / w['B'])
