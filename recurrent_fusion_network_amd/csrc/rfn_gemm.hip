@@ -82,6 +82,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef GEMM_NT_STAGES
 #define GEMM_NT_STAGES 1   /* LDS stages of the big NT tile: measured 131 TF single-buffered (3 blocks/CU) vs 125 */
 #endif
+#ifndef GEMM_MEDIUM_TARGET_NT
+#define GEMM_MEDIUM_TARGET_NT 512
+#endif
 #ifndef GEMM_TAIL_HALF
 #define GEMM_TAIL_HALF 1   /* half-height tiles for the last, partly filled round of a big NT launch */
 #endif
@@ -587,6 +590,7 @@ static int launch_cfg(const GemmArgs& a, hipStream_t st) {
     using StB = Stage<BN, BKF, VEC, BK, THREADS>;
     const size_t lds = STAGES * (StA::LDS_FLOATS + StB::LDS_FLOATS) * sizeof(float);
     const int nblk = a.ngroups * a.tiles_m * a.tiles_n * a.splitk;
+    bool launched = false;
 #if GEMM_TAIL_HALF && GEMM_XCD_REMAP
     // Tile quantisation: with S resident blocks per XCD a launch of 8*q tiles runs ceil(q/S) rounds and the last
     // one is only (q mod S)/S full.  When that fraction is at most a half (and there are enough rounds for it to
@@ -600,10 +604,10 @@ static int launch_cfg(const GemmArgs& a, hipStream_t st) {
         // The two-body kernel is also the better-scheduled one (156 VGPRs = three waves per SIMD, the single-body
         // instantiation needs 170 = two), so every unsplit launch of this layout goes through it; launches that
         // do not qualify for a tail simply have no tail blocks.
-        if (a.splitk == 1) {
+        {
             const int q = nblk / 8, tail = slots_per_xcd > 0 ? q % slots_per_xcd : 0;
-            const bool has_tail = nblk % 8 == 0 && slots_per_xcd > 0 && q / slots_per_xcd >= 4 && tail > 0 &&
-                                  2 * tail <= slots_per_xcd;
+            const bool has_tail = a.splitk == 1 && nblk % 8 == 0 && slots_per_xcd > 0 && q / slots_per_xcd >= 4 &&
+                                  tail > 0 && 2 * tail <= slots_per_xcd;
             GemmArgs t = a;
             t.tail_idx_main = has_tail ? q - tail : 0;
             t.tail_main_blocks = has_tail ? 8 * t.tail_idx_main : 0x7fffffff;
@@ -615,18 +619,20 @@ static int launch_cfg(const GemmArgs& a, hipStream_t st) {
             }
             hipLaunchKernelGGL(kt, dim3(has_tail ? t.tail_main_blocks + 16 * tail : nblk), dim3(THREADS), lds, st, t);
             RFN_CHECK_LAUNCH();
-            return RFN_OK;
+            launched = true;
         }
     }
 #endif
-    auto k = rfn_gemm_kernel<BM, BN, AK, BKF, VEC, STAGES, BK, FAST, THREADS>;
-    static bool attr_set = false;  // idempotent; a race only repeats the same call
-    if (!attr_set) {
-        hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
+    if (!launched) {
+        auto k = rfn_gemm_kernel<BM, BN, AK, BKF, VEC, STAGES, BK, FAST, THREADS>;
+        static bool attr_set = false;  // idempotent; a race only repeats the same call
+        if (!attr_set) {
+            hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(k, dim3(nblk), dim3(THREADS), lds, st, a);
+        RFN_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL(k, dim3(nblk), dim3(THREADS), lds, st, a);
-    RFN_CHECK_LAUNCH();
     if (a.splitk > 1) {
         bool colsum = false;
         for (int g = 0; g < a.ngroups; ++g) colsum = colsum || (a.g[g].a_colsum != nullptr);
@@ -659,7 +665,8 @@ static int launch_tile(GemmArgs& a, hipStream_t st) {
         return e ? atol(e) : 256L;   // 256 < big < 384: 64x64 tiles fill the chip better than a 2-way split
     }();
     if (big <= medium_max && a.part && big >= 16 && flops >= GEMM_MEDIUM_MIN_FLOPS) {
-        long want = (512 + big - 1) / big;
+        const long target = (AK && BKF) ? GEMM_MEDIUM_TARGET_NT : 512;   // 768 (three NT blocks per CU) measured worse
+        long want = (target + big - 1) / big;
         if (want > iters32 / 8) want = iters32 / 8;
         if (want > 16) want = 16;
         const long cap = (long)a.pad_ * (1 << 18) / (((long)a.M * a.N + a.M) * a.ngroups);
