@@ -164,7 +164,7 @@ int rfn_attn_bwd(const float* proj, int64_t proj_sb, int64_t proj_sl, const floa
                  const float* alpha, const float* att_seq, int64_t sb, int64_t sl, const float* dz, int64_t lddz,
                  int B, int L, int A, int D, float* dproj, int64_t dproj_sb, int64_t dproj_sl,
                  int accumulate_dproj, float* dhproj, float* dw_part, void* stream);
-
+/* The same for `ngroups` encoders that share (L, A, D) and every stride, one launch (grid = B x ngroups). */
 int rfn_attn_bwd_grouped(int ngroups, const float* const* proj, int64_t proj_sb, int64_t proj_sl,
                          const float* const* hproj, const float* const* w_out, const float* const* alpha,
                          const float* const* att_seq, int64_t sb, int64_t sl, const float* const* dz, int64_t lddz,
