@@ -118,6 +118,8 @@ int rfn_colsum_grouped_f32(const float* X, int64_t group_stride, int64_t ldx, in
 
 /* outs_host[g][0..n) = value for `ngroups` small device buffers in one launch */
 int rfn_fill_small_f32(float* const* outs_host, int ngroups, int n, float value, void* stream);
+/* dst_host[g][0..n) = src_host[g][0..n) for `ngroups` small device buffer pairs in one launch */
+int rfn_copy_small_f32(float* const* dst_host, const float* const* src_host, int ngroups, int n, void* stream);
 
 /* Additive soft attention, AttentionModelCore.forward (misc/AttentionModelCore.py:31-48; inlined
  * copy misc/LSTMSoftAttentionCore.py:64-79), split at the GEMM boundary:
@@ -367,7 +369,8 @@ int rfn_prefix_bwd(const rfn_dims* d, int B, const float* const* params,
  * for all t); this call produces them for one encoder from the same workspace.  `parts` bit 0: H2h, z2h,
  * h_2_att_h (0.27 GB of gradients, short GEMMs); bit 1: att_2_att_h (34 MB, the longest GEMM of backward).
  * A data-parallel host issues part 1, all-reduces that bucket under part 2's GEMM, and so on: only the last
- * encoder's 34 MB bucket remains exposed at the end of backward. */
+ * encoder's 34 MB bucket remains exposed at the end of backward.  Part 1 of an encoder must be issued before its
+ * part 2: att_2_att_h.bias and h_2_att_h.bias have the same gradient, which part 1 computes once and writes to both. */
 int rfn_prefix_bwd_wgrad(const rfn_dims* d, int B, const float* const* att_feats, float* const* grads,
                          void* ws, size_t ws_bytes, int enc, int parts, void* stream);
 

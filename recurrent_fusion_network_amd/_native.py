@@ -62,6 +62,7 @@ def _load():
         'rfn_colsum_f32': (C.c_int, [P, L, I, I, P, I, P]),
         'rfn_colsum_grouped_f32': (C.c_int, [P, L, L, I, I, P, I, P]),
         'rfn_fill_small_f32': (C.c_int, [P, I, I, F, P]),
+        'rfn_copy_small_f32': (C.c_int, [P, P, I, I, P]),
         'rfn_attn_scores_fwd': (C.c_int, [P, L, L, P, P, P, I, I, I, P, P]),
         'rfn_attn_context_fwd': (C.c_int, [P, L, L, P, I, I, I, P, L, P]),
         'rfn_attn_context_bwd_dalpha': (C.c_int, [P, L, L, P, L, I, I, I, P, P]),

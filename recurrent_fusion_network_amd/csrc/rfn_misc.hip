@@ -127,6 +127,30 @@ extern "C" int rfn_fill_small_f32(float* const* outs, int ngroups, int n, float 
     return RFN_OK;
 }
 
+// dst[g][0..n) = src[g][0..n) for up to 64 small buffer pairs per launch (equal-by-construction bias gradients)
+struct CopyPairs { float* dst[64]; const float* src[64]; };
+__global__ __launch_bounds__(64) void copy_small_k(const CopyPairs p, int n) {
+    float* o = p.dst[blockIdx.x];
+    const float* s = p.src[blockIdx.x];
+    for (int i = threadIdx.x; i < n; i += 64) o[i] = s[i];
+}
+extern "C" int rfn_copy_small_f32(float* const* dst, const float* const* src, int ngroups, int n, void* stream) {
+    if (ngroups < 1 || n < 1) return RFN_ERR_SHAPE;
+    if (!dst || !src) return RFN_ERR_ARG;
+    for (int g0 = 0; g0 < ngroups; g0 += 64) {
+        CopyPairs p;
+        const int ng = ngroups - g0 < 64 ? ngroups - g0 : 64;
+        for (int g = 0; g < ng; ++g) {
+            if (!dst[g0 + g] || !src[g0 + g]) return RFN_ERR_ARG;
+            p.dst[g] = dst[g0 + g];
+            p.src[g] = src[g0 + g];
+        }
+        hipLaunchKernelGGL(copy_small_k, dim3(ng), dim3(64), 0, (hipStream_t)stream, p, n);
+        RFN_CHECK_LAUNCH();
+    }
+    return RFN_OK;
+}
+
 // ---- embedding ----------------------------------------------------------------------------------
 __global__ __launch_bounds__(128) void embed_fwd_k(const float* __restrict__ W, int E, long V1,
                                                    const int64_t* __restrict__ ids, int inner, long si, long so,

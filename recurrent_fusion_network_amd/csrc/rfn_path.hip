@@ -858,9 +858,13 @@ extern "C" int rfn_prefix_bwd_wgrad(const rfn_dims* d, int B, const float* const
     const float* Hs = W + Lo.Hs;
     rfn_gemm_problem pr[64];
     const long Li = d->L[i], Di = d->D[i];
+    // att_2_att_h.bias and h_2_att_h.bias enter the same pre-activation (AttentionModelCore.py:36-38), so their
+    // gradients are the same vector: it is produced once, as the rider of the short h_2_att_h GEMM of part A, and
+    // copied -- the 6 ms att_2_att_h GEMM carries no rider (its 32 first-column blocks would otherwise finish last
+    // and, with exactly one round of blocks, delay the whole launch).
     if (parts & 2) {  // part B: the dominant att_2_att_h gradient (small bucket, long GEMM)
         for (int t = 0; t < T1; ++t)
-            pr[t] = prob_dw(grd[P.s1(t, i, 0)], Di, grd[P.s1(t, i, 1)], W + Lo.P1[i] + (long)t * A, (long)T1 * A, att[i], Di,
+            pr[t] = prob_dw(grd[P.s1(t, i, 0)], Di, nullptr, W + Lo.P1[i] + (long)t * A, (long)T1 * A, att[i], Di,
                             (int)(B * Li));
         if (!(parts & 1)) return gemm_groups(A, (int)Di, T1, pr, 0, gx);
     }
@@ -877,9 +881,18 @@ extern "C" int rfn_prefix_bwd_wgrad(const rfn_dims* d, int B, const float* const
         pr[t] = prob_dw(grd[P.s1(t, i, 2)], R, grd[P.s1(t, i, 3)], W + Lo.dhp1 + ((long)t * M + i) * BA, A,
                         Hs + t * BMR + i * R, MR, B);
     RFN_TRY(gemm_groups(A, R, T1, pr, 0, gx));
+    {   // d att_2_att_h.bias[t] = d h_2_att_h.bias[t] (before the large bucket is announced / all-reduced)
+        float* cdst[64];
+        const float* csrc[64];
+        for (int t = 0; t < T1; ++t) {
+            cdst[t] = grd[P.s1(t, i, 1)];
+            csrc[t] = grd[P.s1(t, i, 3)];
+        }
+        RFN_TRY(rfn_copy_small_f32(cdst, csrc, T1, A, st));
+    }
     if (parts & 2) {
         for (int t = 0; t < T1; ++t)
-            pr[t] = prob_dw(grd[P.s1(t, i, 0)], Di, grd[P.s1(t, i, 1)], W + Lo.P1[i] + (long)t * A, (long)T1 * A, att[i], Di,
+            pr[t] = prob_dw(grd[P.s1(t, i, 0)], Di, nullptr, W + Lo.P1[i] + (long)t * A, (long)T1 * A, att[i], Di,
                             (int)(B * Li));
         RFN_TRY(gemm_groups(A, (int)Di, T1, pr, 0, gx));
     }
