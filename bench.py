@@ -2,8 +2,11 @@
 """Headline benchmark: captions/sec of one XE train step of the recurrent-fusion decoder on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+
+With N > 1 and no WORLD_SIZE in the environment this process only LAUNCHES: before it imports torch or touches a
+GPU it starts `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py`
+as a child, relays rank 0's JSON line and exits with the child's code.  Under an external launcher (WORLD_SIZE set)
+it is one rank.
 
 Workload (BASELINE.json configs[2], the configuration the metric is quoted on): RecurrentFusionModel,
 M=4 encoders, L=196 regions, D=2048, B=256 captions per GPU, R=A=E=512, T1=T2=8, V+1=9488, seq_length=16
@@ -11,35 +14,49 @@ M=4 encoders, L=196 regions, D=2048, B=256 captions per GPU, R=A=E=512, T1=T2=8,
 weights, resident in HBM before the timed region.
 
 One step = the reference's timed region train.py:143-166: zero_grad -> forward -> ReviewNetEnsembleCriterion ->
-backward -> (N>1: one RCCL sum all-reduce per gradient bucket, overlapped with backward) -> clamp + Adam.  fp32 throughout.
-Rank 0 prints ONE JSON line; `value` is the whole-job aggregate over all N GPUs.
+backward -> (N>1: one RCCL sum all-reduce per gradient bucket, overlapped with backward) -> clamp + Adam.  fp32
+throughout.  Rank 0 prints ONE JSON line; `value` is the whole-job aggregate over all N GPUs.
+
+Other lines (same schema, not the headline): --workload c2 | c3het (the reference's shipped 5 heterogeneous encoders,
+feat_array.py:240-244) | c5 (BASELINE configs[4]: greedy / beam=5 decode and the self-critical RL step at B=128);
+--recipe (the published XE recipe train_recurrent_fusion_model.sh:17-27: drop_prob_lm 0.3, label smoothing, scheduled
+sampling); --strong (global batch 256 sharded over the ranks instead of 256 per rank).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak (spec)
+METRIC = 'captions/sec (train fwd+bwd) at B=256, M=4, L=196, D=2048, seq=16; 1/2/4/8 GPU'
+CPU_SAMPLE_B = 32               # captions in the CPU-baseline sample: fixed, so rounds and hosts are comparable
 
 WORKLOADS = {
-    # name: (M, L, D, B per GPU)
-    'c3': dict(M=4, L=196, D=2048, B=256, desc='C3'),
-    'c2': dict(M=2, L=49, D=512, B=64, desc='C2'),
+    # encoders: (att_num L, att_feat_size D, fc_feat_size F) per encoder; B = captions per GPU
+    'c3': dict(desc='C3', B=256, enc=[(196, 2048, 2048)] * 4, step_tflop=7.667),
+    'c2': dict(desc='C2', B=64, enc=[(49, 512, 512)] * 2, step_tflop=0.1706),
+    # resnet / inception_v4 / inception_v3 / densenet / inception_resnet_v2 (feat_array.py:6-9,53-56,100-103,147-150,194-197)
+    'c3het': dict(desc='shipped 5 heterogeneous encoders', B=256,
+                  enc=[(196, 2048, 2048), (64, 1536, 1536), (64, 1280, 2048), (49, 2208, 2208), (64, 1536, 1536)],
+                  step_tflop=None),
+    'c5': dict(desc='C5 decode', B=128, enc=[(196, 2048, 2048)] * 4, step_tflop=None),
 }
+for _w in WORKLOADS.values():       # uniform-encoder shorthands used by tools/
+    _w['M'], _w['L'], _w['D'] = len(_w['enc']), _w['enc'][0][0], _w['enc'][0][1]
 
 
 def make_cfg(w):
     """The `opt` Namespace fields the model and the criteria read (reference opts.py defaults).
     Built here, not taken from oracle/: the oracle is only touched by the cpu_baseline leg."""
     from types import SimpleNamespace
-    info = [dict(att_num=w['L'], att_feat_size=w['D'], fc_feat_size=w['D']) for _ in range(w['M'])]
+    info = [dict(att_num=L, att_feat_size=D, fc_feat_size=F) for (L, D, F) in w['enc']]
     return SimpleNamespace(
         caption_model='recurrent_fusion_model', vocab_size=9487, input_encoding_size=512, rnn_type='lstm',
         rnn_size=512, num_layers=1, drop_prob_lm=0.0, drop_prob_reason=0.0, drop_prob_fusion=0.0, seq_length=16,
@@ -48,8 +65,29 @@ def make_cfg(w):
         label_smoothing_epsilon=0.1, use_ppo=0, ppo_clip=0.2)
 
 
+def train_step_flops(cfg, B, S=17):
+    """Algorithmic FLOP of one XE train step (SURVEY.md 8d accounting: backward = 2x forward, except the attention
+    feature projection and context, whose input needs no gradient: 1x).  Reproduces 7.667 TF at C3 and 0.1706 at C2
+    to within a few tenths of a percent; used for the workloads SURVEY gives no figure for."""
+    R, A, E, K, V1 = cfg.rnn_size, cfg.att_hid_size, cfg.input_encoding_size, cfg.top_words_count, cfg.vocab_size + 1
+    T1, T2, M = cfg.num_review_steps_0, cfg.num_review_steps, len(cfg.feat_array_info)
+    nograd = grad = 0.0
+    for f in cfg.feat_array_info:
+        L, D, F = f['att_num'], f['att_feat_size'], f['fc_feat_size']
+        nograd += 2.0 * B * L * D * A * T1 + 2.0 * B * L * D * T1          # att_2_att_h projection + context bmm
+        grad += 2.0 * B * F * R                                            # fc2h
+        grad += T1 * (2.0 * B * R * A + 2.0 * B * L * A + 2.0 * B * (M * R + D) * 4 * R)
+        grad += 2.0 * T1 * B * R * K
+    grad += T2 * (M * (2.0 * T1 * B * R * A + 2.0 * B * R * A + 4.0 * B * T1 * A + 2.0 * B * T1 * R)
+                  + 2.0 * B * R * 4 * R * (M + 1)) + 2.0 * T2 * B * R * K
+    grad += 2.0 * T2 * B * R * A + S * (2.0 * B * R * A + 4.0 * B * T2 * A + 2.0 * B * T2 * R
+                                        + 2.0 * B * (E + 2 * R) * 4 * R + 2.0 * B * R * V1)
+    return 2.0 * nograd + 3.0 * grad
+
+
 def synthetic_inputs(cfg, B, seed, dev):
     """SURVEY.md 8d, generated on the device (1.64 GB of features at C3)."""
+    import torch
     g = torch.Generator(device=dev).manual_seed(seed)
     fc = [torch.randn(B, f['fc_feat_size'], generator=g, device=dev) for f in cfg.feat_array_info]
     att = [torch.randn(B, f['att_num'], f['att_feat_size'], generator=g, device=dev) for f in cfg.feat_array_info]
@@ -65,6 +103,7 @@ def synthetic_inputs(cfg, B, seed, dev):
 
 def seeded_weights_(model, seed):
     """uniform(+-0.1) for every parameter from a seeded device generator (checkpoints are not available)."""
+    import torch
     g = torch.Generator(device=next(model.parameters()).device).manual_seed(seed)
     with torch.no_grad():
         for _, p in sorted(model.named_parameters()):
@@ -73,8 +112,9 @@ def seeded_weights_(model, seed):
 
 def time_dominant_kernel(model, att, reps):
     """HIP-event timing of the dominant kernel at the workload's shapes, on the stream the path launches on:
-    the grouped fp32-MFMA GEMM that applies all T1 att_2_att_h step weights of one encoder to its
-    (B*L, D) feature matrix (rfn_prefix_fwd's first launch per encoder).  Returns (avg seconds, flops)."""
+    the grouped fp32-MFMA GEMM that applies all T1 att_2_att_h step weights of encoder 0 to its
+    (B*L, D) feature matrix (rfn_prefix_fwd's first big launch).  Returns (avg seconds, flops)."""
+    import torch
     import recurrent_fusion_network_amd._native as N
     B, L, D = att[0].shape
     A, T1 = model.att_hid_size, model.num_review_steps_0
@@ -95,70 +135,248 @@ def time_dominant_kernel(model, att, reps):
     return e0.elapsed_time(e1) * 1e-3 / reps, flops
 
 
-def cpu_baseline(cfg, sample_B, seed):
+def cpu_baseline(cfg, sample_B, seed, mode='train'):
     """The CPU oracle (kind "port": a PyTorch-CPU restatement validated against the reference, see oracle/)
-    timed on this host on a bounded sample of the same workload: one XE train step (forward + criterion +
-    backward) at the full model size on a few captions; cost is linear in B.  sample_B = 0 sizes the sample from
-    a B=8 probe so that the timed step is about 15 s of CPU work whatever the host."""
+    timed on this host on a bounded sample of the same workload at the full model size: one XE train step
+    (forward + criterion + backward) or, for the decode workload, one greedy sample(); cost is linear in B."""
+    import torch
     from oracle import rfn_oracle as O
     P = O.seeded_params(cfg, seed)
 
     def run(nb):
         fc, att, labels, masks, top = O.synthetic_batch(cfg, nb, seed=seed + 1)
         t0 = time.perf_counter()
-        O.train_step_loss_and_grads(cfg, P, fc, att, labels, masks, top)
+        if mode == 'train':
+            O.train_step_loss_and_grads(cfg, P, fc, att, labels, masks, top)
+        else:
+            with torch.no_grad():
+                O.sample_greedy(cfg, P, fc, att)
         return time.perf_counter() - t0
 
     run(1)                                              # warm the allocator and the thread pool
-    if sample_B <= 0:
-        probe = run(8)
-        sample_B = int(min(64, max(8, round(8 * 15.0 / max(probe, 1e-3) / 8) * 8)))
-        dt = run(sample_B)
-        for _ in range(2):                              # fast host: per-caption cost still falls with B, grow the sample
-            if dt >= 10.0 or sample_B >= 128:
-                break
-            sample_B = int(min(128, max(sample_B + 8, round(sample_B * 15.0 / dt / 8) * 8)))
-            dt = run(sample_B)
-    else:
-        dt = run(sample_B)
-    return dict(value=round(sample_B / dt, 4), unit='captions/s', cores=torch.get_num_threads(), kind='port',
-                sample='1 XE train step (fwd+loss+bwd) of the same model at B=%d captions, %.1f s' % (sample_B, dt))
+    dt = run(sample_B)
+    what = '1 XE train step (fwd+loss+bwd)' if mode == 'train' else '1 greedy sample() (stages I/II + 17 decoder steps)'
+    unit = 'captions/s' if mode == 'train' else 'images/s'
+    return dict(value=round(sample_B / dt, 4), unit=unit, cores=torch.get_num_threads(), kind='port',
+                sample='%s of the same model at B=%d, %.1f s' % (what, sample_B, dt))
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--workload', default='c3', choices=sorted(WORKLOADS))
     ap.add_argument('--batch', type=int, default=0, help='captions per GPU (default: the workload value)')
+    ap.add_argument('--strong', action='store_true',
+                    help='strong scaling: the workload batch is the GLOBAL batch, sharded over the ranks')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--label-smoothing', action='store_true', help='XE criterion with label smoothing 0.1 (SURVEY 8d)')
-    ap.add_argument('--cpu-sample', type=int, default=0,
-                    help='captions in the CPU-baseline sample (0: sized for ~15 s of CPU work from a B=8 probe)')
-    args = ap.parse_args()
+    ap.add_argument('--drop-lm', type=float, default=0.0, help='drop_prob_lm (decoder dropout)')
+    ap.add_argument('--ss-prob', type=float, default=0.0, help='scheduled-sampling probability')
+    ap.add_argument('--recipe', action='store_true',
+                    help='published XE recipe: --drop-lm 0.3 --label-smoothing --ss-prob 0.25')
+    ap.add_argument('--cpu-sample', type=int, default=CPU_SAMPLE_B, help='captions in the CPU-baseline sample')
+    ap.add_argument('--micro-batches', type=int, default=-1, help='override model.micro_batches (-1: model default)')
+    ap.add_argument('--selftest-launch', action='store_true',
+                    help='launcher / rendezvous check without a GPU: ranks meet, reduce a timing, rank 0 prints the line')
+    args = ap.parse_args(argv)
+    if args.recipe:
+        args.drop_lm, args.label_smoothing, args.ss_prob = 0.3, True, 0.25
+    return args
 
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(args, argv):
+    """Parent of an N-rank run: starts fresh children through torch.distributed.run BEFORE anything in this process
+    has imported torch or touched a GPU, relays rank 0's JSON line, returns the children's exit code."""
+    port = int(os.environ.get('MASTER_PORT', 0)) or _free_port()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')     # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for out in proc.stdout:
+        if out.startswith('{"metric"'):
+            line = out.strip()
+        else:
+            sys.stderr.write(out)
+    rc = proc.wait()
+    if rc != 0:
+        sys.stderr.write('bench.py: a rank failed (torch.distributed.run exit code %d)\n' % rc)
+        return rc
+    if line is None:
+        sys.stderr.write('bench.py: the ranks exited without printing a result line\n')
+        return 1
+    print(line, flush=True)
+    return 0
+
+
+def selftest_rank(args):
+    """One rank of --selftest-launch: the rendezvous, barrier and max-over-ranks timing of the real run on CPU
+    tensors; no model, no GPU.  `value` is null: this line proves the launch recipe, it is not a measurement."""
+    import torch
+    from recurrent_fusion_network_amd import parallel as DP
+    rank, world, _ = DP.init_from_env(os.environ.get('RFN_DIST_BACKEND', 'gloo'))
+    if world != args.gpus:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+    if os.environ.get('RFN_BENCH_FAIL_RANK') == str(rank):     # test hook: a rank that dies before the result line
+        raise SystemExit('rank %d: injected failure' % rank)
+    cpu = torch.device('cpu')
+    if world > 1:
+        torch.distributed.barrier()
+    t0 = time.perf_counter()
+    flat = torch.full((1024,), float(rank + 1))
+    works = DP.allreduce_flat([flat], world, async_op=True)
+    for wk in works:
+        wk.wait()
+    assert float(flat[0]) == world * (world + 1) / 2.0
+    elapsed = DP.max_over_ranks(time.perf_counter() - t0, world, cpu)
+    if rank == 0:
+        B = args.batch or WORKLOADS[args.workload]['B']
+        print(json.dumps({'metric': METRIC, 'value': None, 'unit': 'captions/s', 'n_gpus': world, 'steps': args.steps,
+                          'warmup': args.warmup, 'ms_per_step': round(elapsed * 1e3, 3), 'higher_is_better': True,
+                          'scaling': 'strong' if args.strong else 'weak', 'vs_baseline': None, 'dtype': 'f32',
+                          'data': 'synthetic', 'selftest': True,
+                          'rccl_ranks': torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
+                          'config': {'workload': 'launcher self-test (no GPU work)', 'captions_per_gpu': B}}), flush=True)
+    if torch.distributed.is_initialized():
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+def run_decode(args, rank, world, dev):
+    """--workload c5 (BASELINE configs[4]): beam=5 sample_beam, greedy sample and the self-critical RL step
+    (train_rl.py:160-203) at M=4, L=196, D=2048, B=128 per GPU; replicas only (no collective on a decode path)."""
+    import torch
+    import recurrent_fusion_network_amd as R
+    from recurrent_fusion_network_amd import parallel as DP
+    w = dict(WORKLOADS['c5'])
+    B = args.batch or w['B']
+    cfg = make_cfg(w)
+    model = R.RecurrentFusionModel(cfg).to(dev)
+    seeded_weights_(model, 100)
+    fc, att, labels, masks, top = synthetic_inputs(cfg, B, 100 + rank, dev)
+    rl_crit = R.ReviewNetRewardCriterion(cfg)
+    opt = R.FusedClampAdam(model, lr=5e-5, weight_decay=0.0, grad_clip=1.0)
+
+    def beam():
+        model.eval()
+        with torch.no_grad():
+            return model.sample(fc, att, {'beam_size': 5})
+
+    def greedy():
+        model.eval()
+        with torch.no_grad():
+            return model.sample(fc, att, {'sample_max': 1})
+
+    def rl_step():
+        model.train()
+        opt.zero_grad()
+        seq, lp, lp_all, reason = model.sample(fc, att, {'sample_max': 0})
+        with torch.no_grad():
+            model.eval()
+            model.sample(fc, att, {'sample_max': 1})
+            model.train()
+        reward = torch.randn(B, 1, device=dev).expand(B, seq.size(1)).contiguous()   # CIDEr-D scoring is out of scope
+        rl_crit(lp, seq, reward, lp_all, 0.01, reason, top, 1.0, None, cfg).backward()
+        opt.step()
+
+    def fence():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    def timed(fn):
+        for _ in range(args.warmup):
+            fn()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            fn()
+        fence()
+        return DP.max_over_ranks(time.perf_counter() - t0, world, dev) / args.steps
+
+    t_beam, t_greedy, t_rl = timed(beam), timed(greedy), timed(rl_step)
+    if rank != 0:
+        return
+    fwd_flops = (train_step_flops(cfg, B) / 7.667 * 3.680)    # forward-only share (SURVEY 8d: 3.680 of 7.667 TF at C3)
+    out = {'metric': 'images/sec (beam=5 sample_beam eval) at B=128, M=4, L=196, D=2048, seq=16',
+           'value': round(world * B / t_beam, 2), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
+           'warmup': args.warmup, 'ms_per_step': round(t_beam * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+           'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+           'config': {'workload': 'C5: beam=5 sample_beam (stages I/II once per image + 16 device-resident beam steps) '
+                                  'at M=4, L=196, D=2048, B=%d per GPU; also greedy sample and the self-critical RL step' % B,
+                      'images_per_gpu': B, 'parallelism': 'replicas only'},
+           'modes': {'beam5_images_per_s': round(world * B / t_beam, 2), 'beam5_ms': round(t_beam * 1e3, 3),
+                     'greedy_images_per_s': round(world * B / t_greedy, 2), 'greedy_ms': round(t_greedy * 1e3, 3),
+                     'rl_step_images_per_s': round(world * B / t_rl, 2), 'rl_step_ms': round(t_rl * 1e3, 3)}}
+    secs, flops = time_dominant_kernel(model, att, reps=5)
+    achieved = flops / secs / 1e12
+    out['roofline'] = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                       'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
+                       'kernel': 'grouped att_2_att_h projection (%.3f TFLOP, %.3f ms per launch)' % (flops / 1e12, secs * 1e3),
+                       'greedy_frac': round(fwd_flops / t_greedy / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                       'beam5_frac': round(fwd_flops / t_beam / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)}
+    if world == 1 and not args.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline(cfg, min(args.cpu_sample, 16), 100, mode='greedy')
+    print(json.dumps(out), flush=True)
+
+
+def run_rank(args):
     if int(os.environ.get('WORLD_SIZE', '1')) > 1:
         # data parallel: keep the big GEMM tiles single-buffered (<= 110 KB LDS per CU) so RCCL's kernels can run
         # beside the long weight-gradient GEMMs instead of waiting for them (read once by librfn_hip.so)
         os.environ.setdefault('RFN_GEMM_LDS_LEAN', '1')
+    import torch
     import recurrent_fusion_network_amd as R
     from recurrent_fusion_network_amd import parallel as DP
 
     rank, world, local = DP.init_from_env('nccl')
     if world != args.gpus:
-        raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run' % (args.gpus, world))
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     dev = torch.device('cuda', int(os.environ.get('RFN_DEVICE_INDEX', local)))   # test hook: ranks sharing one GPU
     torch.cuda.set_device(dev)
+    try:
+        if args.workload == 'c5':
+            run_decode(args, rank, world, dev)
+        else:
+            run_train(args, rank, world, dev, R, DP)
+    finally:
+        if torch.distributed.is_initialized():
+            torch.distributed.barrier()
+            torch.distributed.destroy_process_group()
+
+
+def run_train(args, rank, world, dev, R, DP):
+    import torch
     w = dict(WORKLOADS[args.workload])
     B = args.batch or w['B']
+    global_B = B * world
+    if args.strong:                      # the workload batch is the global batch: each rank takes its row shard
+        global_B = B
+        lo, hi = DP.shard_rows(global_B, rank, world)
+        B = hi - lo
     cfg = make_cfg(w)
     cfg.use_label_smoothing = int(args.label_smoothing)
+    cfg.drop_prob_lm = float(args.drop_lm)
     torch.manual_seed(100 + rank)            # opts.py:178 default seed, + rank (train.py:23)
 
     model = R.RecurrentFusionModel(cfg).to(dev)
     seeded_weights_(model, 100)              # identical replicas on every rank
-    model.train()                            # dropout probabilities are 0 (opts.py defaults)
+    model.train()
+    model.ss_prob = float(args.ss_prob)
+    if args.micro_batches >= 0 and hasattr(model, 'micro_batches'):
+        model.micro_batches = args.micro_batches
     crit = R.ReviewNetEnsembleCriterion(cfg)
     opt = R.FusedClampAdam(model, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5, grad_clip=1.0)
     fc, att, labels, masks, top = synthetic_inputs(cfg, B, 100 + rank, dev)
@@ -188,47 +406,66 @@ def main():
     fence()
     elapsed = DP.max_over_ranks(time.perf_counter() - t0, world, dev)
     final_loss = float(loss.detach())
+    if rank != 0:
+        return
+    ms = elapsed / args.steps * 1e3
+    M = len(w['enc'])
+    uniform = all(e == w['enc'][0] for e in w['enc'])
+    shape = ('M=%d encoders, L=%d, D=%d' % (M, w['enc'][0][0], w['enc'][0][1]) if uniform else
+             'M=%d encoders (L,D,fc)=%s' % (M, ','.join('(%d,%d,%d)' % e for e in w['enc'])))
+    extras = ''.join([', label smoothing 0.1' if args.label_smoothing else '',
+                      ', drop_prob_lm %.2g' % args.drop_lm if args.drop_lm else '',
+                      ', ss_prob %.2g' % args.ss_prob if args.ss_prob else ''])
+    out = {
+        'metric': METRIC, 'value': round(global_B * args.steps / elapsed, 2), 'unit': 'captions/s', 'n_gpus': world,
+        'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 3), 'higher_is_better': True,
+        'scaling': 'strong' if args.strong else 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'rccl_ranks': torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
+        'dist_backend': torch.distributed.get_backend() if torch.distributed.is_initialized() else None,
+        'config': {'workload': '%s: RecurrentFusionModel XE train step (zero_grad+fwd+criterion+bwd+clamp+Adam), '
+                               '%s, R=A=E=512, T1=T2=8, K=1000, V+1=9488, seq=16 (17 decoder steps)%s'
+                               % (w['desc'], shape, extras),
+                   'captions_per_gpu': B, 'global_batch': global_B,
+                   'parallelism': 'dp%d (batch sharded, RCCL all-reduce of grads)' % world if world > 1 else 'single GPU',
+                   'micro_batches': int(getattr(model, 'micro_batches', 1) or 1),
+                   'final_loss': round(final_loss, 4)},
+    }
+    # roofline of the dominant kernel, timed live with HIP events on the launch stream
+    secs, flops = time_dominant_kernel(model, att, reps=5)
+    achieved = flops / secs / 1e12
+    traffic = None               # HBM-side bytes per launch of that kernel, from the rocprofv3 --pmc passes
+    tfile = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    if os.path.exists(tfile) and B == w['B']:
+        try:
+            gb = json.load(open(tfile)).get(args.workload)
+            traffic = None if gb is None else int(gb * 1e9)
+        except Exception:
+            traffic = None
+    L0, D0 = w['enc'][0][0], w['enc'][0][1]
+    out['roofline'] = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': FP32_MFMA_PEAK_TFLOPS,
+                       'unit': 'TFLOP/s', 'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': traffic,
+                       'traffic_unit': 'bytes per launch (2*FETCH_SIZE + WRITE_SIZE)',
+                       'algorithmic_bytes': int(4 * (B * L0 * D0 + 8 * 512 * D0 + B * L0 * 8 * 512)),
+                       'kernel': 'rfn_gemm_kernel NT big tile (grouped att_2_att_h projection of encoder 0, '
+                                 '%.3f TFLOP per launch, %.3f ms per launch)' % (flops / 1e12, secs * 1e3)}
+    # whole-step view against the same peak (SURVEY.md 8d algorithmic FLOP of one step)
+    step_flops = (w['step_tflop'] * 1e12 * (B / w['B'])) if w['step_tflop'] else train_step_flops(cfg, B)
+    out['roofline']['step_frac'] = round(step_flops / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)
+    out['roofline']['step_tflop'] = round(step_flops / 1e12, 4)
+    if world == 1 and not args.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline(cfg, args.cpu_sample, 100)
+    print(json.dumps(out), flush=True)
 
-    if rank == 0:
-        ms = elapsed / args.steps * 1e3
-        out = {
-            'metric': 'captions/sec (train fwd+bwd) at B=256, M=4, L=196, D=2048, seq=16; 1/2/4/8 GPU',
-            'value': round(world * B * args.steps / elapsed, 2), 'unit': 'captions/s', 'n_gpus': world,
-            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 3), 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': '%s: RecurrentFusionModel XE train step (zero_grad+fwd+criterion+bwd+clamp+Adam), '
-                                   'M=%d encoders, L=%d, D=%d, R=A=E=512, T1=T2=8, K=1000, V+1=9488, seq=16 '
-                                   '(17 decoder steps)' % (w['desc'], w['M'], w['L'], w['D']),
-                       'captions_per_gpu': B, 'global_batch': world * B,
-                       'parallelism': 'dp%d (batch sharded, RCCL all-reduce of grads)' % world if world > 1 else 'single GPU',
-                       'final_loss': round(final_loss, 4)},
-        }
-        # roofline of the dominant kernel, timed live with HIP events on the launch stream
-        secs, flops = time_dominant_kernel(model, att, reps=5)
-        achieved = flops / secs / 1e12
-        traffic = None               # HBM-side bytes per launch of that kernel, from the rocprofv3 --pmc passes
-        tfile = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
-        if os.path.exists(tfile):
-            try:
-                gb = json.load(open(tfile)).get(args.workload)
-                traffic = None if gb is None else int(gb * 1e9)
-            except Exception:
-                traffic = None
-        out['roofline'] = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': FP32_MFMA_PEAK_TFLOPS,
-                           'unit': 'TFLOP/s', 'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': traffic,
-                           'traffic_unit': 'bytes per launch (2*FETCH_SIZE + WRITE_SIZE)',
-                           'algorithmic_bytes': int(4 * (B * w['L'] * w['D'] + 8 * 512 * w['D'] + B * w['L'] * 8 * 512)),
-                           'kernel': 'rfn_gemm_kernel<128,128,kfast,kfast,vec,...,tail> (grouped att_2_att_h projection, '
-                                     '%.3f TFLOP per launch, %.3f ms per launch)' % (flops / 1e12, secs * 1e3)}
-        # whole-step view against the same peak (SURVEY.md 8d algorithmic FLOP of one step)
-        step_flops = {'c3': 7.667e12, 'c2': 0.1706e12}[args.workload] * (B / w['B'])
-        out['roofline']['step_frac'] = round(step_flops / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)
-        if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(cfg, args.cpu_sample, 100)
-        print(json.dumps(out), flush=True)
-    if torch.distributed.is_initialized():
-        torch.distributed.barrier()
-        torch.distributed.destroy_process_group()
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(launch_ranks(args, argv))     # nothing has touched torch or the GPU in this process
+    if args.selftest_launch:
+        selftest_rank(args)
+    else:
+        run_rank(args)
 
 
 if __name__ == '__main__':

@@ -588,7 +588,11 @@ template <int BM, int BN, bool AK, bool BKF, bool VEC, int STAGES, int BK, bool 
 static int launch_cfg(const GemmArgs& a, hipStream_t st) {
     using StA = Stage<BM, AK, VEC, BK, THREADS>;
     using StB = Stage<BN, BKF, VEC, BK, THREADS>;
-    const size_t lds = STAGES * (StA::LDS_FLOATS + StB::LDS_FLOATS) * sizeof(float);
+    size_t lds = STAGES * (StA::LDS_FLOATS + StB::LDS_FLOATS) * sizeof(float);
+    if (BM >= 128) {   // EXPERIMENT: pad the big tiles' LDS request so that fewer blocks co-reside per CU
+        static const size_t min_lds = [] { const char* e = getenv("RFN_GEMM_COOP_LDS_KB"); return e ? (size_t)atol(e) << 10 : (size_t)0; }();
+        if (lds < min_lds) lds = min_lds;
+    }
     const int nblk = a.ngroups * a.tiles_m * a.tiles_n * a.splitk;
     bool launched = false;
 #if GEMM_TAIL_HALF && GEMM_XCD_REMAP
