@@ -124,12 +124,12 @@ def time_dominant_kernel(model, att, reps):
         cell = model.review_steps_individual[t].lstm[0].att_model.att_2_att_h
         probs.append((out[:, t * A:], T1 * A, [(att[0], D, 1, cell.weight, D, 1, D, cell.bias)]))
     flops = 2.0 * B * L * D * A * T1
-    N.gemm(B * L, A, probs)
+    N.gemm(B * L, A, probs, flags=int(getattr(model, 'gemm_flags', 0)))
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
-        N.gemm(B * L, A, probs)
+        N.gemm(B * L, A, probs, flags=int(getattr(model, 'gemm_flags', 0)))
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) * 1e-3 / reps, flops
@@ -333,10 +333,6 @@ def run_decode(args, rank, world, dev):
 
 
 def run_rank(args):
-    if int(os.environ.get('WORLD_SIZE', '1')) > 1:
-        # data parallel: keep the big GEMM tiles single-buffered (<= 110 KB LDS per CU) so RCCL's kernels can run
-        # beside the long weight-gradient GEMMs instead of waiting for them (read once by librfn_hip.so)
-        os.environ.setdefault('RFN_GEMM_LDS_LEAN', '1')
     import torch
     import recurrent_fusion_network_amd as R
     from recurrent_fusion_network_amd import parallel as DP

@@ -33,7 +33,7 @@ extern "C" {
 #define RFN_ERR_ARG (-5)         /* null / misaligned pointer */
 
 #define RFN_MAX_ENC 8
-#define RFN_ABI_VERSION 3
+#define RFN_ABI_VERSION 4
 
 /* Model dimensions: the fields RecurrentFusionModel.__init__ reads from `opt`
  * (misc/RecurrentFusionModel.py:118-151).  Limits (RFN_ERR_SHAPE otherwise): M <= RFN_MAX_ENC,
@@ -55,6 +55,7 @@ typedef struct rfn_dims {
     float drop_fusion;         /* opt.drop_prob_fusion (stage I)                          */
     float drop_reason;         /* opt.drop_prob_reason (stage II)                         */
     float drop_lm;             /* opt.drop_prob_lm     (decoder)                          */
+    uint32_t gemm_flags;       /* RFN_GEMM_OPT_* bits applied to every GEMM of the path (0 = defaults)  */
 } rfn_dims;
 
 int rfn_abi_version(void);
@@ -108,6 +109,17 @@ int rfn_gemm_f32(int M, int N, int ngroups, const rfn_gemm_problem* problems_hos
  * kernel, so the result is deterministic (it differs from the unsplit result only by fp32 re-association). */
 int rfn_gemm_f32_ws(int M, int N, int ngroups, const rfn_gemm_problem* problems_host, int accumulate,
                     void* ws, size_t ws_bytes, void* stream);
+/* Same, with option bits (every tuning choice travels with the call: the library reads no environment variable and
+ * keeps no mutable process state beyond write-once, per-device launch attributes of its kernels).
+ *   RFN_GEMM_OPT_LDS_LEAN  the long big-tile GEMMs keep <= 110 KB of each CU's 160 KB of LDS (single-buffered,
+ *                          register-staged tiles), so that kernels of other streams -- RCCL's under data
+ *                          parallelism -- can co-reside instead of waiting for a multi-millisecond GEMM to drain;
+ *   RFN_GEMM_OPT_NO_DMA    interior big tiles use the register-staged kernel instead of the LDS-DMA one (A/B hook;
+ *                          both give bit-identical results: same k order per output element). */
+#define RFN_GEMM_OPT_LDS_LEAN 1u
+#define RFN_GEMM_OPT_NO_DMA 2u
+int rfn_gemm_f32_opt(int M, int N, int ngroups, const rfn_gemm_problem* problems_host, int accumulate,
+                     void* ws, size_t ws_bytes, unsigned flags, void* stream);
 
 /* out[n] (+)= sum_r X[r*ldx + n]   (bias gradients) */
 int rfn_colsum_f32(const float* X, int64_t ldx, int rows, int cols, float* out, int accumulate,
@@ -346,6 +358,8 @@ int rfn_gather_rows(const float* src, float* dst, const int32_t* order, int rows
  * `ws` keeps every activation rfn_prefix_bwd needs (size rfn_prefix_ws_bytes; with train = 0 a
  * smaller inference workspace suffices and rfn_prefix_bwd must not be called). */
 size_t rfn_prefix_ws_bytes(const rfn_dims* d, int B, int train);
+/* `train` selects the workspace layout (activations kept for rfn_prefix_bwd); dropout is applied whenever the
+ * probabilities in `d` are non-zero (masks from `seed`), with or without `train`. */
 int rfn_prefix_fwd(const rfn_dims* d, int B, const float* const* params,
                    const float* const* fc_feats, const float* const* att_feats, float* comb,
                    float* h_out, float* c_out, float* reason_pred, void* ws, size_t ws_bytes,
@@ -394,21 +408,26 @@ int rfn_decoder_bwd(const rfn_dims* d, int B, int S, const float* const* params,
 /* One free-running decoder step for sample()/sample_beam()/one_time_step
  * (misc/RecurrentFusionModel.py:345-350, 616-653, 526-527): state (h,c) is updated in place,
  * logits (B,V1) pre-softmax and/or logp (B,V1) are written when non-NULL.
- * cproj = att_2_att_h(comb) (T2*B, A) must have been filled by rfn_decoder_prepare. */
+ * cproj = att_2_att_h(comb) (T2*B, A) must have been filled by rfn_decoder_prepare.
+ * The step is computed with the operation sequence of step `step` of rfn_decoder_fwd: with d->drop_lm > 0 it applies
+ * the dropout mask of (seed, step) that rfn_decoder_fwd(train, seed) applies at that step, and its log-probs are
+ * bit-identical to the teacher-forced pass fed the same tokens -- the reference samples (scheduled sampling :260-270,
+ * multinomial sample :623-631) from the very distribution it differentiates.  Hosts pass drop_lm = 0 outside
+ * training mode. */
 size_t rfn_decoder_step_ws_bytes(const rfn_dims* d, int B);
 int rfn_decoder_prepare(const rfn_dims* d, int B, const float* const* params, const float* comb,
                         float* cproj, void* stream);
 int rfn_decoder_step(const rfn_dims* d, int B, const float* const* params, const float* comb,
                      const float* cproj, const int64_t* ids, float* h, float* c, float* logits,
                      float* logp, int64_t ld_logp /* row stride of logp, >= V1 */, void* ws,
-                     size_t ws_bytes, void* stream);
+                     size_t ws_bytes, uint64_t seed, int step, void* stream);
 /* The same step fed with an already embedded token xt (B, E) -- the literal signature of the reference's
  * one_time_step(xt, thought_vectors_comb, state) (misc/RecurrentFusionModel.py:345-350), whose callers do
  * xt = model.embed(it) themselves (eval_utils.py:368,516,539). */
 int rfn_decoder_step_embedded(const rfn_dims* d, int B, const float* const* params, const float* comb,
                               const float* cproj, const float* xt, int64_t ld_xt, float* h, float* c,
                               float* logits, float* logp, int64_t ld_logp, void* ws, size_t ws_bytes,
-                              void* stream);
+                              uint64_t seed, int step, void* stream);
 
 #ifdef __cplusplus
 }

@@ -2,7 +2,7 @@
 """Generate golden vectors by RUNNING THE REFERENCE in the build container.
 
 Usage (build container only; /root/reference does not exist on the GPU box):
-    python oracle/make_golden.py [--only tiny0,tiny1,mid,c2,c3]
+    python oracle/make_golden.py [--only tiny0,tiny1,mid,c2,c3,c5,evalmid]
 
 Imports the reference's RecurrentFusionModel / criteria from /root/reference, loads the
 documented seeded weight stream (oracle.rfn_oracle.seeded_params), runs forward / greedy sample /
@@ -41,6 +41,13 @@ CONFIGS = {
                 seed=2, max_words=16),
     'c2': dict(feats=[(49, 512, 512)] * 2, R=512, V=9487, K=1000, T1=8, T2=8, B=8, S=16, seed=3, max_words=16),
     'c3': dict(feats=[(196, 2048, 2048)] * 4, R=512, V=9487, K=1000, T1=8, T2=8, B=2, S=16, seed=4, max_words=16),
+    # decode tiers (BASELINE config 5 and the eval loop, generate_decode): B caption rows = B / spi images, each image's
+    # features repeated spi times in a row as the loader does; beam search with the config's beam size, RL sample
+    # replay on the image rows.  'c5' is C3-shaped (M=4, L=196, D=2048), 'evalmid' the heterogeneous mid shape.
+    'c5': dict(feats=[(196, 2048, 2048)] * 4, R=512, V=9487, K=1000, T1=8, T2=8, B=6, S=16, seed=8, max_words=12,
+               decode=dict(spi=2, beam=5)),
+    'evalmid': dict(feats=[(196, 96, 96), (64, 80, 128), (49, 72, 72)], R=64, V=300, K=50, T1=8, T2=8, B=10, S=16,
+                    seed=9, max_words=9, decode=dict(spi=5, beam=5)),
 }
 
 
@@ -62,6 +69,15 @@ def batch_of(cfg, spec):
             labels[b, 1 + n[b]:] = 0
             masks[b, n[b] + 2:] = 0
     return fc, att, labels, masks, top
+
+
+def caption_rows(cfg, spec):
+    """Decode tiers: the loader's batch layout (dataloader.py:247-252) -- row r holds the features of image
+    r // spi, its own caption, mask and top words."""
+    spi = spec['decode']['spi']
+    fc, att, labels, masks, top = batch_of(cfg, spec)
+    rep = lambda t: t[::spi].repeat_interleave(spi, 0).contiguous()  # noqa: E731
+    return [rep(f) for f in fc], [rep(a) for a in att], labels, masks, top
 
 
 def digest(tensors):
@@ -110,6 +126,64 @@ class LegacyIndexing:
 
     def __exit__(self, *a):
         torch.Tensor.__getitem__ = self.orig
+
+
+def rl_section(model, ref_utils, cfg, spec, P, fc, att, top, out):
+    """train_rl.py:160-191 on the reference: multinomial sample with grad, reward criterion, backward; the drawn ids
+    are replayed through the oracle (asserted equal) and stored so the HIP path can replay them too."""
+    B = fc[0].size(0)
+    torch.manual_seed(77 + spec['seed'])
+    model.zero_grad()
+    s_seq, s_lp, s_all, s_rp = model.sample(fc, att, {'sample_max': 0, 'beam_size': 1, 'temperature': 1.0})
+    T = s_seq.size(1)
+    rng = np.random.default_rng(3000 + spec['seed'])
+    reward = torch.from_numpy(np.repeat(rng.standard_normal((B, 1)).astype(np.float32), T, 1))
+    rl_crit = ref_utils.ReviewNetRewardCriterion(cfg)
+    rl_loss = rl_crit(s_lp, s_seq.data, reward, s_all, 0.01, s_rp, top, 1.0, None, cfg)
+    rl_loss.backward()
+    # replay the drawn ids through the oracle.  The reference masks ids of finished rows to 0 in
+    # `seq` but feeds the UNMASKED draw to embed (:637,:647); finished rows never influence
+    # other rows or unmasked loss terms, but logprobs_all of finished rows does enter the entropy
+    # term only where mask_0 > 0, so replaying the masked ids is loss-equivalent only if no row
+    # finishes early -- store the raw draws instead.
+    torch.manual_seed(77 + spec['seed'])
+    raw = []
+    orig_multinomial = torch.multinomial
+
+    def spy(*a, **k):
+        r = orig_multinomial(*a, **k)
+        raw.append(r.view(-1).clone())
+        return r
+
+    torch.multinomial = spy
+    try:
+        with torch.no_grad():
+            model.sample(fc, att, {'sample_max': 0, 'beam_size': 1, 'temperature': 1.0})
+    finally:
+        torch.multinomial = orig_multinomial
+    raw_ids = torch.stack(raw, 1)[:, :max(T, 1)]
+    full_ids = torch.zeros(B, cfg.seq_length, dtype=torch.long)
+    full_ids[:, :raw_ids.size(1)] = raw_ids
+    Pg = {k: v.detach().clone().requires_grad_(True) for k, v in P.items()}
+    r_seq, r_lp, r_all, r_rp = O.sample_greedy(cfg, Pg, fc, att, force_ids=full_ids)
+    assert torch.equal(r_seq, s_seq), 'RL replay ids differ'
+    close(r_lp, s_lp, 2e-5, 'RL seqLogprobs')
+    o_rl = O.rl_criterion(cfg, r_lp, r_seq, reward, r_all, 0.01, r_rp, top, 1.0)
+    close(o_rl, rl_loss, 1e-4, 'RL loss')
+    o_rl.backward()
+    out['rl_raw_ids'] = full_ids.numpy()
+    out['rl_seq'] = s_seq.numpy()
+    out['rl_seq_logprobs'] = s_lp.detach().numpy()
+    out['rl_reward'] = reward.numpy()
+    out['rl_loss'] = np.float64(rl_loss.item())
+    for k, p in model.named_parameters():
+        close(Pg[k].grad if Pg[k].grad is not None else torch.zeros_like(Pg[k]), p.grad,
+              2e-5 + 1e-4 * float(p.grad.abs().max()), 'RL grad ' + k)
+        n, s = grad_summary(k, p.grad)
+        out['rl_gradnorm/' + k] = n
+        out['rl_gradslice/' + k] = s
+    model.zero_grad()
+
 
 
 def close(a, b, tol, what):
@@ -228,57 +302,7 @@ def generate(name, RefModel, ref_utils, outdir):
 
     # ---- RL: multinomial sample with grad + reward criterion (train_rl.py:160-191) -------------
     if name in ('tiny0', 'tiny1', 'tinymax', 'odd', 'mid', 'c2'):
-        torch.manual_seed(77 + spec['seed'])
-        model.zero_grad()
-        s_seq, s_lp, s_all, s_rp = model.sample(fc, att, {'sample_max': 0, 'beam_size': 1, 'temperature': 1.0})
-        T = s_seq.size(1)
-        rng = np.random.default_rng(3000 + spec['seed'])
-        reward = torch.from_numpy(np.repeat(rng.standard_normal((spec['B'], 1)).astype(np.float32), T, 1))
-        rl_crit = ref_utils.ReviewNetRewardCriterion(cfg)
-        rl_loss = rl_crit(s_lp, s_seq.data, reward, s_all, 0.01, s_rp, top, 1.0, None, cfg)
-        rl_loss.backward()
-        # replay the drawn ids through the oracle.  The reference masks ids of finished rows to 0 in
-        # `seq` but feeds the UNMASKED draw to embed (:637,:647); finished rows never influence
-        # other rows or unmasked loss terms, but logprobs_all of finished rows does enter the entropy
-        # term only where mask_0 > 0, so replaying the masked ids is loss-equivalent only if no row
-        # finishes early -- store the raw draws instead.
-        torch.manual_seed(77 + spec['seed'])
-        raw = []
-        orig_multinomial = torch.multinomial
-
-        def spy(*a, **k):
-            r = orig_multinomial(*a, **k)
-            raw.append(r.view(-1).clone())
-            return r
-
-        torch.multinomial = spy
-        try:
-            with torch.no_grad():
-                model.sample(fc, att, {'sample_max': 0, 'beam_size': 1, 'temperature': 1.0})
-        finally:
-            torch.multinomial = orig_multinomial
-        raw_ids = torch.stack(raw, 1)[:, :max(T, 1)]
-        full_ids = torch.zeros(spec['B'], cfg.seq_length, dtype=torch.long)
-        full_ids[:, :raw_ids.size(1)] = raw_ids
-        Pg = {k: v.detach().clone().requires_grad_(True) for k, v in P.items()}
-        r_seq, r_lp, r_all, r_rp = O.sample_greedy(cfg, Pg, fc, att, force_ids=full_ids)
-        assert torch.equal(r_seq, s_seq), 'RL replay ids differ'
-        close(r_lp, s_lp, 2e-5, 'RL seqLogprobs')
-        o_rl = O.rl_criterion(cfg, r_lp, r_seq, reward, r_all, 0.01, r_rp, top, 1.0)
-        close(o_rl, rl_loss, 1e-4, 'RL loss')
-        o_rl.backward()
-        out['rl_raw_ids'] = full_ids.numpy()
-        out['rl_seq'] = s_seq.numpy()
-        out['rl_seq_logprobs'] = s_lp.detach().numpy()
-        out['rl_reward'] = reward.numpy()
-        out['rl_loss'] = np.float64(rl_loss.item())
-        for k, p in model.named_parameters():
-            close(Pg[k].grad if Pg[k].grad is not None else torch.zeros_like(Pg[k]), p.grad,
-                  2e-5 + 1e-4 * float(p.grad.abs().max()), 'RL grad ' + k)
-            n, s = grad_summary(k, p.grad)
-            out['rl_gradnorm/' + k] = n
-            out['rl_gradslice/' + k] = s
-        model.zero_grad()
+        rl_section(model, ref_utils, cfg, spec, P, fc, att, top, out)
 
     # ---- beam search (misc/RecurrentFusionModel.py:352-543) -----------------------------------
     if name in ('tiny0', 'tinymax', 'odd', 'mid', 'c2'):
@@ -341,16 +365,79 @@ def generate(name, RefModel, ref_utils, outdir):
         name, e1, loss.item(), seq.size(1), path, os.path.getsize(path) / 1024))
 
 
+def generate_decode(name, RefModel, ref_utils, outdir):
+    """Decode tiers: the eval loop body (eval_utils.py:149-151, 159-208) with greedy and with beam search, and the
+    self-critical sample path (train_rl.py:160-191, get_rewards.py:119-126) at the config's shape."""
+    spec = CONFIGS[name]
+    cfg = cfg_of(spec)
+    spi, beam = spec['decode']['spi'], spec['decode']['beam']
+    torch.manual_seed(0)
+    model = RefModel(cfg)
+    P = O.seeded_params(cfg, spec['seed'])
+    model.load_state_dict(P)
+    model.eval()
+    fc0, att0, labels, masks, top = batch_of(cfg, spec)
+    fc, att, _, _, _ = caption_rows(cfg, spec)
+    out = dict(weights_digest=digest([P[k] for k in sorted(P)]), inputs_digest=digest(fc0 + att0),
+               labels=labels.numpy(), masks=masks.numpy(), top_words=top.numpy(), seq_per_img=np.int64(spi),
+               beam_size=np.int64(beam))
+    crit = ref_utils.ReviewNetEnsembleCriterion(cfg)
+    rows = np.arange(spec['B'] // spi) * spi
+    with torch.no_grad():
+        log_prob, top_pred = model(fc, att, labels)                                   # eval_utils.py:149-151
+        loss = crit(log_prob, labels[:, 1:], masks[:, 1:], top_pred, top, 1.0)
+        fc_u, att_u = [f[rows] for f in fc], [a[rows] for a in att]                   # :172-173
+        g = model.sample(fc_u, att_u, {'beam_size': 1, 'sample_max': 1})             # :195
+        g_sent = torch.sum(g[1] * (g[0] > 0).float(), 1)                             # :207
+        with LegacyIndexing():
+            b = model.sample(fc_u, att_u, {'beam_size': beam, 'sample_max': 1})
+        b_sent = torch.sum(b[1] * (b[0] > 0).float(), 1)
+    o_loss, o_seq, o_lp, o_sent = O.eval_step(cfg, P, fc, att, labels, masks, top, spi, 1.0, 1)
+    close(o_loss, loss, 1e-4, 'eval xe loss')
+    assert torch.equal(o_seq, g[0]), 'eval greedy ids differ'
+    close(o_lp, g[1], 2e-5, 'eval greedy seqLogprobs')
+    close(o_sent, g_sent, 1e-4, 'eval greedy sentence log-prob')
+    ob_loss, ob_seq, ob_lp, ob_sent = O.eval_step(cfg, P, fc, att, labels, masks, top, spi, 1.0, beam)
+    assert torch.equal(ob_seq, b[0]), 'eval beam ids differ'
+    close(ob_lp, b[1], 2e-5, 'eval beam seqLogprobs')
+    close(ob_sent, b_sent, 1e-4, 'eval beam sentence log-prob')
+    with torch.no_grad():
+        o_b = O.sample_beam(cfg, P, fc_u, att_u, beam)
+    nb = len(rows)
+    for k in range(nb):
+        assert torch.equal(o_b[2][k], b[2][k]), 'beam top_seq differs'
+    out['eval_xe_loss'] = np.float64(loss.item())
+    out['eval_greedy_seq'], out['eval_greedy_seq_logprobs'] = g[0].numpy(), g[1].numpy()
+    out['eval_greedy_sentence'] = g_sent.numpy()
+    top2 = g[2].topk(2, dim=2).values
+    out['eval_greedy_margin'] = (top2[:, :, 0] - top2[:, :, 1]).numpy()
+    out['beam_seq'], out['beam_seq_logprobs'], out['beam_sentence'] = b[0].numpy(), b[1].numpy(), b_sent.numpy()
+    for k in range(nb):
+        out['beam_top_seq_%d' % k] = b[2][k].numpy()
+        out['beam_top_prob_%d' % k] = np.array([float(x) for x in b[3][k]], dtype=np.float64)
+    # the self-critical sample path on the image rows
+    top_u = top[rows]
+    rl_section(model, ref_utils, cfg, dict(spec, B=nb), P, fc_u, att_u, top_u, out)
+    # get_rewards.py:119-126: the greedy baseline of the same batch is the eval greedy sample above
+    path = os.path.join(outdir, name + '.npz')
+    np.savez_compressed(path, **out)
+    print('%-7s eval xe %.6f  greedy T=%d  beam=%d T=%d  rl loss %.6f -> %s (%.1f KB)' % (
+        name, loss.item(), g[0].size(1), beam, b[0].size(1), float(out['rl_loss']), path, os.path.getsize(path) / 1024))
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--only', default='tiny0,tiny1,tinymax,odd,mid,c2,c3')
+    ap.add_argument('--only', default='tiny0,tiny1,tinymax,odd,mid,c2,c3,c5,evalmid')
     ap.add_argument('--out', default=os.path.join(ROOT, 'tests', 'golden'))
     args = ap.parse_args()
     torch.set_num_threads(8)
     RefModel, ref_utils = load_reference()
     os.makedirs(args.out, exist_ok=True)
     for name in args.only.split(','):
-        generate(name, RefModel, ref_utils, args.out)
+        if 'decode' in CONFIGS[name]:
+            generate_decode(name, RefModel, ref_utils, args.out)
+        else:
+            generate(name, RefModel, ref_utils, args.out)
 
 
 if __name__ == '__main__':

@@ -440,6 +440,26 @@ def rl_criterion(cfg, sample_logprobs, seq, reward, logprobs_all, entropy_reg, t
     return out + disc * reason_weight / len(top_pred)                             # :78-82
 
 
+def eval_step(cfg, P, fc_feats, att_feats, labels, masks, top_words, seq_per_img: int, reason_weight: float = 1.0,
+              beam_size: int = 1):
+    """One iteration of eval_split's loop (eval_utils.py:149-151, 159-208): XE loss on the caption batch (every
+    image's features seq_per_img times in a row), then sample() on ONE row per image (rows arange(n) * seq_per_img)
+    and the sentence score sum(seqLogprobs * (seq > 0)).  -> (loss, seq, seqLogprobs, log_probs_sentence)."""
+    with torch.no_grad():
+        log_prob, top_pred = forward(cfg, P, fc_feats, att_feats, labels)
+        loss = xe_criterion(cfg, log_prob, labels[:, 1:], masks[:, 1:], top_pred, top_words, reason_weight)
+        rows = torch.arange(fc_feats[0].size(0) // seq_per_img) * seq_per_img        # :172-173
+        fc_u = [f[rows] for f in fc_feats]
+        att_u = [a[rows] for a in att_feats]
+        if beam_size > 1:
+            out = sample_beam(cfg, P, fc_u, att_u, beam_size)
+        else:
+            out = sample_greedy(cfg, P, fc_u, att_u)
+        seq, seq_lp = out[0], out[1]
+        sentence = torch.sum(seq_lp * (seq > 0).to(seq_lp.dtype), 1)                   # :207
+    return loss, seq, seq_lp, sentence
+
+
 def clip_and_adam(params: Dict[str, Tensor], grads: Dict[str, Tensor], state: dict, lr=5e-4,
                   betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5, grad_clip=1.0):
     """clip_gradient (misc/utils.py:292-296: element-wise clamp) then torch.optim.Adam with L2

@@ -16,7 +16,9 @@ LIB_PATH = os.path.join(_HERE, 'librfn_hip.so')
 RFN_MAX_ENC = 8
 RFN_GEMM_MAXSEG = 8
 RFN_GEMM_MAXGROUP = 8
-ABI_VERSION = 3
+ABI_VERSION = 4
+GEMM_OPT_LDS_LEAN = 1
+GEMM_OPT_NO_DMA = 2
 
 
 class RfnError(RuntimeError):
@@ -28,7 +30,8 @@ class Dims(C.Structure):
                 ('T2', C.c_int32), ('K', C.c_int32), ('V1', C.c_int32),
                 ('L', C.c_int32 * RFN_MAX_ENC), ('D', C.c_int32 * RFN_MAX_ENC), ('F', C.c_int32 * RFN_MAX_ENC),
                 ('review_maxout', C.c_int32), ('decoder_maxout', C.c_int32),
-                ('drop_fusion', C.c_float), ('drop_reason', C.c_float), ('drop_lm', C.c_float)]
+                ('drop_fusion', C.c_float), ('drop_reason', C.c_float), ('drop_lm', C.c_float),
+                ('gemm_flags', C.c_uint32)]
 
 
 class GemmSeg(C.Structure):
@@ -59,6 +62,7 @@ def _load():
         'rfn_param_shape': (C.c_int, [DP, I, C.POINTER(L), C.POINTER(L)]),
         'rfn_gemm_f32': (C.c_int, [I, I, I, C.POINTER(GemmProblem), I, P]),
         'rfn_gemm_f32_ws': (C.c_int, [I, I, I, C.POINTER(GemmProblem), I, P, SZ, P]),
+        'rfn_gemm_f32_opt': (C.c_int, [I, I, I, C.POINTER(GemmProblem), I, P, SZ, C.c_uint, P]),
         'rfn_colsum_f32': (C.c_int, [P, L, I, I, P, I, P]),
         'rfn_colsum_grouped_f32': (C.c_int, [P, L, L, I, I, P, I, P]),
         'rfn_fill_small_f32': (C.c_int, [P, I, I, F, P]),
@@ -109,8 +113,8 @@ def _load():
         'rfn_decoder_bwd': (C.c_int, [DP, I, I, P, P, P, P, P, L, P, P, P, P, P, P, P, SZ, U64, P]),
         'rfn_decoder_step_ws_bytes': (SZ, [DP, I]),
         'rfn_decoder_prepare': (C.c_int, [DP, I, P, P, P, P]),
-        'rfn_decoder_step': (C.c_int, [DP, I, P, P, P, P, P, P, P, P, L, P, SZ, P]),
-        'rfn_decoder_step_embedded': (C.c_int, [DP, I, P, P, P, P, L, P, P, P, P, L, P, SZ, P]),
+        'rfn_decoder_step': (C.c_int, [DP, I, P, P, P, P, P, P, P, P, L, P, SZ, U64, I, P]),
+        'rfn_decoder_step_embedded': (C.c_int, [DP, I, P, P, P, P, L, P, P, P, P, L, P, SZ, U64, I, P]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
@@ -152,7 +156,7 @@ def ptr_array(tensors):
 
 
 def make_dims(M, R, A, E, T1, T2, K, V1, L, D, Fc, review_maxout=0, decoder_maxout=0, drop_fusion=0.0,
-              drop_reason=0.0, drop_lm=0.0) -> Dims:
+              drop_reason=0.0, drop_lm=0.0, gemm_flags=0) -> Dims:
     if M > RFN_MAX_ENC:
         raise RfnError('at most %d encoders are supported' % RFN_MAX_ENC)
     d = Dims()
@@ -161,6 +165,7 @@ def make_dims(M, R, A, E, T1, T2, K, V1, L, D, Fc, review_maxout=0, decoder_maxo
         d.L[i], d.D[i], d.F[i] = L[i], D[i], Fc[i]
     d.review_maxout, d.decoder_maxout = int(review_maxout), int(decoder_maxout)
     d.drop_fusion, d.drop_reason, d.drop_lm = drop_fusion, drop_reason, drop_lm
+    d.gemm_flags = int(gemm_flags)
     return d
 
 
@@ -183,9 +188,9 @@ def param_shape(d: Dims, idx: int):
 
 
 # ---- thin helpers over the primitive operators (used by the model shell and by the tests) ---------
-def gemm(M, N, problems, accumulate=False, ws=None):
+def gemm(M, N, problems, accumulate=False, ws=None, flags=0):
     """problems: list of (C, ldc, [(A, lda, a_kfast, B, ldb, b_kfast, K, bias), ...][, a_colsum]).
-    ws: optional uint8 scratch tensor enabling split-K for skinny problems."""
+    ws: optional uint8 scratch tensor enabling split-K for skinny problems; flags: GEMM_OPT_* bits."""
     arr = (GemmProblem * len(problems))()
     for g, prob in enumerate(problems):
         Ct, ldc, segs = prob[:3]
@@ -196,11 +201,8 @@ def gemm(M, N, problems, accumulate=False, ws=None):
             sg.A, sg.lda, sg.a_kfast = A.data_ptr(), lda, int(ak)
             sg.B, sg.ldb, sg.b_kfast = B.data_ptr(), ldb, int(bk)
             sg.K, sg.bias = K, ptr(bias)
-    if ws is not None:
-        check(lib.rfn_gemm_f32_ws(M, N, len(problems), arr, int(accumulate), ws.data_ptr(), ws.numel(), stream_ptr()),
-              'rfn_gemm_f32_ws')
-        return
-    check(lib.rfn_gemm_f32(M, N, len(problems), arr, int(accumulate), stream_ptr()), 'rfn_gemm_f32')
+    check(lib.rfn_gemm_f32_opt(M, N, len(problems), arr, int(accumulate), ptr(ws), 0 if ws is None else ws.numel(),
+                               int(flags), stream_ptr()), 'rfn_gemm_f32_opt')
 
 
 def linear(x: torch.Tensor, weight: torch.Tensor, bias=None) -> torch.Tensor:

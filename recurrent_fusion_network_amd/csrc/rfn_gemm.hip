@@ -19,8 +19,6 @@
 //     one barrier per K step; 2 blocks/CU co-reside so the partner's MFMAs cover staging.
 //   * 1-D grid with a bijective XCD remap + 8-row bands so the blocks sharing an A row-panel and a
 //     B column-panel run on one XCD's L2 at the same time.
-#include <stdlib.h>
-
 #include "rfn_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -88,6 +86,24 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef GEMM_TAIL_HALF
 #define GEMM_TAIL_HALF 1   /* half-height tiles for the last, partly filled round of a big NT launch */
 #endif
+#ifndef GEMM_DMA
+#define GEMM_DMA 1         /* big interior tiles are staged by LDS-DMA (global_load_lds_dwordx4) into a ring of slots */
+#endif
+#ifndef GEMM_DMA_MIN_WAVES
+#define GEMM_DMA_MIN_WAVES 3   /* __launch_bounds__ waves per SIMD of the LDS-DMA kernels */
+#endif
+#ifndef GEMM_DMA_ABLATE
+#define GEMM_DMA_ABLATE 0      /* diagnostics only (wrong results): 1 no DMA in the loop, 2 no barrier, 4 no LDS reads */
+#endif
+#ifndef GEMM_DMA_BK
+#define GEMM_DMA_BK 32     /* K step of the LDS-DMA tile (32 or 16) */
+#endif
+#ifndef GEMM_DMA_SLOTS_NT
+#define GEMM_DMA_SLOTS_NT 2  /* ring slots, both operands k-contiguous (projection) */
+#endif
+#ifndef GEMM_DMA_SLOTS_XX
+#define GEMM_DMA_SLOTS_XX 2  /* ring slots, the other layouts (weight gradient, dX) */
+#endif
 #ifndef GEMM_ABLATE
 #define GEMM_ABLATE 0      /* 1: skip global loads after the first tile, 2: skip the epilogue stores */
 #endif
@@ -96,7 +112,8 @@ struct GemmArgs {
     int M, N, ngroups, accumulate;
     int tiles_m, tiles_n;
     int splitk;   // > 1: each tile's K iterations are cut into `splitk` ranges, raw partial tiles go to `part`
-    int pad_;
+    int ws_mib;   // host side only: size of the split-K scratch in MiB
+    unsigned flags;        // host side only: RFN_GEMM_OPT_* bits of the call
     int tail_main_blocks;   // > 0: blocks past this id process HALF-height tiles (see rfn_gemm_kernel)
     int tail_idx_main;      // first per-XCD tile index of the tail round
     float* part;  // [ngroups][splitk][M][N]
@@ -507,14 +524,255 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& args, const int grp, c
     }
 }
 
+// ---- LDS-DMA staging ----------------------------------------------------------------------------------------------
+// global_load_lds_dwordx4 writes 64 lanes x 16 B = 1 KiB of LDS per wave-instruction at a wave-uniform base (lane-
+// linear, no per-lane scatter), so the tile images are unpadded and the bank-conflict fix goes on the SOURCE address:
+//   [row][k] operands: rows of BK floats; 16-B chunk c of row r is stored at chunk position c ^ swz(r), where swz
+//     spreads the 16 rows of each ds_read_b128 lane group over all 64 banks (BK = 32: 128-B rows, swz = (r>>1)&7;
+//     BK = 16: 64-B rows, swz = (r>>2)&3).  Each lane fetches the chunk its LDS position must hold, every 128-B
+//     (64-B) row segment is still read whole by 8 (4) neighbouring lanes.
+//   [k][row] operands: k-rows of ROWS floats, linear; ds_read_b32 of 32 consecutive rows is conflict-free as it is.
+// No staging registers, no ds_write pass, and the data of the next slot(s) stays in flight across the barrier.
+typedef __attribute__((address_space(3))) void rfn_lds_void;
+typedef const __attribute__((address_space(1))) void rfn_gbl_void;
+
+template <int ROWS, bool KFAST, int BK>
+struct Dma {
+    static constexpr int FLOATS = ROWS * BK;
+    static constexpr int NI = ROWS * BK / 256 / 4;   // 1-KiB wave-instructions per wave (4 waves per block)
+    static constexpr int CPR = BK / 4;               // 16-B chunks per [row][k] row
+    static constexpr int RPI = 64 / CPR;             // rows per wave-instruction   ([row][k])
+    static constexpr int RQ = ROWS / 4;              // 16-B chunks per [k][row] k-row
+    static constexpr int KPI = 64 / RQ;              // k-rows per wave-instruction ([k][row])
+    static_assert(NI >= 1 && ROWS * BK % 1024 == 0 && (KFAST || RQ <= 64), "tile must be whole 1-KiB pieces per wave");
+
+    __device__ __forceinline__ static int swz(int row) { return BK == 32 ? ((row >> 1) & 7) : ((row >> 2) & 3); }
+
+    // Source addressing: a wave-uniform base pointer (the tile's first k, advanced by a SCALAR add per K step) plus
+    // this lane's 32-bit byte offset, fixed for the whole K loop (one per wave-instruction).  The DMA instruction then
+    // takes its address as SGPR pair + one VGPR: half the address-register traffic of a 64-bit per-lane pointer and
+    // no per-lane pointer arithmetic in the loop (the host checks that the operand spans < 4 GiB).
+    __device__ __forceinline__ static void init_offs(uint32_t (&o)[NI], long ld, int row0, int wave, int lane) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int n = wave * NI + j;
+            if constexpr (KFAST) {
+                const int row = n * RPI + lane / CPR;
+                o[j] = (uint32_t)(((long)(row0 + row) * ld + 4 * ((lane % CPR) ^ swz(row))) * 4);
+            } else {
+                o[j] = (uint32_t)(((long)(n * KPI + lane / RQ) * ld + row0 + 4 * (lane % RQ)) * 4);
+            }
+        }
+    }
+    __device__ __forceinline__ static void issue(const char* base, const uint32_t (&o)[NI], float* stage, int wave) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+            __builtin_amdgcn_global_load_lds((rfn_gbl_void*)(base + o[j]), (rfn_lds_void*)(stage + (wave * NI + j) * 256), 16,
+                                             0, 0);
+    }
+    // the 4 k-values (k = 8q + 4h + c) of tile row `row`; sw = swz(row)
+    __device__ __forceinline__ static f32x4 frag(const float* __restrict__ lds, int row, int q, int h, int sw) {
+        if constexpr (KFAST) {
+            return *reinterpret_cast<const f32x4*>(lds + row * BK + 4 * ((2 * q + h) ^ sw));
+        } else {
+            f32x4 x;
+            const float* p = lds + (8 * q + 4 * h) * ROWS + row;
+            x[0] = p[0];
+            x[1] = p[ROWS];
+            x[2] = p[2 * ROWS];
+            x[3] = p[3 * ROWS];
+            return x;
+        }
+    }
+};
+
+template <int N>
+__device__ __forceinline__ void rfn_wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// One BM x BN output tile of an interior single- or multi-segment problem (M % BM == N % BN == K_s % BK == 0, float4
+// aligned), operands staged by LDS-DMA into a ring of SLOTS slots:
+//   iteration it:  wait until this wave's pieces of tile `it` have landed (the younger SLOTS-2 tiles stay in flight)
+//                  -> barrier (every wave's pieces landed; every wave has finished reading slot (it-1) % SLOTS)
+//                  -> issue tile it+SLOTS-1 into that freed slot -> MFMAs on slot it % SLOTS.
+// One barrier per K step; the k order of every output element is the same as in the register-staged kernel.
+template <int BM, int BN, bool AK, bool BKF, int BK, int SLOTS>
+__device__ __forceinline__ void gemm_tile_dma(const GemmArgs& args, const int grp, const int ks, const int row0,
+                                              const int col0) {
+    constexpr int MT = BM / 64, NT = BN / 64;   // 2x2 waves, 32x32 MFMA tiles per wave
+    using DA = Dma<BM, AK, BK>;
+    using DB = Dma<BN, BKF, BK>;
+    constexpr int SLOT_FLOATS = DA::FLOATS + DB::FLOATS;
+    constexpr int NIW = DA::NI + DB::NI;        // DMA instructions per wave per tile
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int swa = DA::swz(l31), swb = DB::swz(l31);   // tile rows are l31 + multiples of 32: same swizzle term
+
+    const int splitk = args.splitk;
+    const rfn_gemm_problem& P = args.g[grp];
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    int total_iters = 0;
+    for (int s = 0; s < P.nseg; ++s) total_iters += P.seg[s].K / BK;
+    int seg = 0, k0 = 0;
+    if (splitk > 1) {
+        const int per = (total_iters + splitk - 1) / splitk;
+        int it_begin = ks * per;
+        const int it_end = min(total_iters, it_begin + per);
+        total_iters = max(0, it_end - it_begin);
+        while (seg < P.nseg) {
+            const int n = P.seg[seg].K / BK;
+            if (it_begin < n) break;
+            it_begin -= n;
+            ++seg;
+        }
+        k0 = it_begin * BK;
+    }
+    uint32_t oa[DA::NI], ob[DB::NI];     // per-lane byte offsets inside the current segment's operands
+    const char* baseA = nullptr;         // wave-uniform: first byte of the k0 column (row) of the segment's operands
+    const char* baseB = nullptr;
+    long stepA = 0, stepB = 0;           // bytes per K step
+    int segK = 0;
+    auto setup = [&]() {
+        if (seg < P.nseg) {
+            const rfn_gemm_seg& sg = P.seg[seg];
+            segK = sg.K;
+            DA::init_offs(oa, sg.lda, row0, wave, lane);
+            DB::init_offs(ob, sg.ldb, col0, wave, lane);
+            stepA = (AK ? (long)BK : (long)BK * sg.lda) * 4;
+            stepB = (BKF ? (long)BK : (long)BK * sg.ldb) * 4;
+            baseA = (const char*)sg.A + (long)(k0 / BK) * stepA;
+            baseB = (const char*)sg.B + (long)(k0 / BK) * stepB;
+#if GEMM_DMA_ABLATE & 8
+            stepA = stepB = 0;   // every K step re-reads the first tile: same instruction stream, cache-resident data
+#endif
+        }
+    };
+    setup();
+    auto issue = [&](int slot) {
+        float* st = smem + slot * SLOT_FLOATS;
+        DA::issue(baseA, oa, st, wave);
+        DB::issue(baseB, ob, st + DA::FLOATS, wave);
+        baseA += stepA;
+        baseB += stepB;
+        k0 += BK;
+        if (k0 >= segK) {   // next K segment (rare)
+            k0 = 0;
+            ++seg;
+            setup();
+        }
+    };
+
+    int issued = 0;
+#pragma unroll
+    for (int s = 0; s < SLOTS - 1; ++s)
+        if (s < total_iters) {
+            issue(s);
+            ++issued;
+        }
+    int cur = 0, fill = SLOTS - 1;   // slot of tile `it`, slot tile it+SLOTS-1 goes to
+    for (int it = 0; it < total_iters; ++it) {
+        const int younger = issued - it - 1;   // tiles issued after tile `it`
+        if (SLOTS >= 4 && younger >= 2) rfn_wait_vmcnt<(SLOTS >= 4 ? 2 : 0) * NIW>();
+        else if (SLOTS >= 3 && younger >= 1) rfn_wait_vmcnt<(SLOTS >= 3 ? 1 : 0) * NIW>();
+        else rfn_wait_vmcnt<0>();
+#if !(GEMM_DMA_ABLATE & 2)
+        __builtin_amdgcn_s_barrier();
+#endif
+        if (issued < total_iters) {
+#if GEMM_DMA_ABLATE & 1
+            k0 += BK;
+#else
+            issue(fill);
+#endif
+            ++issued;
+        }
+        const float* a_l = smem + cur * SLOT_FLOATS;
+        const float* b_l = a_l + DA::FLOATS;
+#pragma unroll
+        for (int q = 0; q < BK / 8; ++q) {
+            f32x4 af[MT], bf[NT];
+#if GEMM_DMA_ABLATE & 4
+#pragma unroll
+            for (int i = 0; i < MT; ++i) { af[i] = f32x4{1.f + q, 2.f, 3.f, 4.f + i}; asm volatile("" : "+v"(af[i])); }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) { bf[j] = f32x4{1.f, 2.f + q, 3.f + j, 4.f}; asm volatile("" : "+v"(bf[j])); }
+#else
+#pragma unroll
+            for (int i = 0; i < MT; ++i) af[i] = DA::frag(a_l, wm * (BM / 2) + i * 32 + l31, q, h, swa);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bf[j] = DB::frag(b_l, wn * (BN / 2) + j * 32 + l31, q, h, swb);
+#endif
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][c], bf[j][c], acc[i][j], 0, 0, 0);
+        }
+        cur = (cur + 1 == SLOTS) ? 0 : cur + 1;
+        fill = (fill + 1 == SLOTS) ? 0 : fill + 1;
+    }
+
+    const int M = args.M, N = args.N;
+    if (splitk > 1) {  // raw partial tile; rfn_gemm_reduce_k adds the bias / previous C in a fixed order
+        float* part = args.part + ((long)grp * splitk + ks) * (long)M * N;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int col = col0 + wn * (BN / 2) + j * 32 + l31;
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = row0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    part[(long)row * N + col] = acc[i][j][r];
+                }
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int col = col0 + wn * (BN / 2) + j * 32 + l31;
+        float bsum = 0.f;
+        for (int s = 0; s < P.nseg; ++s)
+            if (P.seg[s].bias) bsum += P.seg[s].bias[col];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                float* c = P.C + (long)row * P.ldc + col;
+                float val = acc[i][j][r] + bsum;
+                if (args.accumulate) val += *c;
+                *c = val;
+            }
+        }
+    }
+}
+
 // ---- block -> (group, tile_m, tile_n): bijective XCD remap, then 8-row bands --------------------------------------
 // TAIL (big NT launches whose tile count is not a multiple of the resident slots): the blocks of the last, partly
 // filled round each take HALF a tile (BM/2 rows), so that round lasts half as long on twice as many CUs.  Consecutive
 // block ids land on consecutive XCDs, so the tail round is "the last tile indices of every XCD", two blocks per tile.
 template <int BM, int BN, bool AK, bool BKF, bool VEC, int STAGES, int BK, bool FAST, int THREADS = GEMM_THREADS,
-          bool TAIL = false>
-__global__ __launch_bounds__(THREADS, (THREADS == 64) ? 1 : (TAIL ? 3 : GEMM_MIN_WAVES)) void rfn_gemm_kernel(
+          bool TAIL = false, int DMA = 0>
+__global__ __launch_bounds__(THREADS, (THREADS == 64) ? 1 : (DMA ? GEMM_DMA_MIN_WAVES : (TAIL ? 3 : GEMM_MIN_WAVES))) void rfn_gemm_kernel(
     const GemmArgs args) {   // TAIL: 3 waves/SIMD asked for explicitly (the two-body kernel schedules better under it)
+    // DMA > 0: LDS-DMA staging into a ring of DMA slots (gemm_tile_dma); STAGES is then unused
     const int NC = args.ngroups * args.tiles_n;
     const int splitk = args.splitk;
     const int nblk = NC * args.tiles_m * splitk;     // whole tiles (x K ranges)
@@ -547,12 +805,18 @@ __global__ __launch_bounds__(THREADS, (THREADS == 64) ? 1 : (TAIL ? 3 : GEMM_MIN
     const int tn = vcol - grp * args.tiles_n;
     if constexpr (TAIL) {
         if (half >= 0) {
-            gemm_tile<BM / 2, BN, AK, BKF, VEC, STAGES, BK, FAST, THREADS>(args, grp, tn, ks, tm * BM + half * (BM / 2),
-                                                                          tn * BN);
+            if constexpr (DMA > 0)
+                gemm_tile_dma<BM / 2, BN, AK, BKF, BK, DMA>(args, grp, ks, tm * BM + half * (BM / 2), tn * BN);
+            else
+                gemm_tile<BM / 2, BN, AK, BKF, VEC, STAGES, BK, FAST, THREADS>(args, grp, tn, ks,
+                                                                              tm * BM + half * (BM / 2), tn * BN);
             return;
         }
     }
-    gemm_tile<BM, BN, AK, BKF, VEC, STAGES, BK, FAST, THREADS>(args, grp, tn, ks, tm * BM, tn * BN);
+    if constexpr (DMA > 0)
+        gemm_tile_dma<BM, BN, AK, BKF, BK, DMA>(args, grp, ks, tm * BM, tn * BN);
+    else
+        gemm_tile<BM, BN, AK, BKF, VEC, STAGES, BK, FAST, THREADS>(args, grp, tn, ks, tm * BM, tn * BN);
 }
 
 // C = sum_ks part[g][ks] + sum_s bias_s (+ C): fixed summation order, one thread per output element.  The blocks
@@ -584,56 +848,79 @@ __global__ __launch_bounds__(256) void rfn_gemm_reduce_k(const GemmArgs args) {
     *c = args.accumulate ? *c + s : s;
 }
 
-template <int BM, int BN, bool AK, bool BKF, bool VEC, int STAGES, int BK, bool FAST = false, int THREADS = GEMM_THREADS>
+// Per-device launch state of one kernel instantiation: the dynamic-LDS opt-in has been made and the number of blocks
+// a CU hosts is known.  Indexed by device ordinal, so a host that drives several GPUs from one process gets each
+// device's own answer; the entries are write-once (a race repeats the same calls and stores the same values).
+struct KernelDevState {
+    bool attr_set[16] = {};
+    int blocks_per_cu[16] = {};
+};
+template <typename K>
+static int prepare_kernel(K kernel, KernelDevState& st, size_t lds, int threads, int* blocks_per_cu) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return RFN_ERR_LAUNCH;
+    const int slot = dev & 15;
+    if (!st.attr_set[slot]) {
+        if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return RFN_ERR_LAUNCH;
+        int occ = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, threads, lds) != hipSuccess || occ < 1) occ = 1;
+        st.blocks_per_cu[slot] = occ;
+        st.attr_set[slot] = true;
+    }
+    if (blocks_per_cu) *blocks_per_cu = st.blocks_per_cu[slot];
+    return RFN_OK;
+}
+static int device_cus() {
+    static int cus[16] = {};
+    int dev = 0;
+    hipGetDevice(&dev);
+    int& c = cus[dev & 15];
+    if (c == 0) {
+        int v = 256;
+        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
+        c = v;
+    }
+    return c;
+}
+
+template <int BM, int BN, bool AK, bool BKF, bool VEC, int STAGES, int BK, bool FAST = false, int THREADS = GEMM_THREADS,
+          int DMA = 0>
 static int launch_cfg(const GemmArgs& a, hipStream_t st) {
     using StA = Stage<BM, AK, VEC, BK, THREADS>;
     using StB = Stage<BN, BKF, VEC, BK, THREADS>;
-    size_t lds = STAGES * (StA::LDS_FLOATS + StB::LDS_FLOATS) * sizeof(float);
-    if (BM >= 128) {   // EXPERIMENT: pad the big tiles' LDS request so that fewer blocks co-reside per CU
-        static const size_t min_lds = [] { const char* e = getenv("RFN_GEMM_COOP_LDS_KB"); return e ? (size_t)atol(e) << 10 : (size_t)0; }();
-        if (lds < min_lds) lds = min_lds;
-    }
+    size_t lds = DMA > 0 ? (size_t)DMA * (BM + BN) * BK * sizeof(float)
+                         : STAGES * (StA::LDS_FLOATS + StB::LDS_FLOATS) * sizeof(float);
     const int nblk = a.ngroups * a.tiles_m * a.tiles_n * a.splitk;
     bool launched = false;
 #if GEMM_TAIL_HALF && GEMM_XCD_REMAP
     // Tile quantisation: with S resident blocks per XCD a launch of 8*q tiles runs ceil(q/S) rounds and the last
     // one is only (q mod S)/S full.  When that fraction is at most a half (and there are enough rounds for it to
     // be a tail at all), the last round's tiles are processed as two half-height tiles each.
-    if constexpr (FAST && AK && BKF && VEC && STAGES == 1 && THREADS == 256 && BM == 128) {
-        static const int slots_per_xcd = [] {
-            int dev = 0, cus = 256;
-            if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-            return (cus / 8) * 3;   // three single-buffered NT blocks per CU (VGPR-bound)
-        }();
-        // The two-body kernel is also the better-scheduled one (156 VGPRs = three waves per SIMD, the single-body
-        // instantiation needs 170 = two), so every unsplit launch of this layout goes through it; launches that
-        // do not qualify for a tail simply have no tail blocks.
-        {
-            const int q = nblk / 8, tail = slots_per_xcd > 0 ? q % slots_per_xcd : 0;
-            const bool has_tail = a.splitk == 1 && nblk % 8 == 0 && slots_per_xcd > 0 && q / slots_per_xcd >= 4 &&
-                                  tail > 0 && 2 * tail <= slots_per_xcd;
-            GemmArgs t = a;
-            t.tail_idx_main = has_tail ? q - tail : 0;
-            t.tail_main_blocks = has_tail ? 8 * t.tail_idx_main : 0x7fffffff;
-            auto kt = rfn_gemm_kernel<BM, BN, AK, BKF, VEC, STAGES, BK, FAST, THREADS, true>;
-            static bool attr_set_t = false;
-            if (!attr_set_t) {
-                hipFuncSetAttribute((const void*)kt, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                attr_set_t = true;
-            }
-            hipLaunchKernelGGL(kt, dim3(has_tail ? t.tail_main_blocks + 16 * tail : nblk), dim3(THREADS), lds, st, t);
-            RFN_CHECK_LAUNCH();
-            launched = true;
-        }
+    if constexpr (FAST && AK && BKF && VEC && THREADS == 256 && BM == 128 && (DMA > 0 || STAGES == 1)) {
+        // The two-body kernel is also the better-scheduled one of the register-staged path (156 VGPRs = three waves
+        // per SIMD, the single-body instantiation needs 170 = two), so every unsplit launch of this layout goes
+        // through it; launches that do not qualify for a tail simply have no tail blocks.
+        auto kt = rfn_gemm_kernel<BM, BN, AK, BKF, VEC, STAGES, BK, FAST, THREADS, true, DMA>;
+        static KernelDevState ks_t;
+        int occ = 1;
+        RFN_TRY(prepare_kernel(kt, ks_t, lds, THREADS, &occ));
+        const int slots_per_xcd = (device_cus() / 8) * occ;
+        const int q = nblk / 8, tail = slots_per_xcd > 0 ? q % slots_per_xcd : 0;
+        const bool has_tail = a.splitk == 1 && nblk % 8 == 0 && slots_per_xcd > 0 && q / slots_per_xcd >= 4 &&
+                              tail > 0 && 2 * tail <= slots_per_xcd;
+        GemmArgs t = a;
+        t.tail_idx_main = has_tail ? q - tail : 0;
+        t.tail_main_blocks = has_tail ? 8 * t.tail_idx_main : 0x7fffffff;
+        hipLaunchKernelGGL(kt, dim3(has_tail ? t.tail_main_blocks + 16 * tail : nblk), dim3(THREADS), lds, st, t);
+        RFN_CHECK_LAUNCH();
+        launched = true;
     }
 #endif
     if (!launched) {
-        auto k = rfn_gemm_kernel<BM, BN, AK, BKF, VEC, STAGES, BK, FAST, THREADS>;
-        static bool attr_set = false;  // idempotent; a race only repeats the same call
-        if (!attr_set) {
-            hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr_set = true;
-        }
+        auto k = rfn_gemm_kernel<BM, BN, AK, BKF, VEC, STAGES, BK, FAST, THREADS, false, DMA>;
+        static KernelDevState ks;
+        RFN_TRY(prepare_kernel(k, ks, lds, THREADS, nullptr));
         hipLaunchKernelGGL(k, dim3(nblk), dim3(THREADS), lds, st, a);
         RFN_CHECK_LAUNCH();
     }
@@ -664,16 +951,13 @@ static int launch_tile(GemmArgs& a, hipStream_t st) {
     // Medium problems (the heavier per-step GEMMs: M = batch, a few GF): the 128x128 tile is ~1.5x more efficient
     // than 64x64 but yields too few tiles, so cut K across blocks to reach ~2 blocks per CU.
     int big_split = 1;
-    static const long medium_max = [] {
-        const char* e = getenv("RFN_GEMM_MEDIUM_MAX");
-        return e ? atol(e) : 256L;   // 256 < big < 384: 64x64 tiles fill the chip better than a 2-way split
-    }();
+    const long medium_max = 256;   // 256 < big < 384: 64x64 tiles fill the chip better than a 2-way split
     if (big <= medium_max && a.part && big >= 16 && flops >= GEMM_MEDIUM_MIN_FLOPS) {
         const long target = (AK && BKF) ? GEMM_MEDIUM_TARGET_NT : 512;   // 768 (three NT blocks per CU) measured worse
         long want = (target + big - 1) / big;
         if (want > iters32 / 8) want = iters32 / 8;
         if (want > 16) want = 16;
-        const long cap = (long)a.pad_ * (1 << 18) / (((long)a.M * a.N + a.M) * a.ngroups);
+        const long cap = (long)a.ws_mib * (1 << 18) / (((long)a.M * a.N + a.M) * a.ngroups);
         if (want > cap) want = cap;
         if (want >= 2) big_split = (int)want;
     }
@@ -681,12 +965,9 @@ static int launch_tile(GemmArgs& a, hipStream_t st) {
         a.splitk = big_split;
         a.tiles_m = rfn_cdiv(a.M, GEMM_BIG_BM);
         a.tiles_n = rfn_cdiv(a.N, GEMM_BIG_BN);
-        // RFN_GEMM_LDS_LEAN=1 (set by data-parallel hosts): single-buffered big tiles, <= 110 KB of LDS per CU, so
-        // that RCCL's kernels can co-reside with the long weight-gradient GEMMs instead of waiting them out.
-        static const bool lean = [] {
-            const char* e = getenv("RFN_GEMM_LDS_LEAN");
-            return e && e[0] == '1';
-        }();
+        // RFN_GEMM_OPT_LDS_LEAN (set by data-parallel hosts): single-buffered register-staged big tiles, <= 110 KB of
+        // LDS per CU, so that RCCL's kernels can co-reside with the long weight-gradient GEMMs instead of waiting them out.
+        const bool lean = (a.flags & RFN_GEMM_OPT_LDS_LEAN) != 0;
         constexpr int ST = (AK && BKF) ? GEMM_NT_STAGES : GEMM_XX_STAGES;
 #if GEMM_FAST_PATH
         if constexpr (VEC) {
@@ -699,6 +980,22 @@ static int launch_tile(GemmArgs& a, hipStream_t st) {
                 a.tiles_m = a.M / 64;
                 a.tiles_n = a.N / 64;
                 return launch_cfg<64, 64, AK, BKF, true, GEMM_ONE_WAVE_STAGES, GEMM_BIG_BK, true, 64>(a, st);
+            }
+#endif
+#if GEMM_DMA
+            // interior tiles without a bias-gradient rider: LDS-DMA staging (no staging registers, no ds_write pass,
+            // one barrier per K step, the next slot in flight across it)
+            bool span32 = true;   // the LDS-DMA kernel addresses each operand as base + 32-bit byte offset
+            for (int g = 0; g < a.ngroups; ++g)
+                for (int s = 0; s < a.g[g].nseg; ++s) {
+                    const rfn_gemm_seg& sg = a.g[g].seg[s];
+                    const double ea = AK ? (double)a.M * sg.lda : (double)sg.K * sg.lda;
+                    const double eb = BKF ? (double)a.N * sg.ldb : (double)sg.K * sg.ldb;
+                    span32 = span32 && ea * 4 < 4.0e9 && eb * 4 < 4.0e9 && sg.lda >= 0 && sg.ldb >= 0;
+                }
+            if (fast && span32 && !colsum && !lean && !(a.flags & RFN_GEMM_OPT_NO_DMA)) {
+                constexpr int SL = (AK && BKF) ? GEMM_DMA_SLOTS_NT : GEMM_DMA_SLOTS_XX;
+                return launch_cfg<GEMM_BIG_BM, GEMM_BIG_BN, AK, BKF, true, 1, GEMM_DMA_BK, true, GEMM_THREADS, SL>(a, st);
             }
 #endif
             if (fast) {
@@ -721,7 +1018,7 @@ static int launch_tile(GemmArgs& a, hipStream_t st) {
         long want = tiles > 0 ? GEMM_SPLIT_TARGET / tiles : 1;
         if (want > iters / GEMM_SPLIT_MIN_ITERS) want = iters / GEMM_SPLIT_MIN_ITERS;
         if (want > 16) want = 16;
-        const long cap = (long)(a.pad_ /* ws MiB */) * (1 << 18) / (((long)a.M * a.N + a.M) * a.ngroups);  // floats
+        const long cap = (long)(a.ws_mib) * (1 << 18) / (((long)a.M * a.N + a.M) * a.ngroups);  // floats
         if (want > cap) want = cap;
         a.splitk = (want >= 2) ? (int)want : 1;
     }
@@ -730,11 +1027,16 @@ static int launch_tile(GemmArgs& a, hipStream_t st) {
 
 extern "C" int rfn_gemm_f32(int M, int N, int ngroups, const rfn_gemm_problem* problems, int accumulate,
                             void* stream) {
-    return rfn_gemm_f32_ws(M, N, ngroups, problems, accumulate, nullptr, 0, stream);
+    return rfn_gemm_f32_opt(M, N, ngroups, problems, accumulate, nullptr, 0, 0u, stream);
 }
 
 extern "C" int rfn_gemm_f32_ws(int M, int N, int ngroups, const rfn_gemm_problem* problems, int accumulate,
                                void* ws, size_t ws_bytes, void* stream) {
+    return rfn_gemm_f32_opt(M, N, ngroups, problems, accumulate, ws, ws_bytes, 0u, stream);
+}
+
+extern "C" int rfn_gemm_f32_opt(int M, int N, int ngroups, const rfn_gemm_problem* problems, int accumulate,
+                                void* ws, size_t ws_bytes, unsigned flags, void* stream) {
     if (M <= 0 || N <= 0) return RFN_OK;
     if (ngroups < 1 || ngroups > RFN_GEMM_MAXGROUP || !problems) return RFN_ERR_SHAPE;
     GemmArgs a;
@@ -745,8 +1047,9 @@ extern "C" int rfn_gemm_f32_ws(int M, int N, int ngroups, const rfn_gemm_problem
     a.splitk = 1;
     a.tail_main_blocks = 0;
     a.tail_idx_main = 0;
+    a.flags = flags;
     a.part = (ws && ws_bytes >= (1u << 20) && rfn_aligned16(ws)) ? (float*)ws : nullptr;
-    a.pad_ = (int)(ws_bytes >> 20);  // workspace size in MiB (host-side only)
+    a.ws_mib = (int)(ws_bytes >> 20);
     const int ak = problems[0].seg[0].a_kfast, bk = problems[0].seg[0].b_kfast;
     bool vec = true;
     for (int g = 0; g < ngroups; ++g) {

@@ -103,6 +103,7 @@ struct GemmCtx {
     void* st;
     float* ws;
     size_t ws_bytes;
+    unsigned flags;   // RFN_GEMM_OPT_* bits of the phase (rfn_dims.gemm_flags)
 };
 rfn_gemm_problem prob1(float* C, long ldc, const rfn_gemm_seg& s) {
     rfn_gemm_problem p;
@@ -119,12 +120,12 @@ rfn_gemm_problem prob_dw(float* dW, long ldw, float* db, const float* dY, long l
 }
 int gemm1(int M, int N, const rfn_gemm_seg& s, float* C, long ldc, int acc, const GemmCtx& gx) {
     rfn_gemm_problem p = prob1(C, ldc, s);
-    return rfn_gemm_f32_ws(M, N, 1, &p, acc, gx.ws, gx.ws_bytes, gx.st);
+    return rfn_gemm_f32_opt(M, N, 1, &p, acc, gx.ws, gx.ws_bytes, gx.flags, gx.st);
 }
 int gemm_dw(int N, int K, float* dW, long ldw, float* db, const float* dY, long lddy, const float* X, long ldx,
             int rows, const GemmCtx& gx) {
     rfn_gemm_problem p = prob_dw(dW, ldw, db, dY, lddy, X, ldx, rows);
-    return rfn_gemm_f32_ws(N, K, 1, &p, 0, gx.ws, gx.ws_bytes, gx.st);
+    return rfn_gemm_f32_opt(N, K, 1, &p, 0, gx.ws, gx.ws_bytes, gx.flags, gx.st);
 }
 // The vocabulary (V+1 = 9488 at the headline size) is not a multiple of the 128-wide tile: the three logit-layer GEMMs
 // are issued as an aligned main part that takes the unchecked fast path plus a thin remainder (< 128 columns / rows /
@@ -157,7 +158,7 @@ int gemm_segs(int M, int N, int nseg, const rfn_gemm_seg* segs, float* C, long l
         p.C = C; p.ldc = ldc;
         p.nseg = (nseg - s0 < RFN_GEMM_MAXSEG) ? nseg - s0 : RFN_GEMM_MAXSEG;
         for (int s = 0; s < p.nseg; ++s) p.seg[s] = segs[s0 + s];
-        RFN_TRY(rfn_gemm_f32_ws(M, N, 1, &p, (s0 > 0) ? 1 : acc, gx.ws, gx.ws_bytes, gx.st));
+        RFN_TRY(rfn_gemm_f32_opt(M, N, 1, &p, (s0 > 0) ? 1 : acc, gx.ws, gx.ws_bytes, gx.flags, gx.st));
     }
     return RFN_OK;
 }
@@ -165,7 +166,7 @@ int gemm_segs(int M, int N, int nseg, const rfn_gemm_seg* segs, float* C, long l
 int gemm_groups(int M, int N, int n, const rfn_gemm_problem* p, int acc, const GemmCtx& gx) {
     for (int g0 = 0; g0 < n; g0 += RFN_GEMM_MAXGROUP) {
         const int ng = (n - g0 < RFN_GEMM_MAXGROUP) ? n - g0 : RFN_GEMM_MAXGROUP;
-        RFN_TRY(rfn_gemm_f32_ws(M, N, ng, p + g0, acc, gx.ws, gx.ws_bytes, gx.st));
+        RFN_TRY(rfn_gemm_f32_opt(M, N, ng, p + g0, acc, gx.ws, gx.ws_bytes, gx.flags, gx.st));
     }
     return RFN_OK;
 }
@@ -198,7 +199,7 @@ struct Bump {
 
 const size_t GEMM_WS_FLOATS = (size_t)12 << 20;  // 48 MiB of split-K partial tiles
 const int FUSED_ATTN_BWD_MIN_B = 96;   // below this the (L/64, B) grid of the split dalpha kernel fills the chip better
-const size_t STEP_GEMM_WS_FLOATS = (size_t)8 << 20;  // 32 MiB for the free-running decoder step (rows = B * beam)
+const size_t STEP_GEMM_WS_FLOATS = GEMM_WS_FLOATS;   // the free-running step makes the same split-K choices as the teacher-forced pass
 
 struct PrefixLayout {
     size_t P1[RFN_MAX_ENC], al1[RFN_MAX_ENC], z1[RFN_MAX_ENC], P2[RFN_MAX_ENC], dz1[RFN_MAX_ENC];
@@ -440,7 +441,7 @@ static int prefix_fwd_impl(const rfn_dims* d, int B, const float* const* prm, co
     const int G2 = gate_width(d->review_maxout, R);
     const long MR = (long)M * R, BMR = (long)B * MR, BR = (long)B * R;
     float* W = (float*)ws;
-    const GemmCtx gx{st, W + Lo.gws, GEMM_WS_FLOATS * sizeof(float)};
+    const GemmCtx gx{st, W + Lo.gws, GEMM_WS_FLOATS * sizeof(float), d->gemm_flags};
     float* Hs = W + Lo.Hs;
     float* Cs = W + Lo.Cs;
     int32_t* rarg = (int32_t*)(W + Lo.rarg);
@@ -524,7 +525,7 @@ static int prefix_fwd_impl(const rfn_dims* d, int B, const float* const* prm, co
         }
         RFN_TRY(gemm_groups(B, 4 * R, M, pr, 0, gx));
         // the M cells of this step in one launch: encoder i's state is column block i of the (B, M*R) rows
-        RFN_TRY(rfn_lstm_fwd_grouped(g, 4 * R, Cc, MR, Cn, MR, Hn, MR, B, R, 0, train ? d->drop_fusion : 0.f, seed,
+        RFN_TRY(rfn_lstm_fwd_grouped(g, 4 * R, Cc, MR, Cn, MR, Hn, MR, B, R, 0, d->drop_fusion, seed,
                                      (uint64_t)(t * M), M, (long)B * 4 * R, R, R, R, st));
     }
 
@@ -586,7 +587,7 @@ static int prefix_fwd_impl(const rfn_dims* d, int B, const float* const* prm, co
                                        R, a_al, a_z, R, st));
         }
         RFN_TRY(gemm_segs(B, G2, M + 1, segs, g, G2, 0, gx));
-        RFN_TRY(rfn_lstm_fwd(g, G2, cc, R, cn, R, hn, R, B, R, d->review_maxout, train ? d->drop_reason : 0.f, seed,
+        RFN_TRY(rfn_lstm_fwd(g, G2, cc, R, cn, R, hn, R, B, R, d->review_maxout, d->drop_reason, seed,
                              OFF_STAGE2 + (uint64_t)t, st));
     }
     RFN_TRY(gemm1(T2 * B, K, seg_lin(h2 + BR, R, prm[P.r_w()], R, R, prm[P.r_b()]), rmat, K, 0, gx));
@@ -629,7 +630,7 @@ extern "C" int rfn_prefix_bwd(const rfn_dims* d, int B, const float* const* prm,
     const int G2 = gate_width(d->review_maxout, R);
     const long MR = (long)M * R, BMR = (long)B * MR, BR = (long)B * R, BA = (long)B * A;
     float* W = (float*)ws;
-    const GemmCtx gx{st, W + Lo.gws, GEMM_WS_FLOATS * sizeof(float)};
+    const GemmCtx gx{st, W + Lo.gws, GEMM_WS_FLOATS * sizeof(float), d->gemm_flags};
     float* Hs = W + Lo.Hs;
     float* Cs = W + Lo.Cs;
     float* h2 = W + Lo.h2;
@@ -854,7 +855,7 @@ extern "C" int rfn_prefix_bwd_wgrad(const rfn_dims* d, int B, const float* const
     if (T1 > 64) return RFN_ERR_SHAPE;
     const long MR = (long)M * R, BMR = (long)B * MR, BA = (long)B * A;
     float* W = (float*)ws;
-    const GemmCtx gx{st, W + Lo.gws, GEMM_WS_FLOATS * sizeof(float)};
+    const GemmCtx gx{st, W + Lo.gws, GEMM_WS_FLOATS * sizeof(float), d->gemm_flags};
     const float* Hs = W + Lo.Hs;
     rfn_gemm_problem pr[64];
     const long Li = d->L[i], Di = d->D[i];
@@ -933,7 +934,7 @@ extern "C" int rfn_decoder_fwd(const rfn_dims* d, int B, int S, const float* con
     const int GD = gate_width(d->decoder_maxout, R);
     const long BR = (long)B * R, BA = (long)B * A;
     float* W = (float*)ws;
-    const GemmCtx gx{st, W + Lo.gws, GEMM_WS_FLOATS * sizeof(float)};
+    const GemmCtx gx{st, W + Lo.gws, GEMM_WS_FLOATS * sizeof(float), d->gemm_flags};
     float* hd = W + Lo.hd;
     float* cd = W + Lo.cd;
     float* gd = W + Lo.gd;
@@ -941,7 +942,10 @@ extern "C" int rfn_decoder_fwd(const rfn_dims* d, int B, int S, const float* con
     RFN_TRY(gemm1(T2 * B, A, seg_lin(comb, R, prm[P.dec(6)], R, R, prm[P.dec(7)]), W + Lo.Pd, A, 0, gx));
     // all token embeddings and their i2h projections in one go (teacher forcing: ids are known)
     RFN_TRY(rfn_embed_fwd(prm[P.embed()], E, V1, ids, B, ld_ids, 1, S * B, W + Lo.xs, E, st));
-    RFN_TRY(gemm1(S * B, GD, seg_lin(W + Lo.xs, E, prm[P.dec(0)], E, E, prm[P.dec(1)]), gd, GD, 0, gx));
+    // (never split along K: the free-running step applies i2h to one step's rows with the same unsplit k order,
+    // so teacher-forced and free-running log-probs of the same tokens are bit-identical)
+    const GemmCtx gx_whole{st, nullptr, 0, d->gemm_flags};
+    RFN_TRY(gemm1(S * B, GD, seg_lin(W + Lo.xs, E, prm[P.dec(0)], E, E, prm[P.dec(1)]), gd, GD, 0, gx_whole));
     RFN_TRY(copy_f32(hd, h0, BR, st));
     RFN_TRY(copy_f32(cd, c0, BR, st));
     rfn_gemm_seg segs[2];
@@ -957,7 +961,7 @@ extern "C" int rfn_decoder_fwd(const rfn_dims* d, int B, int S, const float* con
         segs[1] = seg_lin(z, R, prm[P.dec(4)], R, R, prm[P.dec(5)]);
         RFN_TRY(gemm_segs(B, GD, 2, segs, g, GD, 1, gx));
         RFN_TRY(rfn_lstm_fwd(g, GD, cd + s * BR, R, cd + (s + 1) * BR, R, hd + (s + 1) * BR, R, B, R, d->decoder_maxout,
-                             train ? d->drop_lm : 0.f, seed, OFF_DECODER + (uint64_t)s, st));
+                             d->drop_lm, seed, OFF_DECODER + (uint64_t)s, st));
     }
     // logits of all steps, then log-softmax written in the reference's (B, S, V+1) layout
     RFN_TRY(gemm_logits(S * B, V1, hd + BR, R, prm[P.logit_w()], prm[P.logit_b()], W + Lo.logits, gx));
@@ -981,7 +985,7 @@ extern "C" int rfn_decoder_bwd(const rfn_dims* d, int B, int S, const float* con
     const int GD = gate_width(d->decoder_maxout, R);
     const long BR = (long)B * R, BA = (long)B * A;
     float* W = (float*)ws;
-    const GemmCtx gx{st, W + Lo.gws, GEMM_WS_FLOATS * sizeof(float)};
+    const GemmCtx gx{st, W + Lo.gws, GEMM_WS_FLOATS * sizeof(float), d->gemm_flags};
     float* hd = W + Lo.hd;
     float* cd = W + Lo.cd;
     float* gd = W + Lo.gd;
@@ -1053,15 +1057,20 @@ extern "C" int rfn_decoder_prepare(const rfn_dims* d, int B, const float* const*
     if (B < 1) return RFN_ERR_SHAPE;
     if (!prm || !comb || !cproj) return RFN_ERR_ARG;
     const PIdx P(d);
-    const GemmCtx gx{st, nullptr, 0};
+    const GemmCtx gx{st, nullptr, 0, d->gemm_flags};
     return gemm1(d->T2 * B, d->A, seg_lin(comb, d->R, prm[P.dec(6)], d->R, d->R, prm[P.dec(7)]), cproj, d->A, 0, gx);
 }
 
+// One decoder step computed with exactly the operation sequence of one step of rfn_decoder_fwd (unsplit i2h, then
+// h2h + z2h accumulated onto it, same split-K scratch size, same dropout stream (seed, OFF_DECODER + step)), so the
+// distribution a host samples from here IS the one the teacher-forced gradient pass differentiates
+// (misc/RecurrentFusionModel.py:260-270, 623-631: the reference samples from the dropout-affected outputs themselves).
 static int decoder_step_impl(const rfn_dims* d, int B, const float* const* prm, const float* comb, const float* cproj,
                              const int64_t* ids, const float* xt, int64_t ld_xt, float* h, float* c, float* logits,
-                             float* logp, int64_t ld_logp, void* ws, size_t ws_bytes, void* st) {
+                             float* logp, int64_t ld_logp, void* ws, size_t ws_bytes, uint64_t seed, int step,
+                             void* st) {
     RFN_TRY(check_dims(d));
-    if (B < 1) return RFN_ERR_SHAPE;
+    if (B < 1 || step < 0) return RFN_ERR_SHAPE;
     if (!prm || !comb || !cproj || (!ids && !xt) || !h || !c || !ws) return RFN_ERR_ARG;
     if (xt && ld_xt < d->E) return RFN_ERR_SHAPE;
     if (ws_bytes < rfn_decoder_step_ws_bytes(d, B)) return RFN_ERR_WORKSPACE;
@@ -1071,7 +1080,8 @@ static int decoder_step_impl(const rfn_dims* d, int B, const float* const* prm, 
     const long BR = (long)B * R, BA = (long)B * A;
     Bump b;
     float* W = (float*)ws;
-    const GemmCtx gx{st, W + b.take(STEP_GEMM_WS_FLOATS), STEP_GEMM_WS_FLOATS * sizeof(float)};  // split-K scratch
+    const GemmCtx gx{st, W + b.take(STEP_GEMM_WS_FLOATS), STEP_GEMM_WS_FLOATS * sizeof(float), d->gemm_flags};  // split-K scratch
+    const GemmCtx gx_whole{st, nullptr, 0, d->gemm_flags};
     float* x = W + b.take((size_t)B * E);
     float* hp = W + b.take((size_t)B * A);
     float* al = W + b.take((size_t)B * T2);
@@ -1079,14 +1089,15 @@ static int decoder_step_impl(const rfn_dims* d, int B, const float* const* prm, 
     float* g = W + b.take((size_t)B * GD);
     float* lg = logits ? logits : W + b.take((size_t)B * V1);
     if (!xt) RFN_TRY(rfn_embed_fwd(prm[P.embed()], E, V1, ids, B, 1, 0, B, x, E, st));
+    RFN_TRY(gemm1(B, GD, xt ? seg_lin(xt, ld_xt, prm[P.dec(0)], E, E, prm[P.dec(1)]) : seg_lin(x, E, prm[P.dec(0)], E, E, prm[P.dec(1)]),
+                  g, GD, 0, gx_whole));
     RFN_TRY(gemm1(B, A, seg_lin(h, R, prm[P.dec(8)], R, R, prm[P.dec(9)]), hp, A, 0, gx));
     RFN_TRY(attn1_fwd(cproj, A, BA, hp, prm[P.dec(10)], prm[P.dec(11)], comb, R, BR, B, T2, A, R, al, z, R, st));
-    rfn_gemm_seg segs[3];
-    segs[0] = xt ? seg_lin(xt, ld_xt, prm[P.dec(0)], E, E, prm[P.dec(1)]) : seg_lin(x, E, prm[P.dec(0)], E, E, prm[P.dec(1)]);
-    segs[1] = seg_lin(h, R, prm[P.dec(2)], R, R, prm[P.dec(3)]);
-    segs[2] = seg_lin(z, R, prm[P.dec(4)], R, R, prm[P.dec(5)]);
-    RFN_TRY(gemm_segs(B, GD, 3, segs, g, GD, 0, gx));
-    RFN_TRY(rfn_lstm_fwd(g, GD, c, R, c, R, h, R, B, R, d->decoder_maxout, 0.f, 0, 0, st));  // eval: no dropout
+    rfn_gemm_seg segs[2];
+    segs[0] = seg_lin(h, R, prm[P.dec(2)], R, R, prm[P.dec(3)]);
+    segs[1] = seg_lin(z, R, prm[P.dec(4)], R, R, prm[P.dec(5)]);
+    RFN_TRY(gemm_segs(B, GD, 2, segs, g, GD, 1, gx));
+    RFN_TRY(rfn_lstm_fwd(g, GD, c, R, c, R, h, R, B, R, d->decoder_maxout, d->drop_lm, seed, OFF_DECODER + (uint64_t)step, st));
     if (logits || logp) {
         RFN_TRY(gemm_logits(B, V1, h, R, prm[P.logit_w()], prm[P.logit_b()], lg, gx));
         if (logp) {
@@ -1099,15 +1110,17 @@ static int decoder_step_impl(const rfn_dims* d, int B, const float* const* prm, 
 
 extern "C" int rfn_decoder_step(const rfn_dims* d, int B, const float* const* prm, const float* comb,
                                 const float* cproj, const int64_t* ids, float* h, float* c, float* logits, float* logp,
-                                int64_t ld_logp, void* ws, size_t ws_bytes, void* st) {
+                                int64_t ld_logp, void* ws, size_t ws_bytes, uint64_t seed, int step, void* st) {
     if (!ids) return RFN_ERR_ARG;
-    return decoder_step_impl(d, B, prm, comb, cproj, ids, nullptr, 0, h, c, logits, logp, ld_logp, ws, ws_bytes, st);
+    return decoder_step_impl(d, B, prm, comb, cproj, ids, nullptr, 0, h, c, logits, logp, ld_logp, ws, ws_bytes, seed,
+                             step, st);
 }
 // the reference's one_time_step signature: the caller has already embedded the token (xt = model.embed(it))
 extern "C" int rfn_decoder_step_embedded(const rfn_dims* d, int B, const float* const* prm, const float* comb,
                                          const float* cproj, const float* xt, int64_t ld_xt, float* h, float* c,
                                          float* logits, float* logp, int64_t ld_logp, void* ws, size_t ws_bytes,
-                                         void* st) {
+                                         uint64_t seed, int step, void* st) {
     if (!xt) return RFN_ERR_ARG;
-    return decoder_step_impl(d, B, prm, comb, cproj, nullptr, xt, ld_xt, h, c, logits, logp, ld_logp, ws, ws_bytes, st);
+    return decoder_step_impl(d, B, prm, comb, cproj, nullptr, xt, ld_xt, h, c, logits, logp, ld_logp, ws, ws_bytes,
+                             seed, step, st);
 }

@@ -35,7 +35,7 @@ class FeatureFeeder:
         self.device = torch.device(device)
         self.cuda = self.device.type == 'cuda'
         pin = self.cuda
-        self.host, self.dev, self.events, self.count = [], [], [], []
+        self.host, self.dev, self.events, self.count, self.uploaded = [], [], [], [], []
         for _ in range(depth):
             self.host.append((
                 [torch.empty(images_per_batch, f['fc_feat_size'], pin_memory=pin) for f in feat_array_info],
@@ -46,13 +46,18 @@ class FeatureFeeder:
                  for f in feat_array_info]))
             self.events.append(torch.cuda.Event() if self.cuda else None)
             self.count.append(0)
+            self.uploaded.append(False)
         self.copy_stream = torch.cuda.Stream(device=self.device) if self.cuda else None
 
     def stage(self, slot, images):
         """images: list (<= images_per_batch) of (fc_list, att_list) as read_image_features returns.  Writes the
-        pinned slot; the caller must not restage a slot before the batch() that consumed it was issued."""
+        pinned slot.  A slot whose previous upload() may still be reading the pinned memory is waited for first
+        (host-side wait on that upload's event), so restaging right after batch() is safe."""
         if len(images) > self.n_img:
             raise ValueError('more images than the feeder was sized for')
+        if self.cuda and self.uploaded[slot]:
+            self.events[slot].synchronize()     # the asynchronous H2D of this slot has finished reading the host buffer
+            self.uploaded[slot] = False
         fc_h, att_h = self.host[slot]
         for k, (fc, att) in enumerate(images):
             for i, f in enumerate(self.info):
@@ -76,6 +81,7 @@ class FeatureFeeder:
             for src, dst in zip(self.host[slot][0] + self.host[slot][1], self.dev[slot][0] + self.dev[slot][1]):
                 dst[:n].copy_(src[:n], non_blocking=True)
             self.events[slot].record(self.copy_stream)
+        self.uploaded[slot] = True
 
     def batch(self, slot, expand=True):
         """(fc_feats, att_feats) lists on the device.  expand=True: caption rows (each image seq_per_img times, the

@@ -121,7 +121,7 @@ class _PrefixFn(torch.autograd.Function):
                                      int(train), seed, N.stream_ptr()), 'rfn_prefix_fwd')
         if train:
             ctx.model, ctx.seed, ctx.M, ctx.B, ctx.drop = model, seed, M, B, drop
-            ctx.ws, ctx.fc, ctx.att, ctx.params = ws, fc, att, params
+            ctx.ws, ctx.fc, ctx.att, ctx.params, ctx.consumed = ws, fc, att, params, False
         return comb, h, c, reason
 
     @staticmethod
@@ -135,6 +135,18 @@ class _PrefixFn(torch.autograd.Function):
         d_comb, d_h, d_c, d_reason = cont(d_comb), cont(d_h), cont(d_c), cont(d_reason)
         ws_bytes = ctx.ws.numel()
         att_ptrs = N.ptr_array(ctx.att)
+        if ctx.consumed:
+            # backward overwrites activations in place (projections -> their gradients, gates -> gate gradients), so a
+            # second backward over the same graph (loss.backward(retain_graph=True) in the PPO loop, train_rl.py:190-201)
+            # first recomputes phase 1 into the workspace: same inputs, same dropout seed
+            R, T2, K = d.R, d.T2, d.K
+            scratch = torch.empty(T2 * B * R + 2 * B * R + (M + 1) * B * K, device=dev)
+            o1, o2, o3 = T2 * B * R, T2 * B * R + B * R, T2 * B * R + 2 * B * R
+            N.check(N.lib.rfn_prefix_fwd(C.byref(d), B, table, N.ptr_array(ctx.fc), att_ptrs, scratch.data_ptr(),
+                                         scratch[o1:].data_ptr(), scratch[o2:].data_ptr(), scratch[o3:].data_ptr(),
+                                         ctx.ws.data_ptr(), ws_bytes, 1, ctx.seed, N.stream_ptr()),
+                    'rfn_prefix_fwd (recompute)')
+        ctx.consumed = True
         # everything except the per-encoder stage-I weight gradients ...
         N.check(N.lib.rfn_prefix_bwd(C.byref(d), B, table, N.ptr_array(ctx.fc), att_ptrs, N.ptr(d_comb),
                                      N.ptr(d_h), N.ptr(d_c), N.ptr(d_reason), gtable, ctx.ws.data_ptr(), ws_bytes,
@@ -147,8 +159,6 @@ class _PrefixFn(torch.autograd.Function):
                 N.check(N.lib.rfn_prefix_bwd_wgrad(C.byref(d), B, att_ptrs, gtable, ctx.ws.data_ptr(), ws_bytes, i,
                                                    part, N.stream_ptr()), 'rfn_prefix_bwd_wgrad')
                 model._bucket_done('enc%d%s' % (i, tag), flats['enc%d%s' % (i, tag)])
-        ctx.ws = None
-        model._deliver_grads(ctx.params, [by_slot[sl] for sl in model._prefix_slots])
         return (None, None, None, None, None) + (None,) * (2 * M) + (None,) * len(ctx.params)
 
 
@@ -172,7 +182,7 @@ class _DecoderFn(torch.autograd.Function):
                                       int(train), seed, N.stream_ptr()), 'rfn_decoder_fwd')
         if train:
             ctx.model, ctx.seed, ctx.B, ctx.S, ctx.drop = model, seed, B, S, drop
-            ctx.ws, ctx.ids, ctx.params = ws, ids, params
+            ctx.ws, ctx.ids, ctx.params, ctx.consumed = ws, ids, params, False
             ctx.save_for_backward(comb, h0, c0, log_prob)
         return log_prob
 
@@ -188,14 +198,18 @@ class _DecoderFn(torch.autograd.Function):
         d_comb = torch.empty_like(comb)
         d_h0 = torch.empty_like(h0)
         d_c0 = torch.empty_like(c0)
+        if ctx.consumed:     # second backward over the same graph: recompute phase 2 first (see _PrefixFn.backward)
+            N.check(N.lib.rfn_decoder_fwd(C.byref(d), B, S, table, comb.data_ptr(), h0.data_ptr(), c0.data_ptr(),
+                                          ctx.ids.data_ptr(), ctx.ids.stride(0), torch.empty_like(log_prob).data_ptr(),
+                                          ctx.ws.data_ptr(), ctx.ws.numel(), 1, ctx.seed, N.stream_ptr()),
+                    'rfn_decoder_fwd (recompute)')
+        ctx.consumed = True
         N.check(N.lib.rfn_decoder_bwd(C.byref(d), B, S, table, comb.data_ptr(), h0.data_ptr(), c0.data_ptr(),
                                       ctx.ids.data_ptr(), ctx.ids.stride(0), log_prob.data_ptr(),
                                       d_log_prob.data_ptr(), d_comb.data_ptr(), d_h0.data_ptr(), d_c0.data_ptr(),
                                       gtable, ctx.ws.data_ptr(), ctx.ws.numel(), ctx.seed, N.stream_ptr()),
                 'rfn_decoder_bwd')
         model._bucket_done('decoder', flats['decoder'])
-        ctx.ws = None
-        model._deliver_grads(ctx.params, [by_slot[sl] for sl in model._decoder_slots])
         return (None, None, None, None, None, d_comb, d_h0, d_c0) + (None,) * len(ctx.params)
 
 
@@ -240,6 +254,9 @@ class RecurrentFusionModel(nn.Module):
         self.decoder = _DecoderParams(E, R, A, self.decoder_maxout)
         self.init_weights()
 
+        # RFN_GEMM_OPT_* bits handed to every GEMM of the path (rfn.h); a data-parallel host sets
+        # N.GEMM_OPT_LDS_LEAN so RCCL's kernels can co-reside with the long weight-gradient GEMMs (parallel.GradSync does)
+        self.gemm_flags = 0
         self._dims = {}
         self._param_cache = {}
         self._slot_names = N.param_names(self._dims_for(False))
@@ -291,7 +308,7 @@ class RecurrentFusionModel(nn.Module):
 
     # ---- plumbing -------------------------------------------------------------------------------
     def _dims_for(self, train: bool) -> N.Dims:
-        key = bool(train)
+        key = (bool(train), int(self.gemm_flags))
         if key not in self._dims:
             self._dims[key] = N.make_dims(
                 self.num_feat_array, self.rnn_size, self.att_hid_size, self.input_encoding_size,
@@ -300,7 +317,7 @@ class RecurrentFusionModel(nn.Module):
                 review_maxout=self.review_maxout, decoder_maxout=self.decoder_maxout,
                 drop_fusion=self.drop_prob_fusion if train else 0.0,
                 drop_reason=self.drop_prob_reason if train else 0.0,
-                drop_lm=self.drop_prob_lm if train else 0.0)
+                drop_lm=self.drop_prob_lm if train else 0.0, gemm_flags=self.gemm_flags)
         return self._dims[key]
 
     def _params_of(self, slots):
@@ -347,23 +364,34 @@ class RecurrentFusionModel(nn.Module):
         return flats, by_slot, table
 
     def _bucket_done(self, name, flat):
+        """Backward has queued every kernel that writes bucket `name`: hand its gradients over.
+
+        `.grad` of the bucket's parameters become VIEWS of the flat buffer, so `.grad`, the all-reduce operand and the
+        fused optimizer's operand are the same memory (returning the gradients through autograd instead makes
+        AccumulateGrad clone most of them: hundreds of small D2D copies per step).  A second backward before
+        zero_grad() accumulates into the buffer already registered -- as autograd would -- so the optimizer operand
+        always equals `.grad`."""
+        params, offs, _ = self.bucket_layout(name)
+        live = self._last_flat_grads.get(name)
+        first = next((i for i, p in enumerate(params) if p.requires_grad), None)
+        if (live is not None and first is not None and params[first].grad is not None
+                and params[first].grad.data_ptr() == live.data_ptr() + 4 * offs[first]):
+            if self.grad_ready_hook is not None:
+                raise N.RfnError('bucket %s was produced twice before zero_grad(): gradient accumulation over several '
+                                 'backward passes cannot be combined with a grad_ready_hook (GradSync all-reduces each '
+                                 'bucket once per step)' % name)
+            live.add_(flat)
+            return
+        for p, o in zip(params, offs):
+            if not p.requires_grad:
+                continue
+            v = flat[o:o + p.numel()].view_as(p)
+            if p.grad is not None:      # a gradient that did not come from this path (or was never zeroed): fold it in
+                v.add_(p.grad)
+            p.grad = v
         self._last_flat_grads[name] = flat
         if self.grad_ready_hook is not None:
             self.grad_ready_hook(name, flat)
-
-    @staticmethod
-    def _deliver_grads(params, views):
-        """Hands the parameter gradients over as VIEWS of the phase's flat buffer (so `.grad`, the all-reduce
-        bucket and the fused optimizer operand are the same memory).  Returning them through autograd instead
-        makes AccumulateGrad clone most of them (hundreds of small D2D copies per step); a second backward
-        before zero_grad accumulates, as autograd would."""
-        for p, v in zip(params, views):
-            if not p.requires_grad:
-                continue
-            if p.grad is None:
-                p.grad = v
-            else:
-                p.grad = p.grad + v
 
     def _check_inputs(self, fc_feats, att_feats):
         M = self.num_feat_array
@@ -422,7 +450,7 @@ class RecurrentFusionModel(nn.Module):
             comb, h, c, reason = self._prefix(fc_feats, att_feats, train, seed)
         ids = seq[:, :S]
         if self.ss_prob > 0.0 and S > 1:
-            ids = self._scheduled_sampling_ids(ids, comb.detach(), h.detach(), c.detach())
+            ids = self._scheduled_sampling_ids(ids, comb.detach(), h.detach(), c.detach(), train, seed)
         log_prob = self._decode_teacher_forced(ids, comb, h, c, train, seed)
         return log_prob, list(reason.unbind(0))
 
@@ -443,23 +471,30 @@ class RecurrentFusionModel(nn.Module):
         self._steps_cache = (key, seq, S)     # holds `seq` so its storage cannot be recycled under the key
         return S
 
-    def _scheduled_sampling_ids(self, ids, comb, h, c):
+    def _scheduled_sampling_ids(self, ids, comb, h, c, drop, seed):
         """misc/RecurrentFusionModel.py:260-270: with probability ss_prob a row's input token is drawn from the
-        model's previous output distribution.  The draws need the free-running distributions, so they are made
-        in a no-grad stepwise pass; the gradient pass is then teacher-forced on the drawn ids (identical
-        outputs, since the decoder is deterministic given its inputs at dropout 0)."""
+        model's previous output distribution.  The draws need the free-running distributions, so they are made in a
+        no-grad stepwise pass; the gradient pass is then teacher-forced on the drawn ids.  The stepwise pass applies
+        the SAME dropout masks (seed, step) and the same operation order as the gradient pass, so the distribution
+        that is sampled is bit for bit the one that is differentiated -- as in the reference, which samples from
+        `outputs[-1]` of the dropout-affected pass itself.  No host read-back: the draw is made for every row and
+        kept where the row's coin says so."""
         B, S = ids.shape
         ids = ids.clone()
+        trace = [] if getattr(self, '_trace_ss', False) else None
         with torch.no_grad():
-            stepper = _Stepper(self, comb, h.clone(), c.clone())
+            stepper = _Stepper(self, comb, h.clone(), c.clone(), drop, seed)
             logp = stepper.step(ids[:, 0].contiguous())
             for i in range(1, S):
+                if trace is not None:
+                    trace.append(logp.clone())
                 mask = torch.rand(B, device=ids.device) < self.ss_prob
-                if bool(mask.any()):
-                    draw = torch.multinomial(torch.exp(logp), 1).view(-1)
-                    ids[:, i] = torch.where(mask, draw, ids[:, i])
+                draw = torch.multinomial(torch.exp(logp), 1).view(-1)
+                ids[:, i] = torch.where(mask, draw, ids[:, i])
                 if i < S - 1:
                     logp = stepper.step(ids[:, i].contiguous())
+        if trace is not None:
+            self._ss_trace = trace       # test hook: free-running log-probs of steps 0 .. S-2
         return ids
 
     def get_init_state(self, fc_feats):
@@ -517,7 +552,9 @@ class RecurrentFusionModel(nn.Module):
         token ids (B,), in which case the embedding is fused into the step."""
         with torch.no_grad():
             comb = thought_vectors_comb.transpose(0, 1).contiguous()
-            stepper = _Stepper(self, comb, state_decode[0][-1].clone(), state_decode[1][-1].clone())
+            drop = bool(self.training)
+            stepper = _Stepper(self, comb, state_decode[0][-1].clone(), state_decode[1][-1].clone(), drop,
+                               _fresh_seed() if drop else 0)
             logits = stepper.step(xt.contiguous(), want='logits')
             return logits, (stepper.h.unsqueeze(0), stepper.c.unsqueeze(0))
 
@@ -529,7 +566,10 @@ class RecurrentFusionModel(nn.Module):
         if beam_size > 1:
             return self.sample_beam(fc_feats, att_feats, opt)
         want_grad = torch.is_grad_enabled() and not sample_max
-        train = bool(self.training) and want_grad
+        # dropout follows the module's mode, as the reference's nn.Dropout layers do (train_rl.py samples in train()
+        # mode); the free-running steps and the differentiable teacher-forced replay below share one seed, so the
+        # tokens are drawn from the very distribution whose log-probs carry the gradient (:623-631)
+        train = bool(self.training)
         seed = _fresh_seed() if train else 0
         with torch.set_grad_enabled(want_grad):
             comb, h, c, reason = self._prefix(fc_feats, att_feats, train, seed)
@@ -538,7 +578,7 @@ class RecurrentFusionModel(nn.Module):
         reason_pred = list(reason.unbind(0))
         force = opt.get('force_ids', None)
         with torch.no_grad():
-            stepper = _Stepper(self, comb.detach(), h.detach().clone(), c.detach().clone())
+            stepper = _Stepper(self, comb.detach(), h.detach().clone(), c.detach().clone(), train, seed)
             logp_all = torch.empty(B, S + 1, V1, device=dev)
             seq = torch.zeros(B, S, dtype=torch.long, device=dev)
             seq_lp = torch.zeros(B, S, device=dev)
@@ -574,6 +614,8 @@ class RecurrentFusionModel(nn.Module):
                 t_stop = t
                 break
         n_seq = t_stop - 1
+        if getattr(self, '_trace_ss', False):
+            self._sample_trace = logp_all[:, :t_stop].clone()    # test hook: the distributions the ids were drawn from
         if want_grad:
             # differentiable log-probs (train_rl.py:160-166): teacher-force the drawn ids through phase 2
             logp_g = self._decode_teacher_forced(raw[:, :t_stop].contiguous(), comb, h, c, train, seed)
@@ -595,11 +637,13 @@ class RecurrentFusionModel(nn.Module):
             raise N.RfnError('beam search supports beam_size <= 16 and seq_length <= 32')
         W = beam_size
         with torch.no_grad():
-            comb_b, h_b, c_b, reason = self._prefix(fc_feats, att_feats, False, 0)
+            drop = bool(self.training)
+            seed = _fresh_seed() if drop else 0
+            comb_b, h_b, c_b, reason = self._prefix(fc_feats, att_feats, drop, seed)
             dev = comb_b.device
             comb = comb_b.repeat_interleave(W, dim=1).contiguous()         # (T2, B*W, R): row k*W+q = image k
             stepper = _Stepper(self, comb, h_b.repeat_interleave(W, dim=0).contiguous(),
-                               c_b.repeat_interleave(W, dim=0).contiguous())
+                               c_b.repeat_interleave(W, dim=0).contiguous(), drop, seed)
             rows, max_done = B * W, W * S
             bs = torch.zeros(S, B, W, dtype=torch.long, device=dev)
             bl = torch.zeros(S, B, W, device=dev)
@@ -656,9 +700,12 @@ class RecurrentFusionModel(nn.Module):
 class _Stepper:
     """Free-running decoder state for sample / beam / one_time_step: rfn_decoder_prepare + rfn_decoder_step."""
 
-    def __init__(self, model, comb, h, c):
+    def __init__(self, model, comb, h, c, drop=False, seed=0):
+        """drop / seed: apply the decoder dropout masks of (seed, step index) -- the ones rfn_decoder_fwd applies at
+        the same steps -- so a free-running pass in training mode reproduces the teacher-forced pass bit for bit."""
         self.model = model
-        self.d = model._dims_for(False)
+        self.d = model._dims_for(bool(drop))
+        self.seed, self.t = int(seed), 0
         self.comb = comb.contiguous()
         self.h, self.c = h.contiguous(), c.contiguous()
         self.B = self.h.size(0)
@@ -684,15 +731,18 @@ class _Stepper:
             N.check(N.lib.rfn_decoder_step_embedded(C.byref(self.d), self.B, self.table, self.comb.data_ptr(),
                                                     self.cproj.data_ptr(), xt.data_ptr(), xt.stride(0),
                                                     self.h.data_ptr(), self.c.data_ptr(), logits_ptr, logp_ptr,
-                                                    out.stride(0), self.ws.data_ptr(), self.ws_bytes, N.stream_ptr()),
+                                                    out.stride(0), self.ws.data_ptr(), self.ws_bytes, self.seed,
+                                                    self.t, N.stream_ptr()),
                     'rfn_decoder_step_embedded')
+            self.t += 1
             return out
         if ids.dtype != torch.long or not ids.is_contiguous():
             ids = ids.long().contiguous()
         N.check(N.lib.rfn_decoder_step(C.byref(self.d), self.B, self.table, self.comb.data_ptr(),
                                        self.cproj.data_ptr(), ids.data_ptr(), self.h.data_ptr(), self.c.data_ptr(),
                                        logits_ptr, logp_ptr, out.stride(0), self.ws.data_ptr(), self.ws_bytes,
-                                       N.stream_ptr()), 'rfn_decoder_step')
+                                       self.seed, self.t, N.stream_ptr()), 'rfn_decoder_step')
+        self.t += 1
         return out
 
     def reorder(self, index):

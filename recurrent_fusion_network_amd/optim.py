@@ -1,9 +1,13 @@
 """Fused clip_gradient + Adam (misc/utils.py:292-296 + train.py:69-71,162-163) on flat buffers.
 
-The model keeps one flat gradient buffer per bucket (decoder, fusion core, one per encoder); ``FusedClampAdam``
+The model keeps one flat gradient buffer per bucket (decoder, fusion core, two per encoder); ``FusedClampAdam``
 re-points the parameters at flat buffers with the same layout, so the whole update -- clamp to +-grad_clip, L2
 weight decay, Adam moments, bias correction -- is one rfn_adam_step launch per bucket (7 streams over 1.56 GB at
-the headline config) instead of ~625 per-tensor updates, and a data-parallel run all-reduces M+2 buffers.
+the headline config) instead of ~625 per-tensor updates, and a data-parallel run all-reduces 2M+2 buffers.
+
+Trainer-facing surface of ``torch.optim.Adam`` that the reference's loops touch: ``zero_grad()``, ``step()``,
+``param_groups[0]['lr']`` (``utils.set_lr``, misc/utils.py:286-290; train.py:102-104), ``state_dict()`` /
+``load_state_dict()`` (``optimizer_<id>.pth``, train.py:86-88,232-233).
 """
 import torch
 
@@ -13,8 +17,9 @@ from . import _native as N
 class FusedClampAdam:
     def __init__(self, model, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_clip=1.0):
         self.model = model
-        self.lr, self.betas, self.eps = lr, betas, eps
-        self.weight_decay, self.grad_clip = weight_decay, grad_clip
+        # one group, torch.optim layout: utils.set_lr writes group['lr'], which step() reads
+        self.param_groups = [dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay, grad_clip=grad_clip,
+                                  params=list(model.parameters()))]
         self.step_count = 0
         self.flat = {}
         if not next(model.parameters()).is_cuda:
@@ -27,16 +32,63 @@ class FusedClampAdam:
                 p.data = buf[o:o + p.numel()].view_as(p)
             self.flat[name] = dict(p=buf, m=torch.zeros_like(buf), v=torch.zeros_like(buf), n=total)
 
+    # ---- torch.optim-style accessors ---------------------------------------------------------------
+    @property
+    def lr(self):
+        return self.param_groups[0]['lr']
+
+    @lr.setter
+    def lr(self, value):
+        self.param_groups[0]['lr'] = value
+
+    @property
+    def betas(self):
+        return self.param_groups[0]['betas']
+
+    @property
+    def eps(self):
+        return self.param_groups[0]['eps']
+
+    @property
+    def weight_decay(self):
+        return self.param_groups[0]['weight_decay']
+
+    @property
+    def grad_clip(self):
+        return self.param_groups[0]['grad_clip']
+
+    def set_lr(self, lr):
+        self.param_groups[0]['lr'] = lr
+
     def zero_grad(self):
         for p in self.model.parameters():
             p.grad = None
         self.model._last_flat_grads.clear()
 
-    def set_lr(self, lr):
-        self.lr = lr
+    def state_dict(self):
+        """Adam moments per bucket (flat, same layout as the parameters), the step count and the hyper-parameters."""
+        hyper = {k: v for k, v in self.param_groups[0].items() if k != 'params'}
+        return {'step_count': self.step_count, 'hyper': hyper,
+                'buckets': {name: {'m': st['m'].detach().clone(), 'v': st['v'].detach().clone(), 'n': st['n']}
+                            for name, st in self.flat.items()}}
 
+    def load_state_dict(self, sd):
+        if set(sd['buckets']) != set(self.flat):
+            raise N.RfnError('optimizer state has buckets %s, the model has %s' % (sorted(sd['buckets']), sorted(self.flat)))
+        for name, st in self.flat.items():
+            src = sd['buckets'][name]
+            if int(src['n']) != st['n']:
+                raise N.RfnError('optimizer bucket %s holds %d values, expected %d' % (name, int(src['n']), st['n']))
+            st['m'].copy_(src['m'])
+            st['v'].copy_(src['v'])
+        self.step_count = int(sd['step_count'])
+        for k, v in sd.get('hyper', {}).items():
+            self.param_groups[0][k] = tuple(v) if k == 'betas' else v
+
+    # ---- the update ------------------------------------------------------------------------------------
     def step(self, grad_scale=1.0):
         """grad_scale multiplies the gradient before the clamp (1/world_size after a sum all-reduce)."""
+        g0 = self.param_groups[0]
         self.step_count += 1
         self.model._weights_epoch = getattr(self.model, '_weights_epoch', 0) + 1   # invalidates reuse_prefix entries
         for name, st in self.flat.items():
@@ -46,6 +98,7 @@ class FusedClampAdam:
             if g.numel() != st['n']:
                 raise N.RfnError('flat gradient layout changed')
             N.check(N.lib.rfn_adam_step(st['p'].data_ptr(), g.data_ptr(), st['m'].data_ptr(), st['v'].data_ptr(),
-                                        st['n'], self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
-                                        self.grad_clip, grad_scale, self.step_count, N.stream_ptr()),
+                                        st['n'], g0['lr'], g0['betas'][0], g0['betas'][1], g0['eps'],
+                                        g0['weight_decay'], g0['grad_clip'], grad_scale, self.step_count,
+                                        N.stream_ptr()),
                     'rfn_adam_step')

@@ -3,8 +3,8 @@
 The reference has no data parallelism (its "8 GPUs" are 8 independent seeds); this is the
 north-star's sharded training.  Every batch row is independent through the whole path, so
 the batch is split on dim 0, each rank runs the full path on its shard, and the ONLY exchange is one sum
-all-reduce per flat gradient buffer (2 buffers: decoder first, as soon as its backward finishes, then the
-fusion stages).  The reference divides the loss by the LOCAL batch size, so the sum is scaled by
+all-reduce per flat gradient bucket (2M+2 buckets, in the order backward finishes them: decoder, fusion core,
+then two per encoder).  The reference divides the loss by the LOCAL batch size, so the sum is scaled by
 1/world_size inside the fused optimizer BEFORE the element-wise clamp -- which keeps an N-rank step equal
 to the 1-rank step on the concatenated batch.
 """
@@ -67,6 +67,11 @@ class GradSync:
         self.works = []
         self.buckets = []
         model.grad_ready_hook = self.on_bucket
+        if world > 1 and hasattr(model, 'gemm_flags'):
+            # The double-buffered weight-gradient GEMM holds 147 of each CU's 160 KB of LDS for its whole 6 ms and
+            # would starve RCCL's kernels: keep the big tiles lean while collectives run beside them (rfn.h)
+            from . import _native as N
+            model.gemm_flags |= N.GEMM_OPT_LDS_LEAN
 
     def on_bucket(self, name, flat):
         self.buckets.append(name)

@@ -63,3 +63,24 @@ def test_feeder_matches_reference_batch_layout(tmp_path, device):
     bad[1][0] = bad[1][0][:-1]
     with pytest.raises(ValueError):
         feeder.stage(0, [bad])
+
+
+@pytest.mark.parametrize('device', ['cpu', pytest.param('cuda', marks=pytest.mark.gpu)])
+def test_restaging_a_slot_right_after_batch_keeps_the_uploaded_features(tmp_path, device):
+    """stage() waits for the slot's pending asynchronous H2D before it rewrites the pinned host buffer."""
+    from recurrent_fusion_network_amd.feeder import FeatureFeeder, read_image_features
+    rng = np.random.default_rng(1)
+    files = _write_images(str(tmp_path), 8, rng)
+    feeder = FeatureFeeder(INFO, images_per_batch=4, seq_per_img=2, device=device, depth=1)
+    first = [read_image_features(*f) for f in files[:4]]
+    second = [read_image_features(*f) for f in files[4:]]
+    for _ in range(3):
+        feeder.stage(0, first)
+        feeder.upload(0)
+        fc, att = feeder.batch(0, expand=True)          # expanded copies: independent of the slot's device buffers
+        feeder.stage(0, second)                         # immediately: must not corrupt the upload in flight
+        if device == 'cuda':
+            torch.cuda.synchronize()
+        ref_fc, ref_att = _reference_batch(files[:4], 2)
+        for i in range(len(INFO)):
+            assert np.array_equal(fc[i].cpu().numpy(), ref_fc[i]) and np.array_equal(att[i].cpu().numpy(), ref_att[i])

@@ -195,6 +195,44 @@ def test_gemm_half_height_tail_round(dev):
         assert torch.equal(p[0], c)
 
 
+@pytest.mark.parametrize('ak,bk', [(1, 1), (1, 0), (0, 1), (0, 0)])
+def test_gemm_big_tile_variants_are_bit_identical(dev, ak, bk):
+    """Interior big-tile problems have three kernels behind one entry point: LDS-DMA staging (default), register
+    staging (RFN_GEMM_OPT_NO_DMA) and the single-buffered register-staged tiles data-parallel hosts ask for
+    (RFN_GEMM_OPT_LDS_LEAN).  All keep the same k order per output element, so their results must be bit-identical --
+    and right (fp64), for every operand layout, with K segments, groups, accumulate and a half-height tail round."""
+    n = N()
+    M, Nn, G = 12800, 512, 2                 # 100 x 4 tiles x 2 groups = 800 tiles of 128 x 128
+    Ks = [64, 96]
+    if not (ak and bk):
+        M = 1536                               # 12 x 4 x 2 = 96 big tiles would not take the big path: widen N instead
+        Nn = 4096
+    probs, refs, keep = [], [], []
+    for g in range(G):
+        segs, ref = [], torch.zeros(M, Nn, dtype=torch.float64)
+        for s_, K in enumerate(Ks):
+            A, Bm, b = rnd(M, K, seed=7 * g + s_), rnd(Nn, K, seed=50 + 7 * g + s_), rnd(Nn, seed=90 + s_)
+            ref += A.double() @ Bm.double().t() + b.double()
+            A_st = (A if ak else A.t().contiguous()).to(dev)
+            B_st = (Bm if bk else Bm.t().contiguous()).to(dev)
+            bd = b.to(dev)
+            keep += [A_st, B_st, bd]
+            segs.append((A_st, K if ak else M, ak, B_st, K if bk else Nn, bk, K, bd))
+        probs.append([None, Nn, segs])
+        refs.append(ref)
+    outs = {}
+    for name, flags in (('dma', 0), ('reg', n.GEMM_OPT_NO_DMA), ('lean', n.GEMM_OPT_LDS_LEAN)):
+        res = []
+        for p in probs:
+            p[0] = torch.full((M, Nn), 0.5, device=dev)
+            res.append(p[0])
+        n.gemm(M, Nn, [tuple(p) for p in probs], accumulate=True, flags=flags)
+        outs[name] = res
+    for g in range(G):
+        assert maxerr(outs['dma'][g], refs[g] + 0.5) < 2e-4
+        assert torch.equal(outs['dma'][g], outs['reg'][g]) and torch.equal(outs['dma'][g], outs['lean'][g])
+
+
 def test_gemm_strided_views_like_the_path(dev):
     """The path feeds column blocks of wider buffers (lda > K, ldc > N): e.g. encoder i's slice of H."""
     n = N()

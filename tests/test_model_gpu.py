@@ -435,6 +435,49 @@ def test_scheduled_sampling(dev):
     assert torch.equal(ss, again)
 
 
+@pytest.mark.parametrize('name', ['mid', 'tinymax'])
+def test_sampling_under_dropout_draws_from_the_differentiated_distribution(dev, name):
+    """misc/RecurrentFusionModel.py:260-270, 623-631: in training mode the reference samples (scheduled sampling, and
+    sample(sample_max=0)) from the outputs of the dropout-affected pass it differentiates.  Here the tokens are drawn in
+    a free-running pass and the gradient comes from a teacher-forced replay: both must apply the same dropout masks and
+    produce the same log-probs bit for bit (the published recipe is drop_prob_lm 0.3 + scheduled
+    sampling, train_recurrent_fusion_model.sh:25-26)."""
+    cfg, spec, P, batch, gold = load_case(name)
+    cfg.drop_prob_lm, cfg.drop_prob_reason, cfg.drop_prob_fusion = 0.3, 0.2, 0.1
+    model = build(cfg, P, dev, train=True)
+    fc, att, labels, masks, top = to_dev(batch, dev)
+    model._trace_ss = True
+    model.ss_prob = 1.0
+    torch.manual_seed(3)
+    lp, _ = model(fc, att, labels)
+    trace = model._ss_trace
+    assert len(trace) == lp.size(1) - 1
+    for i, t in enumerate(trace):
+        assert torch.equal(lp[:, i], t), 'step %d: gradient pass differs from the distribution that was sampled' % i
+    eval_lp = build(cfg, P, dev)(fc, att, labels)[0]
+    assert not torch.equal(lp[:, 0], eval_lp[:, 0])             # dropout really was active
+    lp.sum().backward()
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters())
+    # multinomial sample with grad (train_rl.py:160)
+    model.ss_prob = 0.0
+    torch.manual_seed(4)
+    seq, seq_lp, lp_all, _ = model.sample(fc, att, {'sample_max': 0})
+    assert lp_all.requires_grad and torch.equal(lp_all.detach(), model._sample_trace)
+    picked = model._sample_trace[:, :seq.size(1)].gather(2, seq.clamp(min=0).unsqueeze(2)).squeeze(2)
+    alive = seq > 0
+    assert torch.equal(seq_lp.detach()[alive], picked[alive])
+    # eval mode: no dropout anywhere, teacher-forced and free-running passes still agree bit for bit
+    model.eval()
+    with torch.no_grad():
+        g_seq, g_lp, g_all, _ = model.sample(fc, att, {'sample_max': 1})
+        S = g_all.size(1)
+        ids = torch.zeros(g_seq.size(0), S, dtype=torch.long, device=dev)
+        ids[:, 1:] = g_all[:, :S - 1].argmax(2)
+        comb, h, c, _ = model._prefix(fc, att, False, 0)
+        tf = model._decode_teacher_forced(ids, comb, h, c, False, 0)
+    assert torch.equal(tf, g_all)
+
+
 def test_ensemble_decode_matches_oracle(dev):
     """eval_utils.py:268-290: mean of the members' logits, log_softmax, shared greedy token."""
     from oracle import rfn_oracle as O

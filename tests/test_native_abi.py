@@ -35,7 +35,8 @@ def test_struct_layouts_match_the_header():
     N = native()
     assert C.sizeof(N.GemmSeg) == 56
     assert C.sizeof(N.GemmProblem) == 32 + 8 * 56
-    assert C.sizeof(N.Dims) == 8 * 4 + 3 * 8 * 4 + 2 * 4 + 3 * 4
+    assert C.sizeof(N.Dims) == 8 * 4 + 3 * 8 * 4 + 2 * 4 + 3 * 4 + 4          # ... + gemm_flags (ABI 4)
+    assert N.GEMM_OPT_LDS_LEAN == 1 and N.GEMM_OPT_NO_DMA == 2             # rfn.h RFN_GEMM_OPT_*
 
 
 def test_param_table_matches_reference_schema():

@@ -1,0 +1,126 @@
+"""Trainer-facing contract the reference's loops rely on beyond forward/backward:
+  * loss.backward(retain_graph=True) called repeatedly on one graph (PPO loop, train_rl.py:190-201);
+  * gradients accumulated over two backward passes stay the fused optimizer's operand;
+  * optimizer.param_groups[0]['lr'] (utils.set_lr, misc/utils.py:286-290) and optimizer state save / resume
+    (optimizer_<id>.pth, train.py:86-88,232-233)."""
+import pytest
+import torch
+
+from conftest import load_case
+from test_model_gpu import build, maxerr, to_dev
+
+pytestmark = pytest.mark.gpu
+
+
+def _loss(model, crit, fc, att, labels, masks, top):
+    lp, reason = model(fc, att, labels)
+    return crit(lp, labels[:, 1:], masks[:, 1:], reason, top, 1.0)
+
+
+@pytest.mark.parametrize('drop', [0.0, 0.3])
+def test_backward_twice_over_one_graph(dev, drop):
+    import recurrent_fusion_network_amd as R
+    cfg, spec, P, batch, gold = load_case('mid')
+    cfg.drop_prob_lm = cfg.drop_prob_reason = cfg.drop_prob_fusion = drop
+    model = build(cfg, P, dev, train=True)
+    fc, att, labels, masks, top = to_dev(batch, dev)
+    crit = R.ReviewNetEnsembleCriterion(cfg)
+    opt = R.FusedClampAdam(model, lr=0.0)                 # lr 0: the weights stay put between the passes
+    torch.manual_seed(11)
+    loss = _loss(model, crit, fc, att, labels, masks, top)
+    opt.zero_grad()
+    loss.backward(retain_graph=True)
+    first = {k: p.grad.clone() for k, p in model.named_parameters()}
+    for _ in range(2):                                    # ppo_k further passes over the same graph
+        opt.zero_grad()
+        loss.backward(retain_graph=True)
+        for k, p in model.named_parameters():
+            assert torch.equal(p.grad, first[k]), k       # same graph, same seed, fixed-order reductions: bit-equal
+
+
+def test_rl_graph_backward_twice(dev):
+    """The PPO loop itself: sample(sample_max=0) graph + reward criterion, backward three times."""
+    import recurrent_fusion_network_amd as R
+    cfg, spec, P, batch, gold = load_case('mid')
+    cfg.use_ppo = 1
+    model = build(cfg, P, dev, train=True)
+    fc, att, labels, masks, top = to_dev(batch, dev)
+    raw = torch.from_numpy(gold['rl_raw_ids'])
+    seq, seq_lp, lp_all, reason = model.sample(fc, att, {'sample_max': 0, 'force_ids': raw})
+    crit = R.ReviewNetRewardCriterion(cfg)
+    reward = torch.from_numpy(gold['rl_reward']).to(dev)
+    loss = crit(seq_lp, seq, reward, lp_all, 0.01, reason, top, 1.0, seq_lp.detach(), cfg)
+    opt = R.FusedClampAdam(model, lr=0.0)
+    grads = []
+    for _ in range(3):
+        opt.zero_grad()
+        loss.backward(retain_graph=True)
+        grads.append({k: p.grad.clone() for k, p in model.named_parameters()})
+    for k in grads[0]:
+        assert torch.equal(grads[0][k], grads[1][k]) and torch.equal(grads[0][k], grads[2][k]), k
+
+
+def test_accumulated_gradients_reach_the_fused_optimizer(dev):
+    import recurrent_fusion_network_amd as R
+    cfg, spec, P, batch, gold = load_case('tiny0')
+    fc, att, labels, masks, top = to_dev(batch, dev)
+    crit = R.ReviewNetEnsembleCriterion(cfg)
+    kw = dict(lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5, grad_clip=1e9)
+    m1 = build(cfg, P, dev, train=True)
+    o1 = R.FusedClampAdam(m1, **kw)
+    o1.zero_grad()
+    for _ in range(2):                                    # two forward/backward passes, one step
+        _loss(m1, crit, fc, att, labels, masks, top).backward()
+    for name, flat in m1._last_flat_grads.items():        # .grad and the optimizer operand are the same memory
+        p0 = m1.bucket_layout(name)[0][0]
+        assert p0.grad.data_ptr() == flat.data_ptr()
+    o1.step()
+    m2 = build(cfg, P, dev, train=True)
+    o2 = R.FusedClampAdam(m2, **kw)
+    o2.zero_grad()
+    (2.0 * _loss(m2, crit, fc, att, labels, masks, top)).backward()
+    g1, g2 = dict(m1.named_parameters()), dict(m2.named_parameters())
+    for k in g1:
+        assert maxerr(g1[k].grad, g2[k].grad.cpu()) <= 1e-6 + 1e-5 * float(g2[k].grad.abs().max()), k
+    o2.step()
+    for k in g1:
+        sel = (g2[k].grad.abs() > 1e-4).cpu()
+        if bool(sel.any()):
+            assert float((g1[k].detach().cpu()[sel] - g2[k].detach().cpu()[sel]).abs().max()) < 5e-6, k
+    # accumulation over passes and per-bucket all-reduce hooks do not mix: loud error, not a silent partial update
+    m1.grad_ready_hook = lambda name, flat: None
+    with pytest.raises(R._native.RfnError):
+        _loss(m1, crit, fc, att, labels, masks, top).backward()
+
+
+def test_optimizer_param_groups_and_state_round_trip(dev, tmp_path):
+    import recurrent_fusion_network_amd as R
+    cfg, spec, P, batch, gold = load_case('tiny1')
+    fc, att, labels, masks, top = to_dev(batch, dev)
+    crit = R.ReviewNetEnsembleCriterion(cfg)
+
+    def run(model, opt, steps):
+        for _ in range(steps):
+            opt.zero_grad()
+            _loss(model, crit, fc, att, labels, masks, top).backward()
+            opt.step()
+
+    kw = dict(lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5, grad_clip=1.0)
+    m1 = build(cfg, P, dev, train=True)
+    o1 = R.FusedClampAdam(m1, **kw)
+    run(m1, o1, 2)
+    for group in o1.param_groups:                          # utils.set_lr (misc/utils.py:286-290)
+        group['lr'] = 1e-4
+    assert o1.lr == 1e-4
+    torch.save(o1.state_dict(), str(tmp_path / 'optimizer_x.pth'))
+    torch.save(m1.state_dict(), str(tmp_path / 'model_x.pth'))
+    run(m1, o1, 2)
+    # resume: fresh model + optimizer from the two files, same two further steps
+    m2 = build(cfg, torch.load(str(tmp_path / 'model_x.pth')), dev, train=True)
+    o2 = R.FusedClampAdam(m2, **kw)
+    o2.load_state_dict(torch.load(str(tmp_path / 'optimizer_x.pth')))
+    assert o2.step_count == 2 and o2.lr == 1e-4
+    run(m2, o2, 2)
+    p2 = dict(m2.named_parameters())
+    for k, p in m1.named_parameters():
+        assert torch.equal(p.detach(), p2[k].detach()), k

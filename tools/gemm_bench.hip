@@ -40,19 +40,38 @@ int main() {
     }
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const double flops = 2.0 * BL * D * A * T;
-    for (int which = 0; which < 2; ++which) {
+    // bit-equality of the LDS-DMA kernel and the register-staged kernel (same k order per output element)
+    {
+        std::vector<float> r0((size_t)T * A * D), r1((size_t)T * A * D), p0(1 << 22), p1(1 << 22);
+        for (unsigned fl = 0; fl < 2; ++fl) {
+            const unsigned flags = fl ? RFN_GEMM_OPT_NO_DMA : 0u;
+            hipMemset(P, 0, (size_t)BL * T * A * 4);
+            rfn_gemm_f32_opt(BL, A, T, nt, 0, ws, ws_bytes, flags, 0);
+            hipMemcpy((fl ? p1 : p0).data(), P + (size_t)12345 * T * A, p0.size() * 4, hipMemcpyDeviceToHost);
+            rfn_gemm_f32_opt(A, D, T, tn, 0, ws, ws_bytes, flags, 0);
+            hipMemcpy((fl ? r1 : r0).data(), dW, r0.size() * 4, hipMemcpyDeviceToHost);
+        }
+        size_t bad_p = 0, bad_w = 0;
+        for (size_t i = 0; i < p0.size(); ++i) bad_p += memcmp(&p0[i], &p1[i], 4) != 0;
+        for (size_t i = 0; i < r0.size(); ++i) bad_w += memcmp(&r0[i], &r1[i], 4) != 0;
+        printf("%-28s DMA vs register-staged: %zu / %zu projection values differ, %zu / %zu dW values differ (p[7]=%g w[7]=%g)\n", VARIANT,
+               bad_p, p0.size(), bad_w, r0.size(), p0[7], r0[7]);
+    }
+    for (int which = 0; which < 4; ++which) {
+        const unsigned flags = (which & 2) ? RFN_GEMM_OPT_NO_DMA : 0u;
         float best = 1e9, sum = 0;
         const int reps = 6;
         for (int r = 0; r < reps + 1; ++r) {
             hipEventRecord(e0);
-            int rc = which == 0 ? rfn_gemm_f32_ws(BL, A, T, nt, 0, ws, ws_bytes, 0) : rfn_gemm_f32_ws(A, D, T, tn, 0, ws, ws_bytes, 0);
+            int rc = (which & 1) == 0 ? rfn_gemm_f32_opt(BL, A, T, nt, 0, ws, ws_bytes, flags, 0)
+                                      : rfn_gemm_f32_opt(A, D, T, tn, 0, ws, ws_bytes, flags, 0);
             hipEventRecord(e1); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);
             if (rc) { printf("rc %d\n", rc); return 1; }
             if (r) { sum += ms; if (ms < best) best = ms; }
         }
-        printf("%-28s %s: avg %.3f ms (%.1f TF)  best %.3f ms (%.1f TF)\n", VARIANT, which ? "TN dW  " : "NT proj",
-               sum / reps, flops / (sum / reps) / 1e9, best, flops / best / 1e9);
+        printf("%-28s %s %s: avg %.3f ms (%.1f TF)  best %.3f ms (%.1f TF)\n", VARIANT, (which & 1) ? "TN dW  " : "NT proj",
+               flags ? "reg-staged" : "LDS-DMA   ", sum / reps, flops / (sum / reps) / 1e9, best, flops / best / 1e9);
     }
     return 0;
 }

@@ -28,7 +28,15 @@ cfg = BN.make_cfg(w)
 model = R.RecurrentFusionModel(cfg).to(dev)
 BN.seeded_weights_(model, 100)
 model.train()
-model._deliver_grads = lambda params, views: None        # timing only: keep the flat buffers, skip p.grad bookkeeping
+PARAMS = list(model.parameters())
+
+
+def reset():
+    model._last_flat_grads.clear()
+    for p in PARAMS:
+        p.grad = None
+
+
 crit = R.ReviewNetEnsembleCriterion(cfg)
 fc, att, labels, masks, top = BN.synthetic_inputs(cfg, B, 100, dev)
 labels[:] = labels[0]                                     # identical label rows: one cached step count for every slice
@@ -56,18 +64,21 @@ def loss_of(p, lp, tp):
 
 
 def run_full():
+    reset()
     p = parts(1)[0]
     lp, tp = fwd(p)
     loss_of(p, lp, tp).backward()
 
 
 def run_seq(n):
+    reset()
     for p in parts(n):
         lp, tp = fwd(p)
         loss_of(p, lp, tp).backward()
 
 
 def run_streams(n, join, prio):
+    reset()
     main = torch.cuda.current_stream()
     ps = parts(n)
     streams = STREAMS[(n, prio)]

@@ -1,9 +1,11 @@
 #!/bin/bash
-# builds + runs the GEMM ablation variants (run on the GPU box; hipcc is available there too)
+# builds + runs the GEMM A/B variants (run on the GPU box; hipcc is available there too)
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p /tmp/gb
-build() { hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-unused-value -Wno-unused-result -DVARIANT="\"$1\"" $2 tools/gemm_bench.hip -o /tmp/gb/$1; }
-build default ""
-build notail "-DGEMM_TAIL_HALF=0"
-for r in 1 2; do for v in default notail; do /tmp/gb/$v; done; done
+build() { hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-unused-value -Wno-unused-result -DVARIANT="\"$1\"" $2 tools/gemm_bench.hip -o /tmp/gb/$1 & }
+build dma ""
+build dma_s3 "-DGEMM_DMA_SLOTS_NT=3 -DGEMM_DMA_SLOTS_XX=3 -DGEMM_DMA_BK=16"
+build abl1 "-DGEMM_DMA_ABLATE=1"
+wait
+for r in 1 2 3; do for v in dma dma_s3 abl1; do /tmp/gb/$v; done; done
