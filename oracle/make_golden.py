@@ -425,15 +425,80 @@ def generate_decode(name, RefModel, ref_utils, outdir):
         name, loss.item(), g[0].size(1), beam, b[0].size(1), float(out['rl_loss']), path, os.path.getsize(path) / 1024))
 
 
+SHOWTELL = dict(fc=2048, R=512, V=9487, B=4, S=16, seed=11, max_words=9)   # BASELINE config 1
+
+
+def showtell_cfg():
+    from types import SimpleNamespace
+    c = SHOWTELL
+    return SimpleNamespace(vocab_size=c['V'], input_encoding_size=c['R'], rnn_type='lstm', rnn_size=c['R'], num_layers=1,
+                           drop_prob_lm=0.0, seq_length=c['S'], fc_feat_size=c['fc'], use_cuda=0, use_label_smoothing=0,
+                           label_smoothing_epsilon=0.1, caption_model='show_tell')
+
+
+def showtell_weights(model, seed):
+    """our documented stream: uniform(+-0.1) over sorted(state_dict keys) from np.random.default_rng(seed)"""
+    rng = np.random.default_rng(seed)
+    sd = model.state_dict()
+    return {k: torch.from_numpy(rng.uniform(-0.1, 0.1, tuple(sd[k].shape)).astype(np.float32)) for k in sorted(sd)}
+
+
+def showtell_batch():
+    c = SHOWTELL
+    rng = np.random.default_rng(1000 + c['seed'])
+    fc = torch.from_numpy(rng.standard_normal((c['B'], c['fc'])).astype(np.float32))
+    labels = torch.zeros(c['B'], c['S'] + 2, dtype=torch.long)
+    masks = torch.zeros(c['B'], c['S'] + 2)
+    for b in range(c['B']):
+        n = int(rng.integers(1, c['max_words'] + 1))
+        labels[b, 1:1 + n] = torch.from_numpy(rng.integers(1, c['V'] + 1, n))
+        masks[b, :n + 2] = 1
+    return fc, labels, masks
+
+
+def generate_showtell(outdir):
+    """BASELINE config 1 (ShowTellModel single-encoder greedy decode on CPU, B=4, 2048-d feats, seq_len 16): the
+    reference's forward + LanguageModelCriterion + greedy sample on seeded weights."""
+    sys.path.insert(0, REF)
+    from misc.ShowTellModel import ShowTellModel as RefShowTell  # noqa
+    import misc.utils as ref_utils  # noqa
+    cfg = showtell_cfg()
+    torch.manual_seed(0)
+    model = RefShowTell(cfg)
+    W = showtell_weights(model, SHOWTELL['seed'])
+    model.load_state_dict(W)
+    model.eval()
+    fc, labels, masks = showtell_batch()
+    with torch.no_grad():
+        lp = model(fc, None, labels)
+        loss = ref_utils.LanguageModelCriterion(cfg)(lp, labels[:, 1:], masks[:, 1:])
+        cfg.use_label_smoothing = 1
+        loss_ls = ref_utils.LanguageModelCriterion(cfg)(lp, labels[:, 1:], masks[:, 1:])
+        seq, seq_lp, lp_all = model.sample(fc, None, {'sample_max': 1})
+    t5 = lp.topk(5, dim=2)
+    out = dict(weights_digest=digest([W[k] for k in sorted(W)]), inputs_digest=digest([fc]), labels=labels.numpy(),
+               log_prob_shape=np.array(lp.shape), log_prob_top5_val=t5.values.numpy(), log_prob_top5_idx=t5.indices.numpy(),
+               log_prob_target=lp.gather(2, labels[:, 1:1 + lp.size(1)].unsqueeze(2)).squeeze(2).numpy(),
+               xe_loss=np.float64(loss.item()), xe_loss_ls=np.float64(loss_ls.item()),
+               greedy_seq=seq.numpy(), greedy_seq_logprobs=seq_lp.numpy(), greedy_logprobs_all_shape=np.array(lp_all.shape),
+               state_dict_keys=np.array(sorted(W)))
+    path = os.path.join(outdir, 'showtell.npz')
+    np.savez_compressed(path, **out)
+    print('showtell xe %.6f greedy T=%d -> %s (%.1f KB)' % (loss.item(), seq.size(1), path, os.path.getsize(path) / 1024))
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--only', default='tiny0,tiny1,tinymax,odd,mid,c2,c3,c5,evalmid')
+    ap.add_argument('--only', default='tiny0,tiny1,tinymax,odd,mid,c2,c3,c5,evalmid,showtell')
     ap.add_argument('--out', default=os.path.join(ROOT, 'tests', 'golden'))
     args = ap.parse_args()
     torch.set_num_threads(8)
     RefModel, ref_utils = load_reference()
     os.makedirs(args.out, exist_ok=True)
     for name in args.only.split(','):
+        if name == 'showtell':
+            generate_showtell(args.out)
+            continue
         if 'decode' in CONFIGS[name]:
             generate_decode(name, RefModel, ref_utils, args.out)
         else:

@@ -728,37 +728,41 @@ __device__ __forceinline__ void gemm_tile_dma(const GemmArgs& args, const int gr
         fill = (fill + 1 == SLOTS) ? 0 : fill + 1;
     }
 
+    // ---- epilogue.  Addresses are a wave-uniform tile base (SGPR pair) + a 32-bit lane offset: no 64-bit per-lane
+    // address arithmetic, and the stores take the cheap saddr form (the host checks that a tile spans < 4 GiB).
     const int M = args.M, N = args.N;
-    if (splitk > 1) {  // raw partial tile; rfn_gemm_reduce_k adds the bias / previous C in a fixed order
-        float* part = args.part + ((long)grp * splitk + ks) * (long)M * N;
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int col = col0 + wn * (BN / 2) + j * 32 + l31;
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = row0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    part[(long)row * N + col] = acc[i][j][r];
-                }
-        }
-        return;
-    }
+    const long ldo = (splitk > 1) ? (long)N : P.ldc;
+    float* const obase = (splitk > 1) ? args.part + ((long)grp * splitk + ks) * (long)M * N + (long)row0 * N + col0
+                                      : P.C + (long)row0 * P.ldc + col0;
+    char* const tile = (char*)obase;
+    const uint32_t ld4 = (uint32_t)ldo * 4u;
+    const uint32_t lane_off = (uint32_t)(wm * (BM / 2) + 4 * h) * ld4 + (uint32_t)(wn * (BN / 2) + l31) * 4u;
+    const bool raw = splitk > 1;   // raw partial tile; rfn_gemm_reduce_k adds the bias / previous C in a fixed order
+    const bool accumulate = !raw && args.accumulate;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-        const int col = col0 + wn * (BN / 2) + j * 32 + l31;
         float bsum = 0.f;
-        for (int s = 0; s < P.nseg; ++s)
-            if (P.seg[s].bias) bsum += P.seg[s].bias[col];
+        if (!raw) {
+            const int col = col0 + wn * (BN / 2) + j * 32 + l31;
+            for (int s = 0; s < P.nseg; ++s)
+                if (P.seg[s].bias) bsum += P.seg[s].bias[col];
+        }
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
+            const uint32_t sub = lane_off + (uint32_t)(i * 32) * ld4 + (uint32_t)(j * 32) * 4u;
+            if (accumulate) {
+                float prev[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = row0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                float* c = P.C + (long)row * P.ldc + col;
-                float val = acc[i][j][r] + bsum;
-                if (args.accumulate) val += *c;
-                *c = val;
+                for (int r = 0; r < 16; ++r)
+                    prev[r] = *reinterpret_cast<const float*>(tile + (sub + (uint32_t)((r & 3) + 8 * (r >> 2)) * ld4));
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    *reinterpret_cast<float*>(tile + (sub + (uint32_t)((r & 3) + 8 * (r >> 2)) * ld4)) =
+                        (acc[i][j][r] + bsum) + prev[r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    *reinterpret_cast<float*>(tile + (sub + (uint32_t)((r & 3) + 8 * (r >> 2)) * ld4)) = acc[i][j][r] + bsum;
             }
         }
     }
@@ -993,6 +997,8 @@ static int launch_tile(GemmArgs& a, hipStream_t st) {
                     const double eb = BKF ? (double)a.N * sg.ldb : (double)sg.K * sg.ldb;
                     span32 = span32 && ea * 4 < 4.0e9 && eb * 4 < 4.0e9 && sg.lda >= 0 && sg.ldb >= 0;
                 }
+            for (int g = 0; g < a.ngroups; ++g)   // ... and one output tile as tile base + 32-bit byte offset
+                span32 = span32 && a.g[g].ldc >= 0 && (double)a.g[g].ldc * 4 * GEMM_BIG_BM < 4.0e9 && (double)a.N * 4 * GEMM_BIG_BM < 4.0e9;
             if (fast && span32 && !colsum && !lean && !(a.flags & RFN_GEMM_OPT_NO_DMA)) {
                 constexpr int SL = (AK && BKF) ? GEMM_DMA_SLOTS_NT : GEMM_DMA_SLOTS_XX;
                 return launch_cfg<GEMM_BIG_BM, GEMM_BIG_BN, AK, BKF, true, 1, GEMM_DMA_BK, true, GEMM_THREADS, SL>(a, st);

@@ -938,13 +938,16 @@ extern "C" int rfn_decoder_fwd(const rfn_dims* d, int B, int S, const float* con
     float* hd = W + Lo.hd;
     float* cd = W + Lo.cd;
     float* gd = W + Lo.gd;
+    // The three batched products of this pass (thought projection, i2h, logits) are never split along K: the
+    // free-running step (rfn_decoder_prepare / rfn_decoder_step) computes the same products for one step's rows with the
+    // same unsplit k order, so teacher-forced and free-running log-probs of the same tokens are bit-identical whatever
+    // the batch size (split-K choices depend on the row count).  The per-step products (h_2_att_h, h2h + z2h) have the
+    // same shape in both passes and take the same split.
+    const GemmCtx gx_whole{st, nullptr, 0, d->gemm_flags};
     // loop-invariant projection of the fused thoughts, applied once instead of every step
-    RFN_TRY(gemm1(T2 * B, A, seg_lin(comb, R, prm[P.dec(6)], R, R, prm[P.dec(7)]), W + Lo.Pd, A, 0, gx));
+    RFN_TRY(gemm1(T2 * B, A, seg_lin(comb, R, prm[P.dec(6)], R, R, prm[P.dec(7)]), W + Lo.Pd, A, 0, gx_whole));
     // all token embeddings and their i2h projections in one go (teacher forcing: ids are known)
     RFN_TRY(rfn_embed_fwd(prm[P.embed()], E, V1, ids, B, ld_ids, 1, S * B, W + Lo.xs, E, st));
-    // (never split along K: the free-running step applies i2h to one step's rows with the same unsplit k order,
-    // so teacher-forced and free-running log-probs of the same tokens are bit-identical)
-    const GemmCtx gx_whole{st, nullptr, 0, d->gemm_flags};
     RFN_TRY(gemm1(S * B, GD, seg_lin(W + Lo.xs, E, prm[P.dec(0)], E, E, prm[P.dec(1)]), gd, GD, 0, gx_whole));
     RFN_TRY(copy_f32(hd, h0, BR, st));
     RFN_TRY(copy_f32(cd, c0, BR, st));
@@ -964,7 +967,7 @@ extern "C" int rfn_decoder_fwd(const rfn_dims* d, int B, int S, const float* con
                              d->drop_lm, seed, OFF_DECODER + (uint64_t)s, st));
     }
     // logits of all steps, then log-softmax written in the reference's (B, S, V+1) layout
-    RFN_TRY(gemm_logits(S * B, V1, hd + BR, R, prm[P.logit_w()], prm[P.logit_b()], W + Lo.logits, gx));
+    RFN_TRY(gemm_logits(S * B, V1, hd + BR, R, prm[P.logit_w()], prm[P.logit_b()], W + Lo.logits, gx_whole));
     RFN_TRY(rfn_log_softmax_fwd(W + Lo.logits, V1, S * B, V1, B, (long)S * V1, V1, log_prob, st));
     return RFN_OK;
 }
@@ -1099,7 +1102,7 @@ static int decoder_step_impl(const rfn_dims* d, int B, const float* const* prm, 
     RFN_TRY(gemm_segs(B, GD, 2, segs, g, GD, 1, gx));
     RFN_TRY(rfn_lstm_fwd(g, GD, c, R, c, R, h, R, B, R, d->decoder_maxout, d->drop_lm, seed, OFF_DECODER + (uint64_t)step, st));
     if (logits || logp) {
-        RFN_TRY(gemm_logits(B, V1, h, R, prm[P.logit_w()], prm[P.logit_b()], lg, gx));
+        RFN_TRY(gemm_logits(B, V1, h, R, prm[P.logit_w()], prm[P.logit_b()], lg, gx_whole));
         if (logp) {
             if (ld_logp < V1) return RFN_ERR_SHAPE;
             RFN_TRY(rfn_log_softmax_fwd(lg, V1, B, V1, B, ld_logp, 0, logp, st));

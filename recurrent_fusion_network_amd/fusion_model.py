@@ -440,9 +440,14 @@ class RecurrentFusionModel(nn.Module):
         if g > 1:
             if train and (self.drop_prob_fusion > 0 or self.drop_prob_reason > 0):
                 raise N.RfnError('dedup_seq_per_img needs drop_prob_fusion = drop_prob_reason = 0')
-            if fc_feats[0].size(0) % g:
-                raise N.RfnError('batch size is not a multiple of dedup_seq_per_img')
-            comb, h, c, reason = self._prefix([f[::g] for f in fc_feats], [a[::g] for a in att_feats], train, seed)
+            rows, n_feat = seq.size(0), fc_feats[0].size(0)
+            if n_feat == rows and rows % g == 0:      # caption rows (the loader's layout): keep one row per image
+                fc_u, att_u = [f[::g] for f in fc_feats], [a[::g] for a in att_feats]
+            elif n_feat * g == rows:                  # unique images already (FeatureFeeder.batch(expand=False))
+                fc_u, att_u = list(fc_feats), list(att_feats)
+            else:
+                raise N.RfnError('dedup_seq_per_img = %d: %d feature rows do not match %d caption rows' % (g, n_feat, rows))
+            comb, h, c, reason = self._prefix(fc_u, att_u, train, seed)
             comb = comb.repeat_interleave(g, dim=1)       # autograd sums the caption rows back onto the image
             h, c = h.repeat_interleave(g, dim=0), c.repeat_interleave(g, dim=0)
             reason = reason.repeat_interleave(g, dim=1)

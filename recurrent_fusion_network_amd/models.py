@@ -2,16 +2,18 @@
 
 ``setup(opt)`` keeps the reference's contract -- build the captioner named by ``opt.caption_model`` and, when
 ``opt.start_from`` is set, resume from ``<start_from>/model_<load_model_id>.pth`` (same state_dict keys, so
-checkpoints written by the reference load unchanged).  Only ``recurrent_fusion_model`` is on the accelerated path
-(SURVEY.md section 2); every other name raises.
+checkpoints written by the reference load unchanged).  ``recurrent_fusion_model`` is the accelerated path;
+``show_tell`` (BASELINE config 1) is the reference's simplest captioner on stock PyTorch modules for CPU plumbing
+checks; every other name raises.
 """
 import os
 
 import torch
 
 from .fusion_model import RecurrentFusionModel
+from .show_tell import ShowTellModel
 
-_REGISTRY = {'recurrent_fusion_model': RecurrentFusionModel}
+_REGISTRY = {'recurrent_fusion_model': RecurrentFusionModel, 'show_tell': ShowTellModel}
 
 
 def _resume_paths(opt):

@@ -149,7 +149,8 @@ def test_config5_size_beam5_and_rl_sample_properties(dev):
         p = np.array(a[3][k])
         assert len(p) >= 1 and np.all(np.diff(p) <= 1e-6)
         assert torch.equal(a[2][k][0], a[0][k].cpu())                             # returned seq = best done beam
-    assert torch.equal(gp[0], g[0][3:6]) and torch.equal(gp[1], g[1][3:6])        # greedy: batch independent, bit-exact
+    # greedy ids do not depend on the batch an image sits in (log-probs to rounding: split-K choices follow the row count)
+    assert torch.equal(gp[0], g[0][3:6]) and maxerr(gp[1], g[1][3:6].cpu()) < 1e-5
     # beam search never scores below the greedy sentence when the greedy sentence ended inside the beam
     model.train()
     model._trace_ss = True

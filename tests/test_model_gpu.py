@@ -255,6 +255,13 @@ def test_dedup_of_replicated_images_is_exact(dev):
     for k in outs[0][2]:
         ref = outs[0][2][k]
         assert maxerr(outs[1][2][k], ref.cpu()) <= 1e-6 + 1e-4 * float(ref.abs().max()), k
+    # the feeder's unique-image batch (FeatureFeeder.batch(expand=False)) composes with dedup: same outputs again
+    model = build(cfg, P, dev)
+    model.dedup_seq_per_img = g
+    lp_u, reason_u = model([f[:2].contiguous() for f in fc], [a[:2].contiguous() for a in att], labels)
+    assert torch.equal(lp_u, outs[0][0]) and all(torch.equal(a, b) for a, b in zip(reason_u, outs[0][1]))
+    with pytest.raises(R._native.RfnError):
+        model([f[:3] for f in fc], [a[:3] for a in att], labels)          # 3 images x 3 != 6 caption rows
 
 
 def test_reuse_prefix_serves_the_baseline_sample_and_is_invalidated(dev):

@@ -110,8 +110,8 @@ def test_model_shell_schema_and_loud_failure_on_cpu():
     fc, att, labels, masks, top = O.synthetic_batch(cfg, 3, seed=1)
     with pytest.raises(R._native.RfnError):                   # no CPU fallback
         model(fc, att, labels)
-    cfg.caption_model = 'show_tell'
-    with pytest.raises(Exception):
+    cfg.caption_model = 'review_net'                          # not provided: only the fusion model and show_tell
+    with pytest.raises(Exception, match='not supported'):
         R.setup(cfg)
     cfg.caption_model = 'recurrent_fusion_model'
     cfg.maxout, cfg.review_maxout, cfg.fusion_maxout = 1, 1, 1
