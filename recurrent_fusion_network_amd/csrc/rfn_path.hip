@@ -860,31 +860,43 @@ extern "C" int rfn_prefix_bwd_wgrad(const rfn_dims* d, int B, const float* const
     rfn_gemm_problem pr[64];
     const long Li = d->L[i], Di = d->D[i];
     // att_2_att_h.bias and h_2_att_h.bias enter the same pre-activation (AttentionModelCore.py:36-38), so their
-    // gradients are the same vector: it is produced once, as the rider of the short h_2_att_h GEMM of part A, and
-    // copied -- the 6 ms att_2_att_h GEMM carries no rider (its 32 first-column blocks would otherwise finish last
-    // and, with exactly one round of blocks, delay the whole launch).
+    // gradients are the same vector: it is produced once in part A and copied; the long att_2_att_h GEMM carries no
+    // bias-gradient rider.
     if (parts & 2) {  // part B: the dominant att_2_att_h gradient (small bucket, long GEMM)
         for (int t = 0; t < T1; ++t)
             pr[t] = prob_dw(grd[P.s1(t, i, 0)], Di, nullptr, W + Lo.P1[i] + (long)t * A, (long)T1 * A, att[i], Di,
                             (int)(B * Li));
         if (!(parts & 1)) return gemm_groups(A, (int)Di, T1, pr, 0, gx);
     }
-    // part A: H2h, z2h, h_2_att_h (large bucket, short GEMMs)
+    // part A: H2h, z2h, h_2_att_h (large bucket, short GEMMs: K = B rows per step).  Their bias gradients are column
+    // sums of tensors that are tiny next to the weight gradients (dgates: T1*B*4R floats per encoder), so they come from
+    // one grouped column-sum launch each instead of riding on the GEMMs -- which keeps the two big products
+    // (2 x T1 x 4R x {M*R, D}) on the LDS-DMA kernel.  H2h.bias and z2h.bias enter the same pre-activation and share
+    // one gradient, like h_2_att_h.bias and att_2_att_h.bias.
+    float* outs[64];
+    const float* g1i = W + Lo.g1 + (long)i * B * 4 * R;           // (t, i) slab = g1i + t * M*B*4R
+    for (int t = 0; t < T1; ++t) outs[t] = grd[P.s1(t, i, 7)];
+    RFN_TRY(rfn_colsum_grouped_f32(g1i, (long)M * B * 4 * R, 4 * R, B, 4 * R, outs, T1, st));
+    for (int t = 0; t < T1; ++t) outs[t] = grd[P.s1(t, i, 3)];
+    RFN_TRY(rfn_colsum_grouped_f32(W + Lo.dhp1 + (long)i * BA, (long)M * BA, A, B, A, outs, T1, st));
     for (int t = 0; t < T1; ++t)
-        pr[t] = prob_dw(grd[P.s1(t, i, 6)], MR, grd[P.s1(t, i, 7)], W + Lo.g1 + ((long)t * M + i) * B * 4 * R, 4 * R,
-                        Hs + t * BMR, MR, B);
+        pr[t] = prob_dw(grd[P.s1(t, i, 6)], MR, nullptr, g1i + (long)t * M * B * 4 * R, 4 * R, Hs + t * BMR, MR, B);
     RFN_TRY(gemm_groups(4 * R, (int)MR, T1, pr, 0, gx));
     for (int t = 0; t < T1; ++t)
-        pr[t] = prob_dw(grd[P.s1(t, i, 8)], Di, grd[P.s1(t, i, 9)], W + Lo.g1 + ((long)t * M + i) * B * 4 * R, 4 * R,
+        pr[t] = prob_dw(grd[P.s1(t, i, 8)], Di, nullptr, g1i + (long)t * M * B * 4 * R, 4 * R,
                         W + Lo.z1[i] + (long)t * B * Di, Di, B);
     RFN_TRY(gemm_groups(4 * R, (int)Di, T1, pr, 0, gx));
     for (int t = 0; t < T1; ++t)
-        pr[t] = prob_dw(grd[P.s1(t, i, 2)], R, grd[P.s1(t, i, 3)], W + Lo.dhp1 + ((long)t * M + i) * BA, A,
-                        Hs + t * BMR + i * R, MR, B);
+        pr[t] = prob_dw(grd[P.s1(t, i, 2)], R, nullptr, W + Lo.dhp1 + ((long)t * M + i) * BA, A, Hs + t * BMR + i * R, MR, B);
     RFN_TRY(gemm_groups(A, R, T1, pr, 0, gx));
-    {   // d att_2_att_h.bias[t] = d h_2_att_h.bias[t] (before the large bucket is announced / all-reduced)
+    {   // z2h.bias = H2h.bias and att_2_att_h.bias = h_2_att_h.bias gradients (before the large bucket is announced)
         float* cdst[64];
         const float* csrc[64];
+        for (int t = 0; t < T1; ++t) {
+            cdst[t] = grd[P.s1(t, i, 9)];
+            csrc[t] = grd[P.s1(t, i, 7)];
+        }
+        RFN_TRY(rfn_copy_small_f32(cdst, csrc, T1, 4 * R, st));
         for (int t = 0; t < T1; ++t) {
             cdst[t] = grd[P.s1(t, i, 1)];
             csrc[t] = grd[P.s1(t, i, 3)];
