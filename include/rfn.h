@@ -111,9 +111,10 @@ int rfn_gemm_f32_ws(int M, int N, int ngroups, const rfn_gemm_problem* problems_
                     void* ws, size_t ws_bytes, void* stream);
 /* Same, with option bits (every tuning choice travels with the call: the library reads no environment variable and
  * keeps no mutable process state beyond write-once, per-device launch attributes of its kernels).
- *   RFN_GEMM_OPT_LDS_LEAN  the long big-tile GEMMs keep <= 110 KB of each CU's 160 KB of LDS (single-buffered,
- *                          register-staged tiles), so that kernels of other streams -- RCCL's under data
- *                          parallelism -- can co-reside instead of waiting for a multi-millisecond GEMM to drain;
+ *   RFN_GEMM_OPT_LDS_LEAN  the long big-tile GEMMs take 32 KB of LDS per block (64 KB per CU for a one-round
+ *                          weight-gradient launch) instead of 64 KB per block, so that kernels of other streams --
+ *                          RCCL's under data parallelism -- can co-reside instead of waiting for a
+ *                          multi-millisecond GEMM to drain; same results, same speed within 1 %;
  *   RFN_GEMM_OPT_NO_DMA    interior big tiles use the register-staged kernel instead of the LDS-DMA one (A/B hook;
  *                          both give bit-identical results: same k order per output element). */
 #define RFN_GEMM_OPT_LDS_LEAN 1u

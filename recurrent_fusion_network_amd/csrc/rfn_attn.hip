@@ -373,6 +373,9 @@ extern "C" int rfn_attn_context_bwd_dseq(const float* alpha, const float* dz, in
 // the four waves' sums are combined through LDS in a fixed order (deterministic).
 #define SB_THREADS 1024
 #define SB_WAVES 16
+#ifndef SB_UNROLL
+#define SB_UNROLL 4
+#endif
 // FUSED: dalpha[l] = <dz, x[l]> is computed here first (into LDS, same per-row arithmetic as attn_dalpha_k), so the
 // context backward and the score backward of one (step, encoder) are a single launch: x is streamed, then P.
 template <bool VEC, bool FUSED>
@@ -463,31 +466,47 @@ __global__ __launch_bounds__(SB_THREADS) void attn_scores_bwd_k(const AttnEncPtr
                 hh[e] = hp_s[a + e];
                 ww[e] = w_s[a + e];
             }
-            for (int l = wave; l < L; l += SB_WAVES) {
-                const float dsl_v = ds_s[l];
-                const float* p = proj + b * sb + l * sl + a;
-                float* o = dproj + b * dsb + l * dsl + a;
-                float xv[W], ov[W];
-                if constexpr (VEC) {
-                    const f32x4 t = *reinterpret_cast<const f32x4*>(p);
-                    xv[0] = t[0]; xv[1] = t[1]; xv[2] = t[2]; xv[3] = t[3];
-                } else {
-                    xv[0] = p[0];
+            // SB_UNROLL rows of this wave are in flight together: each lane issues its loads first, then does the
+            // arithmetic and the stores (one row at a time left a single 1-KiB load in flight per wave and the sweep
+            // latency-bound).  The per-column sums still add the rows in ascending order.
+            for (int l0 = wave; l0 < L; l0 += SB_WAVES * SB_UNROLL) {
+                float xv[SB_UNROLL][W];
+#pragma unroll
+                for (int u = 0; u < SB_UNROLL; ++u) {
+                    const int l = l0 + u * SB_WAVES;
+                    if (l < L) {
+                        const float* p = proj + b * sb + l * sl + a;
+                        if constexpr (VEC) {
+                            const f32x4 t = *reinterpret_cast<const f32x4*>(p);
+                            xv[u][0] = t[0]; xv[u][1] = t[1]; xv[u][2] = t[2]; xv[u][3] = t[3];
+                        } else {
+                            xv[u][0] = p[0];
+                        }
+                    }
                 }
 #pragma unroll
-                for (int e = 0; e < W; ++e) {
-                    const float t = rfn_tanh_fast(xv[e] + hh[e]);
-                    const float dpre = dsl_v * ww[e] * (1.0f - t * t);
-                    ov[e] = dpre;
-                    ah[e] += dpre;
-                    aw[e] += dsl_v * t;
-                }
-                if constexpr (VEC) {
-                    f32x4 t = {ov[0], ov[1], ov[2], ov[3]};
-                    if (accumulate) t += *reinterpret_cast<const f32x4*>(o);
-                    *reinterpret_cast<f32x4*>(o) = t;
-                } else {
-                    o[0] = accumulate ? o[0] + ov[0] : ov[0];
+                for (int u = 0; u < SB_UNROLL; ++u) {
+                    const int l = l0 + u * SB_WAVES;
+                    if (l < L) {
+                        const float dsl_v = ds_s[l];
+                        float* o = dproj + b * dsb + l * dsl + a;
+                        float ov[W];
+#pragma unroll
+                        for (int e = 0; e < W; ++e) {
+                            const float t = rfn_tanh_fast(xv[u][e] + hh[e]);
+                            const float dpre = dsl_v * ww[e] * (1.0f - t * t);
+                            ov[e] = dpre;
+                            ah[e] += dpre;
+                            aw[e] += dsl_v * t;
+                        }
+                        if constexpr (VEC) {
+                            f32x4 t = {ov[0], ov[1], ov[2], ov[3]};
+                            if (accumulate) t += *reinterpret_cast<const f32x4*>(o);
+                            *reinterpret_cast<f32x4*>(o) = t;
+                        } else {
+                            o[0] = accumulate ? o[0] + ov[0] : ov[0];
+                        }
+                    }
                 }
             }
 #pragma unroll

@@ -969,8 +969,8 @@ static int launch_tile(GemmArgs& a, hipStream_t st) {
         a.splitk = big_split;
         a.tiles_m = rfn_cdiv(a.M, GEMM_BIG_BM);
         a.tiles_n = rfn_cdiv(a.N, GEMM_BIG_BN);
-        // RFN_GEMM_OPT_LDS_LEAN (set by data-parallel hosts): single-buffered register-staged big tiles, <= 110 KB of
-        // LDS per CU, so that RCCL's kernels can co-reside with the long weight-gradient GEMMs instead of waiting them out.
+        // RFN_GEMM_OPT_LDS_LEAN (set by data-parallel hosts): big tiles that leave most of each CU's LDS free, so that
+        // RCCL's kernels can co-reside with the long one-round weight-gradient GEMMs instead of waiting them out.
         const bool lean = (a.flags & RFN_GEMM_OPT_LDS_LEAN) != 0;
         constexpr int ST = (AK && BKF) ? GEMM_NT_STAGES : GEMM_XX_STAGES;
 #if GEMM_FAST_PATH
@@ -999,8 +999,11 @@ static int launch_tile(GemmArgs& a, hipStream_t st) {
                 }
             for (int g = 0; g < a.ngroups; ++g)   // ... and one output tile as tile base + 32-bit byte offset
                 span32 = span32 && a.g[g].ldc >= 0 && (double)a.g[g].ldc * 4 * GEMM_BIG_BM < 4.0e9 && (double)a.N * 4 * GEMM_BIG_BM < 4.0e9;
-            if (fast && span32 && !colsum && !lean && !(a.flags & RFN_GEMM_OPT_NO_DMA)) {
+            if (fast && span32 && !colsum && !(a.flags & RFN_GEMM_OPT_NO_DMA)) {
                 constexpr int SL = (AK && BKF) ? GEMM_DMA_SLOTS_NT : GEMM_DMA_SLOTS_XX;
+                // lean: 16-deep K steps, two slots = 32 KB of LDS per block (64 KB per CU at the two blocks per CU of a
+                // one-round weight-gradient launch) instead of 64 KB per block; same speed (profiles/r02_pmc_gemm.md)
+                if (lean) return launch_cfg<GEMM_BIG_BM, GEMM_BIG_BN, AK, BKF, true, 1, 16, true, GEMM_THREADS, 2>(a, st);
                 return launch_cfg<GEMM_BIG_BM, GEMM_BIG_BN, AK, BKF, true, 1, GEMM_DMA_BK, true, GEMM_THREADS, SL>(a, st);
             }
 #endif

@@ -73,19 +73,24 @@ extern "C" int rfn_colsum_f32(const float* X, int64_t ldx, int rows, int cols, f
 }
 
 struct ColsumOuts { float* out[64]; };
-__global__ __launch_bounds__(256) void colsum_grouped_k(const float* __restrict__ X, long gstride, long ldx,
-                                                        int rows, int cols, const ColsumOuts outs) {
-    __shared__ float red[4][64];
+// 64 columns x 16 row-lanes per block: a thread sums every 16th row of its column, the 16 partial sums are added in a
+// fixed order through LDS (deterministic).
+#define CSG_LANES 16
+__global__ __launch_bounds__(64 * CSG_LANES) void colsum_grouped_k(const float* __restrict__ X, long gstride, long ldx,
+                                                                  int rows, int cols, const ColsumOuts outs) {
+    __shared__ float red[CSG_LANES][64];
     const float* Xg = X + blockIdx.y * gstride;
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+    const int l = threadIdx.x & 63, c = blockIdx.x * 64 + l, rl = threadIdx.x >> 6;
     float acc = 0.f;
     if (c < cols)
-        for (int r = rl; r < rows; r += 4) acc += Xg[r * ldx + c];
-    red[rl][threadIdx.x & 63] = acc;
+        for (int r = rl; r < rows; r += CSG_LANES) acc += Xg[r * ldx + c];
+    red[rl][l] = acc;
     __syncthreads();
     if (rl == 0 && c < cols) {
-        const int l = threadIdx.x & 63;
-        outs.out[blockIdx.y][c] = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < CSG_LANES; ++k) t += red[k][l];
+        outs.out[blockIdx.y][c] = t;
     }
 }
 extern "C" int rfn_colsum_grouped_f32(const float* X, int64_t group_stride, int64_t ldx, int rows, int cols,
@@ -99,7 +104,7 @@ extern "C" int rfn_colsum_grouped_f32(const float* X, int64_t group_stride, int6
             if (!outs[g0 + g]) return RFN_ERR_ARG;
             o.out[g] = outs[g0 + g];
         }
-        hipLaunchKernelGGL(colsum_grouped_k, dim3(rfn_cdiv(cols, 64), ng), dim3(256), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL(colsum_grouped_k, dim3(rfn_cdiv(cols, 64), ng), dim3(64 * CSG_LANES), 0, (hipStream_t)stream,
                            X + (long)g0 * group_stride, (long)group_stride, (long)ldx, rows, cols, o);
         RFN_CHECK_LAUNCH();
     }

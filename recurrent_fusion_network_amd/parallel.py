@@ -68,8 +68,8 @@ class GradSync:
         self.buckets = []
         model.grad_ready_hook = self.on_bucket
         if world > 1 and hasattr(model, 'gemm_flags'):
-            # The double-buffered weight-gradient GEMM holds 147 of each CU's 160 KB of LDS for its whole 6 ms and
-            # would starve RCCL's kernels: keep the big tiles lean while collectives run beside them (rfn.h)
+            # A one-round weight-gradient GEMM holds its LDS on every CU for its whole 6 ms: keep the big tiles lean
+            # (64 KB per CU instead of 128) while collectives run beside them, so RCCL's kernels can co-reside (rfn.h)
             from . import _native as N
             model.gemm_flags |= N.GEMM_OPT_LDS_LEAN
 
