@@ -118,11 +118,11 @@ def time_dominant_kernel(model, att, reps):
     import recurrent_fusion_network_amd._native as N
     B, L, D = att[0].shape
     A, T1 = model.att_hid_size, model.num_review_steps_0
-    out = torch.empty(B * L, T1 * A, device=att[0].device)
+    out = torch.empty(T1, B * L, A, device=att[0].device)          # step-major slabs, as rfn_prefix_fwd lays them out
     probs = []
     for t in range(T1):
         cell = model.review_steps_individual[t].lstm[0].att_model.att_2_att_h
-        probs.append((out[:, t * A:], T1 * A, [(att[0], D, 1, cell.weight, D, 1, D, cell.bias)]))
+        probs.append((out[t], A, [(att[0], D, 1, cell.weight, D, 1, D, cell.bias)]))
     flops = 2.0 * B * L * D * A * T1
     N.gemm(B * L, A, probs, flags=int(getattr(model, 'gemm_flags', 0)))
     torch.cuda.synchronize()

@@ -96,13 +96,16 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define GEMM_DMA_ABLATE 0      /* diagnostics only (wrong results): 1 no DMA in the loop, 2 no barrier, 4 no LDS reads */
 #endif
 #ifndef GEMM_DMA_BK
-#define GEMM_DMA_BK 32     /* K step of the LDS-DMA tile (32 or 16) */
+#define GEMM_DMA_BK 32     /* K step of the LDS-DMA tile, both operands k-contiguous (projection): 32 or 16 */
+#endif
+#ifndef GEMM_DMA_BK_XX
+#define GEMM_DMA_BK_XX 16  /* K step of the other layouts (weight gradient, dX): 16 x 3 slots measured 1 % over 32 x 2 */
 #endif
 #ifndef GEMM_DMA_SLOTS_NT
 #define GEMM_DMA_SLOTS_NT 2  /* ring slots, both operands k-contiguous (projection) */
 #endif
 #ifndef GEMM_DMA_SLOTS_XX
-#define GEMM_DMA_SLOTS_XX 2  /* ring slots, the other layouts (weight gradient, dX) */
+#define GEMM_DMA_SLOTS_XX 3  /* ring slots, the other layouts */
 #endif
 #ifndef GEMM_ABLATE
 #define GEMM_ABLATE 0      /* 1: skip global loads after the first tile, 2: skip the epilogue stores */
@@ -1001,10 +1004,11 @@ static int launch_tile(GemmArgs& a, hipStream_t st) {
                 span32 = span32 && a.g[g].ldc >= 0 && (double)a.g[g].ldc * 4 * GEMM_BIG_BM < 4.0e9 && (double)a.N * 4 * GEMM_BIG_BM < 4.0e9;
             if (fast && span32 && !colsum && !(a.flags & RFN_GEMM_OPT_NO_DMA)) {
                 constexpr int SL = (AK && BKF) ? GEMM_DMA_SLOTS_NT : GEMM_DMA_SLOTS_XX;
+                constexpr int DBK = (AK && BKF) ? GEMM_DMA_BK : GEMM_DMA_BK_XX;
                 // lean: 16-deep K steps, two slots = 32 KB of LDS per block (64 KB per CU at the two blocks per CU of a
                 // one-round weight-gradient launch) instead of 64 KB per block; same speed (profiles/r02_pmc_gemm.md)
                 if (lean) return launch_cfg<GEMM_BIG_BM, GEMM_BIG_BN, AK, BKF, true, 1, 16, true, GEMM_THREADS, 2>(a, st);
-                return launch_cfg<GEMM_BIG_BM, GEMM_BIG_BN, AK, BKF, true, 1, GEMM_DMA_BK, true, GEMM_THREADS, SL>(a, st);
+                return launch_cfg<GEMM_BIG_BM, GEMM_BIG_BN, AK, BKF, true, 1, DBK, true, GEMM_THREADS, SL>(a, st);
             }
 #endif
             if (fast) {

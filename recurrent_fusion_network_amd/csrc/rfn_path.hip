@@ -462,12 +462,13 @@ static int prefix_fwd_impl(const rfn_dims* d, int B, const float* const* prm, co
         RFN_TRY(copy_f32(Cs, Hs, BMR, st));
     }
 
-    // hoisted feature projections of stage I: P1_i[(b,l), t*A + a], all T1 step weights grouped
+    // hoisted feature projections of stage I, all T1 step weights grouped: step-major slabs P1_i[t][(b,l)][a], so that
+    // every consumer streams contiguous memory (the attention kernels of step t, the weight-gradient GEMM's k-rows)
     rfn_gemm_problem pr[64];
     for (int i = 0; i < M; ++i) {
         if (T1 > 64) return RFN_ERR_SHAPE;
         for (int t = 0; t < T1; ++t)
-            pr[t] = prob1(W + Lo.P1[i] + (long)t * A, (long)T1 * A,
+            pr[t] = prob1(W + Lo.P1[i] + (long)t * B * d->L[i] * A, A,
                           seg_lin(att[i], d->D[i], prm[P.s1(t, i, 0)], d->D[i], d->D[i], prm[P.s1(t, i, 1)]));
         RFN_TRY(gemm_groups(B * d->L[i], A, T1, pr, 0, gx));
     }
@@ -494,7 +495,7 @@ static int prefix_fwd_impl(const rfn_dims* d, int B, const float* const* prm, co
             const float *a_p[RFN_MAX_ENC], *a_hp[RFN_MAX_ENC], *a_w[RFN_MAX_ENC], *a_b[RFN_MAX_ENC];
             float *a_sc[RFN_MAX_ENC], *a_al[RFN_MAX_ENC], *a_z[RFN_MAX_ENC];
             for (int i = 0; i < M; ++i) {
-                a_p[i] = W + Lo.P1[i] + (long)t * A;
+                a_p[i] = W + Lo.P1[i] + (long)t * B * L0 * A;
                 a_hp[i] = hp + (long)i * B * A;
                 a_w[i] = prm[P.s1(t, i, 4)];
                 a_b[i] = prm[P.s1(t, i, 5)];
@@ -502,7 +503,7 @@ static int prefix_fwd_impl(const rfn_dims* d, int B, const float* const* prm, co
                 a_al[i] = W + Lo.al1[i] + (long)t * B * L0;
                 a_z[i] = W + Lo.z1[i] + (long)t * B * D0;
             }
-            RFN_TRY(rfn_attn_fwd_grouped(M, a_p, L0 * T1 * A, (long)T1 * A, a_hp, a_w, a_b, att, L0 * D0, D0, B, (int)L0,
+            RFN_TRY(rfn_attn_fwd_grouped(M, a_p, L0 * A, (long)A, a_hp, a_w, a_b, att, L0 * D0, D0, B, (int)L0,
                                          A, (int)D0, a_sc, a_al, a_z, D0, st));
         }
         for (int i = 0; i < M; ++i) {
@@ -511,7 +512,7 @@ static int prefix_fwd_impl(const rfn_dims* d, int B, const float* const* prm, co
             float* z = W + Lo.z1[i] + (long)t * B * Di;
             if (!same_ld) {
                 if ((size_t)B * Li > GEMM_WS_FLOATS) return RFN_ERR_SHAPE;
-                RFN_TRY(rfn_attn_fwd(W + Lo.P1[i] + (long)t * A, Li * T1 * A, (long)T1 * A, hp + (long)i * B * A,
+                RFN_TRY(rfn_attn_fwd(W + Lo.P1[i] + (long)t * B * Li * A, Li * A, (long)A, hp + (long)i * B * A,
                                      prm[P.s1(t, i, 4)], prm[P.s1(t, i, 5)], att[i], Li * Di, Di, B, (int)Li, A,
                                      (int)Di, W + Lo.gws, al, z, Di, st));
             }
@@ -783,7 +784,7 @@ extern "C" int rfn_prefix_bwd(const rfn_dims* d, int B, const float* const* prm,
             const float *a_p[RFN_MAX_ENC], *a_hp[RFN_MAX_ENC], *a_w[RFN_MAX_ENC], *a_al[RFN_MAX_ENC], *a_dz[RFN_MAX_ENC];
             float *a_dp[RFN_MAX_ENC], *a_dhp[RFN_MAX_ENC], *a_dw[RFN_MAX_ENC];
             for (int i = 0; i < M; ++i) {
-                a_dp[i] = W + Lo.P1[i] + (long)t * A;
+                a_dp[i] = W + Lo.P1[i] + (long)t * B * L0 * A;
                 a_p[i] = a_dp[i];
                 a_hp[i] = hp + i * BA;
                 a_w[i] = prm[P.s1(t, i, 4)];
@@ -792,8 +793,8 @@ extern "C" int rfn_prefix_bwd(const rfn_dims* d, int B, const float* const* prm,
                 a_dhp[i] = dhp + i * BA;
                 a_dw[i] = dwp + ((long)t * M + i) * BA;
             }
-            RFN_TRY(rfn_attn_bwd_grouped(M, a_p, L0 * T1 * A, (long)T1 * A, a_hp, a_w, a_al, att, L0 * D0, D0, a_dz, D0,
-                                         B, (int)L0, A, (int)D0, a_dp, L0 * T1 * A, (long)T1 * A, 0, a_dhp, a_dw, st));
+            RFN_TRY(rfn_attn_bwd_grouped(M, a_p, L0 * A, (long)A, a_hp, a_w, a_al, att, L0 * D0, D0, a_dz, D0,
+                                         B, (int)L0, A, (int)D0, a_dp, L0 * A, (long)A, 0, a_dhp, a_dw, st));
         }
         for (int i = 0; i < M; ++i) {
             const long Li = d->L[i], Di = d->D[i];
@@ -801,19 +802,19 @@ extern "C" int rfn_prefix_bwd(const rfn_dims* d, int B, const float* const* prm,
             if (!(same_d && M > 1))
                 RFN_TRY(gemm1(B, (int)Di, seg_dx(g + (long)i * B * 4 * R, 4 * R, prm[P.s1(t, i, 8)], Di, 4 * R), dz, Di, 0, gx));
             float* dali = dal + (long)i * B * Li;
-            float* p1 = W + Lo.P1[i] + (long)t * A;
+            float* p1 = W + Lo.P1[i] + (long)t * B * Li * A;
             if (grouped_bwd) {
                 // done above
             } else if (B >= FUSED_ATTN_BWD_MIN_B) {   // one block per row fills the chip: dalpha stays in LDS, one launch
-                RFN_TRY(rfn_attn_bwd(p1, Li * T1 * A, (long)T1 * A, hp + i * BA, prm[P.s1(t, i, 4)],
+                RFN_TRY(rfn_attn_bwd(p1, Li * A, (long)A, hp + i * BA, prm[P.s1(t, i, 4)],
                                      W + Lo.al1[i] + (long)t * B * Li, att[i], Li * Di, Di, dz, Di, B, (int)Li, A,
-                                     (int)Di, p1, Li * T1 * A, (long)T1 * A, 0, dhp + i * BA,
+                                     (int)Di, p1, Li * A, (long)A, 0, dhp + i * BA,
                                      dwp + ((long)t * M + i) * BA, st));
             } else {
                 RFN_TRY(rfn_attn_context_bwd_dalpha(att[i], Li * Di, Di, dz, Di, B, (int)Li, (int)Di, dali, st));
-                RFN_TRY(rfn_attn_scores_bwd(p1, Li * T1 * A, (long)T1 * A, hp + i * BA, prm[P.s1(t, i, 4)],
-                                            W + Lo.al1[i] + (long)t * B * Li, dali, B, (int)Li, A, p1, Li * T1 * A,
-                                            (long)T1 * A, 0, dhp + i * BA, dwp + ((long)t * M + i) * BA, st));
+                RFN_TRY(rfn_attn_scores_bwd(p1, Li * A, (long)A, hp + i * BA, prm[P.s1(t, i, 4)],
+                                            W + Lo.al1[i] + (long)t * B * Li, dali, B, (int)Li, A, p1, Li * A,
+                                            (long)A, 0, dhp + i * BA, dwp + ((long)t * M + i) * BA, st));
             }
             pr[i] = prob1(dHc + i * R, MR, seg_dx(dhp + i * BA, A, prm[P.s1(t, i, 2)], R, A));
         }
@@ -864,7 +865,7 @@ extern "C" int rfn_prefix_bwd_wgrad(const rfn_dims* d, int B, const float* const
     // bias-gradient rider.
     if (parts & 2) {  // part B: the dominant att_2_att_h gradient (small bucket, long GEMM)
         for (int t = 0; t < T1; ++t)
-            pr[t] = prob_dw(grd[P.s1(t, i, 0)], Di, nullptr, W + Lo.P1[i] + (long)t * A, (long)T1 * A, att[i], Di,
+            pr[t] = prob_dw(grd[P.s1(t, i, 0)], Di, nullptr, W + Lo.P1[i] + (long)t * B * Li * A, A, att[i], Di,
                             (int)(B * Li));
         if (!(parts & 1)) return gemm_groups(A, (int)Di, T1, pr, 0, gx);
     }
@@ -905,7 +906,7 @@ extern "C" int rfn_prefix_bwd_wgrad(const rfn_dims* d, int B, const float* const
     }
     if (parts & 2) {
         for (int t = 0; t < T1; ++t)
-            pr[t] = prob_dw(grd[P.s1(t, i, 0)], Di, nullptr, W + Lo.P1[i] + (long)t * A, (long)T1 * A, att[i], Di,
+            pr[t] = prob_dw(grd[P.s1(t, i, 0)], Di, nullptr, W + Lo.P1[i] + (long)t * B * Li * A, A, att[i], Di,
                             (int)(B * Li));
         RFN_TRY(gemm_groups(A, (int)Di, T1, pr, 0, gx));
     }

@@ -19,11 +19,14 @@ def main():
     ap.add_argument('--A', type=int, default=512)
     ap.add_argument('--D', type=int, default=2048)
     ap.add_argument('--T1', type=int, default=8)
+    ap.add_argument('--contig', action='store_true', help='step-major projection slices (row stride A) instead of the path layout (row stride T1*A)')
     a = ap.parse_args()
     dev = torch.device('cuda:0')
     B, L, A, D, T1, M = a.B, a.L, a.A, a.D, a.T1, 4
     x = [torch.randn(B, L, D, device=dev) for _ in range(M)]
     proj = [torch.randn(B, L, T1 * A, device=dev) for _ in range(M)]   # step-t slice has row stride T1*A
+    PSL = A if a.contig else T1 * A          # row stride of one step's slice
+    PSB = L * PSL
     hp = torch.randn(B, A, device=dev)
     w = torch.randn(A, device=dev) * 0.1
     bo = torch.zeros(1, device=dev)
@@ -37,7 +40,7 @@ def main():
     L_ = n.lib
 
     def scores(i):
-        n.check(L_.rfn_attn_scores_fwd(proj[i].data_ptr(), L * T1 * A, T1 * A, hp.data_ptr(), w.data_ptr(),
+        n.check(L_.rfn_attn_scores_fwd(proj[i].data_ptr(), PSB, PSL, hp.data_ptr(), w.data_ptr(),
                                        bo.data_ptr(), B, L, A, al.data_ptr(), st))
 
     def context(i):
@@ -48,14 +51,14 @@ def main():
                                                st))
 
     def scores_bwd(i):
-        n.check(L_.rfn_attn_scores_bwd(proj[i].data_ptr(), L * T1 * A, T1 * A, hp.data_ptr(), w.data_ptr(),
-                                       al.data_ptr(), dal.data_ptr(), B, L, A, proj[i].data_ptr(), L * T1 * A, T1 * A,
+        n.check(L_.rfn_attn_scores_bwd(proj[i].data_ptr(), PSB, PSL, hp.data_ptr(), w.data_ptr(),
+                                       al.data_ptr(), dal.data_ptr(), B, L, A, proj[i].data_ptr(), PSB, PSL,
                                        0, dhp.data_ptr(), dwp.data_ptr(), st))
 
     def fused_bwd(i):
-        n.check(L_.rfn_attn_bwd(proj[i].data_ptr(), L * T1 * A, T1 * A, hp.data_ptr(), w.data_ptr(), al.data_ptr(),
+        n.check(L_.rfn_attn_bwd(proj[i].data_ptr(), PSB, PSL, hp.data_ptr(), w.data_ptr(), al.data_ptr(),
                                 x[i].data_ptr(), L * D, D, dz.data_ptr(), D, B, L, A, D, proj[i].data_ptr(),
-                                L * T1 * A, T1 * A, 0, dhp.data_ptr(), dwp.data_ptr(), st))
+                                PSB, PSL, 0, dhp.data_ptr(), dwp.data_ptr(), st))
 
     def split_bwd(i):
         dalpha(i)

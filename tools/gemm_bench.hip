@@ -31,11 +31,11 @@ int main() {
     rfn_gemm_problem nt[8], tn[8];
     for (int t = 0; t < T; ++t) {
         memset(&nt[t], 0, sizeof(nt[t])); memset(&tn[t], 0, sizeof(tn[t]));
-        nt[t].C = P + (size_t)t * A; nt[t].ldc = (long)T * A; nt[t].nseg = 1;
+        nt[t].C = P + (size_t)t * BL * A; nt[t].ldc = A; nt[t].nseg = 1;   // step-major slabs, as rfn_prefix_fwd lays them out
         nt[t].seg[0].A = X; nt[t].seg[0].lda = D; nt[t].seg[0].a_kfast = 1;
         nt[t].seg[0].B = W + (size_t)t * A * D; nt[t].seg[0].ldb = D; nt[t].seg[0].b_kfast = 1; nt[t].seg[0].K = D;
         tn[t].C = dW + (size_t)t * A * D; tn[t].ldc = D; tn[t].nseg = 1;
-        tn[t].seg[0].A = P + (size_t)t * A; tn[t].seg[0].lda = (long)T * A; tn[t].seg[0].a_kfast = 0;
+        tn[t].seg[0].A = P + (size_t)t * BL * A; tn[t].seg[0].lda = A; tn[t].seg[0].a_kfast = 0;
         tn[t].seg[0].B = X; tn[t].seg[0].ldb = D; tn[t].seg[0].b_kfast = 0; tn[t].seg[0].K = BL;
     }
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -47,7 +47,7 @@ int main() {
             const unsigned flags = fl ? RFN_GEMM_OPT_NO_DMA : 0u;
             hipMemset(P, 0, (size_t)BL * T * A * 4);
             rfn_gemm_f32_opt(BL, A, T, nt, 0, ws, ws_bytes, flags, 0);
-            hipMemcpy((fl ? p1 : p0).data(), P + (size_t)12345 * T * A, p0.size() * 4, hipMemcpyDeviceToHost);
+            hipMemcpy((fl ? p1 : p0).data(), P + (size_t)3 * BL * A + 12345, p0.size() * 4, hipMemcpyDeviceToHost);
             rfn_gemm_f32_opt(A, D, T, tn, 0, ws, ws_bytes, flags, 0);
             hipMemcpy((fl ? r1 : r0).data(), dW, r0.size() * 4, hipMemcpyDeviceToHost);
         }
