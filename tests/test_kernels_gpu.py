@@ -193,6 +193,14 @@ def test_gemm_half_height_tail_round(dev):
     n.gemm(M, Nn, probs)
     for p, c in zip(probs, first):
         assert torch.equal(p[0], c)
+    # the LDS-DMA kernel (default) and the register-staged round-1 kernel walk k in the same order: bit-identical,
+    # half-height tail tiles included (the slot count per CU differs between them, so do their tail rounds)
+    for flags in (n.GEMM_OPT_NO_DMA, n.GEMM_OPT_LDS_LEAN):
+        for p in probs:
+            p[0].fill_(float('nan'))
+        n.gemm(M, Nn, probs, flags=flags)
+        for p, c in zip(probs, first):
+            assert torch.equal(p[0], c)
 
 
 @pytest.mark.parametrize('ak,bk', [(1, 1), (1, 0), (0, 1), (0, 0)])
