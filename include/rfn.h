@@ -12,7 +12,10 @@
  *   - all floating-point data is IEEE fp32, row-major; token / target ids are int64;
  *   - the caller owns every buffer, including workspaces (sizes from the *_ws_bytes queries);
  *   - `stream` is a hipStream_t passed as void*; calls are asynchronous on it, never allocate,
- *     never synchronise, and are re-entrant (no global mutable state);
+ *     never synchronise, and are re-entrant.  The library reads no environment variable and keeps
+ *     no mutable state except write-once, per-device launch attributes of its kernels (dynamic-LDS
+ *     opt-in, blocks per CU), so one process may drive several devices; every tuning choice
+ *     travels with the call (rfn_dims.gemm_flags, rfn_gemm_f32_opt);
  *   - return RFN_OK (0) or a negative RFN_ERR_* code; nothing is launched on a shape error.
  */
 #ifndef RFN_H_

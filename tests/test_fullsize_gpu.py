@@ -135,6 +135,44 @@ def test_edge_shapes_against_oracle(dev, case):
     assert torch.equal(seq.cpu(), O.sample_greedy(cfg, P, fc, att)[0])
 
 
+def test_empty_and_full_length_captions_against_oracle(dev):
+    """Ragged extremes of the label matrix: every caption empty (all-zero labels: the loop feeds BOS and stops at the
+    first all-zero column, misc/RecurrentFusionModel.py:274 -> one step), and every caption filling all seq_length
+    columns (seq_length + 1 steps); masks follow dataloader.py:312-314 (words + 2 ones)."""
+    import recurrent_fusion_network_amd as R
+    from oracle import rfn_oracle as O
+    info = [dict(att_num=5, att_feat_size=24, fc_feat_size=24), dict(att_num=7, att_feat_size=40, fc_feat_size=32)]
+    cfg = O.make_cfg(info, vocab_size=50, rnn_size=16, input_encoding_size=16, att_hid_size=16, num_review_steps_0=3,
+                     num_review_steps=3, top_words_count=20, seq_length=5)
+    P = O.seeded_params(cfg, 3)
+    fc, att, labels, masks, top = O.synthetic_batch(cfg, 4, seed=5)
+    model = R.RecurrentFusionModel(cfg)
+    model.load_state_dict(P)
+    model = model.to(dev).eval()
+    crit = R.ReviewNetEnsembleCriterion(cfg)
+    d = lambda ts: [t.to(dev) for t in ts]  # noqa: E731
+    for kind in ('empty', 'full'):
+        lab, msk = labels.clone(), masks.clone()
+        if kind == 'empty':
+            lab.zero_()
+            msk.zero_()
+            msk[:, :2] = 1
+        else:
+            assert bool((lab[:, 1:cfg.seq_length + 1] > 0).all()) and bool((msk == 1).all())
+        lp, reason = model(d(fc), d(att), lab.to(dev))
+        o_lp, o_reason = O.forward(cfg, P, fc, att, lab)
+        assert tuple(lp.shape) == tuple(o_lp.shape) == (4, 1 if kind == 'empty' else cfg.seq_length + 1, 51)
+        assert float((lp.detach().cpu() - o_lp).abs().max()) < 1e-3
+        model.zero_grad(set_to_none=True)
+        loss = crit(lp, lab.to(dev)[:, 1:], msk.to(dev)[:, 1:], reason, top.to(dev), 1.0)
+        loss.backward()
+        o_loss, o_grads = O.train_step_loss_and_grads(cfg, P, fc, att, lab, msk, top, 1.0)
+        assert abs(float(loss.detach()) - float(o_loss)) < 1e-4 * max(1.0, abs(float(o_loss)))
+        named = dict(model.named_parameters())
+        for k, g in o_grads.items():
+            assert float((named[k].grad.cpu() - g).abs().max()) <= 1e-5 + 2e-3 * float(g.abs().max()), (kind, k)
+
+
 def test_c3_shape_batch32_every_gradient_against_the_oracle(dev):
     """The B = 2 golden tier cannot reach the big-tile GEMM dispatch (LDS-DMA kernels, half-height tail round,
     split-K mediums): at B = 32 the feature matrices have 6272 = 49 x 128 rows, so the hoisted projections, their weight
