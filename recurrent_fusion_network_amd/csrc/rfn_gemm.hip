@@ -41,6 +41,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef GEMM_MEDIUM_MIN_FLOPS
 #define GEMM_MEDIUM_MIN_FLOPS 6e9 /* per launch; below this the 64x64 tile + split-K stays */
 #endif
+#ifndef GEMM_MEDIUM_MAX
+#define GEMM_MEDIUM_MAX 383   /* up to this many 128x128 tiles a problem is cut along K on big tiles; above, unsplit */
+#endif
 #ifndef GEMM_SPLIT_MIN_ITERS
 #define GEMM_SPLIT_MIN_ITERS 4 /* K iterations every split block keeps at least */
 #endif
@@ -958,7 +961,7 @@ static int launch_tile(GemmArgs& a, hipStream_t st) {
     // Medium problems (the heavier per-step GEMMs: M = batch, a few GF): the 128x128 tile is ~1.5x more efficient
     // than 64x64 but yields too few tiles, so cut K across blocks to reach ~2 blocks per CU.
     int big_split = 1;
-    const long medium_max = 256;   // 256 < big < 384: 64x64 tiles fill the chip better than a 2-way split
+    const long medium_max = GEMM_MEDIUM_MAX;
     if (big <= medium_max && a.part && big >= 16 && flops >= GEMM_MEDIUM_MIN_FLOPS) {
         const long target = (AK && BKF) ? GEMM_MEDIUM_TARGET_NT : 512;   // 768 (three NT blocks per CU) measured worse
         long want = (target + big - 1) / big;

@@ -170,6 +170,28 @@ int gemm_groups(int M, int N, int n, const rfn_gemm_problem* p, int acc, const G
     }
     return RFN_OK;
 }
+// The same for big problems whose column count is not a multiple of the 128-wide tile (a 2208-wide DenseNet feature
+// map, feat_array.py:147-150): the aligned main part takes the interior fast path (LDS-DMA kernel), a thin remainder
+// (< 128 columns) the bounds-checked one -- as the logit layer does for the vocabulary.  Same sums, same k order per
+// output element.  A bias-gradient rider (row sums of the A operand) rides on the main part only.
+int gemm_groups_split_cols(int M, int N, int n, const rfn_gemm_problem* p, int acc, const GemmCtx& gx) {
+    const int Na = aligned_part(N);
+    if (Na == N || Na == 0 || M % 128 != 0) return gemm_groups(M, N, n, p, acc, gx);
+    RFN_TRY(gemm_groups(M, Na, n, p, acc, gx));
+    rfn_gemm_problem rest[64];
+    if (n > 64) return RFN_ERR_SHAPE;
+    for (int g = 0; g < n; ++g) {
+        rest[g] = p[g];
+        rest[g].C = p[g].C + Na;
+        rest[g].a_colsum = nullptr;
+        for (int s = 0; s < p[g].nseg; ++s) {
+            rfn_gemm_seg& sg = rest[g].seg[s];
+            sg.B = sg.b_kfast ? sg.B + (long)Na * sg.ldb : sg.B + Na;
+            if (sg.bias) sg.bias += Na;
+        }
+    }
+    return gemm_groups(M, N - Na, n, rest, acc, gx);
+}
 
 int copy_f32(float* dst, const float* src, size_t n, void* st) {
     if (hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)st) != hipSuccess)
@@ -867,7 +889,7 @@ extern "C" int rfn_prefix_bwd_wgrad(const rfn_dims* d, int B, const float* const
         for (int t = 0; t < T1; ++t)
             pr[t] = prob_dw(grd[P.s1(t, i, 0)], Di, nullptr, W + Lo.P1[i] + (long)t * B * Li * A, A, att[i], Di,
                             (int)(B * Li));
-        if (!(parts & 1)) return gemm_groups(A, (int)Di, T1, pr, 0, gx);
+        if (!(parts & 1)) return gemm_groups_split_cols(A, (int)Di, T1, pr, 0, gx);
     }
     // part A: H2h, z2h, h_2_att_h (large bucket, short GEMMs: K = B rows per step).  Their bias gradients are column
     // sums of tensors that are tiny next to the weight gradients (dgates: T1*B*4R floats per encoder), so they come from
@@ -886,7 +908,7 @@ extern "C" int rfn_prefix_bwd_wgrad(const rfn_dims* d, int B, const float* const
     for (int t = 0; t < T1; ++t)
         pr[t] = prob_dw(grd[P.s1(t, i, 8)], Di, nullptr, g1i + (long)t * M * B * 4 * R, 4 * R,
                         W + Lo.z1[i] + (long)t * B * Di, Di, B);
-    RFN_TRY(gemm_groups(4 * R, (int)Di, T1, pr, 0, gx));
+    RFN_TRY(gemm_groups_split_cols(4 * R, (int)Di, T1, pr, 0, gx));
     for (int t = 0; t < T1; ++t)
         pr[t] = prob_dw(grd[P.s1(t, i, 2)], R, nullptr, W + Lo.dhp1 + ((long)t * M + i) * BA, A, Hs + t * BMR + i * R, MR, B);
     RFN_TRY(gemm_groups(A, R, T1, pr, 0, gx));
@@ -908,7 +930,7 @@ extern "C" int rfn_prefix_bwd_wgrad(const rfn_dims* d, int B, const float* const
         for (int t = 0; t < T1; ++t)
             pr[t] = prob_dw(grd[P.s1(t, i, 0)], Di, nullptr, W + Lo.P1[i] + (long)t * B * Li * A, A, att[i], Di,
                             (int)(B * Li));
-        RFN_TRY(gemm_groups(A, (int)Di, T1, pr, 0, gx));
+        RFN_TRY(gemm_groups_split_cols(A, (int)Di, T1, pr, 0, gx));
     }
     return RFN_OK;
 }
