@@ -11,14 +11,20 @@
 // Structure (MI355X-first, not a CUDA tiling):
 //   * 256 threads = 4 waves (2x2); block tile BMxBNx32, wave tile (BM/2)x(BN/2) built from 32x32
 //     MFMA tiles, accumulators stay in the unified VGPR/AGPR file.
-//   * operands whose reduction index is contiguous are staged [row][k] with a 36-float row
-//     (conflict-free ds_read_b128 for the 16-lane b128 groups); operands whose OUTPUT index is
-//     contiguous (the transposed operands of the backward GEMMs) are staged [k][row] and read with
-//     conflict-free ds_read_b32 -- no transposition pass anywhere.
-//   * global -> register prefetch of tile i+1 overlaps the MFMAs of tile i; LDS is double buffered,
-//     one barrier per K step; 2 blocks/CU co-reside so the partner's MFMAs cover staging.
+//   * two staging paths behind one entry point, bit-identical results (same k order per output element):
+//       - LDS-DMA tile (gemm_tile_dma; interior 128x128 tiles): global_load_lds_dwordx4 into a ring of LDS slots,
+//         one barrier per K step with the next slot in flight across it, unpadded images with the bank-conflict fix
+//         as an XOR swizzle on the SOURCE address, and EVERY vector-memory instruction addressed as a wave-uniform
+//         SGPR base + a 32-bit lane offset (with 64-bit per-lane addresses the issue of those instructions cost 10 %
+//         of the matrix pipe: profiles/r02_pmc_gemm.md);
+//       - register-staged tile (gemm_tile; ragged shapes, scalar-aligned operands, bias-gradient riders, 64x64
+//         tiles): operands whose reduction index is contiguous staged [row][k] with a 36-float row (conflict-free
+//         ds_read_b128), operands whose OUTPUT index is contiguous (the transposed operands of the backward GEMMs)
+//         staged [k][row] and read with conflict-free ds_read_b32 -- no transposition pass anywhere.
 //   * 1-D grid with a bijective XCD remap + 8-row bands so the blocks sharing an A row-panel and a
-//     B column-panel run on one XCD's L2 at the same time.
+//     B column-panel run on one XCD's L2 at the same time; the last, partly filled round of a big launch runs as
+//     half-height tiles.
+//   * options travel with the call (rfn_gemm_f32_opt flags); no environment variable is read.
 #include "rfn_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
