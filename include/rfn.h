@@ -401,6 +401,16 @@ int rfn_decoder_fwd(const rfn_dims* d, int B, int S, const float* const* params,
                     const float* h0, const float* c0, const int64_t* ids, int64_t ld_ids,
                     float* log_prob /* (B,S,V1) */, void* ws, size_t ws_bytes, int train,
                     uint64_t seed, void* stream);
+/* The same pass one step at a time, for scheduled sampling (misc/RecurrentFusionModel.py:260-270: the token fed at
+ * step s may be drawn from the distribution of step s-1, so the host interleaves its draws with the steps).
+ * rfn_decoder_fwd_begin + rfn_decoder_fwd_step for s = 0 .. S-1 leave `ws` and log_prob[:, 0..S-1, :] exactly as
+ * rfn_decoder_fwd on the final ids does (bit for bit), so rfn_decoder_bwd runs on the result unchanged: the sampled
+ * pass IS the differentiated pass.  ids_s points at the B tokens of step s (element b at ids_s[b * ld_ids]). */
+int rfn_decoder_fwd_begin(const rfn_dims* d, int B, int S, const float* const* params, const float* comb,
+                          const float* h0, const float* c0, void* ws, size_t ws_bytes, int train, void* stream);
+int rfn_decoder_fwd_step(const rfn_dims* d, int B, int S, int s, const float* const* params, const float* comb,
+                         const int64_t* ids_s, int64_t ld_ids, float* log_prob /* (B,S,V1) base */, void* ws,
+                         size_t ws_bytes, int train, uint64_t seed, void* stream);
 /* d_log_prob (B,S,V1) in; d_comb (T2,B,R), d_h0, d_c0 (B,R) out (overwritten); the phase-2 slots of
  * grads[] (embed, logit, decoder.*) are overwritten. */
 int rfn_decoder_bwd(const rfn_dims* d, int B, int S, const float* const* params, const float* comb,

@@ -110,6 +110,8 @@ def _load():
         'rfn_prefix_bwd_wgrad': (C.c_int, [DP, I, P, P, P, SZ, I, I, P]),
         'rfn_decoder_ws_bytes': (SZ, [DP, I, I, I]),
         'rfn_decoder_fwd': (C.c_int, [DP, I, I, P, P, P, P, P, L, P, P, SZ, I, U64, P]),
+        'rfn_decoder_fwd_begin': (C.c_int, [DP, I, I, P, P, P, P, P, SZ, I, P]),
+        'rfn_decoder_fwd_step': (C.c_int, [DP, I, I, I, P, P, P, L, P, P, SZ, I, U64, P]),
         'rfn_decoder_bwd': (C.c_int, [DP, I, I, P, P, P, P, P, L, P, P, P, P, P, P, P, SZ, U64, P]),
         'rfn_decoder_step_ws_bytes': (SZ, [DP, I]),
         'rfn_decoder_prepare': (C.c_int, [DP, I, P, P, P, P]),

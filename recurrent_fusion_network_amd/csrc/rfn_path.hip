@@ -956,6 +956,47 @@ extern "C" size_t rfn_decoder_ws_bytes(const rfn_dims* d, int B, int S, int trai
     return decoder_layout(d, B, S, train).total * sizeof(float);
 }
 
+// The decoder cell of step s on the training workspace (gd[s] already holds i2h(x_s)): h_2_att_h, attention over the
+// fused thoughts, h2h + z2h accumulated onto the gates, LSTM epilogue with the dropout mask of (seed, s).
+static int decoder_fwd_cell(const rfn_dims* d, int B, int s, const float* const* prm, const float* comb, float* W,
+                            const DecoderLayout& Lo, const GemmCtx& gx, uint64_t seed, void* st) {
+    const PIdx P(d);
+    const int R = d->R, A = d->A, T2 = d->T2;
+    const int GD = gate_width(d->decoder_maxout, R);
+    const long BR = (long)B * R, BA = (long)B * A;
+    float* hd = W + Lo.hd;
+    float* cd = W + Lo.cd;
+    float* hc = hd + s * BR;
+    float* hp = W + Lo.hpd + s * BA;
+    float* al = W + Lo.ald + (long)s * B * T2;
+    float* z = W + Lo.zd + s * BR;
+    float* g = W + Lo.gd + (long)s * B * GD;
+    RFN_TRY(gemm1(B, A, seg_lin(hc, R, prm[P.dec(8)], R, R, prm[P.dec(9)]), hp, A, 0, gx));
+    RFN_TRY(attn1_fwd(W + Lo.Pd, A, BA, hp, prm[P.dec(10)], prm[P.dec(11)], comb, R, BR, B, T2, A, R, al, z, R, st));
+    rfn_gemm_seg segs[2];
+    segs[0] = seg_lin(hc, R, prm[P.dec(2)], R, R, prm[P.dec(3)]);
+    segs[1] = seg_lin(z, R, prm[P.dec(4)], R, R, prm[P.dec(5)]);
+    RFN_TRY(gemm_segs(B, GD, 2, segs, g, GD, 1, gx));
+    return rfn_lstm_fwd(g, GD, cd + s * BR, R, cd + (s + 1) * BR, R, hd + (s + 1) * BR, R, B, R, d->decoder_maxout,
+                        d->drop_lm, seed, OFF_DECODER + (uint64_t)s, st);
+}
+
+// Loop-invariant part of phase 2: projection of the fused thoughts (applied once instead of every step) and the
+// initial state.  The batched products of the pass (this projection, i2h, logits) are never split along K: the
+// free-running step (rfn_decoder_prepare / rfn_decoder_step) and the step-wise training pass (rfn_decoder_fwd_step)
+// compute the same products for one step's rows with the same unsplit k order, so log-probs of the same tokens are
+// bit-identical across all three whatever the batch size (split-K choices depend on the row count).  The per-step
+// products (h_2_att_h, h2h + z2h) have the same shape everywhere and take the same split.
+static int decoder_fwd_begin(const rfn_dims* d, int B, const float* const* prm, const float* comb, const float* h0,
+                             const float* c0, float* W, const DecoderLayout& Lo, void* st) {
+    const PIdx P(d);
+    const int R = d->R, A = d->A, T2 = d->T2;
+    const GemmCtx gx_whole{st, nullptr, 0, d->gemm_flags};
+    RFN_TRY(gemm1(T2 * B, A, seg_lin(comb, R, prm[P.dec(6)], R, R, prm[P.dec(7)]), W + Lo.Pd, A, 0, gx_whole));
+    RFN_TRY(copy_f32(W + Lo.hd, h0, (size_t)B * R, st));
+    return copy_f32(W + Lo.cd, c0, (size_t)B * R, st);
+}
+
 extern "C" int rfn_decoder_fwd(const rfn_dims* d, int B, int S, const float* const* prm, const float* comb,
                                const float* h0, const float* c0, const int64_t* ids, int64_t ld_ids, float* log_prob,
                                void* ws, size_t ws_bytes, int train, uint64_t seed, void* st) {
@@ -965,46 +1006,57 @@ extern "C" int rfn_decoder_fwd(const rfn_dims* d, int B, int S, const float* con
     const DecoderLayout Lo = decoder_layout(d, B, S, train);
     if (ws_bytes < Lo.total * sizeof(float)) return RFN_ERR_WORKSPACE;
     const PIdx P(d);
-    const int R = d->R, A = d->A, E = d->E, T2 = d->T2, V1 = d->V1;
+    const int R = d->R, E = d->E, V1 = d->V1;
     const int GD = gate_width(d->decoder_maxout, R);
-    const long BR = (long)B * R, BA = (long)B * A;
     float* W = (float*)ws;
     const GemmCtx gx{st, W + Lo.gws, GEMM_WS_FLOATS * sizeof(float), d->gemm_flags};
-    float* hd = W + Lo.hd;
-    float* cd = W + Lo.cd;
-    float* gd = W + Lo.gd;
-    // The three batched products of this pass (thought projection, i2h, logits) are never split along K: the
-    // free-running step (rfn_decoder_prepare / rfn_decoder_step) computes the same products for one step's rows with the
-    // same unsplit k order, so teacher-forced and free-running log-probs of the same tokens are bit-identical whatever
-    // the batch size (split-K choices depend on the row count).  The per-step products (h_2_att_h, h2h + z2h) have the
-    // same shape in both passes and take the same split.
     const GemmCtx gx_whole{st, nullptr, 0, d->gemm_flags};
-    // loop-invariant projection of the fused thoughts, applied once instead of every step
-    RFN_TRY(gemm1(T2 * B, A, seg_lin(comb, R, prm[P.dec(6)], R, R, prm[P.dec(7)]), W + Lo.Pd, A, 0, gx_whole));
+    RFN_TRY(decoder_fwd_begin(d, B, prm, comb, h0, c0, W, Lo, st));
     // all token embeddings and their i2h projections in one go (teacher forcing: ids are known)
     RFN_TRY(rfn_embed_fwd(prm[P.embed()], E, V1, ids, B, ld_ids, 1, S * B, W + Lo.xs, E, st));
-    RFN_TRY(gemm1(S * B, GD, seg_lin(W + Lo.xs, E, prm[P.dec(0)], E, E, prm[P.dec(1)]), gd, GD, 0, gx_whole));
-    RFN_TRY(copy_f32(hd, h0, BR, st));
-    RFN_TRY(copy_f32(cd, c0, BR, st));
-    rfn_gemm_seg segs[2];
-    for (int s = 0; s < S; ++s) {
-        float* hc = hd + s * BR;
-        float* hp = W + Lo.hpd + s * BA;
-        float* al = W + Lo.ald + (long)s * B * T2;
-        float* z = W + Lo.zd + s * BR;
-        float* g = gd + (long)s * B * GD;
-        RFN_TRY(gemm1(B, A, seg_lin(hc, R, prm[P.dec(8)], R, R, prm[P.dec(9)]), hp, A, 0, gx));
-        RFN_TRY(attn1_fwd(W + Lo.Pd, A, BA, hp, prm[P.dec(10)], prm[P.dec(11)], comb, R, BR, B, T2, A, R, al, z, R, st));
-        segs[0] = seg_lin(hc, R, prm[P.dec(2)], R, R, prm[P.dec(3)]);
-        segs[1] = seg_lin(z, R, prm[P.dec(4)], R, R, prm[P.dec(5)]);
-        RFN_TRY(gemm_segs(B, GD, 2, segs, g, GD, 1, gx));
-        RFN_TRY(rfn_lstm_fwd(g, GD, cd + s * BR, R, cd + (s + 1) * BR, R, hd + (s + 1) * BR, R, B, R, d->decoder_maxout,
-                             d->drop_lm, seed, OFF_DECODER + (uint64_t)s, st));
-    }
+    RFN_TRY(gemm1(S * B, GD, seg_lin(W + Lo.xs, E, prm[P.dec(0)], E, E, prm[P.dec(1)]), W + Lo.gd, GD, 0, gx_whole));
+    for (int s = 0; s < S; ++s) RFN_TRY(decoder_fwd_cell(d, B, s, prm, comb, W, Lo, gx, seed, st));
     // logits of all steps, then log-softmax written in the reference's (B, S, V+1) layout
-    RFN_TRY(gemm_logits(S * B, V1, hd + BR, R, prm[P.logit_w()], prm[P.logit_b()], W + Lo.logits, gx_whole));
+    RFN_TRY(gemm_logits(S * B, V1, W + Lo.hd + (long)B * R, R, prm[P.logit_w()], prm[P.logit_b()], W + Lo.logits, gx_whole));
     RFN_TRY(rfn_log_softmax_fwd(W + Lo.logits, V1, S * B, V1, B, (long)S * V1, V1, log_prob, st));
     return RFN_OK;
+}
+
+// Step-wise form of the same pass for scheduled sampling (misc/RecurrentFusionModel.py:260-270): the token fed at
+// step s may be drawn from the distribution of step s-1, so the host interleaves its draws with the steps.  begin +
+// S steps leave the workspace and log_prob exactly as rfn_decoder_fwd on the final ids does (bit for bit), so
+// rfn_decoder_bwd runs on it unchanged -- the sampled pass IS the differentiated pass, nothing is computed twice.
+extern "C" int rfn_decoder_fwd_begin(const rfn_dims* d, int B, int S, const float* const* prm, const float* comb,
+                                     const float* h0, const float* c0, void* ws, size_t ws_bytes, int train, void* st) {
+    RFN_TRY(check_dims(d));
+    if (B < 1 || S < 1) return RFN_ERR_SHAPE;
+    if (!prm || !comb || !h0 || !c0 || !ws) return RFN_ERR_ARG;
+    const DecoderLayout Lo = decoder_layout(d, B, S, train);
+    if (ws_bytes < Lo.total * sizeof(float)) return RFN_ERR_WORKSPACE;
+    return decoder_fwd_begin(d, B, prm, comb, h0, c0, (float*)ws, Lo, st);
+}
+
+extern "C" int rfn_decoder_fwd_step(const rfn_dims* d, int B, int S, int s, const float* const* prm, const float* comb,
+                                    const int64_t* ids_s, int64_t ld_ids, float* log_prob, void* ws, size_t ws_bytes,
+                                    int train, uint64_t seed, void* st) {
+    RFN_TRY(check_dims(d));
+    if (B < 1 || S < 1 || s < 0 || s >= S) return RFN_ERR_SHAPE;
+    if (!prm || !comb || !ids_s || !log_prob || !ws) return RFN_ERR_ARG;
+    const DecoderLayout Lo = decoder_layout(d, B, S, train);
+    if (ws_bytes < Lo.total * sizeof(float)) return RFN_ERR_WORKSPACE;
+    const PIdx P(d);
+    const int R = d->R, E = d->E, V1 = d->V1;
+    const int GD = gate_width(d->decoder_maxout, R);
+    float* W = (float*)ws;
+    const GemmCtx gx{st, W + Lo.gws, GEMM_WS_FLOATS * sizeof(float), d->gemm_flags};
+    const GemmCtx gx_whole{st, nullptr, 0, d->gemm_flags};
+    float* xs = W + Lo.xs + (long)s * B * E;
+    float* lg = W + Lo.logits + (long)s * B * V1;
+    RFN_TRY(rfn_embed_fwd(prm[P.embed()], E, V1, ids_s, B, ld_ids, 1, B, xs, E, st));
+    RFN_TRY(gemm1(B, GD, seg_lin(xs, E, prm[P.dec(0)], E, E, prm[P.dec(1)]), W + Lo.gd + (long)s * B * GD, GD, 0, gx_whole));
+    RFN_TRY(decoder_fwd_cell(d, B, s, prm, comb, W, Lo, gx, seed, st));
+    RFN_TRY(gemm_logits(B, V1, W + Lo.hd + (long)(s + 1) * B * R, R, prm[P.logit_w()], prm[P.logit_b()], lg, gx_whole));
+    return rfn_log_softmax_fwd(lg, V1, B, V1, B, (long)S * V1, V1, log_prob + (long)s * V1, st);
 }
 
 extern "C" int rfn_decoder_bwd(const rfn_dims* d, int B, int S, const float* const* prm, const float* comb,

@@ -163,10 +163,17 @@ class _PrefixFn(torch.autograd.Function):
 
 
 class _DecoderFn(torch.autograd.Function):
-    """Phase 2 (teacher-forced decoder + logit + log-softmax): rfn_decoder_fwd / rfn_decoder_bwd."""
+    """Phase 2 (decoder + logit + log-softmax): rfn_decoder_fwd / rfn_decoder_bwd.
+
+    ss_prob > 0 (scheduled sampling, misc/RecurrentFusionModel.py:260-270): the pass runs one step at a time
+    (rfn_decoder_fwd_begin / rfn_decoder_fwd_step) and, between steps, replaces a row's next input token with
+    probability ss_prob by a draw from the distribution the step just produced.  The step-wise pass leaves the
+    workspace exactly as the batched pass on the final ids would (bit for bit), so backward is the same call: the pass
+    that is sampled IS the pass that is differentiated -- dropout masks included -- and nothing is computed twice.  No
+    host read-back: the draw is made for every row and kept where the row's coin says so."""
 
     @staticmethod
-    def forward(ctx, model, save_bwd, drop, seed, ids, comb, h0, c0, *params):
+    def forward(ctx, model, save_bwd, drop, seed, ids, comb, h0, c0, ss_prob, *params):
         d = model._dims_for(drop)
         train = bool(save_bwd)
         B, S = ids.shape
@@ -177,9 +184,25 @@ class _DecoderFn(torch.autograd.Function):
         ws_bytes = N.lib.rfn_decoder_ws_bytes(C.byref(d), B, S, int(train))
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         log_prob = torch.empty(B, S, d.V1, device=dev)
-        N.check(N.lib.rfn_decoder_fwd(C.byref(d), B, S, table, comb.data_ptr(), h0.data_ptr(), c0.data_ptr(),
-                                      ids.data_ptr(), ids.stride(0), log_prob.data_ptr(), ws.data_ptr(), ws_bytes,
-                                      int(train), seed, N.stream_ptr()), 'rfn_decoder_fwd')
+        if ss_prob > 0.0 and S > 1:
+            ids = ids.clone()
+            st = N.stream_ptr()
+            N.check(N.lib.rfn_decoder_fwd_begin(C.byref(d), B, S, table, comb.data_ptr(), h0.data_ptr(), c0.data_ptr(),
+                                                ws.data_ptr(), ws_bytes, int(train), st), 'rfn_decoder_fwd_begin')
+            for s in range(S):
+                if s >= 1:
+                    coin = torch.rand(B, device=dev) < ss_prob
+                    draw = torch.multinomial(torch.exp(log_prob[:, s - 1]), 1).view(-1)
+                    ids[:, s] = torch.where(coin, draw, ids[:, s])
+                N.check(N.lib.rfn_decoder_fwd_step(C.byref(d), B, S, s, table, comb.data_ptr(), ids[:, s].data_ptr(),
+                                                   ids.stride(0), log_prob.data_ptr(), ws.data_ptr(), ws_bytes,
+                                                   int(train), seed, st), 'rfn_decoder_fwd_step')
+            if getattr(model, '_trace_ss', False):
+                model._ss_ids = ids.clone()      # test hook: the token matrix the pass ended up feeding
+        else:
+            N.check(N.lib.rfn_decoder_fwd(C.byref(d), B, S, table, comb.data_ptr(), h0.data_ptr(), c0.data_ptr(),
+                                          ids.data_ptr(), ids.stride(0), log_prob.data_ptr(), ws.data_ptr(), ws_bytes,
+                                          int(train), seed, N.stream_ptr()), 'rfn_decoder_fwd')
         if train:
             ctx.model, ctx.seed, ctx.B, ctx.S, ctx.drop = model, seed, B, S, drop
             ctx.ws, ctx.ids, ctx.params, ctx.consumed = ws, ids, params, False
@@ -210,7 +233,7 @@ class _DecoderFn(torch.autograd.Function):
                                       gtable, ctx.ws.data_ptr(), ctx.ws.numel(), ctx.seed, N.stream_ptr()),
                 'rfn_decoder_bwd')
         model._bucket_done('decoder', flats['decoder'])
-        return (None, None, None, None, None, d_comb, d_h0, d_c0) + (None,) * len(ctx.params)
+        return (None, None, None, None, None, d_comb, d_h0, d_c0, None) + (None,) * len(ctx.params)
 
 
 class RecurrentFusionModel(nn.Module):
@@ -426,9 +449,10 @@ class RecurrentFusionModel(nn.Module):
             self._prefix_cache = ([weakref.ref(t) for t in ins], stamp, tuple(o.detach() for o in out))
         return out
 
-    def _decode_teacher_forced(self, ids, comb, h, c, drop, seed):
+    def _decode_teacher_forced(self, ids, comb, h, c, drop, seed, ss_prob=0.0):
         params = self._params_of(self._decoder_slots)
-        return _DecoderFn.apply(self, torch.is_grad_enabled(), bool(drop), seed, ids, comb, h, c, *params)
+        return _DecoderFn.apply(self, torch.is_grad_enabled(), bool(drop), seed, ids, comb, h, c, float(ss_prob),
+                                *params)
 
     # ---- reference API ----------------------------------------------------------------------------
     def forward(self, fc_feats, att_feats, seq):
@@ -453,10 +477,7 @@ class RecurrentFusionModel(nn.Module):
             reason = reason.repeat_interleave(g, dim=1)
         else:
             comb, h, c, reason = self._prefix(fc_feats, att_feats, train, seed)
-        ids = seq[:, :S]
-        if self.ss_prob > 0.0 and S > 1:
-            ids = self._scheduled_sampling_ids(ids, comb.detach(), h.detach(), c.detach(), train, seed)
-        log_prob = self._decode_teacher_forced(ids, comb, h, c, train, seed)
+        log_prob = self._decode_teacher_forced(seq[:, :S], comb, h, c, train, seed, self.ss_prob)
         return log_prob, list(reason.unbind(0))
 
     def _decoder_steps(self, seq):
@@ -475,32 +496,6 @@ class RecurrentFusionModel(nn.Module):
                 break
         self._steps_cache = (key, seq, S)     # holds `seq` so its storage cannot be recycled under the key
         return S
-
-    def _scheduled_sampling_ids(self, ids, comb, h, c, drop, seed):
-        """misc/RecurrentFusionModel.py:260-270: with probability ss_prob a row's input token is drawn from the
-        model's previous output distribution.  The draws need the free-running distributions, so they are made in a
-        no-grad stepwise pass; the gradient pass is then teacher-forced on the drawn ids.  The stepwise pass applies
-        the SAME dropout masks (seed, step) and the same operation order as the gradient pass, so the distribution
-        that is sampled is bit for bit the one that is differentiated -- as in the reference, which samples from
-        `outputs[-1]` of the dropout-affected pass itself.  No host read-back: the draw is made for every row and
-        kept where the row's coin says so."""
-        B, S = ids.shape
-        ids = ids.clone()
-        trace = [] if getattr(self, '_trace_ss', False) else None
-        with torch.no_grad():
-            stepper = _Stepper(self, comb, h.clone(), c.clone(), drop, seed)
-            logp = stepper.step(ids[:, 0].contiguous())
-            for i in range(1, S):
-                if trace is not None:
-                    trace.append(logp.clone())
-                mask = torch.rand(B, device=ids.device) < self.ss_prob
-                draw = torch.multinomial(torch.exp(logp), 1).view(-1)
-                ids[:, i] = torch.where(mask, draw, ids[:, i])
-                if i < S - 1:
-                    logp = stepper.step(ids[:, i].contiguous())
-        if trace is not None:
-            self._ss_trace = trace       # test hook: free-running log-probs of steps 0 .. S-2
-        return ids
 
     def get_init_state(self, fc_feats):
         """misc/RecurrentFusionModel.py:333-343 (inference helper, no autograd)."""

@@ -445,22 +445,30 @@ def test_scheduled_sampling(dev):
 @pytest.mark.parametrize('name', ['mid', 'tinymax'])
 def test_sampling_under_dropout_draws_from_the_differentiated_distribution(dev, name):
     """misc/RecurrentFusionModel.py:260-270, 623-631: in training mode the reference samples (scheduled sampling, and
-    sample(sample_max=0)) from the outputs of the dropout-affected pass it differentiates.  Here the tokens are drawn in
-    a free-running pass and the gradient comes from a teacher-forced replay: both must apply the same dropout masks and
-    produce the same log-probs bit for bit (the published recipe is drop_prob_lm 0.3 + scheduled
-    sampling, train_recurrent_fusion_model.sh:25-26)."""
+    sample(sample_max=0)) from the outputs of the dropout-affected pass it differentiates.  Scheduled sampling here
+    is ONE step-wise pass that is both sampled and differentiated (rfn_decoder_fwd_step), pinned against a batched
+    teacher-forced replay of the tokens it fed; sample(sample_max=0) draws in a free-running pass and takes the gradient
+    from a teacher-forced replay.  In both cases the two passes must apply the same dropout masks and produce the same
+    log-probs bit for bit (the published recipe is drop_prob_lm 0.3 + scheduled sampling,
+    train_recurrent_fusion_model.sh:25-26)."""
     cfg, spec, P, batch, gold = load_case(name)
     cfg.drop_prob_lm, cfg.drop_prob_reason, cfg.drop_prob_fusion = 0.3, 0.2, 0.1
     model = build(cfg, P, dev, train=True)
     fc, att, labels, masks, top = to_dev(batch, dev)
+    from recurrent_fusion_network_amd.fusion_model import _fresh_seed
     model._trace_ss = True
     model.ss_prob = 1.0
     torch.manual_seed(3)
     lp, _ = model(fc, att, labels)
-    trace = model._ss_trace
-    assert len(trace) == lp.size(1) - 1
-    for i, t in enumerate(trace):
-        assert torch.equal(lp[:, i], t), 'step %d: gradient pass differs from the distribution that was sampled' % i
+    fed = model._ss_ids                                          # the tokens the sampled pass ended up feeding
+    assert torch.equal(fed[:, 0], labels[:, 0].to(dev)) and not torch.equal(fed[:, 1:], labels[:, 1:fed.size(1)].to(dev))
+    # a teacher-forced (batched) pass on those tokens with the same dropout seed reproduces the sampled pass bit for bit
+    torch.manual_seed(3)
+    seed = _fresh_seed()
+    with torch.no_grad():
+        comb, h, c, _ = model._prefix(fc, att, True, seed)
+        tf = model._decode_teacher_forced(fed, comb, h, c, True, seed)
+    assert torch.equal(tf, lp.detach()), 'the sampled pass is not the pass a teacher-forced replay computes'
     eval_lp = build(cfg, P, dev)(fc, att, labels)[0]
     assert not torch.equal(lp[:, 0], eval_lp[:, 0])             # dropout really was active
     lp.sum().backward()
