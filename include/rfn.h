@@ -338,6 +338,15 @@ int rfn_greedy_pick(const float* logp, int64_t ldl, int B, int V1, int t, int64_
                     int64_t* seq_out, int64_t ld_seq, float* lp_out, int64_t ld_lp,
                     const int32_t* unf_prev, int32_t* unf_out, void* stream);
 
+/* multinomial pick of sample() (misc/RecurrentFusionModel.py:623-631) and of scheduled sampling (:260-270), on the
+ * device: ids[b] = inverse-CDF draw from p[v] ~ exp(logp[b,v] * inv_temperature) with the caller's uniform u[b] in
+ * [0,1) -- a deterministic function of (logp, u).  With coin != NULL only rows with coin[b] < keep_prob are redrawn,
+ * the others keep the token ids[b] already holds (the scheduled-sampling mask).  Element b of ids lives at
+ * ids[b * ld_ids].  (The reference draws on the host with torch.multinomial; RNG streams are not portable, the
+ * distribution is the same.) */
+int rfn_multinomial_pick(const float* logp, int64_t ldl, int B, int V1, float inv_temperature, const float* u,
+                         const float* coin, float keep_prob, int64_t* ids, int64_t ld_ids, void* stream);
+
 /* Batched beam-search bookkeeping of sample_beam (misc/RecurrentFusionModel.py:451-531) for step t in [1, S]:
  * one block per image consumes the log-probs of its W beam rows (rows k*W .. k*W+W-1 of `logp`), reproduces the
  * reference's candidate order / stable sort / fork / done-beam rules on the device and emits

@@ -101,6 +101,7 @@ def _load():
         'rfn_rl_loss': (C.c_int, [P, L, P, L, P, L, P, L, L, I, I, I, F, P, L, I, F, P, P, I, P, L, P, L, L, P]),
         'rfn_adam_step': (C.c_int, [P, P, P, P, L, F, F, F, F, F, F, F, I, P]),
         'rfn_greedy_pick': (C.c_int, [P, L, I, I, I, P, P, L, P, L, P, P, P]),
+        'rfn_multinomial_pick': (C.c_int, [P, L, I, I, F, P, P, F, P, L, P]),
         'rfn_beam_step': (C.c_int, [P, L, I, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P]),
         'rfn_gather_rows': (C.c_int, [P, P, P, I, I, P]),
         'rfn_prefix_ws_bytes': (SZ, [DP, I, I]),

@@ -763,6 +763,64 @@ extern "C" int rfn_adam_step(float* p, const float* g, float* m, float* v, int64
     return RFN_OK;
 }
 
+// ---- multinomial pick of sample() / scheduled sampling (misc/RecurrentFusionModel.py:623-631, 260-270) --------
+// One block per row: inverse-CDF draw from p[v] ~ exp(logp[v] * inv_temperature) with the caller's uniform u[b].
+// Thread t owns the contiguous index range [t*C, (t+1)*C); the 256 range sums are scanned in LDS in index order, the
+// thread whose range contains u * total walks it.  The reference draws on the host with torch.multinomial; RNG streams
+// are not portable anyway, the DISTRIBUTION is the same and the draw is a deterministic function of (logp, u).
+__global__ __launch_bounds__(256) void multinomial_pick_k(const float* __restrict__ logp, long ldl, int V1,
+                                                          float inv_temp, const float* __restrict__ u,
+                                                          const float* __restrict__ coin, float keep_prob,
+                                                          int64_t* __restrict__ ids, long ld_ids) {
+    __shared__ float part[256];
+    __shared__ int pick;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (coin && !(coin[b] < keep_prob)) return;   // block-uniform: this row keeps the token it already has
+    const float* x = logp + b * ldl;
+    const int C = (V1 + 255) / 256, v0 = tid * C, v1 = min(V1, v0 + C);
+    float sum = 0.f;
+    for (int v = v0; v < v1; ++v) sum += __expf(x[v] * inv_temp);
+    part[tid] = sum;
+    if (tid == 0) pick = -1;
+    __syncthreads();
+    float before = 0.f, total = 0.f;
+    for (int k = 0; k < 256; ++k) {   // 256 LDS broadcasts per thread: same order for everyone
+        const float pk = part[k];
+        if (k < tid) before += pk;
+        total += pk;
+    }
+    const float target = u[b] * total;
+    // the owner is the first range with before <= target < before + sum; target == total (u -> 1) goes to the last
+    // non-empty range
+    const bool owner = sum > 0.f && target >= before && (target < before + sum);
+    if (owner) atomicMax(&pick, tid);
+    __syncthreads();
+    if (pick < 0) {   // rounding put target at / past the total: last range with mass
+        if (sum > 0.f) atomicMax(&pick, tid);
+        __syncthreads();
+    }
+    if (tid == pick) {
+        float acc = before;
+        int chosen = v0;   // rounding corner (target at / past the range's end): the last index WITH mass
+        for (int v = v0; v < v1; ++v) {
+            const float e = __expf(x[v] * inv_temp);
+            acc += e;
+            if (e > 0.f) chosen = v;
+            if (target < acc) break;
+        }
+        ids[b * ld_ids] = chosen;
+    }
+}
+extern "C" int rfn_multinomial_pick(const float* logp, int64_t ldl, int B, int V1, float inv_temperature, const float* u,
+                                    const float* coin, float keep_prob, int64_t* ids, int64_t ld_ids, void* stream) {
+    if (B <= 0 || V1 <= 0 || ldl < V1 || !(inv_temperature > 0.f)) return RFN_ERR_SHAPE;
+    if (!logp || !u || !ids) return RFN_ERR_ARG;
+    hipLaunchKernelGGL(multinomial_pick_k, dim3(B), dim3(256), 0, (hipStream_t)stream, logp, (long)ldl, V1,
+                       inv_temperature, u, coin, keep_prob, ids, (long)ld_ids);
+    RFN_CHECK_LAUNCH();
+    return RFN_OK;
+}
+
 // ---- greedy pick of sample() (misc/RecurrentFusionModel.py:619-649) -----------------------------------
 __global__ __launch_bounds__(256) void greedy_pick_k(const float* __restrict__ logp, long ldl, int V1, int t,
                                                      int64_t* __restrict__ next_ids, int64_t* __restrict__ seq_out,

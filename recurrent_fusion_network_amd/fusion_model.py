@@ -190,10 +190,12 @@ class _DecoderFn(torch.autograd.Function):
             N.check(N.lib.rfn_decoder_fwd_begin(C.byref(d), B, S, table, comb.data_ptr(), h0.data_ptr(), c0.data_ptr(),
                                                 ws.data_ptr(), ws_bytes, int(train), st), 'rfn_decoder_fwd_begin')
             for s in range(S):
-                if s >= 1:
-                    coin = torch.rand(B, device=dev) < ss_prob
-                    draw = torch.multinomial(torch.exp(log_prob[:, s - 1]), 1).view(-1)
-                    ids[:, s] = torch.where(coin, draw, ids[:, s])
+                if s >= 1:   # rows whose coin says so get a token drawn from the previous step's distribution
+                    r = torch.rand(2, B, device=dev)
+                    prev = log_prob[:, s - 1]
+                    N.check(N.lib.rfn_multinomial_pick(prev.data_ptr(), prev.stride(0), B, d.V1, 1.0, r[0].data_ptr(),
+                                                       r[1].data_ptr(), ss_prob, ids[:, s].data_ptr(), ids.stride(0),
+                                                       st), 'rfn_multinomial_pick')
                 N.check(N.lib.rfn_decoder_fwd_step(C.byref(d), B, S, s, table, comb.data_ptr(), ids[:, s].data_ptr(),
                                                    ids.stride(0), log_prob.data_ptr(), ws.data_ptr(), ws_bytes,
                                                    int(train), seed, st), 'rfn_decoder_fwd_step')
@@ -598,8 +600,10 @@ class RecurrentFusionModel(nn.Module):
                         if force is not None:
                             it = force[:, t - 1].to(dev).contiguous()
                         else:  # :623-631 (the reference draws on the CPU; the stream is not portable anyway)
-                            p = torch.exp(prev if temperature == 1.0 else prev / temperature)
-                            it = torch.multinomial(p, 1).view(-1)
+                            uni = torch.rand(B, device=dev)
+                            N.check(N.lib.rfn_multinomial_pick(prev.data_ptr(), prev.stride(0), B, V1,
+                                                               1.0 / float(temperature), uni.data_ptr(), None, 1.0,
+                                                               it.data_ptr(), 1, N.stream_ptr()), 'rfn_multinomial_pick')
                         u = (it > 0) if t == 1 else (unf[t - 1].bool() & (it > 0))
                         unf[t] = u.int()
                         seq[:, t - 1] = it * u.long()

@@ -870,3 +870,51 @@ def test_rl_reward_criterion_matches_oracle(dev, use_ppo):
     assert maxerr(ldv.grad, lr.grad) < 1e-7
     for a, b in zip(pdv, pr):
         assert maxerr(a.grad, b.grad) < 1e-7
+
+
+def test_multinomial_pick_is_the_inverse_cdf_of_its_uniform(dev):
+    """rfn_multinomial_pick (sample(sample_max=0), scheduled sampling; misc/RecurrentFusionModel.py:623-631, 260-270):
+    the drawn index is the inverse CDF of exp(logp / T) at the caller's uniform -- checked against an fp64 cumulative
+    sum --, tokens without mass are never drawn, the coin mask keeps the other rows' tokens, and the empirical
+    frequencies of many draws follow the distribution."""
+    n = N()
+    g = torch.Generator().manual_seed(0)
+    B, V1 = 64, 9488
+    logits = torch.randn(B, V1 + 5, generator=g) * 3.0
+    logits[:, 100:200] = float('-inf')                       # a block of impossible tokens
+    logp = torch.log_softmax(logits[:, :V1].double(), 1).float()
+    pad = torch.full((B, V1 + 5), float('nan'))
+    pad[:, :V1] = logp                                       # row stride > V1, as a column of (B, S, V1)
+    for temp in (1.0, 0.7):
+        u = torch.rand(B, generator=g)
+        u[0], u[1] = 0.0, 0.99999994                         # both ends of the interval
+        ids = torch.full((B, 3), -7, dtype=torch.long, device=dev)
+        n.check(n.lib.rfn_multinomial_pick(pad.to(dev).data_ptr(), V1 + 5, B, V1, 1.0 / temp, u.to(dev).data_ptr(), None,
+                                           1.0, ids[:, 1].data_ptr(), 3, n.stream_ptr()))
+        got = ids.cpu()
+        assert bool((got[:, 0] == -7).all()) and bool((got[:, 2] == -7).all())      # only the addressed column
+        p = torch.exp(logp.double() / temp)
+        cdf = torch.cumsum(p, 1)
+        tgt = u.double() * cdf[:, -1]
+        for b in range(B):
+            v = int(got[b, 1])
+            assert 0 <= v < V1 and not (100 <= v < 200)
+            lo = float(cdf[b, v - 1]) if v > 0 else 0.0
+            tol = 2e-6 * float(cdf[b, -1])                   # fp32 partial sums vs the fp64 cumulative sum
+            assert lo - tol <= float(tgt[b]) <= float(cdf[b, v]) + tol, (b, v, lo, float(tgt[b]), float(cdf[b, v]))
+    # scheduled-sampling mask: rows with coin >= keep_prob keep their token
+    keep = torch.tensor([0.1, 0.9] * (B // 2))
+    ids = torch.full((B,), 5, dtype=torch.long, device=dev)
+    u = torch.rand(B, generator=g)
+    n.check(n.lib.rfn_multinomial_pick(pad.to(dev).data_ptr(), V1 + 5, B, V1, 1.0, u.to(dev).data_ptr(),
+                                       keep.to(dev).data_ptr(), 0.5, ids.data_ptr(), 1, n.stream_ptr()))
+    assert bool((ids.cpu()[1::2] == 5).all()) and not bool((ids.cpu()[0::2] == 5).all())
+    # empirical frequencies on a small vocabulary: 200 000 draws of one distribution
+    V, R = 13, 200000
+    lp = torch.log_softmax(torch.randn(V, generator=g) * 1.5, 0)
+    rows = lp.repeat(R, 1).contiguous().to(dev)
+    out = torch.empty(R, dtype=torch.long, device=dev)
+    n.check(n.lib.rfn_multinomial_pick(rows.data_ptr(), V, R, V, 1.0, torch.rand(R, generator=g).to(dev).data_ptr(), None,
+                                       1.0, out.data_ptr(), 1, n.stream_ptr()))
+    freq = torch.bincount(out.cpu(), minlength=V).double() / R
+    assert float((freq - torch.exp(lp.double())).abs().max()) < 5e-3
