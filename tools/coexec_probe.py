@@ -1,7 +1,7 @@
 """Diagnostic: how fast does a dependent chain of recurrence kernels run on a second HIP stream while the big grouped
 projection GEMM occupies the chip on the first?  (Stream overlap only pays if the chain keeps close to its stand-alone
-speed; the answer depends on how many GEMM blocks each CU hosts -- RFN_GEMM_COOP_LDS_KB pads the GEMM's LDS request to
-lower that number.)  Prints, per chain kind: chain alone, GEMM alone, both together, and the overlap that was realised."""
+speed.  The round-2 runs recorded in profiles/r02_overlap_probes.md also varied how many GEMM blocks a CU hosts through a
+probe-only build option, RFN_GEMM_COOP_LDS_KB, which padded the GEMM's LDS request; the product has no such knob.)  Prints, per chain kind: chain alone, GEMM alone, both together, and the overlap that was realised."""
 import os
 import sys
 import time
@@ -95,7 +95,6 @@ def both(g, c):
     main.wait_stream(side)
 
 
-print('RFN_GEMM_COOP_LDS_KB=%s RFN_GEMM_LDS_LEAN=%s' % (os.environ.get('RFN_GEMM_COOP_LDS_KB'), os.environ.get('RFN_GEMM_LDS_LEAN')))
 for gname, g in (('NT proj', gemm_nt), ('TN dW', gemm_tn)):
     tg = timeit(g)
     for cname, c in (('200 x lstm_fwd', lambda: chain_tiny(200)), ('40 x gate GEMM M=256', lambda: chain_gemm(40)),
