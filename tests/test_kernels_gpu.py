@@ -918,3 +918,66 @@ def test_multinomial_pick_is_the_inverse_cdf_of_its_uniform(dev):
                                        1.0, out.data_ptr(), 1, n.stream_ptr()))
     freq = torch.bincount(out.cpu(), minlength=V).double() / R
     assert float((freq - torch.exp(lp.double())).abs().max()) < 5e-3
+
+
+def test_gemm_big_tile_fuzz_across_kernels(dev):
+    """Random interior big-tile problems (rows / columns multiples of 128, K segments multiples of 32, 1-3 groups, 1-3
+    segments, every operand layout, with and without accumulate, wide leading dimensions): the LDS-DMA kernel, the
+    register-staged kernel and the lean tiles must agree bit for bit and match fp64 -- including launches with a
+    half-height tail round and K ranges shorter than the DMA ring."""
+    n = N()
+    rng = np.random.default_rng(11)
+    for case in range(14):
+        ak, bk = int(rng.integers(0, 2)), int(rng.integers(0, 2))
+        G = int(rng.integers(1, 4))
+        # at least 384 tiles of 128 x 128 so that the big-tile dispatch is taken
+        tm, tn = int(rng.integers(1, 40)), int(rng.integers(1, 12))
+        while tm * tn * G < 384:
+            tm += int(rng.integers(1, 24))
+        M, Nn = 128 * tm, 128 * tn
+        Ks = [32 * int(rng.integers(1, 5)) for _ in range(int(rng.integers(1, 4)))]
+        pad_a, pad_b, pad_c = 4 * int(rng.integers(0, 3)), 4 * int(rng.integers(0, 3)), 4 * int(rng.integers(0, 3))
+        acc = bool(rng.integers(0, 2))
+        probs, refs, keep = [], [], []
+        for g in range(G):
+            segs, ref = [], torch.zeros(M, Nn, dtype=torch.float64)
+            for s_, K in enumerate(Ks):
+                A, Bm = rnd(M, K, seed=1000 * case + 10 * g + s_), rnd(Nn, K, seed=5000 + 1000 * case + 10 * g + s_)
+                b = rnd(Nn, seed=9000 + case + s_) if rng.integers(0, 2) else None
+                ref += A.double() @ Bm.double().t() + (b.double() if b is not None else 0.0)
+                if ak:
+                    A_st = torch.zeros(M, K + pad_a)
+                    A_st[:, :K] = A
+                    lda = K + pad_a
+                else:
+                    A_st = torch.zeros(K, M + pad_a)
+                    A_st[:, :M] = A.t()
+                    lda = M + pad_a
+                if bk:
+                    B_st = torch.zeros(Nn, K + pad_b)
+                    B_st[:, :K] = Bm
+                    ldb = K + pad_b
+                else:
+                    B_st = torch.zeros(K, Nn + pad_b)
+                    B_st[:, :Nn] = Bm.t()
+                    ldb = Nn + pad_b
+                A_d, B_d, b_d = A_st.to(dev), B_st.to(dev), (b.to(dev) if b is not None else None)
+                keep += [A_d, B_d, b_d]
+                segs.append((A_d, lda, ak, B_d, ldb, bk, K, b_d))
+            probs.append([None, Nn + pad_c, segs])
+            refs.append(ref + (0.25 if acc else 0.0))
+        outs = {}
+        for name, flags in (('dma', 0), ('reg', n.GEMM_OPT_NO_DMA), ('lean', n.GEMM_OPT_LDS_LEAN)):
+            res = []
+            for p in probs:
+                p[0] = torch.full((M, Nn + pad_c), 0.25 if acc else float('nan'), device=dev)
+                res.append(p[0])
+            n.gemm(M, Nn, [tuple(p) for p in probs], accumulate=acc, flags=flags)
+            outs[name] = res
+        for g in range(G):
+            got = outs['dma'][g][:, :Nn]
+            assert maxerr(got, refs[g]) < 1e-4 * max(1.0, sum(Ks) / 64), (case, ak, bk, M, Nn, Ks, G, acc)
+            assert torch.equal(outs['dma'][g][:, :Nn], outs['reg'][g][:, :Nn]), (case, 'reg')
+            assert torch.equal(outs['dma'][g][:, :Nn], outs['lean'][g][:, :Nn]), (case, 'lean')
+            if pad_c and acc:
+                assert bool((outs['dma'][g][:, Nn:] == 0.25).all())
