@@ -173,7 +173,7 @@ class _DecoderFn(torch.autograd.Function):
     host read-back: the draw is made for every row and kept where the row's coin says so."""
 
     @staticmethod
-    def forward(ctx, model, save_bwd, drop, seed, ids, comb, h0, c0, ss_prob, *params):
+    def forward(ctx, model, save_bwd, drop, seed, ids, comb, h0, c0, ss_prob, inv_temp, *params):
         d = model._dims_for(drop)
         train = bool(save_bwd)
         B, S = ids.shape
@@ -193,9 +193,9 @@ class _DecoderFn(torch.autograd.Function):
                 if s >= 1:   # rows whose coin says so get a token drawn from the previous step's distribution
                     r = torch.rand(2, B, device=dev)
                     prev = log_prob[:, s - 1]
-                    N.check(N.lib.rfn_multinomial_pick(prev.data_ptr(), prev.stride(0), B, d.V1, 1.0, r[0].data_ptr(),
-                                                       r[1].data_ptr(), ss_prob, ids[:, s].data_ptr(), ids.stride(0),
-                                                       st), 'rfn_multinomial_pick')
+                    N.check(N.lib.rfn_multinomial_pick(prev.data_ptr(), prev.stride(0), B, d.V1, inv_temp,
+                                                       r[0].data_ptr(), r[1].data_ptr(), ss_prob, ids[:, s].data_ptr(),
+                                                       ids.stride(0), st), 'rfn_multinomial_pick')
                 N.check(N.lib.rfn_decoder_fwd_step(C.byref(d), B, S, s, table, comb.data_ptr(), ids[:, s].data_ptr(),
                                                    ids.stride(0), log_prob.data_ptr(), ws.data_ptr(), ws_bytes,
                                                    int(train), seed, st), 'rfn_decoder_fwd_step')
@@ -209,10 +209,11 @@ class _DecoderFn(torch.autograd.Function):
             ctx.model, ctx.seed, ctx.B, ctx.S, ctx.drop = model, seed, B, S, drop
             ctx.ws, ctx.ids, ctx.params, ctx.consumed = ws, ids, params, False
             ctx.save_for_backward(comb, h0, c0, log_prob)
-        return log_prob
+        ctx.mark_non_differentiable(ids)
+        return log_prob, ids
 
     @staticmethod
-    def backward(ctx, d_log_prob):
+    def backward(ctx, d_log_prob, _d_ids=None):
         model, B, S = ctx.model, ctx.B, ctx.S
         comb, h0, c0, log_prob = ctx.saved_tensors
         d = model._dims_for(ctx.drop)
@@ -235,7 +236,7 @@ class _DecoderFn(torch.autograd.Function):
                                       gtable, ctx.ws.data_ptr(), ctx.ws.numel(), ctx.seed, N.stream_ptr()),
                 'rfn_decoder_bwd')
         model._bucket_done('decoder', flats['decoder'])
-        return (None, None, None, None, None, d_comb, d_h0, d_c0, None) + (None,) * len(ctx.params)
+        return (None, None, None, None, None, d_comb, d_h0, d_c0, None, None) + (None,) * len(ctx.params)
 
 
 class RecurrentFusionModel(nn.Module):
@@ -453,7 +454,15 @@ class RecurrentFusionModel(nn.Module):
 
     def _decode_teacher_forced(self, ids, comb, h, c, drop, seed, ss_prob=0.0):
         params = self._params_of(self._decoder_slots)
-        return _DecoderFn.apply(self, torch.is_grad_enabled(), bool(drop), seed, ids, comb, h, c, float(ss_prob),
+        return _DecoderFn.apply(self, torch.is_grad_enabled(), bool(drop), seed, ids, comb, h, c, float(ss_prob), 1.0,
+                                *params)[0]
+
+    def _decode_sampled(self, comb, h, c, drop, seed, steps, inv_temp):
+        """Free-running multinomial decode as ONE step-wise pass of the training decoder (every row's next token is
+        drawn from the distribution the step just produced): -> (log_prob (B, steps, V+1), ids (B, steps) fed)."""
+        params = self._params_of(self._decoder_slots)
+        ids0 = torch.zeros(h.size(0), steps, dtype=torch.long, device=h.device)     # column 0 = BOS
+        return _DecoderFn.apply(self, torch.is_grad_enabled(), bool(drop), seed, ids0, comb, h, c, 1.0, float(inv_temp),
                                 *params)
 
     # ---- reference API ----------------------------------------------------------------------------
@@ -569,8 +578,7 @@ class RecurrentFusionModel(nn.Module):
             return self.sample_beam(fc_feats, att_feats, opt)
         want_grad = torch.is_grad_enabled() and not sample_max
         # dropout follows the module's mode, as the reference's nn.Dropout layers do (train_rl.py samples in train()
-        # mode); the free-running steps and the differentiable teacher-forced replay below share one seed, so the
-        # tokens are drawn from the very distribution whose log-probs carry the gradient (:623-631)
+        # mode)
         train = bool(self.training)
         seed = _fresh_seed() if train else 0
         with torch.set_grad_enabled(want_grad):
@@ -579,52 +587,50 @@ class RecurrentFusionModel(nn.Module):
         dev = comb.device
         reason_pred = list(reason.unbind(0))
         force = opt.get('force_ids', None)
-        with torch.no_grad():
+        if not sample_max or force is not None:
+            # multinomial (:623-631) or replayed ids.  ONE pass of the training decoder is both the pass that is sampled
+            # and, under grad, the pass that is differentiated (train_rl.py:160-166): step-wise with a device-side
+            # inverse-CDF draw between steps, or -- when the ids are given -- simply teacher-forced.
+            with torch.set_grad_enabled(want_grad):
+                if force is not None:
+                    raw = torch.zeros(B, S + 1, dtype=torch.long, device=dev)      # column t = token fed at step t
+                    raw[:, 1:] = force[:, :S].to(dev)
+                else:
+                    logp_full, raw = self._decode_sampled(comb, h, c, train, seed, S + 1, 1.0 / float(temperature))
+                tok = raw[:, 1:]
+                unf = torch.cumprod((tok > 0).long(), 1)                           # a row is finished after its first 0
+                seq = tok * unf
+                alive = unf.sum(0).tolist()                                        # one read-back: the early exit (:645)
+                t_stop = next((t for t in range(1, S + 1) if alive[t - 1] == 0), S + 1)
+                n_seq = t_stop - 1
+                if force is not None:
+                    logp = self._decode_teacher_forced(raw[:, :t_stop].contiguous(), comb, h, c, train, seed)
+                else:
+                    logp = logp_full[:, :t_stop]
+                seq_lp = logp[:, :n_seq].gather(2, tok[:, :n_seq].unsqueeze(2)).squeeze(2)
+            if getattr(self, '_trace_ss', False):
+                self._sample_ids = raw[:, :t_stop].clone()       # test hook: the tokens the pass fed
+            return seq[:, :n_seq], seq_lp, logp.contiguous(), reason_pred
+        with torch.no_grad():      # greedy: free-running steps with the argmax pick on the device
             stepper = _Stepper(self, comb.detach(), h.detach().clone(), c.detach().clone(), train, seed)
             logp_all = torch.empty(B, S + 1, V1, device=dev)
             seq = torch.zeros(B, S, dtype=torch.long, device=dev)
             seq_lp = torch.zeros(B, S, device=dev)
-            raw = torch.zeros(B, S + 1, dtype=torch.long, device=dev)  # column t = token fed at step t
             unf = torch.zeros(S + 1, B, dtype=torch.int32, device=dev)
             it = torch.zeros(B, dtype=torch.long, device=dev)
             for t in range(S + 1):
                 if t >= 1:
                     prev = logp_all[:, t - 1]
-                    if sample_max and force is None:
-                        N.check(N.lib.rfn_greedy_pick(prev.data_ptr(), prev.stride(0), B, V1, t, it.data_ptr(),
-                                                      seq[:, t - 1].data_ptr(), seq.stride(0),
-                                                      seq_lp[:, t - 1].data_ptr(), seq_lp.stride(0),
-                                                      unf[t - 1].data_ptr() if t > 1 else None, unf[t].data_ptr(),
-                                                      N.stream_ptr()), 'rfn_greedy_pick')
-                    else:
-                        if force is not None:
-                            it = force[:, t - 1].to(dev).contiguous()
-                        else:  # :623-631 (the reference draws on the CPU; the stream is not portable anyway)
-                            uni = torch.rand(B, device=dev)
-                            N.check(N.lib.rfn_multinomial_pick(prev.data_ptr(), prev.stride(0), B, V1,
-                                                               1.0 / float(temperature), uni.data_ptr(), None, 1.0,
-                                                               it.data_ptr(), 1, N.stream_ptr()), 'rfn_multinomial_pick')
-                        u = (it > 0) if t == 1 else (unf[t - 1].bool() & (it > 0))
-                        unf[t] = u.int()
-                        seq[:, t - 1] = it * u.long()
-                        seq_lp[:, t - 1] = prev.gather(1, it.view(-1, 1)).view(-1)
-                    raw[:, t] = it
+                    N.check(N.lib.rfn_greedy_pick(prev.data_ptr(), prev.stride(0), B, V1, t, it.data_ptr(),
+                                                  seq[:, t - 1].data_ptr(), seq.stride(0),
+                                                  seq_lp[:, t - 1].data_ptr(), seq_lp.stride(0),
+                                                  unf[t - 1].data_ptr() if t > 1 else None, unf[t].data_ptr(),
+                                                  N.stream_ptr()), 'rfn_greedy_pick')
                 stepper.step(it, out=logp_all[:, t])
             # the reference's early exit (:645): stop at the first t >= 1 with no unfinished row
             alive = unf[1:].sum(1).tolist()
-        t_stop = S + 1
-        for t in range(1, S + 1):
-            if alive[t - 1] == 0:
-                t_stop = t
-                break
+        t_stop = next((t for t in range(1, S + 1) if alive[t - 1] == 0), S + 1)
         n_seq = t_stop - 1
-        if getattr(self, '_trace_ss', False):
-            self._sample_trace = logp_all[:, :t_stop].clone()    # test hook: the distributions the ids were drawn from
-        if want_grad:
-            # differentiable log-probs (train_rl.py:160-166): teacher-force the drawn ids through phase 2
-            logp_g = self._decode_teacher_forced(raw[:, :t_stop].contiguous(), comb, h, c, train, seed)
-            seq_lp_g = logp_g[:, :n_seq].gather(2, raw[:, 1:t_stop].unsqueeze(2)).squeeze(2)
-            return seq[:, :n_seq], seq_lp_g, logp_g, reason_pred
         return seq[:, :n_seq], seq_lp[:, :n_seq], logp_all[:, :t_stop].contiguous(), reason_pred
 
     def sample_beam(self, fc_feats, att_feats, opt={}):

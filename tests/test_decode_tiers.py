@@ -156,4 +156,9 @@ def test_config5_size_beam5_and_rl_sample_properties(dev):
     model._trace_ss = True
     torch.manual_seed(5)
     seq, seq_lp, lp_all, _ = model.sample(fc, att, {'sample_max': 0})
-    assert torch.equal(lp_all.detach(), model._sample_trace) and lp_all.requires_grad
+    fed = model._sample_ids
+    assert lp_all.requires_grad and tuple(fed.shape) == (w['B'], lp_all.size(1))
+    with torch.no_grad():     # the sampled pass equals a batched teacher-forced replay of the tokens it fed (dropout is 0)
+        comb, h, c, _ = model._prefix(fc, att, True, 0)
+        tf = model._decode_teacher_forced(fed, comb, h, c, True, 0)
+    assert torch.equal(tf, lp_all.detach())

@@ -473,14 +473,24 @@ def test_sampling_under_dropout_draws_from_the_differentiated_distribution(dev, 
     assert not torch.equal(lp[:, 0], eval_lp[:, 0])             # dropout really was active
     lp.sum().backward()
     assert all(torch.isfinite(p.grad).all() for p in model.parameters())
-    # multinomial sample with grad (train_rl.py:160)
+    # multinomial sample with grad (train_rl.py:160): one step-wise pass, pinned against a batched replay of its tokens
     model.ss_prob = 0.0
     torch.manual_seed(4)
     seq, seq_lp, lp_all, _ = model.sample(fc, att, {'sample_max': 0})
-    assert lp_all.requires_grad and torch.equal(lp_all.detach(), model._sample_trace)
-    picked = model._sample_trace[:, :seq.size(1)].gather(2, seq.clamp(min=0).unsqueeze(2)).squeeze(2)
+    fed = model._sample_ids
+    assert lp_all.requires_grad and fed.size(1) == lp_all.size(1)
+    torch.manual_seed(4)
+    seed = _fresh_seed()
+    with torch.no_grad():
+        comb, h, c, _ = model._prefix(fc, att, True, seed)
+        tf = model._decode_teacher_forced(fed, comb, h, c, True, seed)
+    assert torch.equal(tf, lp_all.detach())
+    picked = lp_all.detach()[:, :seq.size(1)].gather(2, fed[:, 1:seq.size(1) + 1].unsqueeze(2)).squeeze(2)
+    assert torch.equal(seq_lp.detach(), picked)
     alive = seq > 0
-    assert torch.equal(seq_lp.detach()[alive], picked[alive])
+    assert torch.equal(seq[alive], fed[:, 1:seq.size(1) + 1][alive])
+    (seq_lp * alive).sum().backward()
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters())
     # eval mode: no dropout anywhere, teacher-forced and free-running passes still agree bit for bit
     model.eval()
     with torch.no_grad():
