@@ -371,8 +371,10 @@ extern "C" int rfn_attn_context_bwd_dseq(const float* alpha, const float* dz, in
 // One block per batch row.  For each 64*W-wide chunk of A (W = 4 with 16-B accesses) every wave
 // sweeps its rows l = wave, wave+4, ... keeping the chunk's column sums (dhproj, dw) in registers;
 // the four waves' sums are combined through LDS in a fixed order (deterministic).
-#define SB_THREADS 1024
+#ifndef SB_WAVES
 #define SB_WAVES 16
+#endif
+#define SB_THREADS (64 * SB_WAVES)
 #ifndef SB_UNROLL
 #define SB_UNROLL 4
 #endif
