@@ -36,7 +36,7 @@ extern "C" {
 #define RFN_ERR_ARG (-5)         /* null / misaligned pointer */
 
 #define RFN_MAX_ENC 8
-#define RFN_ABI_VERSION 4
+#define RFN_ABI_VERSION 5
 
 /* Model dimensions: the fields RecurrentFusionModel.__init__ reads from `opt`
  * (misc/RecurrentFusionModel.py:118-151).  Limits (RFN_ERR_SHAPE otherwise): M <= RFN_MAX_ENC,
@@ -119,11 +119,45 @@ int rfn_gemm_f32_ws(int M, int N, int ngroups, const rfn_gemm_problem* problems_
  *                          RCCL's under data parallelism -- can co-reside instead of waiting for a
  *                          multi-millisecond GEMM to drain; same results, same speed within 1 %;
  *   RFN_GEMM_OPT_NO_DMA    interior big tiles use the register-staged kernel instead of the LDS-DMA one (A/B hook;
- *                          both give bit-identical results: same k order per output element). */
+ *                          both give bit-identical results: same k order per output element);
+ *   RFN_GEMM_OPT_BF16X3    (rfn_dims.gemm_flags only) the two long products of the path -- the hoisted stage-I feature
+ *                          projection and its weight gradient -- run on the bf16 matrix cores with every f32 operand
+ *                          held as three bf16 planes and six plane products accumulated in f32 (rfn_x3_*, below):
+ *                          f32-level accuracy (at least as close to an f64 product as the f32 MFMA chain), not
+ *                          bit-identical to it.  Off by default. */
 #define RFN_GEMM_OPT_LDS_LEAN 1u
 #define RFN_GEMM_OPT_NO_DMA 2u
+#define RFN_GEMM_OPT_BF16X3 4u
 int rfn_gemm_f32_opt(int M, int N, int ngroups, const rfn_gemm_problem* problems_host, int accumulate,
                      void* ws, size_t ws_bytes, unsigned flags, void* stream);
+
+/* ---- f32 GEMM on the bf16 matrix cores (csrc/rfn_gemm_x3.hip) -------------------------------------------------------
+ * Replaces, when RFN_GEMM_OPT_BF16X3 is set, the two nn.Linear products the reference spends most of its time in:
+ * att_2_att_h over all B*L regions (misc/AttentionModelCore.py:33-35, hoisted over the T1 review steps) and its
+ * weight gradient (autograd of the same line).
+ *
+ * A logical operand Y[rows][K] (row = output index, K = reduction index) is held as a PLANE IMAGE: x = x0 + x1 + x2 with
+ * x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1) (round to nearest even; exact for finite x below 2^127), stored
+ * as 1-KiB pieces in MFMA operand order: piece (kc, rb, p) at byte ((kc * nrb + rb) * 3 + p) * 1024 holds, at 16 * l,
+ * plane p of Y[rb * 32 + l % 32][kc * 16 + 8 * (l / 32) + 0..7]; nrb = rows padded to 256, over 32; K is padded to 32;
+ * pad rows / columns are zero.  rfn_x3_image_bytes gives the size (6 bytes per padded element). */
+size_t rfn_x3_image_bytes(int rows, int K);
+/* Image of Y[ngroups * rows][K] whose row block g is the f32 matrix srcs_host[g] (device pointers in a host array;
+ * k_fast = 1: element (row, k) at src[row * ld + k], k_fast = 0: at src[k * ld + row]).  rows % 32 == 0 unless
+ * ngroups == 1; ngroups <= 64. */
+int rfn_x3_split(const float* const* srcs_host, int ngroups, int64_t ld, int rows, int K, int k_fast, void* image,
+                 void* stream);
+/* C (+)= A . B^T from two images (A: M rows, B: N rows, both with reduction length K): the six plane products
+ * a0.b0, a0.b1, a1.b0, a0.b2, a1.b1, a2.b0, smallest first, accumulated in f32 by v_mfma_f32_32x32x16_bf16.
+ * The output is cut into groups of gm rows x gn columns, group (i, j) written to C_host[i * ceil(N/gn) + j] with leading
+ * dimension ldc (+ bias_host[..][column inside the group] when bias_host and the entry are non-NULL); gm and gn must be
+ * multiples of 256 unless they cover the whole dimension; at most 64 groups.  splitk > 1 cuts K over blocks; the partial
+ * tiles (part: rfn_x3_part_floats floats) are summed in slice order by a second kernel (deterministic; N % 4 == 0). */
+int rfn_x3_gemm(int M, int N, int K, const void* imageA, const void* imageB, int gm, int gn, float* const* C_host,
+                const float* const* bias_host, int64_t ldc, int accumulate, int splitk, float* part, void* stream);
+size_t rfn_x3_part_floats(int M, int N, int splitk);
+/* the number of K slices with which one round of blocks covers the chip (1 for launches of many tiles) */
+int rfn_x3_splitk_for(int M, int N, int K);
 
 /* out[n] (+)= sum_r X[r*ldx + n]   (bias gradients) */
 int rfn_colsum_f32(const float* X, int64_t ldx, int rows, int cols, float* out, int accumulate,

@@ -16,9 +16,10 @@ LIB_PATH = os.path.join(_HERE, 'librfn_hip.so')
 RFN_MAX_ENC = 8
 RFN_GEMM_MAXSEG = 8
 RFN_GEMM_MAXGROUP = 8
-ABI_VERSION = 4
+ABI_VERSION = 5
 GEMM_OPT_LDS_LEAN = 1
 GEMM_OPT_NO_DMA = 2
+GEMM_OPT_BF16X3 = 4
 
 
 class RfnError(RuntimeError):
@@ -63,6 +64,11 @@ def _load():
         'rfn_gemm_f32': (C.c_int, [I, I, I, C.POINTER(GemmProblem), I, P]),
         'rfn_gemm_f32_ws': (C.c_int, [I, I, I, C.POINTER(GemmProblem), I, P, SZ, P]),
         'rfn_gemm_f32_opt': (C.c_int, [I, I, I, C.POINTER(GemmProblem), I, P, SZ, C.c_uint, P]),
+        'rfn_x3_image_bytes': (SZ, [I, I]),
+        'rfn_x3_split': (C.c_int, [P, I, L, I, I, I, P, P]),
+        'rfn_x3_gemm': (C.c_int, [I, I, I, P, P, I, I, P, P, L, I, I, P, P]),
+        'rfn_x3_part_floats': (SZ, [I, I, I]),
+        'rfn_x3_splitk_for': (C.c_int, [I, I, I]),
         'rfn_colsum_f32': (C.c_int, [P, L, I, I, P, I, P]),
         'rfn_colsum_grouped_f32': (C.c_int, [P, L, L, I, I, P, I, P]),
         'rfn_fill_small_f32': (C.c_int, [P, I, I, F, P]),
@@ -206,6 +212,29 @@ def gemm(M, N, problems, accumulate=False, ws=None, flags=0):
             sg.K, sg.bias = K, ptr(bias)
     check(lib.rfn_gemm_f32_opt(M, N, len(problems), arr, int(accumulate), ptr(ws), 0 if ws is None else ws.numel(),
                                int(flags), stream_ptr()), 'rfn_gemm_f32_opt')
+
+
+def x3_image(srcs, rows, K, k_fast=True, ld=None) -> torch.Tensor:
+    """bf16 plane image (uint8 tensor) of the logical operand whose row block g is the f32 matrix srcs[g]
+    (rows x K; k_fast: element (row, k) at [row * ld + k], else at [k * ld + row])."""
+    srcs = [require_cuda_f32(t, 'src') for t in srcs]
+    if ld is None:
+        ld = K if k_fast else rows
+    img = torch.empty(lib.rfn_x3_image_bytes(len(srcs) * rows, K), dtype=torch.uint8, device=srcs[0].device)
+    check(lib.rfn_x3_split(ptr_array(srcs), len(srcs), ld, rows, K, int(k_fast), img.data_ptr(), stream_ptr()), 'rfn_x3_split')
+    return img
+
+
+def x3_gemm(M, N, K, img_a, img_b, outs, gm=None, gn=None, ldc=None, bias=None, accumulate=False, splitk=1):
+    """outs: list of f32 output tensors, group (i, j) = outs[i * ceil(N / gn) + j] (gm x gn each); bias: same shape list or None."""
+    gm, gn = gm or M, gn or N
+    ldc = ldc or gn
+    part = None
+    if splitk > 1:
+        part = torch.empty(lib.rfn_x3_part_floats(M, N, splitk), dtype=torch.float32, device=img_a.device)
+    check(lib.rfn_x3_gemm(M, N, K, img_a.data_ptr(), img_b.data_ptr(), gm, gn, ptr_array(outs),
+                          None if bias is None else ptr_array(bias), ldc, int(accumulate), splitk, ptr(part), stream_ptr()),
+          'rfn_x3_gemm')
 
 
 def linear(x: torch.Tensor, weight: torch.Tensor, bias=None) -> torch.Tensor:

@@ -1,0 +1,499 @@
+// f32 GEMM on the bf16 matrix cores: every f32 operand is held as THREE bf16 planes (x = x0 + x1 + x2 exactly for
+// 2^-109 <= |x| < 2^128 and to 2^-133 absolute below that: 3 x 8 significant bits + 2 sign bits cover the 24-bit
+// significand, bf16 has f32's exponent range) and C = A . B^T is formed from the six
+// products whose weight is >= 2^-16 of the leading one,
+//     a0.b0 + (a0.b1 + a1.b0) + (a0.b2 + a1.b1 + a2.b0),
+// with v_mfma_f32_{32x32x16,16x16x32}_bf16 accumulating in f32.  The three dropped products are below 2^-24 relative,
+// i.e. below the rounding of an f32 accumulation step.  Measured against f64 (tools/split_numerics_probe.hip, K = 512 ...
+// 50176, normal / all-positive / wide-range data) the result is at least as close as the exact-f32 MFMA chain of
+// rfn_gemm.hip (0.75-0.85x its rms error): the matrix cores run the bf16 shapes 16x faster than the f32 shape, so six
+// products still leave 2.7x the f32 rate.
+//
+// Plane image of a logical operand Y[rows][K] (row = output index, K = reduction index), written by rfn_x3_split from an
+// f32 matrix in either orientation: 1-KiB pieces in the lane order of the MFMA operand,
+//     piece(kc, rb, p) at byte (((kc * nrb) + rb) * 3 + p) * 1024, lane l at + 16 * l:
+//         plane p of Y[rb * RB + l % RB][kc * KC + 8 * (l / RB) + 0..7]        (RB x KC = 32 x 16 or 16 x 32)
+// rows are padded to a multiple of 256 and K to a multiple of KC with zeros, so the GEMM loads need no bounds checks.
+// One wave-instruction of LDS-DMA (global_load_lds_dwordx4, 64 lanes x 16 B) moves one piece as one contiguous KiB of
+// global memory into one contiguous KiB of LDS, which one ds_read_b128 per lane then reads back conflict-free (lane-
+// linear 1 KiB): no swizzle, no staging registers, no address arithmetic per lane beyond lane * 16.
+#include "rfn_common.h"
+
+typedef float x3_f32x16 __attribute__((ext_vector_type(16)));
+typedef float x3_f32x4 __attribute__((ext_vector_type(4)));
+typedef short x3_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void x3_lds_void;
+typedef const __attribute__((address_space(1))) void x3_gbl_void;
+
+#define X3_ROW_PAD 256
+#define X3_MAX_GROUPS 64
+
+template <int SHAPE>
+struct X3Shape {
+    static constexpr int RB = SHAPE;                 // rows per piece
+    static constexpr int KC = SHAPE == 32 ? 16 : 32; // reduction indices per piece
+    static constexpr int ACC = SHAPE == 32 ? 16 : 4; // accumulator registers per lane and MFMA tile
+};
+
+// ---- f32 -> three bf16 planes ----------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned x3_bf16_rne(float x) {
+    const unsigned u = __float_as_uint(x);
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ void x3_split(float x, unsigned& p0, unsigned& p1, unsigned& p2) {
+    const unsigned u = __float_as_uint(x);
+    if ((u & 0x7F800000u) == 0x7F800000u) {   // infinity / NaN: the leading plane carries it, the others stay zero
+        p0 = (u >> 16) | ((u & 0xFFFFu) ? 1u : 0u);   // a NaN stays a NaN even if its payload sat in the low half
+        p1 = p2 = 0u;
+        return;
+    }
+    p0 = x3_bf16_rne(x);
+    if ((p0 & 0x7F80u) == 0x7F80u) p0 = u >> 16;   // rounding up would overflow: truncate, the residual takes the rest
+    float r = x - __uint_as_float(p0 << 16);
+    p1 = x3_bf16_rne(r);
+    r -= __uint_as_float(p1 << 16);
+    p2 = x3_bf16_rne(r);
+}
+
+struct X3SplitArgs {
+    const float* src[X3_MAX_GROUPS];   // group g fills rows [g * rows, (g + 1) * rows) of the image
+    long ld;
+    int rows, K, kfast;
+    int nrb, nkc;       // row blocks written per group (the last group also zero-fills the pad rows), pieces of K
+    int nrb_img;        // row blocks per kc in the whole image
+    int nrb_group;      // row-block distance between groups
+    char* img;
+};
+
+// one wave per (kc, rb): reads 8 reduction indices of one row per lane, writes the three 1-KiB pieces
+//   kfast = 1: src[row * ld + k]   kfast = 0: src[k * ld + row]
+template <int SHAPE>
+__global__ __launch_bounds__(256) void x3_split_k(const X3SplitArgs a) {
+    using S = X3Shape<SHAPE>;
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.y;
+    const float* __restrict__ src = a.src[g];
+    const int nrb = a.nrb, nkc = a.nkc, rows = a.rows, K = a.K;
+    const long ld = a.ld;
+    const long piece = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (piece >= (long)nrb * nkc) return;
+    // consecutive waves take consecutive kc of one row block when the source is k-fast (they share cache lines),
+    // consecutive row blocks of one kc when it is row-fast
+    int kc, rb;
+    if (a.kfast) {
+        rb = (int)(piece / nkc);
+        kc = (int)(piece % nkc);
+    } else {
+        kc = (int)(piece / nrb);
+        rb = (int)(piece % nrb);
+    }
+    const int row = rb * S::RB + lane % S::RB;
+    const int k0 = kc * S::KC + 8 * (lane / S::RB);
+    float x[8];
+    if (a.kfast) {
+        const float* p = src + (long)row * ld + k0;
+        if (row < rows && k0 + 8 <= K && ((ld & 3) == 0) && ((((uintptr_t)src) & 15u) == 0)) {
+            const x3_f32x4 u = *reinterpret_cast<const x3_f32x4*>(p);
+            const x3_f32x4 v = *reinterpret_cast<const x3_f32x4*>(p + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                x[j] = u[j];
+                x[4 + j] = v[j];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = (row < rows && k0 + j < K) ? p[j] : 0.f;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = (row < rows && k0 + j < K) ? src[(long)(k0 + j) * ld + row] : 0.f;
+    }
+    unsigned q[3][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x3_split(x[j], q[0][j], q[1][j], q[2][j]);
+    char* dst = a.img + (((long)kc * a.nrb_img + (long)g * a.nrb_group + rb) * 3) * 1024 + lane * 16;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        uint4 w;
+        w.x = q[p][0] | (q[p][1] << 16);
+        w.y = q[p][2] | (q[p][3] << 16);
+        w.z = q[p][4] | (q[p][5] << 16);
+        w.w = q[p][6] | (q[p][7] << 16);
+        *reinterpret_cast<uint4*>(dst + p * 1024) = w;
+    }
+}
+
+static inline long x3_rows_pad(long rows) { return (rows + X3_ROW_PAD - 1) / X3_ROW_PAD * X3_ROW_PAD; }
+static inline long x3_k_pad(long K) { return (K + 31) / 32 * 32; }
+
+extern "C" size_t rfn_x3_image_bytes(int rows, int K) {
+    if (rows < 1 || K < 1) return 0;
+    return (size_t)x3_rows_pad(rows) * (size_t)x3_k_pad(K) * 6;
+}
+
+#ifndef X3_SHAPE
+#define X3_SHAPE 32
+#endif
+
+// Image of the logical operand Y[ngroups * rows][K] whose row block g is the f32 matrix srcs_host[g] (rows x K, leading
+// dimension ld; k_fast = 1: element (row, k) at src[row * ld + k], k_fast = 0: at src[k * ld + row]).  With more than
+// one group, rows must be a multiple of 32.  One launch; the pad rows and pad columns of the image are zero-filled.
+extern "C" int rfn_x3_split(const float* const* srcs_host, int ngroups, int64_t ld, int rows, int K, int k_fast, void* image,
+                            void* stream) {
+    if (!srcs_host || !image || rows < 1 || K < 1 || ngroups < 1 || ngroups > X3_MAX_GROUPS) return RFN_ERR_ARG;
+    if (ngroups > 1 && rows % 32) return RFN_ERR_SHAPE;
+    using S = X3Shape<X3_SHAPE>;
+    X3SplitArgs a;
+    for (int g = 0; g < ngroups; ++g) {
+        if (!srcs_host[g]) return RFN_ERR_ARG;
+        a.src[g] = srcs_host[g];
+    }
+    const long total = (long)ngroups * rows;
+    a.ld = ld;
+    a.rows = rows;
+    a.K = K;
+    a.kfast = k_fast;
+    a.nkc = (int)(x3_k_pad(K) / S::KC);
+    a.nrb_img = (int)(x3_rows_pad(total) / S::RB);
+    a.nrb_group = rows / S::RB;
+    // every group writes its own ceil(rows / RB) row blocks; the pad rows behind the last group get a second, small launch
+    a.nrb = (rows + S::RB - 1) / S::RB;
+    a.img = (char*)image;
+    hipLaunchKernelGGL((x3_split_k<X3_SHAPE>), dim3((unsigned)(((long)a.nrb * a.nkc + 3) / 4), ngroups), dim3(256), 0,
+                       (hipStream_t)stream, a);
+    RFN_CHECK_LAUNCH();
+    const int pad_rb = a.nrb_img - (int)((total + S::RB - 1) / S::RB);
+    if (pad_rb > 0) {   // zero rows: a "group" of 0 valid rows placed behind the last one
+        X3SplitArgs z = a;
+        z.src[0] = srcs_host[0];
+        z.rows = 0;
+        z.nrb = pad_rb;
+        z.nrb_group = 0;
+        z.img = (char*)image + (long)(a.nrb_img - pad_rb) * 3 * 1024;
+        hipLaunchKernelGGL((x3_split_k<X3_SHAPE>), dim3((unsigned)(((long)z.nrb * z.nkc + 3) / 4), 1), dim3(256), 0,
+                           (hipStream_t)stream, z);
+        RFN_CHECK_LAUNCH();
+    }
+    return RFN_OK;
+}
+
+// ---- the GEMM ----------------------------------------------------------------------------------------------------------
+struct X3Args {
+    const char* A;   // plane image of the M-side operand  [M][K]
+    const char* B;   // plane image of the N-side operand  [N][K]
+    int nrbA, nrbB;  // row blocks per kc in each image
+    int M, N;        // logical output size (stores are bounds-checked)
+    int nkc;         // K_pad / KC
+    int splitk;      // > 1: blockIdx.z cuts nkc; raw partial tiles go to part[ks][M][N]
+    float* part;
+    int gm, gn, ngn; // output groups: gm rows x gn columns each, C[(m / gm) * ngn + n / gn], leading dimension ldc
+    long ldc;
+    int accumulate;
+    int tiles_m, tiles_n;
+    int main_tiles;  // tiles [0, main_tiles) are whole; each later tile is done by four blocks, a quarter each
+    float* C[X3_MAX_GROUPS];
+    const float* bias[X3_MAX_GROUPS];   // per group: bias[g][column inside the group] or nullptr
+};
+
+template <int N>
+__device__ __forceinline__ void x3_wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int SHAPE>
+using x3_acc_t = typename std::conditional<SHAPE == 32, x3_f32x16, x3_f32x4>::type;
+
+template <int SHAPE>
+__device__ __forceinline__ void x3_mfma(const x3_bf16x8& a, const x3_bf16x8& b, x3_acc_t<SHAPE>& c) {
+    if constexpr (SHAPE == 32) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    else c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+// One BM x BN output tile at (row0, col0) over the pieces [kc0, kc0 + iters * KCS) of K, by WGM x WGN waves; operands
+// staged by LDS-DMA into a ring of SLOTS slots of KCS pieces of K each:
+//   iteration it:  wait until this wave's pieces of slot `it` have landed (younger slots stay in flight) -> barrier (every
+//                  wave's pieces landed; every wave is done reading slot it-1) -> issue slot it+SLOTS-1 -> MFMAs on slot it.
+template <int SHAPE, int BM, int BN, int WGM, int WGN, int KCS, int SLOTS>
+__device__ __forceinline__ void x3_tile(const X3Args& args, const int row0, const int col0, const int kc0, const int iters,
+                                        const int ks) {
+    using S = X3Shape<SHAPE>;
+    constexpr int NW = WGM * WGN;
+    constexpr int RB = S::RB;
+    constexpr int WM = BM / WGM, WN = BN / WGN;
+    constexpr int MI = WM / RB, NI = WN / RB;
+    constexpr int PA = (BM / RB) * 3, PB = (BN / RB) * 3;   // pieces per kc
+    constexpr int PT = KCS * (PA + PB);                     // pieces per slot
+    constexpr int PPW = PT / NW;                            // per wave
+    static_assert(PT % NW == 0 && MI >= 1 && NI >= 1, "pieces must divide over the waves");
+    constexpr int SLOT_BYTES = PT * 1024;
+    extern __shared__ __attribute__((aligned(16))) char x3_smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave % WGN;
+
+    // this wave's pieces of a slot: piece n -> (kcs, operand, piece inside the kc's tile rows); wave-uniform addresses
+    const char* src[PPW];
+    long step[PPW];
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+        const int n = wave * PPW + j;
+        const int kcs = n / (PA + PB), rem = n % (PA + PB);
+        if (rem < PA) {
+            src[j] = args.A + (((long)(kc0 + kcs) * args.nrbA + row0 / RB) * 3 + rem) * 1024;
+            step[j] = (long)KCS * args.nrbA * 3072;
+        } else {
+            src[j] = args.B + (((long)(kc0 + kcs) * args.nrbB + col0 / RB) * 3 + (rem - PA)) * 1024;
+            step[j] = (long)KCS * args.nrbB * 3072;
+        }
+    }
+    const unsigned lane16 = lane * 16;
+    auto issue = [&](int slot) {
+        char* st = x3_smem + slot * SLOT_BYTES + wave * PPW * 1024;
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) {
+            __builtin_amdgcn_global_load_lds((x3_gbl_void*)(src[j] + lane16), (x3_lds_void*)(st + j * 1024), 16, 0, 0);
+            src[j] += step[j];
+        }
+    };
+
+    x3_acc_t<SHAPE> acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < S::ACC; ++r) acc[i][j][r] = 0.f;
+
+    int issued = 0;
+#pragma unroll
+    for (int s = 0; s < SLOTS - 1; ++s)
+        if (s < iters) {
+            issue(s);
+            ++issued;
+        }
+    int cur = 0, fill = SLOTS - 1;
+    for (int it = 0; it < iters; ++it) {
+        const int younger = issued - it - 1;
+        if (SLOTS >= 4 && younger >= 2) x3_wait_vmcnt<(SLOTS >= 4 ? 2 : 0) * PPW>();
+        else if (SLOTS >= 3 && younger >= 1) x3_wait_vmcnt<(SLOTS >= 3 ? 1 : 0) * PPW>();
+        else x3_wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (issued < iters) {
+            issue(fill);
+            ++issued;
+        }
+        const char* sl = x3_smem + cur * SLOT_BYTES + lane16;
+#pragma unroll
+        for (int kcs = 0; kcs < KCS; ++kcs) {
+            const char* a_l = sl + (kcs * (PA + PB) + wm * MI * 3) * 1024;
+            const char* b_l = sl + (kcs * (PA + PB) + PA + wn * NI * 3) * 1024;
+            x3_bf16x8 b[NI][3];
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) b[j][p] = *reinterpret_cast<const x3_bf16x8*>(b_l + (j * 3 + p) * 1024);
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                x3_bf16x8 a[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) a[p] = *reinterpret_cast<const x3_bf16x8*>(a_l + (i * 3 + p) * 1024);
+                // smallest products first
+#pragma unroll
+                for (int j = 0; j < NI; ++j) x3_mfma<SHAPE>(a[2], b[j][0], acc[i][j]);
+#pragma unroll
+                for (int j = 0; j < NI; ++j) x3_mfma<SHAPE>(a[1], b[j][1], acc[i][j]);
+#pragma unroll
+                for (int j = 0; j < NI; ++j) x3_mfma<SHAPE>(a[0], b[j][2], acc[i][j]);
+#pragma unroll
+                for (int j = 0; j < NI; ++j) x3_mfma<SHAPE>(a[1], b[j][0], acc[i][j]);
+#pragma unroll
+                for (int j = 0; j < NI; ++j) x3_mfma<SHAPE>(a[0], b[j][1], acc[i][j]);
+#pragma unroll
+                for (int j = 0; j < NI; ++j) x3_mfma<SHAPE>(a[0], b[j][0], acc[i][j]);
+            }
+        }
+        cur = (cur + 1 == SLOTS) ? 0 : cur + 1;
+        fill = (fill + 1 == SLOTS) ? 0 : fill + 1;
+    }
+    // the ring is reused by the caller only after every wave is past its last read (one block does one tile)
+
+    // ---- epilogue ----
+    const int M = args.M, N = args.N;
+    const int row_w = row0 + wm * WM, col_w = col0 + wn * WN;
+    const bool raw = args.splitk > 1;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int col = col_w + j * RB + (lane % RB);
+        if (col >= N) continue;
+        const int gj = raw ? 0 : col / args.gn;
+        const int cin = raw ? col : col - gj * args.gn;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+#pragma unroll
+            for (int r = 0; r < S::ACC; ++r) {
+                const int row = row_w + i * RB + (SHAPE == 32 ? (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) : 4 * (lane >> 4) + r);
+                if (row >= M) continue;
+                if (raw) {
+                    args.part[((long)ks * M + row) * N + col] = acc[i][j][r];
+                } else {
+                    const int gi = row / args.gm;
+                    const int g = gi * args.ngn + gj;
+                    float* o = args.C[g] + (long)(row - gi * args.gm) * args.ldc + cin;
+                    float v = acc[i][j][r];
+                    if (args.bias[g]) v += args.bias[g][cin];
+                    if (args.accumulate) v += *o;
+                    *o = v;
+                }
+            }
+        }
+    }
+}
+
+// grid.x: main_tiles whole tiles (blocks that share an XCD, id % 8, take consecutive tiles, tn fastest: the 16 column
+// tiles of a row panel run side by side on one XCD and share the panel through its L2), then 4 quarter-tile blocks per
+// remaining tile: the last, partly filled round of a long launch is spread over four times as many CUs.  grid.z: K slices.
+template <int SHAPE, int BM, int BN, int WGM, int WGN, int KCS, int SLOTS>
+__global__ __launch_bounds__(64 * WGM * WGN) void x3_gemm_k(const X3Args args) {
+    int per = (args.nkc / KCS + args.splitk - 1) / args.splitk;   // host: nkc % KCS == 0
+    const int ks = blockIdx.z;
+    const int kc0 = ks * per * KCS;
+    per = min(per, args.nkc / KCS - ks * per);
+    if ((int)blockIdx.x < args.main_tiles) {
+        int wg = blockIdx.x;
+        const int q = args.main_tiles / 8, r = args.main_tiles % 8, xcd = wg % 8;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + wg / 8;
+        const int tm = wg / args.tiles_n, tn = wg % args.tiles_n;
+        x3_tile<SHAPE, BM, BN, WGM, WGN, KCS, SLOTS>(args, tm * BM, tn * BN, kc0, per, ks);
+    } else {
+        const int t = blockIdx.x - args.main_tiles;
+        const int wg = args.main_tiles + t / 4, qd = t % 4;
+        const int tm = wg / args.tiles_n, tn = wg % args.tiles_n;
+        x3_tile<SHAPE, BM / 2, BN / 2, WGM, WGN, KCS, SLOTS>(args, tm * BM + (qd >> 1) * (BM / 2), tn * BN + (qd & 1) * (BN / 2),
+                                                             kc0, per, ks);
+    }
+}
+
+// out = sum over the K slices in a fixed order (+ bias) (+ previous C)
+__global__ __launch_bounds__(256) void x3_reduce_k(const X3Args args) {
+    const long n4 = (long)args.M * args.N / 4;   // host: N % 4 == 0, gn % 4 == 0
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        x3_f32x4 s = reinterpret_cast<const x3_f32x4*>(args.part)[i];
+        for (int k = 1; k < args.splitk; ++k) {
+            const x3_f32x4 t = reinterpret_cast<const x3_f32x4*>(args.part + (long)k * args.M * args.N)[i];
+            s += t;
+        }
+        const long e = i * 4;
+        const int row = (int)(e / args.N), col = (int)(e % args.N);
+        const int gi = row / args.gm, gj = col / args.gn, g = gi * args.ngn + gj;
+        const int cin = col - gj * args.gn;
+        float* o = args.C[g] + (long)(row - gi * args.gm) * args.ldc + cin;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float v = s[c];
+            if (args.bias[g]) v += args.bias[g][cin + c];
+            if (args.accumulate) v += o[c];
+            o[c] = v;
+        }
+    }
+}
+
+#ifndef X3_BM
+#define X3_BM 256
+#endif
+#ifndef X3_BN
+#define X3_BN 256
+#endif
+#ifndef X3_WGM
+#define X3_WGM 4
+#endif
+#ifndef X3_WGN
+#define X3_WGN 2
+#endif
+#ifndef X3_KCS
+#define X3_KCS 1
+#endif
+#ifndef X3_SLOTS
+#define X3_SLOTS 2
+#endif
+#ifndef X3_TAIL
+#define X3_TAIL 1   /* quarter tiles for a last round that is at most a quarter full */
+#endif
+
+extern "C" size_t rfn_x3_part_floats(int M, int N, int splitk) { return splitk > 1 ? (size_t)splitk * M * N : 0; }
+
+// how many K slices a launch of this shape should take so that one round of blocks covers the chip (1 for long launches)
+extern "C" int rfn_x3_splitk_for(int M, int N, int K) {
+    using S = X3Shape<X3_SHAPE>;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const long tiles = (long)((M + X3_BM - 1) / X3_BM) * ((N + X3_BN - 1) / X3_BN);
+    if (tiles >= cus) return 1;
+    const int iters = (int)(x3_k_pad(K) / S::KC / X3_KCS);
+    int sk = (int)((cus + tiles / 2) / tiles);
+    while (sk > 1 && iters / sk < 64) --sk;   // keep slices long enough to amortise the pipeline fill and the reduce
+    return sk < 1 ? 1 : sk;
+}
+
+// C groups (+)= A . B^T on plane images.  M, N: logical output size; K: logical reduction length (the images hold it
+// padded).  Output groups of gm rows x gn columns, pointer table C_host[(m / gm) * ngn + n / gn] (device pointers, host
+// array), leading dimension ldc; bias_host may be NULL.  splitk > 1 needs part (splitk * M * N floats).
+extern "C" int rfn_x3_gemm(int M, int N, int K, const void* imgA, const void* imgB, int gm, int gn, float* const* C_host,
+                           const float* const* bias_host, int64_t ldc, int accumulate, int splitk, float* part, void* stream) {
+    using S = X3Shape<X3_SHAPE>;
+    if (M < 1 || N < 1 || K < 1 || !imgA || !imgB || !C_host || gm < 1 || gn < 1) return RFN_ERR_ARG;
+    X3Args a;
+    a.A = (const char*)imgA;
+    a.B = (const char*)imgB;
+    a.nrbA = (int)(x3_rows_pad(M) / S::RB);
+    a.nrbB = (int)(x3_rows_pad(N) / S::RB);
+    a.M = M;
+    a.N = N;
+    a.nkc = (int)(x3_k_pad(K) / S::KC);
+    a.splitk = splitk < 1 ? 1 : splitk;
+    a.part = part;
+    a.gm = gm;
+    a.gn = gn;
+    const int ngm = (M + gm - 1) / gm;
+    a.ngn = (N + gn - 1) / gn;
+    if ((long)ngm * a.ngn > X3_MAX_GROUPS) return RFN_ERR_SHAPE;
+    if ((ngm > 1 && gm % (X3_BM / 2)) || (a.ngn > 1 && gn % (X3_BN / 2))) return RFN_ERR_SHAPE;   // no tile straddles groups
+    if ((ngm > 1 && gm % X3_BM) || (a.ngn > 1 && gn % X3_BN)) return RFN_ERR_SHAPE;
+    if (a.nkc % X3_KCS || a.splitk > a.nkc / X3_KCS) return RFN_ERR_SHAPE;
+    if (a.splitk > 1 && (!part || (N & 3) || (gn & 3))) return RFN_ERR_ARG;
+    a.ldc = ldc;
+    a.accumulate = accumulate;
+    a.tiles_m = (M + X3_BM - 1) / X3_BM;
+    a.tiles_n = (N + X3_BN - 1) / X3_BN;
+    for (int g = 0; g < ngm * a.ngn; ++g) {
+        a.C[g] = C_host[g];
+        a.bias[g] = bias_host ? bias_host[g] : nullptr;
+    }
+    auto kern = x3_gemm_k<X3_SHAPE, X3_BM, X3_BN, X3_WGM, X3_WGN, X3_KCS, X3_SLOTS>;
+    constexpr int lds = X3_SLOTS * X3_KCS * ((X3_BM + X3_BN) / S::RB) * 3 * 1024;
+    static bool attr_set[16] = {};   // write-once per device
+    static int cus[16] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return RFN_ERR_LAUNCH;
+    if (!attr_set[dev & 15]) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+            return RFN_ERR_LAUNCH;
+        int v = 256;
+        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
+        cus[dev & 15] = v;
+        attr_set[dev & 15] = true;
+    }
+    const int tiles = a.tiles_m * a.tiles_n, slots = cus[dev & 15];
+    const int rem = tiles % slots;
+    const bool tail = X3_TAIL && a.splitk == 1 && tiles / slots >= 2 && rem > 0 && 4 * rem <= slots;
+    a.main_tiles = tail ? tiles - rem : tiles;
+    hipLaunchKernelGGL(kern, dim3(a.main_tiles + 4 * (tiles - a.main_tiles), 1, a.splitk), dim3(64 * X3_WGM * X3_WGN), lds,
+                       (hipStream_t)stream, a);
+    RFN_CHECK_LAUNCH();
+    if (a.splitk > 1) {
+        hipLaunchKernelGGL(x3_reduce_k, dim3(1024), dim3(256), 0, (hipStream_t)stream, a);
+        RFN_CHECK_LAUNCH();
+    }
+    return RFN_OK;
+}

@@ -228,8 +228,32 @@ struct PrefixLayout {
     size_t Hs, Cs, hp1, g1, rmat, rarg, h2, c2, hp2, al2, z2, g2;
     size_t dHs, dC, dal, dwp, dhp1, dh2e, dhrec, dc2, dz2, dhp2;
     size_t gws;
+    size_t x3;      // plane images + split-K partials of the bf16-plane GEMMs (RFN_GEMM_OPT_BF16X3), 0 floats otherwise
     size_t total;
 };
+// Does encoder i's hoisted projection (and its weight gradient) take the bf16-plane GEMM?  Only when asked for
+// (RFN_GEMM_OPT_BF16X3), when the per-step output groups are whole 256-wide tiles and when the product is long enough to
+// pay for the two split passes; everything else stays on the exact-f32 kernels.
+static bool x3_takes(const rfn_dims* d, int B, int i) {
+    if (!(d->gemm_flags & RFN_GEMM_OPT_BF16X3)) return false;
+    if (d->A % 256 || d->D[i] % 4 || d->T1 > 64) return false;
+    return 2.0 * B * d->L[i] * d->D[i] * d->A * d->T1 >= 2e10;
+}
+static size_t x3_scratch_floats(const rfn_dims* d, int B, int train) {
+    size_t most = 0;
+    for (int i = 0; i < d->M; ++i) {
+        if (!x3_takes(d, B, i)) continue;
+        const int BL = B * d->L[i], TA = d->T1 * d->A, Di = d->D[i];
+        size_t fwd = rfn_x3_image_bytes(BL, Di) + rfn_x3_image_bytes(TA, Di);
+        size_t bwd = 0;
+        if (train)
+            bwd = rfn_x3_image_bytes(Di, BL) + rfn_x3_image_bytes(TA, BL) +
+                  4 * rfn_x3_part_floats(TA, Di, rfn_x3_splitk_for(TA, Di, BL));
+        const size_t need = (fwd > bwd ? fwd : bwd) / 4 + 256;
+        if (need > most) most = need;
+    }
+    return most;
+}
 PrefixLayout prefix_layout(const rfn_dims* d, int B, int train) {
     const size_t G2 = (size_t)gate_width(d->review_maxout, d->R);
     PrefixLayout L;
@@ -257,6 +281,7 @@ PrefixLayout prefix_layout(const rfn_dims* d, int B, int train) {
     L.z2 = b.take(T2 * M * Bz * R);
     L.g2 = b.take(T2 * Bz * G2);
     L.gws = b.take(GEMM_WS_FLOATS);
+    L.x3 = b.take(x3_scratch_floats(d, B, train));
     if (train) {
         for (int i = 0; i < d->M; ++i) L.dz1[i] = b.take(Bz * d->D[i]);
         L.dHs = b.take((T1 + 1) * Bz * M * R);
@@ -489,6 +514,25 @@ static int prefix_fwd_impl(const rfn_dims* d, int B, const float* const* prm, co
     rfn_gemm_problem pr[64];
     for (int i = 0; i < M; ++i) {
         if (T1 > 64) return RFN_ERR_SHAPE;
+        if (x3_takes(d, B, i)) {
+            // bf16-plane GEMM: the features and the T1 stacked step weights as plane images, one launch for all steps
+            const int BL = B * d->L[i], Di = d->D[i];
+            char* imgX = (char*)(W + Lo.x3);
+            char* imgW = imgX + rfn_x3_image_bytes(BL, Di);
+            const float* srcs[64];
+            float* outs[64];
+            const float* bias[64];
+            srcs[0] = att[i];
+            RFN_TRY(rfn_x3_split(srcs, 1, Di, BL, Di, 1, imgX, st));
+            for (int t = 0; t < T1; ++t) {
+                srcs[t] = prm[P.s1(t, i, 0)];
+                outs[t] = W + Lo.P1[i] + (long)t * BL * A;
+                bias[t] = prm[P.s1(t, i, 1)];
+            }
+            RFN_TRY(rfn_x3_split(srcs, T1, Di, A, Di, 1, imgW, st));
+            RFN_TRY(rfn_x3_gemm(BL, T1 * A, Di, imgX, imgW, BL, A, outs, bias, A, 0, 1, nullptr, st));
+            continue;
+        }
         for (int t = 0; t < T1; ++t)
             pr[t] = prob1(W + Lo.P1[i] + (long)t * B * d->L[i] * A, A,
                           seg_lin(att[i], d->D[i], prm[P.s1(t, i, 0)], d->D[i], d->D[i], prm[P.s1(t, i, 1)]));
@@ -885,12 +929,32 @@ extern "C" int rfn_prefix_bwd_wgrad(const rfn_dims* d, int B, const float* const
     // att_2_att_h.bias and h_2_att_h.bias enter the same pre-activation (AttentionModelCore.py:36-38), so their
     // gradients are the same vector: it is produced once in part A and copied; the long att_2_att_h GEMM carries no
     // bias-gradient rider.
-    if (parts & 2) {  // part B: the dominant att_2_att_h gradient (small bucket, long GEMM)
+    auto part_b = [&]() -> int {   // the dominant att_2_att_h gradient (small bucket, long GEMM)
+        if (x3_takes(d, B, i)) {
+            // bf16-plane GEMM: dW[t] = dP1[t]^T . att as (T1*A x B*L) . (D x B*L)^T; both operands are k-slow in memory, so
+            // the split passes transpose them into the images
+            const int BL = (int)(B * Li), TA = T1 * A;
+            char* imgXT = (char*)(W + Lo.x3);
+            char* imgPT = imgXT + rfn_x3_image_bytes((int)Di, BL);
+            float* part = (float*)(imgPT + rfn_x3_image_bytes(TA, BL));
+            const int sk = rfn_x3_splitk_for(TA, (int)Di, BL);
+            const float* srcs[64];
+            float* outs[64];
+            srcs[0] = att[i];
+            RFN_TRY(rfn_x3_split(srcs, 1, Di, (int)Di, BL, 0, imgXT, st));
+            for (int t = 0; t < T1; ++t) {
+                srcs[t] = W + Lo.P1[i] + (long)t * BL * A;
+                outs[t] = grd[P.s1(t, i, 0)];
+            }
+            RFN_TRY(rfn_x3_split(srcs, T1, A, A, BL, 0, imgPT, st));
+            return rfn_x3_gemm(TA, (int)Di, BL, imgPT, imgXT, A, (int)Di, outs, nullptr, Di, 0, sk, part, st);
+        }
         for (int t = 0; t < T1; ++t)
             pr[t] = prob_dw(grd[P.s1(t, i, 0)], Di, nullptr, W + Lo.P1[i] + (long)t * B * Li * A, A, att[i], Di,
                             (int)(B * Li));
-        if (!(parts & 1)) return gemm_groups_split_cols(A, (int)Di, T1, pr, 0, gx);
-    }
+        return gemm_groups_split_cols(A, (int)Di, T1, pr, 0, gx);
+    };
+    if ((parts & 2) && !(parts & 1)) return part_b();
     // part A: H2h, z2h, h_2_att_h (large bucket, short GEMMs: K = B rows per step).  Their bias gradients are column
     // sums of tensors that are tiny next to the weight gradients (dgates: T1*B*4R floats per encoder), so they come from
     // one grouped column-sum launch each instead of riding on the GEMMs -- which keeps the two big products
@@ -926,12 +990,7 @@ extern "C" int rfn_prefix_bwd_wgrad(const rfn_dims* d, int B, const float* const
         }
         RFN_TRY(rfn_copy_small_f32(cdst, csrc, T1, A, st));
     }
-    if (parts & 2) {
-        for (int t = 0; t < T1; ++t)
-            pr[t] = prob_dw(grd[P.s1(t, i, 0)], Di, nullptr, W + Lo.P1[i] + (long)t * B * Li * A, A, att[i], Di,
-                            (int)(B * Li));
-        RFN_TRY(gemm_groups_split_cols(A, (int)Di, T1, pr, 0, gx));
-    }
+    if (parts & 2) RFN_TRY(part_b());
     return RFN_OK;
 }
 

@@ -1,0 +1,153 @@
+"""The f32 GEMM on the bf16 matrix cores (csrc/rfn_gemm_x3.hip, RFN_GEMM_OPT_BF16X3): the plane images are an exact
+three-way split in the documented layout, and the six-product GEMM is as close to an f64 product as an f32 product is.
+Tolerances are relative to sum_k |a||b| (the scale of an f32 dot product's forward error): 2^-24 is one rounding."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+U = 2.0 ** -24
+
+
+def _decode(img, rows, K):
+    """image (uint8) -> three f32 planes [3][rows_pad][K_pad], following include/rfn.h's layout."""
+    rows_pad, k_pad = (rows + 255) // 256 * 256, (K + 31) // 32 * 32
+    nrb, nkc = rows_pad // 32, k_pad // 16
+    assert img.numel() == rows_pad * k_pad * 6
+    w = img.view(torch.int16).view(nkc, nrb, 3, 2, 32, 8)            # [kc][rb][plane][l / 32][l % 32][j]
+    f = (w.to(torch.int32) << 16).view(torch.float32)
+    return f.permute(2, 1, 4, 0, 3, 5).reshape(3, rows_pad, k_pad)   # [plane][rb, l % 32][kc, l / 32, j]
+
+
+@pytest.mark.parametrize('k_fast', [True, False])
+def test_plane_images_are_an_exact_split(dev, k_fast):
+    import recurrent_fusion_network_amd._native as N
+    g = torch.Generator(device='cpu').manual_seed(3)
+    rows, K = 77, 45                      # ragged: neither a multiple of 32 / 16
+    x = torch.randn(rows, K, generator=g) * torch.exp(4 * torch.randn(rows, K, generator=g))
+    x[0, 0], x[1, 1], x[2, 2], x[3, 3] = 0.0, 1e-30, -3.0e38, 1.0 + 2.0 ** -23
+    x[4, 4], x[5, 5] = 2.0 ** -100 * (1 + 2.0 ** -23), -(2.0 ** -127)    # low planes / the value itself denormal in bf16
+    x[6, 6] = 3.4e38                                                    # rounds past the largest bf16: truncated plane
+    src = x.to(dev) if k_fast else x.t().contiguous().to(dev)
+    img = N.x3_image([src], rows, K, k_fast=k_fast)
+    pl = _decode(img, rows, K).cpu()
+    s = (pl[2].double() + pl[1].double() + pl[0].double())
+    assert torch.equal(s[:rows, :K].float(), x), 'x0 + x1 + x2 must reproduce every finite f32 exactly'
+    assert torch.equal(s[:rows, :K], x.double())
+    assert float(s[rows:].abs().max()) == 0.0 and float(s[:, K:].abs().max()) == 0.0       # zero padding
+    # plane magnitudes fall by 2^-8 each (round to nearest): |x1| <= 2^-7 |x0|, |x2| <= 2^-15 |x0| (2^-9, 2^-17 unless x0 was truncated)
+    a0 = pl[0][:rows, :K].abs().double()
+    assert bool((pl[1][:rows, :K].abs().double() <= a0 * 2.0 ** -7 + 1e-300).all())
+    assert bool((pl[2][:rows, :K].abs().double() <= a0 * 2.0 ** -15 + 1e-300).all())
+
+
+def test_plane_image_of_row_groups_and_non_finite_values(dev):
+    import recurrent_fusion_network_amd._native as N
+    g = torch.Generator(device='cpu').manual_seed(4)
+    mats = [torch.randn(64, 40, generator=g) for _ in range(3)]
+    img = N.x3_image([m.to(dev) for m in mats], 64, 40)
+    pl = _decode(img, 192, 40).cpu()
+    s = pl.double().sum(0)
+    assert torch.equal(s[:192, :40].float(), torch.cat(mats, 0))
+    assert float(s[192:].abs().max()) == 0.0
+    bad = torch.tensor([[float('inf'), float('-inf'), float('nan'), 1.0]] * 32).to(dev)
+    pl = _decode(N.x3_image([bad], 32, 4), 32, 4).cpu()
+    assert bool(torch.isinf(pl[0][0, 0])) and bool(torch.isinf(pl[0][0, 1])) and bool(torch.isnan(pl[0][0, 2]))
+    assert float(pl[1][:, :2].abs().max()) == 0.0 and float(pl[2][:, :3].abs().max()) == 0.0   # no inf - inf = nan planes
+
+
+def _check(dev, M, N_, K, gm=None, gn=None, bias=False, accumulate=False, splitk=1, seed=0, wide=False):
+    import recurrent_fusion_network_amd._native as N
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    a = torch.randn(M, K, generator=g)
+    b = torch.randn(N_, K, generator=g)
+    if wide:
+        a = a * torch.exp(3 * torch.randn(M, K, generator=g))
+        b = b * torch.exp(3 * torch.randn(N_, K, generator=g))
+    a, b = a.to(dev), b.to(dev)
+    gm_, gn_ = gm or M, gn or N_
+    ngm, ngn = -(-M // gm_), -(-N_ // gn_)
+    outs = [torch.randn(min(gm_, M), min(gn_, N_), generator=g).to(dev) for _ in range(ngm * ngn)]
+    prev = [o.clone() for o in outs]
+    biases = [torch.randn(min(gn_, N_), generator=g).to(dev) for _ in range(ngm * ngn)] if bias else None
+    ia, ib = N.x3_image([a], M, K), N.x3_image([b], N_, K)
+    N.x3_gemm(M, N_, K, ia, ib, outs, gm=gm_, gn=gn_, ldc=min(gn_, N_), bias=biases, accumulate=accumulate, splitk=splitk)
+    ref = a.double() @ b.double().t()
+    mag = a.double().abs() @ b.double().abs().t()
+    f32 = (a @ b.t()).double()                  # an f32 library product of the same operands, for scale
+    worst = 0.0
+    for i in range(ngm):
+        for j in range(ngn):
+            k = i * ngn + j
+            r = ref[i * gm_:(i + 1) * gm_, j * gn_:(j + 1) * gn_]
+            want = r + (biases[k].double() if bias else 0) + (prev[k].double() if accumulate else 0)
+            err = (outs[k].double() - want).abs() / (mag[i * gm_:(i + 1) * gm_, j * gn_:(j + 1) * gn_] + 1e-30)
+            worst = max(worst, float(err.max()))
+    f32_worst = float(((f32 - ref).abs() / (mag + 1e-30)).max())
+    return worst, f32_worst
+
+
+@pytest.mark.parametrize('shape', [(300, 520, 70), (256, 256, 16), (1, 1, 1), (513, 257, 1000), (40, 2300, 333)])
+def test_gemm_ragged_shapes_against_f64(dev, shape):
+    worst, f32_worst = _check(dev, *shape, seed=sum(shape))
+    assert worst <= 6 * U, (worst / U, f32_worst / U)
+
+
+def test_gemm_output_groups_bias_accumulate(dev):
+    # projection-style: one row group, three column groups of 256 with their own bias vectors
+    assert _check(dev, 700, 768, 200, gn=256, bias=True, seed=1)[0] <= 8 * U
+    # weight-gradient-style: row groups of 256, one column group, accumulated onto the previous contents
+    assert _check(dev, 512, 300, 4000, gm=256, accumulate=True, seed=2)[0] <= 8 * U
+    # both at once
+    assert _check(dev, 512, 512, 64, gm=256, gn=256, bias=True, accumulate=True, seed=3)[0] <= 8 * U
+
+
+@pytest.mark.parametrize('splitk', [2, 3, 7])
+def test_gemm_split_k_is_deterministic_and_accurate(dev, splitk):
+    import recurrent_fusion_network_amd._native as N
+    worst, _ = _check(dev, 512, 260, 5000, gm=256, splitk=splitk, seed=5, bias=True)    # 313 pieces of K: uneven slices
+    assert worst <= 6 * U
+    g = torch.Generator(device='cpu').manual_seed(9)
+    a, b = torch.randn(256, 3000, generator=g).to(dev), torch.randn(256, 3000, generator=g).to(dev)
+    ia, ib = N.x3_image([a], 256, 3000), N.x3_image([b], 256, 3000)
+    o1, o2 = torch.empty(256, 256, device=dev), torch.empty(256, 256, device=dev)
+    N.x3_gemm(256, 256, 3000, ia, ib, [o1], splitk=splitk)
+    N.x3_gemm(256, 256, 3000, ia, ib, [o2], splitk=splitk)
+    assert torch.equal(o1, o2)
+
+
+def test_gemm_wide_range_operands_no_worse_than_an_f32_product(dev):
+    worst, f32_worst = _check(dev, 256, 256, 2048, seed=11, wide=True)
+    assert worst <= max(2.0 * f32_worst, 8 * U), (worst / U, f32_worst / U)
+
+
+def test_gemm_tail_round_of_quarter_tiles(dev):
+    """More tiles than two rounds of the chip with a last round at most a quarter full: the remaining tiles are done as
+    four quarter tiles each (csrc/rfn_gemm_x3.hip: main_tiles).  Row independence: the same rows through a short launch
+    (no tail) give the same bits."""
+    import recurrent_fusion_network_amd._native as N
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    tiles_n = 16
+    tiles_m = (2 * cus + 16) // tiles_n + (1 if (2 * cus + 16) % tiles_n else 0)
+    M, N_, K = tiles_m * 256 - 100, tiles_n * 256, 48
+    g = torch.Generator(device='cpu').manual_seed(13)
+    a, b = torch.randn(M, K, generator=g).to(dev), torch.randn(N_, K, generator=g).to(dev)
+    ia, ib = N.x3_image([a], M, K), N.x3_image([b], N_, K)
+    out = torch.empty(M, N_, device=dev)
+    N.x3_gemm(M, N_, K, ia, ib, [out])
+    ref = a.double() @ b.double().t()
+    mag = a.double().abs() @ b.double().abs().t()
+    assert float(((out.double() - ref).abs() / mag).max()) <= 16 * U     # the max over 3.4e7 outputs of a short (K = 48) product
+    last = a[M - 300:].contiguous()
+    out2 = torch.empty(300, N_, device=dev)
+    N.x3_gemm(300, N_, K, N.x3_image([last], 300, K), ib, [out2])
+    assert torch.equal(out2, out[M - 300:])
+
+
+def test_gemm_rejects_groups_that_straddle_tiles(dev):
+    import recurrent_fusion_network_amd._native as N
+    a = torch.randn(256, 32, device=dev)
+    ia = N.x3_image([a], 256, 32)
+    outs = [torch.empty(256, 100, device=dev) for _ in range(3)]
+    with pytest.raises(N.RfnError):
+        N.x3_gemm(256, 256, 32, ia, ia, outs, gn=100)
