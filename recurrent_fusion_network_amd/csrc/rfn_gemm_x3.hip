@@ -317,33 +317,84 @@ __device__ __forceinline__ void x3_tile(const X3Args& args, const int row0, cons
         cur = (cur + 1 == SLOTS) ? 0 : cur + 1;
         fill = (fill + 1 == SLOTS) ? 0 : fill + 1;
     }
-    // the ring is reused by the caller only after every wave is past its last read (one block does one tile)
+    __builtin_amdgcn_s_barrier();   // every wave is past its last fragment read: the ring's LDS is free for the epilogue
 
     // ---- epilogue ----
+#ifdef X3_ABLATE_STORE   /* diagnostic builds only: keep the accumulators alive, store nothing */
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) asm volatile("" ::"v"(acc[i][j]));
+    return;
+#endif
+    // One wave tile lies inside one output group (the host checks gm % BM == gn % BN == 0), so the group, its base pointer
+    // and its bias row are wave-uniform: addresses are that base (SGPR pair) + a 32-bit lane offset, and a wave tile that
+    // lies wholly inside M x N stores without per-element checks.
     const int M = args.M, N = args.N;
     const int row_w = row0 + wm * WM, col_w = col0 + wn * WN;
+    if (row_w >= M || col_w >= N) return;
     const bool raw = args.splitk > 1;
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-        const int col = col_w + j * RB + (lane % RB);
-        if (col >= N) continue;
-        const int gj = raw ? 0 : col / args.gn;
-        const int cin = raw ? col : col - gj * args.gn;
+    char* cbase;
+    const float* bias_w = nullptr;
+    unsigned ld4;
+    if (raw) {
+        cbase = (char*)(args.part + ((long)ks * M + row_w) * N + col_w);
+        ld4 = (unsigned)N * 4u;
+    } else {
+        const int gi = row_w / args.gm, gj = col_w / args.gn, g = gi * args.ngn + gj;
+        cbase = (char*)(args.C[g] + (long)(row_w - gi * args.gm) * args.ldc + (col_w - gj * args.gn));
+        if (args.bias[g]) bias_w = args.bias[g] + (col_w - gj * args.gn);
+        ld4 = (unsigned)args.ldc * 4u;
+    }
+    const int lr = lane % RB;                                      // column inside an MFMA tile
+    const int lrow = SHAPE == 32 ? 4 * (lane >> 5) : 4 * (lane >> 4);   // first row of this lane's register group
+    const unsigned lane_off = (unsigned)lrow * ld4 + (unsigned)lr * 4u;
+    const bool accumulate = !raw && args.accumulate;
+    const bool full = row_w + WM <= M && col_w + WN <= N;
+    if (full && !accumulate && ((((uintptr_t)cbase) | ld4) & 15u) == 0) {
+        // whole wave tile, plain store: RB rows at a time go through this wave's corner of the (now free) LDS so that the
+        // global stores are 16 B per lane, whole rows of the wave tile per instruction -- a quarter of the store
+        // instructions of the register layout (4 B per lane), which is what the epilogue is bound by at one block per CU
+        constexpr int EPW = WN + 4;                 // padded row, floats
+        constexpr int LPR = WN / 4, RPI = 64 / LPR;  // lanes per row, rows per store instruction
+        float* ep = reinterpret_cast<float*>(x3_smem) + wave * (RB * EPW);
+        const int erow = lane / LPR, ecol = 4 * (lane % LPR);
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
 #pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const float bsum = bias_w ? bias_w[j * RB + lr] : 0.f;
+#pragma unroll
+                for (int r = 0; r < S::ACC; ++r) {
+                    const int rr = SHAPE == 32 ? (r & 3) + 8 * (r >> 2) : r;
+                    ep[(lrow + rr) * EPW + j * RB + lr] = acc[i][j][r] + bsum;
+                }
+            }
+            asm volatile("" ::: "memory");   // LDS operations of one wave execute in order: the reads below see the writes
+#pragma unroll
+            for (int it = 0; it < RB / RPI; ++it) {
+                const int row = it * RPI + erow;
+                const x3_f32x4 v = *reinterpret_cast<const x3_f32x4*>(ep + row * EPW + ecol);
+                *reinterpret_cast<x3_f32x4*>(cbase + ((unsigned)(i * RB + row) * ld4 + (unsigned)ecol * 4u)) = v;
+            }
+            asm volatile("" ::: "memory");
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const bool col_ok = full || col_w + j * RB + lr < N;
+        const float bsum = (bias_w && col_ok) ? bias_w[j * RB + lr] : 0.f;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const unsigned sub = lane_off + (unsigned)(i * RB) * ld4 + (unsigned)(j * RB) * 4u;
+#pragma unroll
             for (int r = 0; r < S::ACC; ++r) {
-                const int row = row_w + i * RB + (SHAPE == 32 ? (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) : 4 * (lane >> 4) + r);
-                if (row >= M) continue;
-                if (raw) {
-                    args.part[((long)ks * M + row) * N + col] = acc[i][j][r];
-                } else {
-                    const int gi = row / args.gm;
-                    const int g = gi * args.ngn + gj;
-                    float* o = args.C[g] + (long)(row - gi * args.gm) * args.ldc + cin;
-                    float v = acc[i][j][r];
-                    if (args.bias[g]) v += args.bias[g][cin];
-                    if (args.accumulate) v += *o;
+                const int rr = SHAPE == 32 ? (r & 3) + 8 * (r >> 2) : r;   // row inside the MFMA tile, less lrow
+                float* o = reinterpret_cast<float*>(cbase + (sub + (unsigned)rr * ld4));
+                if (full || (col_ok && row_w + i * RB + lrow + rr < M)) {
+                    float v = acc[i][j][r] + bsum;
+                    if (accumulate) v += *o;
                     *o = v;
                 }
             }
@@ -354,7 +405,7 @@ __device__ __forceinline__ void x3_tile(const X3Args& args, const int row0, cons
 // grid.x: main_tiles whole tiles (blocks that share an XCD, id % 8, take consecutive tiles, tn fastest: the 16 column
 // tiles of a row panel run side by side on one XCD and share the panel through its L2), then 4 quarter-tile blocks per
 // remaining tile: the last, partly filled round of a long launch is spread over four times as many CUs.  grid.z: K slices.
-template <int SHAPE, int BM, int BN, int WGM, int WGN, int KCS, int SLOTS>
+template <int SHAPE, int BM, int BN, int WGM, int WGN, int KCS, int SLOTS, bool TAIL>
 __global__ __launch_bounds__(64 * WGM * WGN) void x3_gemm_k(const X3Args args) {
     int per = (args.nkc / KCS + args.splitk - 1) / args.splitk;   // host: nkc % KCS == 0
     const int ks = blockIdx.z;
@@ -366,7 +417,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void x3_gemm_k(const X3Args args) {
         wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + wg / 8;
         const int tm = wg / args.tiles_n, tn = wg % args.tiles_n;
         x3_tile<SHAPE, BM, BN, WGM, WGN, KCS, SLOTS>(args, tm * BM, tn * BN, kc0, per, ks);
-    } else {
+    } else if constexpr (TAIL) {
         const int t = blockIdx.x - args.main_tiles;
         const int wg = args.main_tiles + t / 4, qd = t % 4;
         const int tm = wg / args.tiles_n, tn = wg % args.tiles_n;
@@ -417,6 +468,9 @@ __global__ __launch_bounds__(256) void x3_reduce_k(const X3Args args) {
 #ifndef X3_SLOTS
 #define X3_SLOTS 2
 #endif
+#ifndef X3_BLOCKS_PER_CU
+#define X3_BLOCKS_PER_CU 1   /* resident blocks per CU of the chosen tile (LDS-bound); sizes the tail round */
+#endif
 #ifndef X3_TAIL
 #define X3_TAIL 1   /* quarter tiles for a last round that is at most a quarter full */
 #endif
@@ -462,6 +516,7 @@ extern "C" int rfn_x3_gemm(int M, int N, int K, const void* imgA, const void* im
     if ((ngm > 1 && gm % X3_BM) || (a.ngn > 1 && gn % X3_BN)) return RFN_ERR_SHAPE;
     if (a.nkc % X3_KCS || a.splitk > a.nkc / X3_KCS) return RFN_ERR_SHAPE;
     if (a.splitk > 1 && (!part || (N & 3) || (gn & 3))) return RFN_ERR_ARG;
+    if ((double)X3_BM * (double)(a.splitk > 1 ? N : ldc) * 4.0 >= 4294967296.0) return RFN_ERR_SHAPE;   // 32-bit tile offsets
     a.ldc = ldc;
     a.accumulate = accumulate;
     a.tiles_m = (M + X3_BM - 1) / X3_BM;
@@ -470,8 +525,10 @@ extern "C" int rfn_x3_gemm(int M, int N, int K, const void* imgA, const void* im
         a.C[g] = C_host[g];
         a.bias[g] = bias_host ? bias_host[g] : nullptr;
     }
-    auto kern = x3_gemm_k<X3_SHAPE, X3_BM, X3_BN, X3_WGM, X3_WGN, X3_KCS, X3_SLOTS>;
-    constexpr int lds = X3_SLOTS * X3_KCS * ((X3_BM + X3_BN) / S::RB) * 3 * 1024;
+    auto kern = x3_gemm_k<X3_SHAPE, X3_BM, X3_BN, X3_WGM, X3_WGN, X3_KCS, X3_SLOTS, (X3_TAIL != 0)>;
+    constexpr int ring = X3_SLOTS * X3_KCS * ((X3_BM + X3_BN) / S::RB) * 3 * 1024;
+    constexpr int epi = X3_WGM * X3_WGN * S::RB * (X3_BN / X3_WGN + 4) * 4;   // the epilogue's staging rows (x3_tile)
+    constexpr int lds = ring > epi ? ring : epi;
     static bool attr_set[16] = {};   // write-once per device
     static int cus[16] = {};
     int dev = 0;
@@ -484,7 +541,7 @@ extern "C" int rfn_x3_gemm(int M, int N, int K, const void* imgA, const void* im
         cus[dev & 15] = v;
         attr_set[dev & 15] = true;
     }
-    const int tiles = a.tiles_m * a.tiles_n, slots = cus[dev & 15];
+    const int tiles = a.tiles_m * a.tiles_n, slots = cus[dev & 15] * X3_BLOCKS_PER_CU;
     const int rem = tiles % slots;
     const bool tail = X3_TAIL && a.splitk == 1 && tiles / slots >= 2 && rem > 0 && 4 * rem <= slots;
     a.main_tiles = tail ? tiles - rem : tiles;

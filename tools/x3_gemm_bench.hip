@@ -83,6 +83,9 @@ int main() {
     float* Cp[8]; const float* bp[8];
     for (int t = 0; t < T; ++t) { Cp[t] = P + (size_t)t * BL * A; bp[t] = bias + t * A; }
     const double flops = 2.0 * BL * D * A * T;
+#ifdef NT_ROWS
+    timeit("NT projection, fewer rows", 2.0 * NT_ROWS * D * A * T, 0, 10, [&] { rfn_x3_gemm(NT_ROWS, T * A, D, imgX, imgW, NT_ROWS, A, Cp, bp, A, 0, 1, nullptr, 0); });
+#endif
     timeit("NT projection", flops, 0, 10, [&] { int rc = rfn_x3_gemm(BL, T * A, D, imgX, imgW, BL, A, Cp, bp, A, 0, 1, nullptr, 0); if (rc) { printf("rc %d\n", rc); exit(1); } });
     // check
     const int NS = 4096;
