@@ -357,27 +357,34 @@ __device__ __forceinline__ void x3_tile(const X3Args& args, const int row0, cons
         // instructions of the register layout (4 B per lane), which is what the epilogue is bound by at one block per CU
         constexpr int EPW = WN + 4;                 // padded row, floats
         constexpr int LPR = WN / 4, RPI = 64 / LPR;  // lanes per row, rows per store instruction
-        float* ep = reinterpret_cast<float*>(x3_smem) + wave * (RB * EPW);
+        // rows staged at a time: a whole MFMA tile row (RB) if 8 waves x RB x EPW floats fit the ring, else half of it
+        constexpr int EPR = (NW * RB * EPW * 4 <= SLOTS * SLOT_BYTES) ? RB : RB / 2;
+        static_assert(NW * EPR * EPW * 4 <= SLOTS * SLOT_BYTES && (SHAPE == 32 || EPR == RB), "epilogue staging must fit the ring");
+        float* ep = reinterpret_cast<float*>(x3_smem) + wave * (EPR * EPW);
         const int erow = lane / LPR, ecol = 4 * (lane % LPR);
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
 #pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                const float bsum = bias_w ? bias_w[j * RB + lr] : 0.f;
+            for (int hb = 0; hb < RB / EPR; ++hb) {   // 32 x 32 tiles: registers 8 hb .. 8 hb + 7 hold rows 16 hb .. 16 hb + 15
 #pragma unroll
-                for (int r = 0; r < S::ACC; ++r) {
-                    const int rr = SHAPE == 32 ? (r & 3) + 8 * (r >> 2) : r;
-                    ep[(lrow + rr) * EPW + j * RB + lr] = acc[i][j][r] + bsum;
+                for (int j = 0; j < NI; ++j) {
+                    const float bsum = bias_w ? bias_w[j * RB + lr] : 0.f;
+#pragma unroll
+                    for (int r = 0; r < S::ACC; ++r) {
+                        const int rr = SHAPE == 32 ? (r & 3) + 8 * (r >> 2) : r;
+                        if (rr / EPR != hb) continue;
+                        ep[(lrow + rr - hb * EPR) * EPW + j * RB + lr] = acc[i][j][r] + bsum;
+                    }
                 }
-            }
-            asm volatile("" ::: "memory");   // LDS operations of one wave execute in order: the reads below see the writes
+                asm volatile("" ::: "memory");   // LDS operations of one wave execute in order: the reads see the writes
 #pragma unroll
-            for (int it = 0; it < RB / RPI; ++it) {
-                const int row = it * RPI + erow;
-                const x3_f32x4 v = *reinterpret_cast<const x3_f32x4*>(ep + row * EPW + ecol);
-                *reinterpret_cast<x3_f32x4*>(cbase + ((unsigned)(i * RB + row) * ld4 + (unsigned)ecol * 4u)) = v;
+                for (int it = 0; it < EPR / RPI; ++it) {
+                    const int row = it * RPI + erow;
+                    const x3_f32x4 v = *reinterpret_cast<const x3_f32x4*>(ep + row * EPW + ecol);
+                    *reinterpret_cast<x3_f32x4*>(cbase + ((unsigned)(i * RB + hb * EPR + row) * ld4 + (unsigned)ecol * 4u)) = v;
+                }
+                asm volatile("" ::: "memory");
             }
-            asm volatile("" ::: "memory");
         }
         return;
     }
@@ -526,9 +533,7 @@ extern "C" int rfn_x3_gemm(int M, int N, int K, const void* imgA, const void* im
         a.bias[g] = bias_host ? bias_host[g] : nullptr;
     }
     auto kern = x3_gemm_k<X3_SHAPE, X3_BM, X3_BN, X3_WGM, X3_WGN, X3_KCS, X3_SLOTS, (X3_TAIL != 0)>;
-    constexpr int ring = X3_SLOTS * X3_KCS * ((X3_BM + X3_BN) / S::RB) * 3 * 1024;
-    constexpr int epi = X3_WGM * X3_WGN * S::RB * (X3_BN / X3_WGN + 4) * 4;   // the epilogue's staging rows (x3_tile)
-    constexpr int lds = ring > epi ? ring : epi;
+    constexpr int lds = X3_SLOTS * X3_KCS * ((X3_BM + X3_BN) / S::RB) * 3 * 1024;   // the ring; the epilogue stages inside it
     static bool attr_set[16] = {};   // write-once per device
     static int cus[16] = {};
     int dev = 0;
