@@ -9,6 +9,7 @@ import os
 import sys
 
 root = sys.argv[1]
+wanted = sys.argv[2] if len(sys.argv) > 2 else 'rfn_gemm_kernel'     # kernel-name substring
 
 
 def load(sub):
@@ -30,7 +31,7 @@ for sub in ('sq', 'fetch', 'write', 'l2'):
         if 'Start_Timestamp' in r and r['Counter_Name'] in ('GRBM_GUI_ACTIVE',):
             agg[k]['_dur'].append(float(r['End_Timestamp']) - float(r['Start_Timestamp']))
 for k, c in agg.items():
-    if 'GRBM_GUI_ACTIVE' not in c or 'rfn_gemm_kernel' not in k[0]:
+    if 'GRBM_GUI_ACTIVE' not in c or wanted not in k[0]:
         continue
     avg = lambda n: sum(c[n]) / max(1, len(c[n]))  # noqa: E731
     gui = avg('GRBM_GUI_ACTIVE') / 8.0
