@@ -138,9 +138,10 @@ int rfn_gemm_f32_opt(int M, int N, int ngroups, const rfn_gemm_problem* problems
  *
  * A logical operand Y[rows][K] (row = output index, K = reduction index) is held as a PLANE IMAGE: x = x0 + x1 + x2 with
  * x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1) (round to nearest even; exact for finite x below 2^127), stored
- * as 1-KiB pieces in MFMA operand order: piece (kc, rb, p) at byte ((kc * nrb + rb) * 3 + p) * 1024 holds, at 16 * l,
- * plane p of Y[rb * 32 + l % 32][kc * 16 + 8 * (l / 32) + 0..7]; nrb = rows padded to 256, over 32; K is padded to 32;
- * pad rows / columns are zero.  rfn_x3_image_bytes gives the size (6 bytes per padded element). */
+ * as 1-KiB pieces in the operand order of v_mfma_f32_16x16x32_bf16: piece (kc, rb, p) at byte
+ * ((kc * nrb + rb) * 3 + p) * 1024 holds, at 16 * l, plane p of Y[rb * 16 + l % 16][kc * 32 + 8 * (l / 16) + 0..7];
+ * nrb = rows padded to 256, over 16; K is padded to 32; pad rows / columns are zero.  rfn_x3_image_bytes gives the size
+ * (6 bytes per padded element). */
 size_t rfn_x3_image_bytes(int rows, int K);
 /* Image of Y[ngroups * rows][K] whose row block g is the f32 matrix srcs_host[g] (device pointers in a host array;
  * k_fast = 1: element (row, k) at src[row * ld + k], k_fast = 0: at src[k * ld + row]).  rows % 32 == 0 unless
@@ -148,7 +149,7 @@ size_t rfn_x3_image_bytes(int rows, int K);
 int rfn_x3_split(const float* const* srcs_host, int ngroups, int64_t ld, int rows, int K, int k_fast, void* image,
                  void* stream);
 /* C (+)= A . B^T from two images (A: M rows, B: N rows, both with reduction length K): the six plane products
- * a0.b0, a0.b1, a1.b0, a0.b2, a1.b1, a2.b0, smallest first, accumulated in f32 by v_mfma_f32_32x32x16_bf16.
+ * a0.b0, a0.b1, a1.b0, a0.b2, a1.b1, a2.b0, smallest first, accumulated in f32 by v_mfma_f32_16x16x32_bf16.
  * The output is cut into groups of gm rows x gn columns, group (i, j) written to C_host[i * ceil(N/gn) + j] with leading
  * dimension ldc (+ bias_host[..][column inside the group] when bias_host and the entry are non-NULL); gm and gn must be
  * multiples of 256 unless they cover the whole dimension; at most 64 groups.  splitk > 1 cuts K over blocks; the partial

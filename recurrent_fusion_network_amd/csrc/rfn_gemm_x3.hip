@@ -132,7 +132,7 @@ extern "C" size_t rfn_x3_image_bytes(int rows, int K) {
 }
 
 #ifndef X3_SHAPE
-#define X3_SHAPE 32
+#define X3_SHAPE 16   /* 16: v_mfma_f32_16x16x32_bf16 (pieces of 16 rows x 32 k); 32: v_mfma_f32_32x32x16_bf16 (32 x 16) */
 #endif
 
 // Image of the logical operand Y[ngroups * rows][K] whose row block g is the f32 matrix srcs_host[g] (rows x K, leading
@@ -266,40 +266,110 @@ __device__ __forceinline__ void x3_tile(const X3Args& args, const int row0, cons
 #pragma unroll
             for (int r = 0; r < S::ACC; ++r) acc[i][j][r] = 0.f;
 
-    int issued = 0;
-#pragma unroll
-    for (int s = 0; s < SLOTS - 1; ++s)
-        if (s < iters) {
-            issue(s);
-            ++issued;
+    if constexpr (SHAPE == 32) {
+        int issued = 0;
+    #pragma unroll
+        for (int s = 0; s < SLOTS - 1; ++s)
+            if (s < iters) {
+                issue(s);
+                ++issued;
+            }
+        int cur = 0, fill = SLOTS - 1;
+        for (int it = 0; it < iters; ++it) {
+            const int younger = issued - it - 1;
+            if (SLOTS >= 4 && younger >= 2) x3_wait_vmcnt<(SLOTS >= 4 ? 2 : 0) * PPW>();
+            else if (SLOTS >= 3 && younger >= 1) x3_wait_vmcnt<(SLOTS >= 3 ? 1 : 0) * PPW>();
+            else x3_wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            if (issued < iters) {
+                issue(fill);
+                ++issued;
+            }
+            const char* sl = x3_smem + cur * SLOT_BYTES + lane16;
+    #pragma unroll
+            for (int kcs = 0; kcs < KCS; ++kcs) {
+                const char* a_l = sl + (kcs * (PA + PB) + wm * MI * 3) * 1024;
+                const char* b_l = sl + (kcs * (PA + PB) + PA + wn * NI * 3) * 1024;
+                x3_bf16x8 b[NI][3];
+    #pragma unroll
+                for (int j = 0; j < NI; ++j)
+    #pragma unroll
+                    for (int p = 0; p < 3; ++p) b[j][p] = *reinterpret_cast<const x3_bf16x8*>(b_l + (j * 3 + p) * 1024);
+    #pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    x3_bf16x8 a[3];
+    #pragma unroll
+                    for (int p = 0; p < 3; ++p) a[p] = *reinterpret_cast<const x3_bf16x8*>(a_l + (i * 3 + p) * 1024);
+                    // smallest products first
+    #pragma unroll
+                    for (int j = 0; j < NI; ++j) x3_mfma<SHAPE>(a[2], b[j][0], acc[i][j]);
+    #pragma unroll
+                    for (int j = 0; j < NI; ++j) x3_mfma<SHAPE>(a[1], b[j][1], acc[i][j]);
+    #pragma unroll
+                    for (int j = 0; j < NI; ++j) x3_mfma<SHAPE>(a[0], b[j][2], acc[i][j]);
+    #pragma unroll
+                    for (int j = 0; j < NI; ++j) x3_mfma<SHAPE>(a[1], b[j][0], acc[i][j]);
+    #pragma unroll
+                    for (int j = 0; j < NI; ++j) x3_mfma<SHAPE>(a[0], b[j][1], acc[i][j]);
+    #pragma unroll
+                    for (int j = 0; j < NI; ++j) x3_mfma<SHAPE>(a[0], b[j][0], acc[i][j]);
+                }
+            }
+            cur = (cur + 1 == SLOTS) ? 0 : cur + 1;
+            fill = (fill + 1 == SLOTS) ? 0 : fill + 1;
         }
-    int cur = 0, fill = SLOTS - 1;
-    for (int it = 0; it < iters; ++it) {
-        const int younger = issued - it - 1;
-        if (SLOTS >= 4 && younger >= 2) x3_wait_vmcnt<(SLOTS >= 4 ? 2 : 0) * PPW>();
-        else if (SLOTS >= 3 && younger >= 1) x3_wait_vmcnt<(SLOTS >= 3 ? 1 : 0) * PPW>();
-        else x3_wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
-        if (issued < iters) {
-            issue(fill);
-            ++issued;
-        }
-        const char* sl = x3_smem + cur * SLOT_BYTES + lane16;
+    } else {
+        // 16x16x32 shape: a K step is 32 deep, so a slot of both operands is 96 KB and does not fit twice.  Instead the step's
+        // B fragments go to registers first (12 per wave for a 64-wide wave tile), which frees the single B buffer for the
+        // next step's DMA while the row blocks of A stream from one of two A buffers:
+        //   step s:  wait for this wave's pieces of A_s, B_s -> barrier 1 (both landed everywhere; every wave is done with
+        //            A_(s-1)) -> issue A_(s+1) -> B_s fragments to registers -> barrier 2 (nobody reads B_s from LDS any
+        //            more) -> issue B_(s+1) -> per 16-row block: 3 fragment reads, NI x 6 MFMAs.
+        constexpr int PAW = PA / NW, PBW = PB / NW;
+        static_assert(PA % NW == 0 && PB % NW == 0 && KCS == 1, "each operand's pieces must divide over the waves");
+        char* const bufA = x3_smem;                   // two A stages
+        char* const bufB = x3_smem + 2 * PA * 1024;   // one B stage
+        const char* gA = args.A + (((long)kc0 * args.nrbA + row0 / RB) * 3 + wave * PAW) * 1024;
+        const char* gB = args.B + (((long)kc0 * args.nrbB + col0 / RB) * 3 + wave * PBW) * 1024;
+        const long sA = (long)args.nrbA * 3072, sB = (long)args.nrbB * 3072;
+        auto issue_a = [&](int buf) {
+            char* st = bufA + (buf * PA + wave * PAW) * 1024;
 #pragma unroll
-        for (int kcs = 0; kcs < KCS; ++kcs) {
-            const char* a_l = sl + (kcs * (PA + PB) + wm * MI * 3) * 1024;
-            const char* b_l = sl + (kcs * (PA + PB) + PA + wn * NI * 3) * 1024;
+            for (int j = 0; j < PAW; ++j)
+                __builtin_amdgcn_global_load_lds((x3_gbl_void*)(gA + j * 1024 + lane16), (x3_lds_void*)(st + j * 1024), 16, 0, 0);
+            gA += sA;
+        };
+        auto issue_b = [&]() {
+            char* st = bufB + wave * PBW * 1024;
+#pragma unroll
+            for (int j = 0; j < PBW; ++j)
+                __builtin_amdgcn_global_load_lds((x3_gbl_void*)(gB + j * 1024 + lane16), (x3_lds_void*)(st + j * 1024), 16, 0, 0);
+            gB += sB;
+        };
+        if (iters > 0) {
+            issue_a(0);
+            issue_b();
+        }
+        for (int st = 0; st < iters; ++st) {
+            x3_wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            const bool more = st + 1 < iters;
+            if (more) issue_a((st + 1) & 1);
             x3_bf16x8 b[NI][3];
+            const char* b_l = bufB + lane16 + (wn * NI * 3) * 1024;
 #pragma unroll
             for (int j = 0; j < NI; ++j)
 #pragma unroll
                 for (int p = 0; p < 3; ++p) b[j][p] = *reinterpret_cast<const x3_bf16x8*>(b_l + (j * 3 + p) * 1024);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's B fragments are in registers
+            __builtin_amdgcn_s_barrier();
+            if (more) issue_b();
+            const char* a_l = bufA + (st & 1) * PA * 1024 + lane16 + (wm * MI * 3) * 1024;
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
                 x3_bf16x8 a[3];
 #pragma unroll
                 for (int p = 0; p < 3; ++p) a[p] = *reinterpret_cast<const x3_bf16x8*>(a_l + (i * 3 + p) * 1024);
-                // smallest products first
 #pragma unroll
                 for (int j = 0; j < NI; ++j) x3_mfma<SHAPE>(a[2], b[j][0], acc[i][j]);
 #pragma unroll
@@ -314,8 +384,6 @@ __device__ __forceinline__ void x3_tile(const X3Args& args, const int row0, cons
                 for (int j = 0; j < NI; ++j) x3_mfma<SHAPE>(a[0], b[j][0], acc[i][j]);
             }
         }
-        cur = (cur + 1 == SLOTS) ? 0 : cur + 1;
-        fill = (fill + 1 == SLOTS) ? 0 : fill + 1;
     }
     __builtin_amdgcn_s_barrier();   // every wave is past its last fragment read: the ring's LDS is free for the epilogue
 
@@ -358,8 +426,9 @@ __device__ __forceinline__ void x3_tile(const X3Args& args, const int row0, cons
         constexpr int EPW = WN + 4;                 // padded row, floats
         constexpr int LPR = WN / 4, RPI = 64 / LPR;  // lanes per row, rows per store instruction
         // rows staged at a time: a whole MFMA tile row (RB) if 8 waves x RB x EPW floats fit the ring, else half of it
-        constexpr int EPR = (NW * RB * EPW * 4 <= SLOTS * SLOT_BYTES) ? RB : RB / 2;
-        static_assert(NW * EPR * EPW * 4 <= SLOTS * SLOT_BYTES && (SHAPE == 32 || EPR == RB), "epilogue staging must fit the ring");
+        constexpr int RING_BYTES = SHAPE == 32 ? SLOTS * SLOT_BYTES : (2 * PA + PB) * 1024;
+        constexpr int EPR = (NW * RB * EPW * 4 <= RING_BYTES) ? RB : RB / 2;
+        static_assert(NW * EPR * EPW * 4 <= RING_BYTES && (SHAPE == 32 || EPR == RB), "epilogue staging must fit the ring");
         float* ep = reinterpret_cast<float*>(x3_smem) + wave * (EPR * EPW);
         const int erow = lane / LPR, ecol = 4 * (lane % LPR);
 #pragma unroll
@@ -533,7 +602,9 @@ extern "C" int rfn_x3_gemm(int M, int N, int K, const void* imgA, const void* im
         a.bias[g] = bias_host ? bias_host[g] : nullptr;
     }
     auto kern = x3_gemm_k<X3_SHAPE, X3_BM, X3_BN, X3_WGM, X3_WGN, X3_KCS, X3_SLOTS, (X3_TAIL != 0)>;
-    constexpr int lds = X3_SLOTS * X3_KCS * ((X3_BM + X3_BN) / S::RB) * 3 * 1024;   // the ring; the epilogue stages inside it
+    // the operand ring; the epilogue stages inside it.  32x32x16: SLOTS slots of both operands; 16x16x32: two A stages + one B
+    constexpr int lds = X3_SHAPE == 32 ? X3_SLOTS * X3_KCS * ((X3_BM + X3_BN) / S::RB) * 3 * 1024
+                                       : (2 * (X3_BM / S::RB) + X3_BN / S::RB) * 3 * 1024;
     static bool attr_set[16] = {};   // write-once per device
     static int cus[16] = {};
     int dev = 0;

@@ -12,11 +12,11 @@ U = 2.0 ** -24
 def _decode(img, rows, K):
     """image (uint8) -> three f32 planes [3][rows_pad][K_pad], following include/rfn.h's layout."""
     rows_pad, k_pad = (rows + 255) // 256 * 256, (K + 31) // 32 * 32
-    nrb, nkc = rows_pad // 32, k_pad // 16
+    nrb, nkc = rows_pad // 16, k_pad // 32
     assert img.numel() == rows_pad * k_pad * 6
-    w = img.view(torch.int16).view(nkc, nrb, 3, 2, 32, 8)            # [kc][rb][plane][l / 32][l % 32][j]
+    w = img.view(torch.int16).view(nkc, nrb, 3, 4, 16, 8)            # [kc][rb][plane][l / 16][l % 16][j]
     f = (w.to(torch.int32) << 16).view(torch.float32)
-    return f.permute(2, 1, 4, 0, 3, 5).reshape(3, rows_pad, k_pad)   # [plane][rb, l % 32][kc, l / 32, j]
+    return f.permute(2, 1, 4, 0, 3, 5).reshape(3, rows_pad, k_pad)   # [plane][rb, l % 16][kc, l / 16, j]
 
 
 @pytest.mark.parametrize('k_fast', [True, False])
