@@ -3,7 +3,7 @@
 // significand, bf16 has f32's exponent range) and C = A . B^T is formed from the six
 // products whose weight is >= 2^-16 of the leading one,
 //     a0.b0 + (a0.b1 + a1.b0) + (a0.b2 + a1.b1 + a2.b0),
-// with v_mfma_f32_{32x32x16,16x16x32}_bf16 accumulating in f32.  The three dropped products are below 2^-24 relative,
+// with v_mfma_f32_16x16x32_bf16 accumulating in f32.  The three dropped products are below 2^-24 relative,
 // i.e. below the rounding of an f32 accumulation step.  Measured against f64 (tools/split_numerics_probe.hip, K = 512 ...
 // 50176, normal / all-positive / wide-range data) the result is at least as close as the exact-f32 MFMA chain of
 // rfn_gemm.hip (0.75-0.85x its rms error): the matrix cores run the bf16 shapes 16x faster than the f32 shape, so six
@@ -12,7 +12,8 @@
 // Plane image of a logical operand Y[rows][K] (row = output index, K = reduction index), written by rfn_x3_split from an
 // f32 matrix in either orientation: 1-KiB pieces in the lane order of the MFMA operand,
 //     piece(kc, rb, p) at byte (((kc * nrb) + rb) * 3 + p) * 1024, lane l at + 16 * l:
-//         plane p of Y[rb * RB + l % RB][kc * KC + 8 * (l / RB) + 0..7]        (RB x KC = 32 x 16 or 16 x 32)
+//         plane p of Y[rb * RB + l % RB][kc * KC + 8 * (l / RB) + 0..7]        (RB x KC = 16 x 32, the product build's
+//         v_mfma_f32_16x16x32_bf16; 32 x 16 with -DX3_SHAPE=32 for the A/B runs of tools/x3_gemm_bench.hip)
 // rows are padded to a multiple of 256 and K to a multiple of KC with zeros, so the GEMM loads need no bounds checks.
 // One wave-instruction of LDS-DMA (global_load_lds_dwordx4, 64 lanes x 16 B) moves one piece as one contiguous KiB of
 // global memory into one contiguous KiB of LDS, which one ds_read_b128 per lane then reads back conflict-free (lane-
@@ -209,11 +210,10 @@ __device__ __forceinline__ void x3_mfma(const x3_bf16x8& a, const x3_bf16x8& b, 
     else c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
-// One BM x BN output tile at (row0, col0) over the pieces [kc0, kc0 + iters * KCS) of K, by WGM x WGN waves; operands
-// staged by LDS-DMA into a ring of SLOTS slots of KCS pieces of K each:
-//   iteration it:  wait until this wave's pieces of slot `it` have landed (younger slots stay in flight) -> barrier (every
-//                  wave's pieces landed; every wave is done reading slot it-1) -> issue slot it+SLOTS-1 -> MFMAs on slot it.
-template <int SHAPE, int BM, int BN, int WGM, int WGN, int KCS, int SLOTS>
+// One BM x BN output tile at (row0, col0) over the piece rows [kc0, kc0 + iters) of K, by WGM x WGN waves; operands staged
+// by LDS-DMA, one piece row of K per step (32 reduction indices for the 16 x 16 shape, 16 for the 32 x 32 shape).  The two
+// shapes have their own main loops (below); setup, accumulators and epilogue are shared.
+template <int SHAPE, int BM, int BN, int WGM, int WGN, int SLOTS>
 __device__ __forceinline__ void x3_tile(const X3Args& args, const int row0, const int col0, const int kc0, const int iters,
                                         const int ks) {
     using S = X3Shape<SHAPE>;
@@ -222,7 +222,7 @@ __device__ __forceinline__ void x3_tile(const X3Args& args, const int row0, cons
     constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int MI = WM / RB, NI = WN / RB;
     constexpr int PA = (BM / RB) * 3, PB = (BN / RB) * 3;   // pieces per kc
-    constexpr int PT = KCS * (PA + PB);                     // pieces per slot
+    constexpr int PT = PA + PB;                             // pieces per step
     constexpr int PPW = PT / NW;                            // per wave
     static_assert(PT % NW == 0 && MI >= 1 && NI >= 1, "pieces must divide over the waves");
     constexpr int SLOT_BYTES = PT * 1024;
@@ -233,30 +233,7 @@ __device__ __forceinline__ void x3_tile(const X3Args& args, const int row0, cons
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WGN, wn = wave % WGN;
 
-    // this wave's pieces of a slot: piece n -> (kcs, operand, piece inside the kc's tile rows); wave-uniform addresses
-    const char* src[PPW];
-    long step[PPW];
-#pragma unroll
-    for (int j = 0; j < PPW; ++j) {
-        const int n = wave * PPW + j;
-        const int kcs = n / (PA + PB), rem = n % (PA + PB);
-        if (rem < PA) {
-            src[j] = args.A + (((long)(kc0 + kcs) * args.nrbA + row0 / RB) * 3 + rem) * 1024;
-            step[j] = (long)KCS * args.nrbA * 3072;
-        } else {
-            src[j] = args.B + (((long)(kc0 + kcs) * args.nrbB + col0 / RB) * 3 + (rem - PA)) * 1024;
-            step[j] = (long)KCS * args.nrbB * 3072;
-        }
-    }
     const unsigned lane16 = lane * 16;
-    auto issue = [&](int slot) {
-        char* st = x3_smem + slot * SLOT_BYTES + wave * PPW * 1024;
-#pragma unroll
-        for (int j = 0; j < PPW; ++j) {
-            __builtin_amdgcn_global_load_lds((x3_gbl_void*)(src[j] + lane16), (x3_lds_void*)(st + j * 1024), 16, 0, 0);
-            src[j] += step[j];
-        }
-    };
 
     x3_acc_t<SHAPE> acc[MI][NI];
 #pragma unroll
@@ -267,8 +244,36 @@ __device__ __forceinline__ void x3_tile(const X3Args& args, const int row0, cons
             for (int r = 0; r < S::ACC; ++r) acc[i][j][r] = 0.f;
 
     if constexpr (SHAPE == 32) {
+        // Symmetric ring of SLOTS slots of both operands:
+        //   iteration it:  wait until this wave's pieces of slot `it` have landed (younger slots stay in flight) -> barrier
+        //                  (every wave's pieces landed; every wave is done reading slot it-1) -> issue slot it+SLOTS-1 ->
+        //                  fragment reads + MFMAs on slot it.
+        // this wave's pieces of a slot: piece n -> (operand, piece inside the tile rows); wave-uniform addresses
+        const char* src[PPW];
+        long step[PPW];
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) {
+            const int n = wave * PPW + j;
+            const int rem = n;
+            if (rem < PA) {
+                src[j] = args.A + (((long)kc0 * args.nrbA + row0 / RB) * 3 + rem) * 1024;
+                step[j] = (long)args.nrbA * 3072;
+            } else {
+                src[j] = args.B + (((long)kc0 * args.nrbB + col0 / RB) * 3 + (rem - PA)) * 1024;
+                step[j] = (long)args.nrbB * 3072;
+            }
+        }
+        auto issue = [&](int slot) {
+            char* st = x3_smem + slot * SLOT_BYTES + wave * PPW * 1024;
+#pragma unroll
+            for (int j = 0; j < PPW; ++j) {
+                __builtin_amdgcn_global_load_lds((x3_gbl_void*)(src[j] + lane16), (x3_lds_void*)(st + j * 1024), 16, 0, 0);
+                src[j] += step[j];
+            }
+        };
+
         int issued = 0;
-    #pragma unroll
+#pragma unroll
         for (int s = 0; s < SLOTS - 1; ++s)
             if (s < iters) {
                 issue(s);
@@ -286,32 +291,31 @@ __device__ __forceinline__ void x3_tile(const X3Args& args, const int row0, cons
                 ++issued;
             }
             const char* sl = x3_smem + cur * SLOT_BYTES + lane16;
-    #pragma unroll
-            for (int kcs = 0; kcs < KCS; ++kcs) {
-                const char* a_l = sl + (kcs * (PA + PB) + wm * MI * 3) * 1024;
-                const char* b_l = sl + (kcs * (PA + PB) + PA + wn * NI * 3) * 1024;
+                {
+                const char* a_l = sl + (wm * MI * 3) * 1024;
+                const char* b_l = sl + (PA + wn * NI * 3) * 1024;
                 x3_bf16x8 b[NI][3];
-    #pragma unroll
+#pragma unroll
                 for (int j = 0; j < NI; ++j)
-    #pragma unroll
+#pragma unroll
                     for (int p = 0; p < 3; ++p) b[j][p] = *reinterpret_cast<const x3_bf16x8*>(b_l + (j * 3 + p) * 1024);
-    #pragma unroll
+#pragma unroll
                 for (int i = 0; i < MI; ++i) {
                     x3_bf16x8 a[3];
-    #pragma unroll
+#pragma unroll
                     for (int p = 0; p < 3; ++p) a[p] = *reinterpret_cast<const x3_bf16x8*>(a_l + (i * 3 + p) * 1024);
                     // smallest products first
-    #pragma unroll
+#pragma unroll
                     for (int j = 0; j < NI; ++j) x3_mfma<SHAPE>(a[2], b[j][0], acc[i][j]);
-    #pragma unroll
+#pragma unroll
                     for (int j = 0; j < NI; ++j) x3_mfma<SHAPE>(a[1], b[j][1], acc[i][j]);
-    #pragma unroll
+#pragma unroll
                     for (int j = 0; j < NI; ++j) x3_mfma<SHAPE>(a[0], b[j][2], acc[i][j]);
-    #pragma unroll
+#pragma unroll
                     for (int j = 0; j < NI; ++j) x3_mfma<SHAPE>(a[1], b[j][0], acc[i][j]);
-    #pragma unroll
+#pragma unroll
                     for (int j = 0; j < NI; ++j) x3_mfma<SHAPE>(a[0], b[j][1], acc[i][j]);
-    #pragma unroll
+#pragma unroll
                     for (int j = 0; j < NI; ++j) x3_mfma<SHAPE>(a[0], b[j][0], acc[i][j]);
                 }
             }
@@ -326,7 +330,7 @@ __device__ __forceinline__ void x3_tile(const X3Args& args, const int row0, cons
         //            A_(s-1)) -> issue A_(s+1) -> B_s fragments to registers -> barrier 2 (nobody reads B_s from LDS any
         //            more) -> issue B_(s+1) -> per 16-row block: 3 fragment reads, NI x 6 MFMAs.
         constexpr int PAW = PA / NW, PBW = PB / NW;
-        static_assert(PA % NW == 0 && PB % NW == 0 && KCS == 1, "each operand's pieces must divide over the waves");
+        static_assert(PA % NW == 0 && PB % NW == 0, "each operand's pieces must divide over the waves");
         char* const bufA = x3_smem;                   // two A stages
         char* const bufB = x3_smem + 2 * PA * 1024;   // one B stage
         const char* gA = args.A + (((long)kc0 * args.nrbA + row0 / RB) * 3 + wave * PAW) * 1024;
@@ -481,23 +485,23 @@ __device__ __forceinline__ void x3_tile(const X3Args& args, const int row0, cons
 // grid.x: main_tiles whole tiles (blocks that share an XCD, id % 8, take consecutive tiles, tn fastest: the 16 column
 // tiles of a row panel run side by side on one XCD and share the panel through its L2), then 4 quarter-tile blocks per
 // remaining tile: the last, partly filled round of a long launch is spread over four times as many CUs.  grid.z: K slices.
-template <int SHAPE, int BM, int BN, int WGM, int WGN, int KCS, int SLOTS, bool TAIL>
+template <int SHAPE, int BM, int BN, int WGM, int WGN, int SLOTS, bool TAIL>
 __global__ __launch_bounds__(64 * WGM * WGN) void x3_gemm_k(const X3Args args) {
-    int per = (args.nkc / KCS + args.splitk - 1) / args.splitk;   // host: nkc % KCS == 0
+    int per = (args.nkc + args.splitk - 1) / args.splitk;
     const int ks = blockIdx.z;
-    const int kc0 = ks * per * KCS;
-    per = min(per, args.nkc / KCS - ks * per);
+    const int kc0 = ks * per;
+    per = min(per, args.nkc - ks * per);
     if ((int)blockIdx.x < args.main_tiles) {
         int wg = blockIdx.x;
         const int q = args.main_tiles / 8, r = args.main_tiles % 8, xcd = wg % 8;
         wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + wg / 8;
         const int tm = wg / args.tiles_n, tn = wg % args.tiles_n;
-        x3_tile<SHAPE, BM, BN, WGM, WGN, KCS, SLOTS>(args, tm * BM, tn * BN, kc0, per, ks);
+        x3_tile<SHAPE, BM, BN, WGM, WGN, SLOTS>(args, tm * BM, tn * BN, kc0, per, ks);
     } else if constexpr (TAIL) {
         const int t = blockIdx.x - args.main_tiles;
         const int wg = args.main_tiles + t / 4, qd = t % 4;
         const int tm = wg / args.tiles_n, tn = wg % args.tiles_n;
-        x3_tile<SHAPE, BM / 2, BN / 2, WGM, WGN, KCS, SLOTS>(args, tm * BM + (qd >> 1) * (BM / 2), tn * BN + (qd & 1) * (BN / 2),
+        x3_tile<SHAPE, BM / 2, BN / 2, WGM, WGN, SLOTS>(args, tm * BM + (qd >> 1) * (BM / 2), tn * BN + (qd & 1) * (BN / 2),
                                                              kc0, per, ks);
     }
 }
@@ -538,9 +542,6 @@ __global__ __launch_bounds__(256) void x3_reduce_k(const X3Args args) {
 #ifndef X3_WGN
 #define X3_WGN 2
 #endif
-#ifndef X3_KCS
-#define X3_KCS 1
-#endif
 #ifndef X3_SLOTS
 #define X3_SLOTS 2
 #endif
@@ -560,7 +561,7 @@ extern "C" int rfn_x3_splitk_for(int M, int N, int K) {
     if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const long tiles = (long)((M + X3_BM - 1) / X3_BM) * ((N + X3_BN - 1) / X3_BN);
     if (tiles >= cus) return 1;
-    const int iters = (int)(x3_k_pad(K) / S::KC / X3_KCS);
+    const int iters = (int)(x3_k_pad(K) / S::KC);
     int sk = (int)((cus + tiles / 2) / tiles);
     while (sk > 1 && iters / sk < 64) --sk;   // keep slices long enough to amortise the pipeline fill and the reduce
     return sk < 1 ? 1 : sk;
@@ -590,7 +591,7 @@ extern "C" int rfn_x3_gemm(int M, int N, int K, const void* imgA, const void* im
     if ((long)ngm * a.ngn > X3_MAX_GROUPS) return RFN_ERR_SHAPE;
     if ((ngm > 1 && gm % (X3_BM / 2)) || (a.ngn > 1 && gn % (X3_BN / 2))) return RFN_ERR_SHAPE;   // no tile straddles groups
     if ((ngm > 1 && gm % X3_BM) || (a.ngn > 1 && gn % X3_BN)) return RFN_ERR_SHAPE;
-    if (a.nkc % X3_KCS || a.splitk > a.nkc / X3_KCS) return RFN_ERR_SHAPE;
+    if (a.splitk > a.nkc) return RFN_ERR_SHAPE;
     if (a.splitk > 1 && (!part || (N & 3) || (gn & 3))) return RFN_ERR_ARG;
     if ((double)X3_BM * (double)(a.splitk > 1 ? N : ldc) * 4.0 >= 4294967296.0) return RFN_ERR_SHAPE;   // 32-bit tile offsets
     a.ldc = ldc;
@@ -601,9 +602,9 @@ extern "C" int rfn_x3_gemm(int M, int N, int K, const void* imgA, const void* im
         a.C[g] = C_host[g];
         a.bias[g] = bias_host ? bias_host[g] : nullptr;
     }
-    auto kern = x3_gemm_k<X3_SHAPE, X3_BM, X3_BN, X3_WGM, X3_WGN, X3_KCS, X3_SLOTS, (X3_TAIL != 0)>;
+    auto kern = x3_gemm_k<X3_SHAPE, X3_BM, X3_BN, X3_WGM, X3_WGN, X3_SLOTS, (X3_TAIL != 0)>;
     // the operand ring; the epilogue stages inside it.  32x32x16: SLOTS slots of both operands; 16x16x32: two A stages + one B
-    constexpr int lds = X3_SHAPE == 32 ? X3_SLOTS * X3_KCS * ((X3_BM + X3_BN) / S::RB) * 3 * 1024
+    constexpr int lds = X3_SHAPE == 32 ? X3_SLOTS * ((X3_BM + X3_BN) / S::RB) * 3 * 1024
                                        : (2 * (X3_BM / S::RB) + X3_BN / S::RB) * 3 * 1024;
     static bool attr_set[16] = {};   // write-once per device
     static int cus[16] = {};
