@@ -222,3 +222,41 @@ def test_c3_shape_batch32_every_gradient_against_the_oracle(dev, gemm):
     with torch.no_grad():
         seq = model.sample(d(fc), d(att), {'sample_max': 1})[0]
     assert torch.equal(seq.cpu(), _ORACLE_B32['seq'])
+
+
+def test_bf16x3_against_the_exact_path_on_the_shipped_heterogeneous_encoders(dev):
+    """The reference's five shipped encoders (feat_array.py:240-244: D in {2048, 1536, 1280, 2208}, L in {196, 64, 49}) at
+    B = 16 with RFN_GEMM_OPT_BF16X3: every encoder's projection and weight gradient takes the bf16-plane GEMM (row counts
+    784 ... 3136 that are no multiple of the 256-row tile, a 2208-wide weight gradient whose last column tile is ragged),
+    and the result must agree with the exact-f32 path of the same model to well inside the parity bars of either against
+    the oracle: log-probs 2e-4, every gradient 1e-6 + 2e-4 max|g|, greedy ids identical."""
+    import bench as HB
+    import recurrent_fusion_network_amd as R
+    import recurrent_fusion_network_amd._native as N
+    cfg = HB.make_cfg(HB.WORKLOADS['c3het'])
+    B = 16
+    model = R.RecurrentFusionModel(cfg).to(dev)
+    HB.seeded_weights_(model, 31)
+    model.eval()
+    fc, att, labels, masks, top = HB.synthetic_inputs(cfg, B, 32, dev)
+    crit = R.ReviewNetEnsembleCriterion(cfg)
+
+    def run(flags):
+        model.gemm_flags = flags
+        model.zero_grad(set_to_none=True)
+        lp, reason = model(fc, att, labels)
+        crit(lp, labels[:, 1:], masks[:, 1:], reason, top, 1.0).backward()
+        grads = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+        with torch.no_grad():
+            seq = model.sample(fc, att, {'sample_max': 1})[0]
+        return lp.detach(), grads, seq
+
+    lp0, g0, s0 = run(0)
+    lp1, g1, s1 = run(N.GEMM_OPT_BF16X3)
+    k = 'review_steps_individual.0.lstm.3.att_model.att_2_att_h.weight'        # the 2208-wide encoder
+    assert not torch.equal(g0[k], g1[k]), 'the flag must change the arithmetic of the weight gradient'
+    assert float((lp0 - lp1).abs().max()) < 2e-4
+    for name in g0:
+        err = float((g0[name] - g1[name]).abs().max())
+        assert err <= 1e-6 + 2e-4 * float(g0[name].abs().max()), (name, err)
+    assert torch.equal(s0, s1)
