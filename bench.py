@@ -198,6 +198,10 @@ def parse_args(argv=None):
                     help="exact: every product on the exact-f32 MFMA (default, the headline).  bf16x3: the hoisted stage-I "
                          "projection and its weight gradient on the bf16 matrix cores, f32 operands as three bf16 planes, six "
                          "plane products, f32 accumulation (RFN_GEMM_OPT_BF16X3): f32-level accuracy, not bit-identical")
+    ap.add_argument('--settle', type=float, default=2.0,
+                    help='seconds of untimed steps BEFORE the W warm-up steps (the first second of GPU work after an idle '
+                         'spell -- e.g. behind a CPU-only phase of the caller -- ran up to 13 %% slow on some boxes while '
+                         'the kernels themselves timed normal); reported as settle_s')
     ap.add_argument('--no-alt-line', action='store_true',
                     help="with --gemm exact (the default): do not append the same workload re-timed with --gemm bf16x3 "
                          "(the 'bf16x3' object of the JSON line; `value` is always the exact-f32 measurement)")
@@ -429,6 +433,16 @@ def run_train(args, rank, world, dev, R, DP):
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    settle_n = 0
+    if args.settle > 0:                  # the same number of untimed steps on every rank: rank 0's clock decides
+        ts = time.perf_counter()
+        while True:
+            step()
+            settle_n += 1
+            torch.cuda.synchronize()
+            # every rank leaves after the same step: continue while ANY rank's clock is still inside the window
+            if DP.max_over_ranks(1.0 if time.perf_counter() - ts < args.settle else 0.0, world, dev) == 0.0:
+                break
     for _ in range(args.warmup):
         step()
     fence()
@@ -477,6 +491,7 @@ def run_train(args, rank, world, dev, R, DP):
         'metric': METRIC, 'value': round(global_B * args.steps / elapsed, 2), 'unit': 'captions/s', 'n_gpus': world,
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 3), 'higher_is_better': True,
         'scaling': 'strong' if args.strong else 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'settle_s': args.settle, 'settle_steps': settle_n,
         'rccl_ranks': torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
         'dist_backend': torch.distributed.get_backend() if torch.distributed.is_initialized() else None,
         'config': {'workload': '%s: RecurrentFusionModel XE train step (zero_grad+fwd+criterion+bwd+clamp+Adam), '
