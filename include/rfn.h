@@ -124,10 +124,14 @@ int rfn_gemm_f32_ws(int M, int N, int ngroups, const rfn_gemm_problem* problems_
  *                          projection and its weight gradient -- run on the bf16 matrix cores with every f32 operand
  *                          held as three bf16 planes and six plane products accumulated in f32 (rfn_x3_*, below):
  *                          f32-level accuracy (at least as close to an f64 product as the f32 MFMA chain), not
- *                          bit-identical to it.  Off by default. */
+ *                          bit-identical to it.  Off by default.  Products too short to pay for the split passes
+ *                          (< 2e10 multiply-adds x 2) stay on the exact kernels unless
+ *   RFN_GEMM_OPT_BF16X3_ANY_SIZE is also set (parity tests run the small reference-generated tiers through the plane
+ *                          GEMM with it). */
 #define RFN_GEMM_OPT_LDS_LEAN 1u
 #define RFN_GEMM_OPT_NO_DMA 2u
 #define RFN_GEMM_OPT_BF16X3 4u
+#define RFN_GEMM_OPT_BF16X3_ANY_SIZE 8u
 int rfn_gemm_f32_opt(int M, int N, int ngroups, const rfn_gemm_problem* problems_host, int accumulate,
                      void* ws, size_t ws_bytes, unsigned flags, void* stream);
 

@@ -20,6 +20,7 @@ ABI_VERSION = 5
 GEMM_OPT_LDS_LEAN = 1
 GEMM_OPT_NO_DMA = 2
 GEMM_OPT_BF16X3 = 4
+GEMM_OPT_BF16X3_ANY_SIZE = 8
 
 
 class RfnError(RuntimeError):

@@ -237,6 +237,7 @@ struct PrefixLayout {
 static bool x3_takes(const rfn_dims* d, int B, int i) {
     if (!(d->gemm_flags & RFN_GEMM_OPT_BF16X3)) return false;
     if (d->A % 256 || d->D[i] % 4 || d->T1 > 64) return false;
+    if (d->gemm_flags & RFN_GEMM_OPT_BF16X3_ANY_SIZE) return true;
     return 2.0 * B * d->L[i] * d->D[i] * d->A * d->T1 >= 2e10;
 }
 static size_t x3_scratch_floats(const rfn_dims* d, int B, int train) {

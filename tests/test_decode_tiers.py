@@ -57,22 +57,25 @@ def test_eval_shim_row_selection_and_errors():
 # ---------------------------------------------------------------------------------------------------------------
 # GPU: the HIP path against the same fixtures
 # ---------------------------------------------------------------------------------------------------------------
-def _build(cfg, P, dev, train=False):
+def _build(cfg, P, dev, train=False, gemm='exact'):
     import recurrent_fusion_network_amd as R
     model = R.RecurrentFusionModel(cfg)
     model.load_state_dict(P)
+    if gemm == 'bf16x3':     # the hoisted projections / their weight gradients on the bf16 matrix cores, at any size
+        import recurrent_fusion_network_amd._native as N
+        model.gemm_flags |= N.GEMM_OPT_BF16X3 | N.GEMM_OPT_BF16X3_ANY_SIZE
     return model.to(dev).train(train)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('name', ['evalmid', 'c5'])
-def test_eval_loop_greedy_and_beam5(dev, name):
+@pytest.mark.parametrize('name,gemm', [('evalmid', 'exact'), ('c5', 'exact'), ('c5', 'bf16x3')])
+def test_eval_loop_greedy_and_beam5(dev, name, gemm):
     import recurrent_fusion_network_amd as R
     cfg, spec, P, batch, gold = load_case(name)
     spi, beam = int(gold['seq_per_img']), int(gold['beam_size'])
     fc, att, labels, masks, top = [[x.to(dev) for x in t] if isinstance(t, list) else t.to(dev)
                                    for t in _caption_rows(spec, batch)]
-    model = _build(cfg, P, dev)
+    model = _build(cfg, P, dev, gemm=gemm)
     crit = R.ReviewNetEnsembleCriterion(cfg)
     out = R.eval_step(model, crit, fc, att, labels, masks, top, spi, 1.0, beam_size=1)
     assert abs(float(out['loss']) - float(gold['eval_xe_loss'])) < 1e-4 * max(1.0, abs(float(gold['eval_xe_loss'])))
@@ -92,8 +95,8 @@ def test_eval_loop_greedy_and_beam5(dev, name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('name', ['evalmid', 'c5'])
-def test_self_critical_sample_path(dev, name):
+@pytest.mark.parametrize('name,gemm', [('evalmid', 'exact'), ('c5', 'exact'), ('c5', 'bf16x3')])
+def test_self_critical_sample_path(dev, name, gemm):
     """train_rl.py:160-191 at the tier's shape: multinomial sample with grad (ids replayed from the reference's draw),
     greedy baseline (get_rewards.py:119-126), reward criterion, backward; gradient norms and slices vs the reference."""
     import recurrent_fusion_network_amd as R
@@ -102,7 +105,7 @@ def test_self_critical_sample_path(dev, name):
     fc, att, labels, masks, top = _caption_rows(spec, batch)
     rows = torch.arange(len(fc[0]) // spi) * spi
     fc_u, att_u, top_u = [f[rows].to(dev) for f in fc], [a[rows].to(dev) for a in att], top[rows].to(dev)
-    model = _build(cfg, P, dev)
+    model = _build(cfg, P, dev, gemm=gemm)
     seq, seq_lp, lp_all, reason = model.sample(fc_u, att_u, {'sample_max': 0, 'force_ids': torch.from_numpy(gold['rl_raw_ids'])})
     assert torch.equal(seq.cpu(), torch.from_numpy(gold['rl_seq']))
     assert maxerr(seq_lp, gold['rl_seq_logprobs']) < 1e-3

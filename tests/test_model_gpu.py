@@ -68,13 +68,24 @@ def test_forward_loss_grads_full(dev, name):
     assert abs(float(loss_ls) - float(gold['xe_loss_ls'])) < 1e-4 * max(1.0, abs(float(gold['xe_loss_ls'])))
 
 
+def _gemm_mode(model, gemm):
+    """'bf16x3': the hoisted projections and their weight gradients on the bf16 matrix cores (RFN_GEMM_OPT_BF16X3), at any
+    size, so that the small reference-generated tiers go through the plane GEMM too."""
+    if gemm == 'bf16x3':
+        import recurrent_fusion_network_amd._native as N
+        model.gemm_flags |= N.GEMM_OPT_BF16X3 | N.GEMM_OPT_BF16X3_ANY_SIZE
+    return model
+
+
+@pytest.mark.parametrize('gemm', ['exact', 'bf16x3'])
 @pytest.mark.parametrize('name', ['c2', 'c3'])
-def test_forward_loss_grads_shape_true(dev, name):
+def test_forward_loss_grads_shape_true(dev, name, gemm):
     """Shape-true tiers (R=A=E=512, V+1=9488; c3: M=4, L=196, D=2048): goldens hold top-5 log-probs, target
-    log-probs, loss, and per-parameter gradient norms + strided slices."""
+    log-probs, loss, and per-parameter gradient norms + strided slices.  Both GEMM modes against the same
+    reference-generated numbers, same tolerances."""
     import recurrent_fusion_network_amd as R
     cfg, spec, P, batch, gold = load_case(name)
-    model = build(cfg, P, dev)
+    model = _gemm_mode(build(cfg, P, dev), gemm)
     fc, att, labels, masks, top = to_dev(batch, dev)
     log_prob, top_pred = model(fc, att, labels)
     assert tuple(log_prob.shape) == tuple(gold['log_prob_shape'])
@@ -104,10 +115,11 @@ def test_forward_loss_grads_shape_true(dev, name):
         assert float((sl - ref).abs().max()) <= 1e-6 + 2e-3 * max(float(ref.abs().max()), gn / max(1.0, got.numel() ** 0.5)), k
 
 
-@pytest.mark.parametrize('name', ['tiny0', 'tiny1', 'tinymax', 'odd', 'mid', 'c2', 'c3'])
-def test_greedy_sample_ids_bit_exact(dev, name):
+@pytest.mark.parametrize('name,gemm', [(n, 'exact') for n in ('tiny0', 'tiny1', 'tinymax', 'odd', 'mid', 'c2', 'c3')] +
+                         [('c2', 'bf16x3'), ('c3', 'bf16x3')])
+def test_greedy_sample_ids_bit_exact(dev, name, gemm):
     cfg, spec, P, batch, gold = load_case(name)
-    model = build(cfg, P, dev)
+    model = _gemm_mode(build(cfg, P, dev), gemm)
     fc, att, labels, masks, top = to_dev(batch, dev)
     with torch.no_grad():
         seq, seq_lp, lp_all, reason = model.sample(fc, att, {'sample_max': 1, 'beam_size': 1})
