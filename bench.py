@@ -433,24 +433,29 @@ def run_train(args, rank, world, dev, R, DP):
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    settle_n = 0
-    if args.settle > 0:                  # the same number of untimed steps on every rank: rank 0's clock decides
-        ts = time.perf_counter()
-        while True:
-            step()
-            settle_n += 1
-            torch.cuda.synchronize()
-            # every rank leaves after the same step: continue while ANY rank's clock is still inside the window
-            if DP.max_over_ranks(1.0 if time.perf_counter() - ts < args.settle else 0.0, world, dev) == 0.0:
-                break
+    def settle():                       # the same number of untimed steps on every rank: the slowest clock decides
+        n = 0
+        if args.settle > 0:
+            ts = time.perf_counter()
+            while True:
+                step()
+                n += 1
+                torch.cuda.synchronize()
+                # every rank leaves after the same step: continue while ANY rank's clock is still inside the window
+                if DP.max_over_ranks(1.0 if time.perf_counter() - ts < args.settle else 0.0, world, dev) == 0.0:
+                    break
+        return n
+
+    settle_n = settle()
     for _ in range(args.warmup):
         step()
     fence()
-    t0 = time.perf_counter()
+    t0, c0 = time.perf_counter(), time.thread_time()
     for _ in range(args.steps):
         loss = step()
     fence()
-    elapsed = DP.max_over_ranks(time.perf_counter() - t0, world, dev)
+    host_cpu = (time.thread_time() - c0) / max(1e-9, time.perf_counter() - t0)   # share of the timed region the launching
+    elapsed = DP.max_over_ranks(time.perf_counter() - t0, world, dev)             # thread was on a CPU (1.0 = never descheduled)
     final_loss = float(loss.detach())
     # the same W + K steps once more with the two long products on the bf16 matrix cores: reported
     # beside the headline as out['bf16x3'], never as `value`
@@ -458,6 +463,7 @@ def run_train(args, rank, world, dev, R, DP):
     if not x3 and not args.no_alt_line:
         import recurrent_fusion_network_amd._native as N
         model.gemm_flags |= N.GEMM_OPT_BF16X3
+        settle()                         # first use of this mode's workspaces and kernels
         for _ in range(args.warmup):
             step()
         fence()
@@ -491,7 +497,7 @@ def run_train(args, rank, world, dev, R, DP):
         'metric': METRIC, 'value': round(global_B * args.steps / elapsed, 2), 'unit': 'captions/s', 'n_gpus': world,
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 3), 'higher_is_better': True,
         'scaling': 'strong' if args.strong else 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-        'settle_s': args.settle, 'settle_steps': settle_n,
+        'settle_s': args.settle, 'settle_steps': settle_n, 'host_thread_cpu_share': round(host_cpu, 3),
         'rccl_ranks': torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
         'dist_backend': torch.distributed.get_backend() if torch.distributed.is_initialized() else None,
         'config': {'workload': '%s: RecurrentFusionModel XE train step (zero_grad+fwd+criterion+bwd+clamp+Adam), '

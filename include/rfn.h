@@ -160,6 +160,15 @@ int rfn_x3_split(const float* const* srcs_host, int ngroups, int64_t ld, int row
  * tiles (part: rfn_x3_part_floats floats) are summed in slice order by a second kernel (deterministic; N % 4 == 0). */
 int rfn_x3_gemm(int M, int N, int K, const void* imageA, const void* imageB, int gm, int gn, float* const* C_host,
                 const float* const* bias_host, int64_t ldc, int accumulate, int splitk, float* part, void* stream);
+/* K-SLOW images: a logical operand stored reduction-index-major in memory, Y[K][cols] (the weight gradient's two operands:
+ * dproj[(b,l)][a] and att[(b,l)][d]), keeps that orientation: element (k, plane, m) at ((k * 3 + plane) * Mp + m) * 2
+ * bytes, Mp = ngroups * cols padded to 256, k padded to 32 with zero rows; rfn_x3_image_bytes(ngroups * cols, K) bytes.
+ * Column block g comes from srcs_host[g][k * ld + c] (cols % 4 == 0, ld % 4 == 0, 16-B aligned).  No transposing pass:
+ * rfn_x3_gemm_ks forms the MFMA operands with the transposing LDS read (ds_read_b64_tr_b16). */
+int rfn_x3_split_ks(const float* const* srcs_host, int ngroups, int64_t ld, int K, int cols, void* image, void* stream);
+/* rfn_x3_gemm with BOTH operands given as k-slow images (A: M columns, B: N columns, K rows each). */
+int rfn_x3_gemm_ks(int M, int N, int K, const void* imageA, const void* imageB, int gm, int gn, float* const* C_host,
+                   const float* const* bias_host, int64_t ldc, int accumulate, int splitk, float* part, void* stream);
 size_t rfn_x3_part_floats(int M, int N, int splitk);
 /* the number of K slices with which one round of blocks covers the chip (1 for launches of many tiles) */
 int rfn_x3_splitk_for(int M, int N, int K);
@@ -227,6 +236,14 @@ int rfn_attn_bwd_grouped(int ngroups, const float* const* proj, int64_t proj_sb,
                          const float* const* att_seq, int64_t sb, int64_t sl, const float* const* dz, int64_t lddz,
                          int B, int L, int A, int D, float* const* dproj, int64_t dproj_sb, int64_t dproj_sl,
                          int accumulate_dproj, float* const* dhproj, float* const* dw_part, void* stream);
+/* The same launch with dproj delivered as bf16 planes into k-slow plane images (rfn_x3_split_ks layout, one image per
+ * encoder, row pitch ks_mp, this call's A columns at column ks_col0; k = b * L + l) instead of f32 -- the operand of
+ * rfn_x3_gemm_ks for d att_2_att_h.weight.  A % 4 == 0 and 16-B aligned contiguous rows only. */
+int rfn_attn_bwd_grouped_ks(int ngroups, const float* const* proj, int64_t proj_sb, int64_t proj_sl,
+                            const float* const* hproj, const float* const* w_out, const float* const* alpha,
+                            const float* const* att_seq, int64_t sb, int64_t sl, const float* const* dz, int64_t lddz,
+                            int B, int L, int A, int D, void* const* ks_images, int ks_mp, int ks_col0,
+                            float* const* dhproj, float* const* dw_part, void* stream);
 
 /* Fused small-L (L <= 1024; meant for a handful) attention of up to RFN_MAX_ENC encoders in one launch: scores + softmax + context
  * (forward) and dalpha + softmax/tanh backward + d att_seq (backward), one block per (batch row, encoder).

@@ -68,6 +68,9 @@ def _load():
         'rfn_x3_image_bytes': (SZ, [I, I]),
         'rfn_x3_split': (C.c_int, [P, I, L, I, I, I, P, P]),
         'rfn_x3_gemm': (C.c_int, [I, I, I, P, P, I, I, P, P, L, I, I, P, P]),
+        'rfn_x3_split_ks': (C.c_int, [P, I, L, I, I, P, P]),
+        'rfn_x3_gemm_ks': (C.c_int, [I, I, I, P, P, I, I, P, P, L, I, I, P, P]),
+        'rfn_attn_bwd_grouped_ks': (C.c_int, [I, P, L, L, P, P, P, P, L, L, P, L, I, I, I, I, P, I, I, P, P, P]),
         'rfn_x3_part_floats': (SZ, [I, I, I]),
         'rfn_x3_splitk_for': (C.c_int, [I, I, I]),
         'rfn_colsum_f32': (C.c_int, [P, L, I, I, P, I, P]),
@@ -226,16 +229,26 @@ def x3_image(srcs, rows, K, k_fast=True, ld=None) -> torch.Tensor:
     return img
 
 
-def x3_gemm(M, N, K, img_a, img_b, outs, gm=None, gn=None, ldc=None, bias=None, accumulate=False, splitk=1):
-    """outs: list of f32 output tensors, group (i, j) = outs[i * ceil(N / gn) + j] (gm x gn each); bias: same shape list or None."""
+def x3_image_ks(srcs, K, cols, ld=None) -> torch.Tensor:
+    """k-slow bf16 plane image (uint8 tensor) of Y[K][len(srcs) * cols] whose column block g is srcs[g][k * ld + c]."""
+    srcs = [require_cuda_f32(t, 'src') for t in srcs]
+    img = torch.empty(lib.rfn_x3_image_bytes(len(srcs) * cols, K), dtype=torch.uint8, device=srcs[0].device)
+    check(lib.rfn_x3_split_ks(ptr_array(srcs), len(srcs), cols if ld is None else ld, K, cols, img.data_ptr(), stream_ptr()),
+          'rfn_x3_split_ks')
+    return img
+
+
+def x3_gemm(M, N, K, img_a, img_b, outs, gm=None, gn=None, ldc=None, bias=None, accumulate=False, splitk=1, k_slow=False):
+    """outs: list of f32 output tensors, group (i, j) = outs[i * ceil(N / gn) + j] (gm x gn each); bias: same shape list or None.
+    k_slow: both images are k-slow images (x3_image_ks)."""
     gm, gn = gm or M, gn or N
     ldc = ldc or gn
     part = None
     if splitk > 1:
         part = torch.empty(lib.rfn_x3_part_floats(M, N, splitk), dtype=torch.float32, device=img_a.device)
-    check(lib.rfn_x3_gemm(M, N, K, img_a.data_ptr(), img_b.data_ptr(), gm, gn, ptr_array(outs),
-                          None if bias is None else ptr_array(bias), ldc, int(accumulate), splitk, ptr(part), stream_ptr()),
-          'rfn_x3_gemm')
+    fn = lib.rfn_x3_gemm_ks if k_slow else lib.rfn_x3_gemm
+    check(fn(M, N, K, img_a.data_ptr(), img_b.data_ptr(), gm, gn, ptr_array(outs),
+             None if bias is None else ptr_array(bias), ldc, int(accumulate), splitk, ptr(part), stream_ptr()), 'rfn_x3_gemm')
 
 
 def linear(x: torch.Tensor, weight: torch.Tensor, bias=None) -> torch.Tensor:

@@ -78,6 +78,7 @@ struct AttnEncPtrs {
     float* dproj[RFN_MAX_ENC];
     float* dhproj[RFN_MAX_ENC];
     float* dw_part[RFN_MAX_ENC];
+    char* ks_img[RFN_MAX_ENC];   // attn_scores_bwd_k<.., EMIT>: k-slow bf16 plane image that receives dproj (rfn.h, rfn_x3_split_ks)
 };
 
 template <bool VEC>
@@ -401,10 +402,14 @@ extern "C" int rfn_attn_context_bwd_dseq(const float* alpha, const float* dz, in
 #endif
 // FUSED: dalpha[l] = <dz, x[l]> is computed here first (into LDS, same per-row arithmetic as attn_dalpha_k), so the
 // context backward and the score backward of one (step, encoder) are a single launch: x is streamed, then P.
-template <bool VEC, bool FUSED>
+// EMIT (with VEC, FUSED): dproj is not written as f32; its three bf16 planes go straight into the k-slow plane image the
+// weight-gradient GEMM on the bf16 matrix cores reads (element (k = b * L + l, plane, column ks_col0 + a) at
+// ((k * 3 + plane) * ks_mp + ks_col0 + a) * 2 bytes): 8 bytes per lane and plane, whole rows coalesced -- the separate split
+// pass over dproj (a read of 4 and a write of 6 bytes per element) disappears.
+template <bool VEC, bool FUSED, bool EMIT = false>
 __global__ __launch_bounds__(SB_THREADS) void attn_scores_bwd_k(const AttnEncPtrs E, long sb, long sl, int L, int A,
                                                                long dsb, long dsl, int accumulate, long xsb, long xsl,
-                                                               long lddz, int D, int vec_x) {
+                                                               long lddz, int D, int vec_x, int ks_mp, int ks_col0) {
     const float* proj = E.proj[blockIdx.y];   // may alias dproj
     const float* __restrict__ hproj = E.hproj[blockIdx.y];
     const float* __restrict__ w_out = E.w_out[blockIdx.y];
@@ -523,7 +528,19 @@ __global__ __launch_bounds__(SB_THREADS) void attn_scores_bwd_k(const AttnEncPtr
                             ah[e] += dpre;
                             aw[e] += dsl_v * t;
                         }
-                        if constexpr (VEC) {
+                        if constexpr (EMIT) {
+                            unsigned q[3][4];
+#pragma unroll
+                            for (int e = 0; e < W; ++e) x3_split(ov[e], q[0][e], q[1][e], q[2][e]);
+                            char* img = E.ks_img[blockIdx.y] + (((long)b * L + l) * 3 * ks_mp + ks_col0 + a) * 2;
+#pragma unroll
+                            for (int p = 0; p < 3; ++p) {
+                                uint2 w2;
+                                w2.x = q[p][0] | (q[p][1] << 16);
+                                w2.y = q[p][2] | (q[p][3] << 16);
+                                *reinterpret_cast<uint2*>(img + (long)p * ks_mp * 2) = w2;
+                            }
+                        } else if constexpr (VEC) {
                             f32x4 t = {ov[0], ov[1], ov[2], ov[3]};
                             if (accumulate) t += *reinterpret_cast<const f32x4*>(o);
                             if (ATT_NT_P) __builtin_nontemporal_store(t, reinterpret_cast<f32x4*>(o));
@@ -557,7 +574,8 @@ __global__ __launch_bounds__(SB_THREADS) void attn_scores_bwd_k(const AttnEncPtr
 template <bool FUSED>
 static int launch_scores_bwd(int ng, const AttnEncPtrs& E, int64_t proj_sb, int64_t proj_sl, int B, int L, int A,
                              int64_t dproj_sb, int64_t dproj_sl, int accumulate_dproj, int64_t xsb, int64_t xsl,
-                             int64_t lddz, int D, hipStream_t st) {
+                             int64_t lddz, int D, hipStream_t st, int ks_mp = 0, int ks_col0 = 0) {
+    const bool emit = ks_mp > 0;   // dproj goes to E.ks_img as bf16 planes instead of f32
     if (B <= 0 || L <= 0 || A <= 0 || ng < 1 || ng > RFN_MAX_ENC) return RFN_ERR_SHAPE;
     size_t fl = (size_t)(2 + 2 * SB_WAVES) * ((A + 3) & ~3) + SB_WAVES + L;
     if (FUSED) fl = (size_t)(2 + 2 * SB_WAVES) * ((A + 3) & ~3) + SB_WAVES + 2 * ((L + 3) & ~3) + ((D + 3) & ~3);
@@ -566,24 +584,32 @@ static int launch_scores_bwd(int ng, const AttnEncPtrs& E, int64_t proj_sb, int6
     bool vec = (A % 4 == 0) && (proj_sb % 4 == 0) && (proj_sl % 4 == 0) && (dproj_sb % 4 == 0) && (dproj_sl % 4 == 0);
     bool vx = FUSED && (D % 4 == 0) && (xsb % 4 == 0) && (xsl % 4 == 0);
     for (int g = 0; g < ng; ++g) {
-        if (!E.proj[g] || !E.hproj[g] || !E.w_out[g] || !E.alpha_in[g] || !E.dproj[g] || !E.dhproj[g] || !E.dw_part[g])
-            return RFN_ERR_ARG;
+        if (!E.proj[g] || !E.hproj[g] || !E.w_out[g] || !E.alpha_in[g] || !E.dhproj[g] || !E.dw_part[g]) return RFN_ERR_ARG;
+        if (emit ? !E.ks_img[g] : !E.dproj[g]) return RFN_ERR_ARG;
         if (FUSED ? (!E.x[g] || !E.dz[g]) : !E.dalpha[g]) return RFN_ERR_ARG;
-        vec = vec && rfn_aligned16(E.proj[g]) && rfn_aligned16(E.dproj[g]);
+        vec = vec && rfn_aligned16(E.proj[g]) && (emit || rfn_aligned16(E.dproj[g]));
         vx = vx && rfn_aligned16(E.x[g]);
     }
-    if (vec) {
+    if (emit) {
+        if (!FUSED || !vec || accumulate_dproj || (ks_mp & 3) || (ks_col0 & 3)) return RFN_ERR_SHAPE;
+        if constexpr (FUSED) {
+            auto k = attn_scores_bwd_k<true, true, true>;
+            if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(k, dim3(B, ng), dim3(SB_THREADS), lds, st, E, (long)proj_sb, (long)proj_sl, L, A, 0L, 0L, 0,
+                               (long)xsb, (long)xsl, (long)lddz, D, (int)vx, ks_mp, ks_col0);
+        }
+    } else if (vec) {
         auto k = attn_scores_bwd_k<true, FUSED>;
         if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(k, dim3(B, ng), dim3(SB_THREADS), lds, st, E, (long)proj_sb, (long)proj_sl, L, A,
                            (long)dproj_sb, (long)dproj_sl, accumulate_dproj, (long)xsb, (long)xsl, (long)lddz, D,
-                           (int)vx);
+                           (int)vx, 0, 0);
     } else {
         auto k = attn_scores_bwd_k<false, FUSED>;
         if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(k, dim3(B, ng), dim3(SB_THREADS), lds, st, E, (long)proj_sb, (long)proj_sl, L, A,
                            (long)dproj_sb, (long)dproj_sl, accumulate_dproj, (long)xsb, (long)xsl, (long)lddz, D,
-                           (int)vx);
+                           (int)vx, 0, 0);
     }
     RFN_CHECK_LAUNCH();
     return RFN_OK;
@@ -620,6 +646,27 @@ extern "C" int rfn_attn_bwd_grouped(int ngroups, const float* const* proj, int64
     }
     return launch_scores_bwd<true>(ngroups, E, proj_sb, proj_sl, B, L, A, dproj_sb, dproj_sl, accumulate_dproj, sb, sl,
                                    lddz, D, (hipStream_t)stream);
+}
+// The same launch with d proj delivered as bf16 planes into k-slow plane images (one per encoder; rfn_x3_split_ks layout
+// with row pitch ks_mp, this call's A columns starting at column ks_col0) instead of f32: what the weight gradient
+// d att_2_att_h.weight = dproj^T . att_seq on the bf16 matrix cores (rfn_x3_gemm_ks) reads.  A % 4 == 0, 16-B aligned
+// contiguous-row operands only (RFN_ERR_SHAPE otherwise).
+extern "C" int rfn_attn_bwd_grouped_ks(int ngroups, const float* const* proj, int64_t proj_sb, int64_t proj_sl,
+                                       const float* const* hproj, const float* const* w_out, const float* const* alpha,
+                                       const float* const* att_seq, int64_t sb, int64_t sl, const float* const* dz,
+                                       int64_t lddz, int B, int L, int A, int D, void* const* ks_images, int ks_mp,
+                                       int ks_col0, float* const* dhproj, float* const* dw_part, void* stream) {
+    if (ngroups < 1 || ngroups > RFN_MAX_ENC || D <= 0 || ks_mp < 1 || ks_col0 < 0 || ks_col0 + A > ks_mp) return RFN_ERR_SHAPE;
+    if (!proj || !hproj || !w_out || !alpha || !att_seq || !dz || !ks_images || !dhproj || !dw_part) return RFN_ERR_ARG;
+    AttnEncPtrs E;
+    memset(&E, 0, sizeof(E));
+    for (int g = 0; g < ngroups; ++g) {
+        E.proj[g] = proj[g]; E.hproj[g] = hproj[g]; E.w_out[g] = w_out[g]; E.alpha_in[g] = alpha[g];
+        E.x[g] = att_seq[g]; E.dz[g] = dz[g];
+        E.ks_img[g] = (char*)ks_images[g]; E.dhproj[g] = dhproj[g]; E.dw_part[g] = dw_part[g];
+    }
+    return launch_scores_bwd<true>(ngroups, E, proj_sb, proj_sl, B, L, A, 0, 0, 0, sb, sl, lddz, D, (hipStream_t)stream,
+                                   ks_mp, ks_col0);
 }
 extern "C" int rfn_attn_bwd(const float* proj, int64_t proj_sb, int64_t proj_sl, const float* hproj, const float* w_out,
                             const float* alpha, const float* att_seq, int64_t sb, int64_t sl, const float* dz,

@@ -45,4 +45,24 @@ __device__ __forceinline__ float rfn_tanh_fast(float x) {
     const float e = __expf(2.0f * x);
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
 }
+// ---- f32 -> three bf16 planes (x = p0 + p1 + p2; csrc/rfn_gemm_x3.hip) ---------------------------------------------
+__device__ __forceinline__ unsigned x3_bf16_rne(float x) {
+    const unsigned u = __float_as_uint(x);
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ void x3_split(float x, unsigned& p0, unsigned& p1, unsigned& p2) {
+    const unsigned u = __float_as_uint(x);
+    if ((u & 0x7F800000u) == 0x7F800000u) {   // infinity / NaN: the leading plane carries it, the others stay zero
+        p0 = (u >> 16) | ((u & 0xFFFFu) ? 1u : 0u);   // a NaN stays a NaN even if its payload sat in the low half
+        p1 = p2 = 0u;
+        return;
+    }
+    p0 = x3_bf16_rne(x);
+    if ((p0 & 0x7F80u) == 0x7F80u) p0 = u >> 16;   // rounding up would overflow: truncate, the residual takes the rest
+    float r = x - __uint_as_float(p0 << 16);
+    p1 = x3_bf16_rne(r);
+    r -= __uint_as_float(p1 << 16);
+    p2 = x3_bf16_rne(r);
+}
+
 #endif

@@ -36,26 +36,7 @@ struct X3Shape {
     static constexpr int ACC = SHAPE == 32 ? 16 : 4; // accumulator registers per lane and MFMA tile
 };
 
-// ---- f32 -> three bf16 planes ----------------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned x3_bf16_rne(float x) {
-    const unsigned u = __float_as_uint(x);
-    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
-}
-__device__ __forceinline__ void x3_split(float x, unsigned& p0, unsigned& p1, unsigned& p2) {
-    const unsigned u = __float_as_uint(x);
-    if ((u & 0x7F800000u) == 0x7F800000u) {   // infinity / NaN: the leading plane carries it, the others stay zero
-        p0 = (u >> 16) | ((u & 0xFFFFu) ? 1u : 0u);   // a NaN stays a NaN even if its payload sat in the low half
-        p1 = p2 = 0u;
-        return;
-    }
-    p0 = x3_bf16_rne(x);
-    if ((p0 & 0x7F80u) == 0x7F80u) p0 = u >> 16;   // rounding up would overflow: truncate, the residual takes the rest
-    float r = x - __uint_as_float(p0 << 16);
-    p1 = x3_bf16_rne(r);
-    r -= __uint_as_float(p1 << 16);
-    p2 = x3_bf16_rne(r);
-}
-
+// (x3_split: rfn_common.h)
 struct X3SplitArgs {
     const float* src[X3_MAX_GROUPS];   // group g fills rows [g * rows, (g + 1) * rows) of the image
     long ld;
@@ -182,7 +163,8 @@ extern "C" int rfn_x3_split(const float* const* srcs_host, int ngroups, int64_t 
 struct X3Args {
     const char* A;   // plane image of the M-side operand  [M][K]
     const char* B;   // plane image of the N-side operand  [N][K]
-    int nrbA, nrbB;  // row blocks per kc in each image
+    int nrbA, nrbB;  // row blocks per kc in each image (fragment-order images)
+    int mpA, mpB;    // padded row counts = plane-row pitch in elements (k-slow images, x3_tile<.., KS = true>)
     int M, N;        // logical output size (stores are bounds-checked)
     int nkc;         // K_pad / KC
     int splitk;      // > 1: blockIdx.z cuts nkc; raw partial tiles go to part[ks][M][N]
@@ -213,7 +195,7 @@ __device__ __forceinline__ void x3_mfma(const x3_bf16x8& a, const x3_bf16x8& b, 
 // One BM x BN output tile at (row0, col0) over the piece rows [kc0, kc0 + iters) of K, by WGM x WGN waves; operands staged
 // by LDS-DMA, one piece row of K per step (32 reduction indices for the 16 x 16 shape, 16 for the 32 x 32 shape).  The two
 // shapes have their own main loops (below); setup, accumulators and epilogue are shared.
-template <int SHAPE, int BM, int BN, int WGM, int WGN, int SLOTS>
+template <int SHAPE, int BM, int BN, int WGM, int WGN, int SLOTS, bool KS = false>
 __device__ __forceinline__ void x3_tile(const X3Args& args, const int row0, const int col0, const int kc0, const int iters,
                                         const int ks) {
     using S = X3Shape<SHAPE>;
@@ -333,22 +315,96 @@ __device__ __forceinline__ void x3_tile(const X3Args& args, const int row0, cons
         static_assert(PA % NW == 0 && PB % NW == 0, "each operand's pieces must divide over the waves");
         char* const bufA = x3_smem;                   // two A stages
         char* const bufB = x3_smem + 2 * PA * 1024;   // one B stage
-        const char* gA = args.A + (((long)kc0 * args.nrbA + row0 / RB) * 3 + wave * PAW) * 1024;
-        const char* gB = args.B + (((long)kc0 * args.nrbB + col0 / RB) * 3 + wave * PBW) * 1024;
-        const long sA = (long)args.nrbA * 3072, sB = (long)args.nrbB * 3072;
+        // k-slow images (KS): element (k, plane, m) at ((k * 3 + plane) * Mp + m) * 2 bytes.  A stage in LDS is, per plane, 32
+        // k-rows of the tile's BM (BN) columns, row-major; a fragment is read with ds_read_b64_tr_b16 (4 k-rows x 16 columns
+        // per 16-lane group, delivered column-major = 8 consecutive k per lane after two reads).  The 8 rows a 32-lane half
+        // reads are RS = 2 BM bytes apart, i.e. on the same banks, so 16-B chunk c of row r is stored at chunk position
+        // c ^ swz(r), swz(r) = 2 ((r & 3) | ((r >> 3) & 1) << 2): the 8 rows x 2 chunks of a half then cover 16 distinct
+        // 16-B bank slots.  The LDS-DMA writes lane-linearly, so the swizzle goes on the SOURCE address.
+        constexpr int RSA = 2 * BM, RSB = 2 * BN;   // stage row pitch in LDS, bytes
+        auto ks_swz = [](int r) { return 2 * ((r & 3) | (((r >> 3) & 1) << 2)); };
+        const char* gA;
+        const char* gB;
+        long sA, sB;
+        unsigned offA[PAW], offB[PBW];   // KS: this lane's source offset per piece (fixed for the whole loop)
+        if constexpr (KS) {
+            gA = args.A + ((long)kc0 * 32 * 3 * args.mpA + row0) * 2;
+            gB = args.B + ((long)kc0 * 32 * 3 * args.mpB + col0) * 2;
+            sA = (long)32 * 3 * args.mpA * 2;
+            sB = (long)32 * 3 * args.mpB * 2;
+#pragma unroll
+            for (int j = 0; j < PAW; ++j) {
+                const int byte = (wave * PAW + j) * 1024 + lane * 16, p = byte / (32 * RSA), rem = byte % (32 * RSA);
+                const int r = rem / RSA, c = (rem % RSA) / 16;
+                offA[j] = (unsigned)(((long)(r * 3 + p) * args.mpA) * 2 + ((c ^ ks_swz(r)) * 16));
+            }
+#pragma unroll
+            for (int j = 0; j < PBW; ++j) {
+                const int byte = (wave * PBW + j) * 1024 + lane * 16, p = byte / (32 * RSB), rem = byte % (32 * RSB);
+                const int r = rem / RSB, c = (rem % RSB) / 16;
+                offB[j] = (unsigned)(((long)(r * 3 + p) * args.mpB) * 2 + ((c ^ ks_swz(r)) * 16));
+            }
+        } else {
+            gA = args.A + (((long)kc0 * args.nrbA + row0 / RB) * 3 + wave * PAW) * 1024;
+            gB = args.B + (((long)kc0 * args.nrbB + col0 / RB) * 3 + wave * PBW) * 1024;
+            sA = (long)args.nrbA * 3072;
+            sB = (long)args.nrbB * 3072;
+#pragma unroll
+            for (int j = 0; j < PAW; ++j) offA[j] = j * 1024 + lane16;
+#pragma unroll
+            for (int j = 0; j < PBW; ++j) offB[j] = j * 1024 + lane16;
+        }
         auto issue_a = [&](int buf) {
             char* st = bufA + (buf * PA + wave * PAW) * 1024;
 #pragma unroll
             for (int j = 0; j < PAW; ++j)
-                __builtin_amdgcn_global_load_lds((x3_gbl_void*)(gA + j * 1024 + lane16), (x3_lds_void*)(st + j * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((x3_gbl_void*)(gA + offA[j]), (x3_lds_void*)(st + j * 1024), 16, 0, 0);
             gA += sA;
         };
         auto issue_b = [&]() {
             char* st = bufB + wave * PBW * 1024;
 #pragma unroll
             for (int j = 0; j < PBW; ++j)
-                __builtin_amdgcn_global_load_lds((x3_gbl_void*)(gB + j * 1024 + lane16), (x3_lds_void*)(st + j * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((x3_gbl_void*)(gB + offB[j]), (x3_lds_void*)(st + j * 1024), 16, 0, 0);
             gB += sB;
+        };
+        // fragment of 16-row block `blk` (of this wave's rows), plane p, from a stage at `base`
+        unsigned fa_off[MI], fb_off[NI];   // KS: this lane's address inside a stage per block (plane 0, first read)
+        if constexpr (KS) {
+            const int g = lane >> 4, jj = lane & 15, r1 = 8 * g + (jj >> 2);
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int c = (wm * WM + 16 * i) / 8 + ((jj & 3) >> 1);
+                fa_off[i] = (unsigned)(r1 * RSA + ((c ^ ks_swz(r1)) * 16) + 8 * (jj & 1));
+            }
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const int c = (wn * WN + 16 * j) / 8 + ((jj & 3) >> 1);
+                fb_off[j] = (unsigned)(r1 * RSB + ((c ^ ks_swz(r1)) * 16) + 8 * (jj & 1));
+            }
+        }
+        // KS fragments are read by inline asm: behind a pending LDS-DMA the compiler puts s_waitcnt vmcnt(0) in front of every
+        // ds_read_b64_tr_b16 it emits itself (it cannot see that the DMA targets another buffer), which drains the prefetch
+        // of the next step in every iteration.  The asm reads are invisible to that pass AND to its lgkmcnt bookkeeping:
+        // every use of their results sits behind an explicit s_waitcnt that names the registers (x3_lgkm_fence).
+        typedef unsigned long long x3_u64;
+        typedef x3_u64 x3_u64x2 __attribute__((ext_vector_type(2)));
+        const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)x3_smem;
+#define X3_TR(dst, addr, OFF) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF))
+        auto frag3_ks = [&](x3_u64x2 (&f)[3], unsigned addr, auto rs) {   // the three planes of one 16-row block
+            constexpr int RS = decltype(rs)::value;
+            X3_TR(f[0][0], addr, 0);
+            X3_TR(f[0][1], addr, 4 * RS);
+            X3_TR(f[1][0], addr, 32 * RS);
+            X3_TR(f[1][1], addr, 32 * RS + 4 * RS);
+            X3_TR(f[2][0], addr, 64 * RS);
+            X3_TR(f[2][1], addr, 64 * RS + 4 * RS);
+        };
+        auto frag_a = [&](const char* base, int i, int p) -> x3_bf16x8 {
+            return *reinterpret_cast<const x3_bf16x8*>(base + lane16 + ((wm * MI + i) * 3 + p) * 1024);
+        };
+        auto frag_b = [&](const char* base, int j, int p) -> x3_bf16x8 {
+            return *reinterpret_cast<const x3_bf16x8*>(base + lane16 + ((wn * NI + j) * 3 + p) * 1024);
         };
         if (iters > 0) {
             issue_a(0);
@@ -359,21 +415,69 @@ __device__ __forceinline__ void x3_tile(const X3Args& args, const int row0, cons
             __builtin_amdgcn_s_barrier();
             const bool more = st + 1 < iters;
             if (more) issue_a((st + 1) & 1);
+            if constexpr (KS) {
+                x3_u64x2 bq[NI][3], aq[2][3];
+                const unsigned bB = lds0 + 2 * PA * 1024, bA = lds0 + (st & 1) * PA * 1024;
+#pragma unroll
+                for (int j = 0; j < NI; ++j) frag3_ks(bq[j], bB + fb_off[j], std::integral_constant<int, RSB>{});
+                frag3_ks(aq[0], bA + fa_off[0], std::integral_constant<int, RSA>{});   // A_s landed with barrier 1
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's B fragments are in registers
+                // (volatile asm statements keep their order; routing each register through one pins its first use behind the wait)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) asm volatile("" : "+v"(bq[j][p]));
+#pragma unroll
+                for (int p = 0; p < 3; ++p) asm volatile("" : "+v"(aq[0][p]));
+                __builtin_amdgcn_s_barrier();
+                if (more) issue_b();
+                x3_bf16x8 b[NI][3];
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) b[j][p] = __builtin_bit_cast(x3_bf16x8, bq[j][p]);
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    // the next row block's fragments travel while this one multiplies
+                    if (i + 1 < MI) frag3_ks(aq[(i + 1) & 1], bA + fa_off[i + 1], std::integral_constant<int, RSA>{});
+                    x3_bf16x8 a[3];
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) a[p] = __builtin_bit_cast(x3_bf16x8, aq[i & 1][p]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) x3_mfma<SHAPE>(a[2], b[j][0], acc[i][j]);
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) x3_mfma<SHAPE>(a[1], b[j][1], acc[i][j]);
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) x3_mfma<SHAPE>(a[0], b[j][2], acc[i][j]);
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) x3_mfma<SHAPE>(a[1], b[j][0], acc[i][j]);
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) x3_mfma<SHAPE>(a[0], b[j][1], acc[i][j]);
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) x3_mfma<SHAPE>(a[0], b[j][0], acc[i][j]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    // the reads issued above are complete before the next row block (or the next step's barrier) uses them
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) asm volatile("" : "+v"(aq[(i + 1) & 1][p]));
+                }
+                continue;
+            }
             x3_bf16x8 b[NI][3];
-            const char* b_l = bufB + lane16 + (wn * NI * 3) * 1024;
 #pragma unroll
             for (int j = 0; j < NI; ++j)
 #pragma unroll
-                for (int p = 0; p < 3; ++p) b[j][p] = *reinterpret_cast<const x3_bf16x8*>(b_l + (j * 3 + p) * 1024);
+                for (int p = 0; p < 3; ++p) b[j][p] = frag_b(bufB, j, p);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's B fragments are in registers
             __builtin_amdgcn_s_barrier();
             if (more) issue_b();
-            const char* a_l = bufA + (st & 1) * PA * 1024 + lane16 + (wm * MI * 3) * 1024;
+            const char* a_s = bufA + (st & 1) * PA * 1024;
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
                 x3_bf16x8 a[3];
 #pragma unroll
-                for (int p = 0; p < 3; ++p) a[p] = *reinterpret_cast<const x3_bf16x8*>(a_l + (i * 3 + p) * 1024);
+                for (int p = 0; p < 3; ++p) a[p] = frag_a(a_s, i, p);
 #pragma unroll
                 for (int j = 0; j < NI; ++j) x3_mfma<SHAPE>(a[2], b[j][0], acc[i][j]);
 #pragma unroll
@@ -485,7 +589,7 @@ __device__ __forceinline__ void x3_tile(const X3Args& args, const int row0, cons
 // grid.x: main_tiles whole tiles (blocks that share an XCD, id % 8, take consecutive tiles, tn fastest: the 16 column
 // tiles of a row panel run side by side on one XCD and share the panel through its L2), then 4 quarter-tile blocks per
 // remaining tile: the last, partly filled round of a long launch is spread over four times as many CUs.  grid.z: K slices.
-template <int SHAPE, int BM, int BN, int WGM, int WGN, int SLOTS, bool TAIL>
+template <int SHAPE, int BM, int BN, int WGM, int WGN, int SLOTS, bool TAIL, bool KS = false>
 __global__ __launch_bounds__(64 * WGM * WGN) void x3_gemm_k(const X3Args args) {
     int per = (args.nkc + args.splitk - 1) / args.splitk;
     const int ks = blockIdx.z;
@@ -496,12 +600,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void x3_gemm_k(const X3Args args) {
         const int q = args.main_tiles / 8, r = args.main_tiles % 8, xcd = wg % 8;
         wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + wg / 8;
         const int tm = wg / args.tiles_n, tn = wg % args.tiles_n;
-        x3_tile<SHAPE, BM, BN, WGM, WGN, SLOTS>(args, tm * BM, tn * BN, kc0, per, ks);
+        x3_tile<SHAPE, BM, BN, WGM, WGN, SLOTS, KS>(args, tm * BM, tn * BN, kc0, per, ks);
     } else if constexpr (TAIL) {
         const int t = blockIdx.x - args.main_tiles;
         const int wg = args.main_tiles + t / 4, qd = t % 4;
         const int tm = wg / args.tiles_n, tn = wg % args.tiles_n;
-        x3_tile<SHAPE, BM / 2, BN / 2, WGM, WGN, SLOTS>(args, tm * BM + (qd >> 1) * (BM / 2), tn * BN + (qd & 1) * (BN / 2),
+        x3_tile<SHAPE, BM / 2, BN / 2, WGM, WGN, SLOTS, KS>(args, tm * BM + (qd >> 1) * (BM / 2), tn * BN + (qd & 1) * (BN / 2),
                                                              kc0, per, ks);
     }
 }
@@ -545,6 +649,12 @@ __global__ __launch_bounds__(256) void x3_reduce_k(const X3Args args) {
 #ifndef X3_SLOTS
 #define X3_SLOTS 2
 #endif
+#ifndef X3_KS_WGM
+#define X3_KS_WGM 2
+#endif
+#ifndef X3_KS_WGN
+#define X3_KS_WGN 4
+#endif
 #ifndef X3_BLOCKS_PER_CU
 #define X3_BLOCKS_PER_CU 1   /* resident blocks per CU of the chosen tile (LDS-bound); sizes the tail round */
 #endif
@@ -570,8 +680,10 @@ extern "C" int rfn_x3_splitk_for(int M, int N, int K) {
 // C groups (+)= A . B^T on plane images.  M, N: logical output size; K: logical reduction length (the images hold it
 // padded).  Output groups of gm rows x gn columns, pointer table C_host[(m / gm) * ngn + n / gn] (device pointers, host
 // array), leading dimension ldc; bias_host may be NULL.  splitk > 1 needs part (splitk * M * N floats).
-extern "C" int rfn_x3_gemm(int M, int N, int K, const void* imgA, const void* imgB, int gm, int gn, float* const* C_host,
-                           const float* const* bias_host, int64_t ldc, int accumulate, int splitk, float* part, void* stream) {
+// KS: both operands are k-slow images (rfn_x3_split_ks) instead of fragment-order images (rfn_x3_split).
+template <bool KS>
+static int x3_launch(int M, int N, int K, const void* imgA, const void* imgB, int gm, int gn, float* const* C_host,
+                     const float* const* bias_host, int64_t ldc, int accumulate, int splitk, float* part, void* stream) {
     using S = X3Shape<X3_SHAPE>;
     if (M < 1 || N < 1 || K < 1 || !imgA || !imgB || !C_host || gm < 1 || gn < 1) return RFN_ERR_ARG;
     X3Args a;
@@ -579,6 +691,8 @@ extern "C" int rfn_x3_gemm(int M, int N, int K, const void* imgA, const void* im
     a.B = (const char*)imgB;
     a.nrbA = (int)(x3_rows_pad(M) / S::RB);
     a.nrbB = (int)(x3_rows_pad(N) / S::RB);
+    a.mpA = (int)x3_rows_pad(M);
+    a.mpB = (int)x3_rows_pad(N);
     a.M = M;
     a.N = N;
     a.nkc = (int)(x3_k_pad(K) / S::KC);
@@ -589,11 +703,11 @@ extern "C" int rfn_x3_gemm(int M, int N, int K, const void* imgA, const void* im
     const int ngm = (M + gm - 1) / gm;
     a.ngn = (N + gn - 1) / gn;
     if ((long)ngm * a.ngn > X3_MAX_GROUPS) return RFN_ERR_SHAPE;
-    if ((ngm > 1 && gm % (X3_BM / 2)) || (a.ngn > 1 && gn % (X3_BN / 2))) return RFN_ERR_SHAPE;   // no tile straddles groups
-    if ((ngm > 1 && gm % X3_BM) || (a.ngn > 1 && gn % X3_BN)) return RFN_ERR_SHAPE;
+    if ((ngm > 1 && gm % X3_BM) || (a.ngn > 1 && gn % X3_BN)) return RFN_ERR_SHAPE;   // no tile straddles groups
     if (a.splitk > a.nkc) return RFN_ERR_SHAPE;
     if (a.splitk > 1 && (!part || (N & 3) || (gn & 3))) return RFN_ERR_ARG;
     if ((double)X3_BM * (double)(a.splitk > 1 ? N : ldc) * 4.0 >= 4294967296.0) return RFN_ERR_SHAPE;   // 32-bit tile offsets
+    if (KS && (96.0 * a.mpA * 2 >= 4294967296.0 || 96.0 * a.mpB * 2 >= 4294967296.0)) return RFN_ERR_SHAPE;
     a.ldc = ldc;
     a.accumulate = accumulate;
     a.tiles_m = (M + X3_BM - 1) / X3_BM;
@@ -602,11 +716,13 @@ extern "C" int rfn_x3_gemm(int M, int N, int K, const void* imgA, const void* im
         a.C[g] = C_host[g];
         a.bias[g] = bias_host ? bias_host[g] : nullptr;
     }
-    auto kern = x3_gemm_k<X3_SHAPE, X3_BM, X3_BN, X3_WGM, X3_WGN, X3_SLOTS, (X3_TAIL != 0)>;
+    // KS keeps 24 more address registers per lane: the 2 x 4 wave arrangement (48 B-fragment registers instead of 96) fits
+    constexpr int WGM = KS ? X3_KS_WGM : X3_WGM, WGN = KS ? X3_KS_WGN : X3_WGN;
+    auto kern = x3_gemm_k<X3_SHAPE, X3_BM, X3_BN, WGM, WGN, X3_SLOTS, (X3_TAIL != 0), KS>;
     // the operand ring; the epilogue stages inside it.  32x32x16: SLOTS slots of both operands; 16x16x32: two A stages + one B
     constexpr int lds = X3_SHAPE == 32 ? X3_SLOTS * ((X3_BM + X3_BN) / S::RB) * 3 * 1024
                                        : (2 * (X3_BM / S::RB) + X3_BN / S::RB) * 3 * 1024;
-    static bool attr_set[16] = {};   // write-once per device
+    static bool attr_set[16] = {};   // write-once per device (one set per instantiation of this function)
     static int cus[16] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return RFN_ERR_LAUNCH;
@@ -622,12 +738,76 @@ extern "C" int rfn_x3_gemm(int M, int N, int K, const void* imgA, const void* im
     const int rem = tiles % slots;
     const bool tail = X3_TAIL && a.splitk == 1 && tiles / slots >= 2 && rem > 0 && 4 * rem <= slots;
     a.main_tiles = tail ? tiles - rem : tiles;
-    hipLaunchKernelGGL(kern, dim3(a.main_tiles + 4 * (tiles - a.main_tiles), 1, a.splitk), dim3(64 * X3_WGM * X3_WGN), lds,
+    hipLaunchKernelGGL(kern, dim3(a.main_tiles + 4 * (tiles - a.main_tiles), 1, a.splitk), dim3(64 * WGM * WGN), lds,
                        (hipStream_t)stream, a);
     RFN_CHECK_LAUNCH();
     if (a.splitk > 1) {
         hipLaunchKernelGGL(x3_reduce_k, dim3(1024), dim3(256), 0, (hipStream_t)stream, a);
         RFN_CHECK_LAUNCH();
     }
+    return RFN_OK;
+}
+
+extern "C" int rfn_x3_gemm(int M, int N, int K, const void* imgA, const void* imgB, int gm, int gn, float* const* C_host,
+                           const float* const* bias_host, int64_t ldc, int accumulate, int splitk, float* part, void* stream) {
+    return x3_launch<false>(M, N, K, imgA, imgB, gm, gn, C_host, bias_host, ldc, accumulate, splitk, part, stream);
+}
+
+#if X3_SHAPE == 16
+extern "C" int rfn_x3_gemm_ks(int M, int N, int K, const void* imgA, const void* imgB, int gm, int gn, float* const* C_host,
+                              const float* const* bias_host, int64_t ldc, int accumulate, int splitk, float* part,
+                              void* stream) {
+    return x3_launch<true>(M, N, K, imgA, imgB, gm, gn, C_host, bias_host, ldc, accumulate, splitk, part, stream);
+}
+#endif
+
+// ---- f32 [k][m] -> k-slow plane image -----------------------------------------------------------------------------------
+// image element (k, plane, m) at ((k * 3 + plane) * Mp + m) * 2 bytes, Mp = total columns padded to 256, k padded to 32;
+// column block g (cols columns) comes from srcs[g][k * ld + c].  One thread per 4 columns: a float4 in, three 8-byte
+// plane groups out, everything coalesced; pad rows and pad columns are written as zeros.
+struct X3SplitKsArgs {
+    const float* src[X3_MAX_GROUPS];
+    long ld;
+    int K, cols, ngroups, mp, kpad;
+    char* img;
+};
+__global__ __launch_bounds__(256) void x3_split_ks_k(const X3SplitKsArgs a) {
+    const int k = blockIdx.y;
+    const int m = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (m >= a.mp) return;
+    const int g = m / a.cols, c = m - g * a.cols;      // host: cols % 4 == 0, so a group of 4 columns never straddles
+    x3_f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (k < a.K && g < a.ngroups) v = *reinterpret_cast<const x3_f32x4*>(a.src[g] + (long)k * a.ld + c);
+    unsigned q[3][4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) x3_split(v[e], q[0][e], q[1][e], q[2][e]);
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        uint2 w;
+        w.x = q[p][0] | (q[p][1] << 16);
+        w.y = q[p][2] | (q[p][3] << 16);
+        *reinterpret_cast<uint2*>(a.img + (((long)k * 3 + p) * a.mp + m) * 2) = w;
+    }
+}
+// k-slow image of Y[K][ngroups * cols] (K = reduction index = source row): the layout the weight-gradient GEMM reads its two
+// operands in when both are stored reduction-index-major in memory (dP[(b,l)][a], att[(b,l)][d]): no transposing pass.
+extern "C" int rfn_x3_split_ks(const float* const* srcs_host, int ngroups, int64_t ld, int K, int cols, void* image,
+                               void* stream) {
+    if (!srcs_host || !image || K < 1 || cols < 1 || ngroups < 1 || ngroups > X3_MAX_GROUPS) return RFN_ERR_ARG;
+    if ((cols & 3) || (ld & 3)) return RFN_ERR_SHAPE;
+    X3SplitKsArgs a;
+    for (int g = 0; g < ngroups; ++g) {
+        if (!srcs_host[g] || (((uintptr_t)srcs_host[g]) & 15u)) return RFN_ERR_ARG;
+        a.src[g] = srcs_host[g];
+    }
+    a.ld = ld;
+    a.K = K;
+    a.cols = cols;
+    a.ngroups = ngroups;
+    a.mp = (int)x3_rows_pad((long)ngroups * cols);
+    a.kpad = (int)x3_k_pad(K);
+    a.img = (char*)image;
+    hipLaunchKernelGGL(x3_split_ks_k, dim3((a.mp / 4 + 255) / 256, a.kpad), dim3(256), 0, (hipStream_t)stream, a);
+    RFN_CHECK_LAUNCH();
     return RFN_OK;
 }

@@ -229,6 +229,8 @@ struct PrefixLayout {
     size_t dHs, dC, dal, dwp, dhp1, dh2e, dhrec, dc2, dz2, dhp2;
     size_t gws;
     size_t x3;      // plane images + split-K partials of the bf16-plane GEMMs (RFN_GEMM_OPT_BF16X3), 0 floats otherwise
+    size_t x3p[RFN_MAX_ENC];   // train: encoder i's dP1 as a k-slow plane image (all T1 steps), kept from the backward
+                               // recurrence to its weight-gradient GEMM
     size_t total;
 };
 // Does encoder i's hoisted projection (and its weight gradient) take the bf16-plane GEMM?  Only when asked for
@@ -240,6 +242,7 @@ static bool x3_takes(const rfn_dims* d, int B, int i) {
     if (d->gemm_flags & RFN_GEMM_OPT_BF16X3_ANY_SIZE) return true;
     return 2.0 * B * d->L[i] * d->D[i] * d->A * d->T1 >= 2e10;
 }
+static int x3_row_pad(int rows) { return (rows + 255) / 256 * 256; }   // row pitch of a k-slow image
 static size_t x3_scratch_floats(const rfn_dims* d, int B, int train) {
     size_t most = 0;
     for (int i = 0; i < d->M; ++i) {
@@ -247,9 +250,7 @@ static size_t x3_scratch_floats(const rfn_dims* d, int B, int train) {
         const int BL = B * d->L[i], TA = d->T1 * d->A, Di = d->D[i];
         size_t fwd = rfn_x3_image_bytes(BL, Di) + rfn_x3_image_bytes(TA, Di);
         size_t bwd = 0;
-        if (train)
-            bwd = rfn_x3_image_bytes(Di, BL) + rfn_x3_image_bytes(TA, BL) +
-                  4 * rfn_x3_part_floats(TA, Di, rfn_x3_splitk_for(TA, Di, BL));
+        if (train) bwd = rfn_x3_image_bytes(Di, BL) + 4 * rfn_x3_part_floats(TA, Di, rfn_x3_splitk_for(TA, Di, BL));
         const size_t need = (fwd > bwd ? fwd : bwd) / 4 + 256;
         if (need > most) most = need;
     }
@@ -283,6 +284,9 @@ PrefixLayout prefix_layout(const rfn_dims* d, int B, int train) {
     L.g2 = b.take(T2 * Bz * G2);
     L.gws = b.take(GEMM_WS_FLOATS);
     L.x3 = b.take(x3_scratch_floats(d, B, train));
+    if (train)
+        for (int i = 0; i < d->M; ++i)
+            if (x3_takes(d, B, i)) L.x3p[i] = b.take(rfn_x3_image_bytes(d->T1 * d->A, B * d->L[i]) / 4 + 64);
     if (train) {
         for (int i = 0; i < d->M; ++i) L.dz1[i] = b.take(Bz * d->D[i]);
         L.dHs = b.take((T1 + 1) * Bz * M * R);
@@ -860,8 +864,15 @@ extern "C" int rfn_prefix_bwd(const rfn_dims* d, int B, const float* const* prm,
                 a_dhp[i] = dhp + i * BA;
                 a_dw[i] = dwp + ((long)t * M + i) * BA;
             }
-            RFN_TRY(rfn_attn_bwd_grouped(M, a_p, L0 * A, (long)A, a_hp, a_w, a_al, att, L0 * D0, D0, a_dz, D0,
-                                         B, (int)L0, A, (int)D0, a_dp, L0 * A, (long)A, 0, a_dhp, a_dw, st));
+            if (x3_takes(d, B, 0)) {   // dP1 of this step straight into the encoders' k-slow plane images
+                void* a_img[RFN_MAX_ENC];
+                for (int i = 0; i < M; ++i) a_img[i] = W + Lo.x3p[i];
+                RFN_TRY(rfn_attn_bwd_grouped_ks(M, a_p, L0 * A, (long)A, a_hp, a_w, a_al, att, L0 * D0, D0, a_dz, D0, B,
+                                                (int)L0, A, (int)D0, a_img, x3_row_pad(T1 * A), t * A, a_dhp, a_dw, st));
+            } else {
+                RFN_TRY(rfn_attn_bwd_grouped(M, a_p, L0 * A, (long)A, a_hp, a_w, a_al, att, L0 * D0, D0, a_dz, D0,
+                                             B, (int)L0, A, (int)D0, a_dp, L0 * A, (long)A, 0, a_dhp, a_dw, st));
+            }
         }
         for (int i = 0; i < M; ++i) {
             const long Li = d->L[i], Di = d->D[i];
@@ -872,6 +883,17 @@ extern "C" int rfn_prefix_bwd(const rfn_dims* d, int B, const float* const* prm,
             float* p1 = W + Lo.P1[i] + (long)t * B * Li * A;
             if (grouped_bwd) {
                 // done above
+            } else if (B >= FUSED_ATTN_BWD_MIN_B && x3_takes(d, B, i)) {   // ... with dP1 as bf16 planes
+                const float* p1c = p1;
+                const float* hpc = hp + i * BA;
+                const float* wc = prm[P.s1(t, i, 4)];
+                const float* alc = W + Lo.al1[i] + (long)t * B * Li;
+                const float* dzc = dz;
+                void* img = W + Lo.x3p[i];
+                float* dhpo = dhp + i * BA;
+                float* dwo = dwp + ((long)t * M + i) * BA;
+                RFN_TRY(rfn_attn_bwd_grouped_ks(1, &p1c, Li * A, (long)A, &hpc, &wc, &alc, &att[i], Li * Di, Di, &dzc, Di, B,
+                                                (int)Li, A, (int)Di, &img, x3_row_pad(T1 * A), t * A, &dhpo, &dwo, st));
             } else if (B >= FUSED_ATTN_BWD_MIN_B) {   // one block per row fills the chip: dalpha stays in LDS, one launch
                 RFN_TRY(rfn_attn_bwd(p1, Li * A, (long)A, hp + i * BA, prm[P.s1(t, i, 4)],
                                      W + Lo.al1[i] + (long)t * B * Li, att[i], Li * Di, Di, dz, Di, B, (int)Li, A,
@@ -932,23 +954,32 @@ extern "C" int rfn_prefix_bwd_wgrad(const rfn_dims* d, int B, const float* const
     // bias-gradient rider.
     auto part_b = [&]() -> int {   // the dominant att_2_att_h gradient (small bucket, long GEMM)
         if (x3_takes(d, B, i)) {
-            // bf16-plane GEMM: dW[t] = dP1[t]^T . att as (T1*A x B*L) . (D x B*L)^T; both operands are k-slow in memory, so
-            // the split passes transpose them into the images
+            // bf16-plane GEMM: dW[t] = dP1[t]^T . att.  Both operands are reduction-index-major in memory ((b,l) rows), so
+            // they are kept that way as k-slow plane images and rfn_x3_gemm_ks transposes while reading LDS: no
+            // transposing pass.  dP1's image was written by the attention backward itself when B >= 96 (fused kernel);
+            // for small batches it is split from the f32 slabs here.
             const int BL = (int)(B * Li), TA = T1 * A;
-            char* imgXT = (char*)(W + Lo.x3);
-            char* imgPT = imgXT + rfn_x3_image_bytes((int)Di, BL);
-            float* part = (float*)(imgPT + rfn_x3_image_bytes(TA, BL));
+            char* ksX = (char*)(W + Lo.x3);
+            float* part = (float*)(ksX + rfn_x3_image_bytes((int)Di, BL));
+            char* ksP = (char*)(W + Lo.x3p[i]);
             const int sk = rfn_x3_splitk_for(TA, (int)Di, BL);
             const float* srcs[64];
             float* outs[64];
             srcs[0] = att[i];
-            RFN_TRY(rfn_x3_split(srcs, 1, Di, (int)Di, BL, 0, imgXT, st));
+            RFN_TRY(rfn_x3_split_ks(srcs, 1, Di, BL, (int)Di, ksX, st));
             for (int t = 0; t < T1; ++t) {
                 srcs[t] = W + Lo.P1[i] + (long)t * BL * A;
                 outs[t] = grd[P.s1(t, i, 0)];
             }
-            RFN_TRY(rfn_x3_split(srcs, T1, A, A, BL, 0, imgPT, st));
-            return rfn_x3_gemm(TA, (int)Di, BL, imgPT, imgXT, A, (int)Di, outs, nullptr, Di, 0, sk, part, st);
+            if (B < FUSED_ATTN_BWD_MIN_B) {
+                RFN_TRY(rfn_x3_split_ks(srcs, T1, A, BL, A, ksP, st));
+            } else if (BL % 32) {   // the attention kernels wrote the B*L real rows; the GEMM also reads the pad rows
+                const long row_bytes = 3L * x3_row_pad(TA) * 2;
+                if (hipMemsetAsync(ksP + BL * row_bytes, 0, (size_t)((BL + 31) / 32 * 32 - BL) * row_bytes, (hipStream_t)st) !=
+                    hipSuccess)
+                    return RFN_ERR_LAUNCH;
+            }
+            return rfn_x3_gemm_ks(TA, (int)Di, BL, ksP, ksX, A, (int)Di, outs, nullptr, Di, 0, sk, part, st);
         }
         for (int t = 0; t < T1; ++t)
             pr[t] = prob_dw(grd[P.s1(t, i, 0)], Di, nullptr, W + Lo.P1[i] + (long)t * B * Li * A, A, att[i], Di,

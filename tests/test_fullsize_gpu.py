@@ -260,3 +260,37 @@ def test_bf16x3_against_the_exact_path_on_the_shipped_heterogeneous_encoders(dev
         err = float((g0[name] - g1[name]).abs().max())
         assert err <= 1e-6 + 2e-4 * float(g0[name].abs().max()), (name, err)
     assert torch.equal(s0, s1)
+
+
+@pytest.mark.parametrize('B', [96, 97])
+def test_bf16x3_with_the_attention_backward_writing_the_plane_image(dev, B):
+    """From B = 96 on the fused stage-I attention backward writes dP1 straight into the k-slow bf16 plane image of the
+    weight-gradient GEMM (rfn_attn_bwd_grouped_ks -> rfn_x3_gemm_ks) instead of f32 slabs + a split pass.  C3 model: against
+    the exact-f32 path, same bars as the heterogeneous-encoder test.  B = 97: B * L = 19012 is no multiple of 32, so the
+    image has pad rows that the GEMM reads and nobody but the memset wrote."""
+    import bench as HB
+    import recurrent_fusion_network_amd as R
+    import recurrent_fusion_network_amd._native as N
+    cfg = HB.make_cfg(HB.WORKLOADS['c3'])
+    model = R.RecurrentFusionModel(cfg).to(dev)
+    HB.seeded_weights_(model, 41)
+    model.eval()
+    fc, att, labels, masks, top = HB.synthetic_inputs(cfg, B, 42, dev)
+    crit = R.ReviewNetEnsembleCriterion(cfg)
+
+    def run(flags):
+        model.gemm_flags = flags
+        model.zero_grad(set_to_none=True)
+        lp, reason = model(fc, att, labels)
+        crit(lp, labels[:, 1:], masks[:, 1:], reason, top, 1.0).backward()
+        return lp.detach(), {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+
+    lp0, g0 = run(0)
+    lp1, g1 = run(N.GEMM_OPT_BF16X3)
+    lp2, g2 = run(N.GEMM_OPT_BF16X3)
+    k = 'review_steps_individual.7.lstm.2.att_model.att_2_att_h.weight'
+    assert not torch.equal(g0[k], g1[k]) and torch.equal(g1[k], g2[k]) and torch.equal(lp1, lp2)   # changed, deterministic
+    assert float((lp0 - lp1).abs().max()) < 2e-4
+    for name in g0:
+        err = float((g0[name] - g1[name]).abs().max())
+        assert err <= 1e-6 + 2e-4 * float(g0[name].abs().max()), (name, err)

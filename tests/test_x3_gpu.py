@@ -151,3 +151,41 @@ def test_gemm_rejects_groups_that_straddle_tiles(dev):
     outs = [torch.empty(256, 100, device=dev) for _ in range(3)]
     with pytest.raises(N.RfnError):
         N.x3_gemm(256, 256, 32, ia, ia, outs, gn=100)
+
+
+def _decode_ks(img, K, cols):
+    """k-slow image (uint8) -> three f32 planes [3][k_pad][m_pad]: element (k, plane, m) at ((k * 3 + plane) * Mp + m) * 2."""
+    mp, k_pad = (cols + 255) // 256 * 256, (K + 31) // 32 * 32
+    assert img.numel() == mp * k_pad * 6
+    w = img.view(torch.int16).view(k_pad, 3, mp)
+    return (w.to(torch.int32) << 16).view(torch.float32).permute(1, 0, 2)
+
+
+def test_k_slow_image_is_an_exact_split_in_the_documented_layout(dev):
+    import recurrent_fusion_network_amd._native as N
+    g = torch.Generator(device='cpu').manual_seed(21)
+    K, cols = 70, 36
+    mats = [(torch.randn(K, cols, generator=g) * torch.exp(3 * torch.randn(K, cols, generator=g))) for _ in range(3)]
+    img = N.x3_image_ks([m.to(dev) for m in mats], K, cols)
+    pl = _decode_ks(img, K, 3 * cols).cpu().double().sum(0)
+    assert torch.equal(pl[:K, :3 * cols].float(), torch.cat(mats, 1))
+    assert float(pl[K:].abs().max()) == 0.0 and float(pl[:, 3 * cols:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('shape,splitk', [((300, 520, 70), 1), ((512, 260, 5000), 3), ((256, 256, 32), 1), ((40, 2300, 333), 2)])
+def test_k_slow_gemm_against_f64(dev, shape, splitk):
+    """C = A^T B with both operands stored reduction-index-major ([K][M], [K][N]): the weight-gradient orientation.  The MFMA
+    operands come from transposing LDS reads of swizzled k-slow tiles."""
+    import recurrent_fusion_network_amd._native as N
+    M, N_, K = shape
+    g = torch.Generator(device='cpu').manual_seed(sum(shape))
+    a, b = torch.randn(K, M, generator=g).to(dev), torch.randn(K, N_, generator=g).to(dev)
+    out = torch.full((M, N_), float('nan'), device=dev)
+    N.x3_gemm(M, N_, K, N.x3_image_ks([a], K, M), N.x3_image_ks([b], K, N_), [out], splitk=splitk, k_slow=True)
+    ref = a.double().t() @ b.double()
+    mag = a.double().abs().t() @ b.double().abs()
+    assert float(((out.double() - ref).abs() / mag).max()) <= 6 * U
+    # the same product from fragment-order images of the transposed operands: same arithmetic per output element
+    out2 = torch.empty(M, N_, device=dev)
+    N.x3_gemm(M, N_, K, N.x3_image([a], M, K, k_fast=False), N.x3_image([b], N_, K, k_fast=False), [out2], splitk=splitk)
+    assert torch.equal(out, out2)

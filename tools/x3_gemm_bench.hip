@@ -121,29 +121,47 @@ int main() {
     float* Cw[8];
     for (int t = 0; t < T; ++t) Cw[t] = dW + (size_t)t * A * D;
     timeit("TN weight gradient (split-K 2)", flops, 0, 10, [&] { int rc = rfn_x3_gemm(T * A, D, BL, imgPT, imgXT, A, D, Cw, nullptr, D, 0, SK, part, 0); if (rc) { printf("rc %d\n", rc); exit(1); } });
-    for (int i = 0; i < NS; ++i) { ms[i] = rand() % (T * A); ns[i] = rand() % D; }
-    ms[0] = 0; ns[0] = 0; ms[1] = T * A - 1; ns[1] = D - 1;
-    CK(hipMemcpy(dms, ms.data(), NS * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dns, ns.data(), NS * 4, hipMemcpyHostToDevice));
-    {
-        // row m = t*A + a of the M-side operand is P[t][k][a]: not a single stride pair over t, so reference per t
-        double emax = 0, e2 = 0;
-        std::vector<int> mt(NS);
-        for (int t = 0; t < T; ++t) {
-            std::vector<int> idx;
-            for (int i = 0; i < NS; ++i) if (ms[i] / A == t) idx.push_back(i);
-            std::vector<int> m2(idx.size()), n2(idx.size());
-            for (size_t j = 0; j < idx.size(); ++j) { m2[j] = ms[idx[j]] % A; n2[j] = ns[idx[j]]; }
-            if (idx.empty()) continue;
-            CK(hipMemcpy(dms, m2.data(), m2.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dns, n2.data(), n2.size() * 4, hipMemcpyHostToDevice));
-            ref_k<<<(int)idx.size(), 256>>>(P + (size_t)t * BL * A, 1, A, X, 1, D, BL, dms, dns, (int)idx.size(), dref, dmag);
-            CK(hipMemcpy(ref.data(), dref, idx.size() * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(mag.data(), dmag, idx.size() * 8, hipMemcpyDeviceToHost));
-            for (size_t j = 0; j < idx.size(); ++j) {
-                float v; CK(hipMemcpy(&v, dW + (size_t)t * A * D + (size_t)m2[j] * D + n2[j], 4, hipMemcpyDeviceToHost));
-                const double e = ((double)v - ref[j]) / mag[j];
-                emax = fmax(emax, fabs(e)); e2 += e * e;
+    auto tn_check = [&](const char* label) {
+        for (int i = 0; i < NS; ++i) { ms[i] = rand() % (T * A); ns[i] = rand() % D; }
+        ms[0] = 0; ns[0] = 0; ms[1] = T * A - 1; ns[1] = D - 1;
+        CK(hipMemcpy(dms, ms.data(), NS * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dns, ns.data(), NS * 4, hipMemcpyHostToDevice));
+        {
+            // row m = t*A + a of the M-side operand is P[t][k][a]: not a single stride pair over t, so reference per t
+            double emax = 0, e2 = 0;
+            std::vector<int> mt(NS);
+            for (int t = 0; t < T; ++t) {
+                std::vector<int> idx;
+                for (int i = 0; i < NS; ++i) if (ms[i] / A == t) idx.push_back(i);
+                std::vector<int> m2(idx.size()), n2(idx.size());
+                for (size_t j = 0; j < idx.size(); ++j) { m2[j] = ms[idx[j]] % A; n2[j] = ns[idx[j]]; }
+                if (idx.empty()) continue;
+                CK(hipMemcpy(dms, m2.data(), m2.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dns, n2.data(), n2.size() * 4, hipMemcpyHostToDevice));
+                ref_k<<<(int)idx.size(), 256>>>(P + (size_t)t * BL * A, 1, A, X, 1, D, BL, dms, dns, (int)idx.size(), dref, dmag);
+                CK(hipMemcpy(ref.data(), dref, idx.size() * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(mag.data(), dmag, idx.size() * 8, hipMemcpyDeviceToHost));
+                for (size_t j = 0; j < idx.size(); ++j) {
+                    float v; CK(hipMemcpy(&v, dW + (size_t)t * A * D + (size_t)m2[j] * D + n2[j], 4, hipMemcpyDeviceToHost));
+                    const double e = ((double)v - ref[j]) / mag[j];
+                    emax = fmax(emax, fabs(e)); e2 += e * e;
+                }
             }
+            printf("%-14s %s: %d samples, error / sum|a||b|: max %.3e rms %.3e  (x 2^-24: %.2f / %.3f)\n", VARIANT, label, NS, emax, sqrt(e2 / NS), emax * 16777216., sqrt(e2 / NS) * 16777216.);
         }
-        printf("%-14s TN check: %d samples, error / sum|a||b|: max %.3e rms %.3e  (x 2^-24: %.2f / %.3f)\n", VARIANT, NS, emax, sqrt(e2 / NS), emax * 16777216., sqrt(e2 / NS) * 16777216.);
-    }
+    };
+    tn_check("TN check");
+#if X3_SHAPE == 16
+    // ---- the same weight gradient from k-slow images (no transposing passes; fragments by ds_read_b64_tr_b16)
+    void *ksX, *ksP;
+    CK(hipMalloc(&ksX, rfn_x3_image_bytes(D, BL)));
+    CK(hipMalloc(&ksP, rfn_x3_image_bytes(T * A, BL)));
+    timeit("split X  k-slow [BL][D]", 0, (double)BL * D * 10, 5, [&] { const float* sp[1] = {X}; rfn_x3_split_ks(sp, 1, D, BL, D, ksX, 0); });
+    timeit("split dP k-slow 8 x [BL][A]", 0, (double)T * BL * A * 10, 5, [&] {
+        const float* sp[8];
+        for (int t = 0; t < T; ++t) sp[t] = P + (size_t)t * BL * A;
+        rfn_x3_split_ks(sp, T, A, BL, A, ksP, 0);
+    });
+    CK(hipMemset(dW, 0, (size_t)T * A * D * 4));
+    timeit("TN weight gradient, k-slow images", flops, 0, 10, [&] { int rc = rfn_x3_gemm_ks(T * A, D, BL, ksP, ksX, A, D, Cw, nullptr, D, 0, SK, part, 0); if (rc) { printf("rc %d\n", rc); exit(1); } });
+    tn_check("TN k-slow check");
+#endif
     return 0;
 }
