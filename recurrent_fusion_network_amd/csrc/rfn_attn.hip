@@ -535,10 +535,9 @@ __global__ __launch_bounds__(SB_THREADS) void attn_scores_bwd_k(const AttnEncPtr
                             char* img = E.ks_img[blockIdx.y] + (((long)b * L + l) * 3 * ks_mp + ks_col0 + a) * 2;
 #pragma unroll
                             for (int p = 0; p < 3; ++p) {
-                                uint2 w2;
-                                w2.x = q[p][0] | (q[p][1] << 16);
-                                w2.y = q[p][2] | (q[p][3] << 16);
-                                *reinterpret_cast<uint2*>(img + (long)p * ks_mp * 2) = w2;
+                                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                                const u32x2 w2 = {q[p][0] | (q[p][1] << 16), q[p][2] | (q[p][3] << 16)};
+                                *reinterpret_cast<u32x2*>(img + (long)p * ks_mp * 2) = w2;   // (a nontemporal store measured no better)
                             }
                         } else if constexpr (VEC) {
                             f32x4 t = {ov[0], ov[1], ov[2], ov[3]};
