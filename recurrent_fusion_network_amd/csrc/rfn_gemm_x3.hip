@@ -18,6 +18,10 @@
 // One wave-instruction of LDS-DMA (global_load_lds_dwordx4, 64 lanes x 16 B) moves one piece as one contiguous KiB of
 // global memory into one contiguous KiB of LDS, which one ds_read_b128 per lane then reads back conflict-free (lane-
 // linear 1 KiB): no swizzle, no staging registers, no address arithmetic per lane beyond lane * 16.
+//
+// Operands that are reduction-index-major in memory (both operands of a weight gradient) are not transposed into that
+// image: they keep their orientation as K-SLOW plane images (rfn_x3_split_ks, or written directly by the producing
+// kernel) and rfn_x3_gemm_ks forms the MFMA operands with the transposing LDS read -- see x3_tile<.., KS = true>.
 #include "rfn_common.h"
 
 typedef float x3_f32x16 __attribute__((ext_vector_type(16)));
