@@ -202,6 +202,9 @@ def parse_args(argv=None):
                     help='seconds of untimed steps BEFORE the W warm-up steps (the first second of GPU work after an idle '
                          'spell -- e.g. behind a CPU-only phase of the caller -- ran up to 13 %% slow on some boxes while '
                          'the kernels themselves timed normal); reported as settle_s')
+    ap.add_argument('--trace-steps', action='store_true',
+                    help='diagnostic: HIP events around the forward / backward / update of every timed step, printed to '
+                         'stderr after the run (no extra synchronisation inside the timed region)')
     ap.add_argument('--no-alt-line', action='store_true',
                     help="with --gemm exact (the default): do not append the same workload re-timed with --gemm bf16x3 "
                          "(the 'bf16x3' object of the JSON line; `value` is always the exact-f32 measurement)")
@@ -419,14 +422,40 @@ def run_train(args, rank, world, dev, R, DP):
 
     sync = DP.GradSync(model, world)     # per-bucket async all-reduce, overlapped with the rest of backward
 
+    trace = [] if args.trace_steps else None
+
+    def mark(row):
+        if trace is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            row.append(e)
+
     def step():
+        row = []
+        mark(row)
         opt.zero_grad()
         log_prob, top_pred = model(fc, att, labels)
         loss = crit(log_prob, labels[:, 1:], masks[:, 1:], top_pred, top, 1.0)
+        mark(row)
         loss.backward()
+        mark(row)
         scale = sync.finish()              # 1/world: applied before the clamp inside the fused update
         opt.step(grad_scale=scale)
+        mark(row)
+        if trace is not None:
+            trace.append((row, time.perf_counter()))
         return loss
+
+    def dump_trace(label, n):
+        if trace is None or rank != 0:
+            return
+        torch.cuda.synchronize()
+        rows = trace[-n:]
+        for i, (r, h) in enumerate(rows):
+            nxt = r[3].elapsed_time(rows[i + 1][0][0]) if i + 1 < len(rows) else 0.0
+            sys.stderr.write('%s step %2d: fwd %.1f bwd %.1f update %.1f gap %.2f | host return at +%.1f ms\n' % (
+                label, i, r[0].elapsed_time(r[1]), r[1].elapsed_time(r[2]), r[2].elapsed_time(r[3]), nxt,
+                (h - rows[0][1]) * 1e3))
 
     def fence():
         if world > 1:
@@ -456,6 +485,7 @@ def run_train(args, rank, world, dev, R, DP):
     fence()
     host_cpu = (time.thread_time() - c0) / max(1e-9, time.perf_counter() - t0)   # share of the timed region the launching
     elapsed = DP.max_over_ranks(time.perf_counter() - t0, world, dev)             # thread was on a CPU (1.0 = never descheduled)
+    dump_trace('exact' if not x3 else 'bf16x3', args.steps)
     final_loss = float(loss.detach())
     # the same W + K steps once more with the two long products on the bf16 matrix cores: reported
     # beside the headline as out['bf16x3'], never as `value`
@@ -472,6 +502,7 @@ def run_train(args, rank, world, dev, R, DP):
             loss_alt = step()
         fence()
         alt_elapsed = DP.max_over_ranks(time.perf_counter() - t1, world, dev)
+        dump_trace('bf16x3', args.steps)
         alt = {'value': round(global_B * args.steps / alt_elapsed, 2), 'unit': 'captions/s',
                'ms_per_step': round(alt_elapsed / args.steps * 1e3, 3), 'final_loss': round(float(loss_alt.detach()), 4),
                'dtype': 'f32 (the two long products as 3 bf16 planes x 6 MFMA products, f32 accumulate; the rest exact f32)'}
