@@ -98,6 +98,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef GEMM_DMA
 #define GEMM_DMA 1         /* big interior tiles are staged by LDS-DMA (global_load_lds_dwordx4) into a ring of slots */
 #endif
+#ifndef GEMM_SMALL_DMA_SLOTS
+#define GEMM_SMALL_DMA_SLOTS 3   /* > 0: interior 64 x 64 tiles take the LDS-DMA ring too, with this many slots (48 KB per block;
+                                   0 / 4 / 3: 65.93-66.09 / 65.93-66.05 / 65.75-65.86 ms per step) */
+#endif
 #ifndef GEMM_DMA_MIN_WAVES
 #define GEMM_DMA_MIN_WAVES 3   /* __launch_bounds__ waves per SIMD of the LDS-DMA kernels */
 #endif
@@ -1044,6 +1048,25 @@ static int launch_tile(GemmArgs& a, hipStream_t st) {
         if (want > cap) want = cap;
         a.splitk = (want >= 2) ? (int)want : 1;
     }
+#if GEMM_DMA && GEMM_SMALL_DMA_SLOTS
+    // Interior skinny problems: the same LDS-DMA ring as the big tile, 64 x 64 x 32 per slot (16 KB).  A block of a split
+    // launch runs 4-8 K steps, each of which used to wait out a full global-load latency (two register-staged buffers);
+    // with GEMM_SMALL_DMA_SLOTS slots the whole K range of the block is in flight after the first wait.  Bit-identical
+    // (same k order per output element).
+    if constexpr (VEC) {
+        bool ok = (a.M % 64 == 0) && (a.N % 64 == 0) && !colsum && !(a.flags & RFN_GEMM_OPT_NO_DMA);
+        for (int g = 0; g < a.ngroups && ok; ++g) {
+            ok = ok && a.g[g].ldc >= 0 && (double)a.g[g].ldc * 4 * 64 < 4.0e9;
+            for (int s = 0; s < a.g[g].nseg; ++s) {
+                const rfn_gemm_seg& sg = a.g[g].seg[s];
+                const double ea = AK ? (double)a.M * sg.lda : (double)sg.K * sg.lda;
+                const double eb = BKF ? (double)a.N * sg.ldb : (double)sg.K * sg.ldb;
+                ok = ok && sg.K > 0 && (sg.K % 32 == 0) && ea * 4 < 4.0e9 && eb * 4 < 4.0e9 && sg.lda >= 0 && sg.ldb >= 0;
+            }
+        }
+        if (ok) return launch_cfg<64, 64, AK, BKF, true, 1, 32, true, GEMM_THREADS, GEMM_SMALL_DMA_SLOTS>(a, st);
+    }
+#endif
     return launch_cfg<64, 64, AK, BKF, VEC, GEMM_SMALL_STAGES, GEMM_SMALL_BK>(a, st);
 }
 

@@ -241,6 +241,32 @@ def test_gemm_big_tile_variants_are_bit_identical(dev, ak, bk):
         assert torch.equal(outs['dma'][g], outs['reg'][g]) and torch.equal(outs['dma'][g], outs['lean'][g])
 
 
+@pytest.mark.parametrize('ak,bk', [(True, True), (True, False), (False, False)])
+@pytest.mark.parametrize('with_ws', [False, True])
+def test_gemm_small_tile_dma_is_bit_identical_to_register_staging(dev, ak, bk, with_ws):
+    """Interior skinny problems (M = batch rows, 64 x 64 tiles, split over K when a scratch buffer is given) take the LDS-DMA
+    ring as well; RFN_GEMM_OPT_NO_DMA selects the register-staged kernel.  Same k order: same bits, and right (fp64)."""
+    n = N()
+    M, Nn, Ks = 256, 2048, [512, 96]
+    segs, ref, keep = [], torch.zeros(M, Nn, dtype=torch.float64), []
+    for s_, K in enumerate(Ks):
+        A, Bm, b = rnd(M, K, seed=3 + s_), rnd(Nn, K, seed=30 + s_), rnd(Nn, seed=60 + s_)
+        ref += A.double() @ Bm.double().t() + b.double()
+        A_st = (A if ak else A.t().contiguous()).to(dev)
+        B_st = (Bm if bk else Bm.t().contiguous()).to(dev)
+        bd = b.to(dev)
+        keep += [A_st, B_st, bd]
+        segs.append((A_st, K if ak else M, ak, B_st, K if bk else Nn, bk, K, bd))
+    ws = torch.empty(32 << 20, dtype=torch.uint8, device=dev) if with_ws else None
+    outs = []
+    for flags in (0, n.GEMM_OPT_NO_DMA):
+        out = torch.full((M, Nn), 0.25, device=dev)
+        n.gemm(M, Nn, [(out, Nn, segs)], accumulate=True, ws=ws, flags=flags)
+        outs.append(out)
+    assert maxerr(outs[0], ref + 0.25) < 2e-4
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_gemm_strided_views_like_the_path(dev):
     """The path feeds column blocks of wider buffers (lda > K, ldc > N): e.g. encoder i's slice of H."""
     n = N()
