@@ -189,3 +189,36 @@ def test_k_slow_gemm_against_f64(dev, shape, splitk):
     out2 = torch.empty(M, N_, device=dev)
     N.x3_gemm(M, N_, K, N.x3_image([a], M, K, k_fast=False), N.x3_image([b], N_, K, k_fast=False), [out2], splitk=splitk)
     assert torch.equal(out, out2)
+
+
+def test_attention_backward_writes_the_plane_image_of_its_f32_result(dev):
+    """rfn_attn_bwd_grouped_ks: the same launch as rfn_attn_bwd_grouped with d proj delivered as bf16 planes into k-slow
+    images (one per encoder, this call's A columns at column ks_col0).  The planes must decode to the f32 values the plain
+    launch writes (to the last bit or one off: separate instantiations), at rows k = b * L + l, and leave the other columns alone; dhproj / dw_part are the same bits."""
+    import recurrent_fusion_network_amd._native as N
+    G, B, L, A, D, T = 2, 5, 50, 64, 96, 3           # image columns: T steps of A
+    g_ = torch.Generator(device='cpu').manual_seed(31)
+    rnd = lambda *s: torch.randn(*s, generator=g_).to(dev)  # noqa: E731
+    proj, hp, w = [rnd(B, L, A) for _ in range(G)], [rnd(B, A) for _ in range(G)], [0.3 * rnd(A) for _ in range(G)]
+    x, dz = [rnd(B, L, D) for _ in range(G)], [rnd(B, D) for _ in range(G)]
+    al = [torch.softmax(rnd(B, L), 1).contiguous() for _ in range(G)]
+    st = N.stream_ptr()
+    new = lambda *shape: [torch.empty(*shape, device=dev) for _ in range(G)]  # noqa: E731
+    dp, dhp, dwp = new(B, L, A), new(B, A), new(B, A)
+    N.check(N.lib.rfn_attn_bwd_grouped(G, N.ptr_array(proj), L * A, A, N.ptr_array(hp), N.ptr_array(w), N.ptr_array(al),
+                                       N.ptr_array(x), L * D, D, N.ptr_array(dz), D, B, L, A, D, N.ptr_array(dp), L * A, A,
+                                       0, N.ptr_array(dhp), N.ptr_array(dwp), st), 'rfn_attn_bwd_grouped')
+    K, cols = B * L, T * A
+    mp = (cols + 255) // 256 * 256
+    imgs = [torch.zeros(N.lib.rfn_x3_image_bytes(cols, K), dtype=torch.uint8, device=dev) for _ in range(G)]
+    dhp2, dwp2 = new(B, A), new(B, A)
+    N.check(N.lib.rfn_attn_bwd_grouped_ks(G, N.ptr_array(proj), L * A, A, N.ptr_array(hp), N.ptr_array(w), N.ptr_array(al),
+                                          N.ptr_array(x), L * D, D, N.ptr_array(dz), D, B, L, A, D, N.ptr_array(imgs), mp, A,
+                                          N.ptr_array(dhp2), N.ptr_array(dwp2), st), 'rfn_attn_bwd_grouped_ks')
+    for g in range(G):
+        s = _decode_ks(imgs[g], K, cols).double().sum(0)             # [k_pad][mp]
+        got, want = s[:K, A:2 * A].float(), dp[g].reshape(K, A)
+        # the two instantiations contract the tanh-backward products differently: equal to the last bit or one off
+        assert bool(((got - want).abs() <= 1.2e-7 * want.abs() + 1e-30).all()), float((got - want).abs().max())
+        assert float(s[:, :A].abs().max()) == 0.0 and float(s[:, 2 * A:].abs().max()) == 0.0 and float(s[K:].abs().max()) == 0.0
+        assert torch.equal(dhp[g], dhp2[g]) and torch.equal(dwp[g], dwp2[g])
