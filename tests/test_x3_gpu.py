@@ -194,7 +194,7 @@ def test_k_slow_gemm_against_f64(dev, shape, splitk):
 def test_attention_backward_writes_the_plane_image_of_its_f32_result(dev):
     """rfn_attn_bwd_grouped_ks: the same launch as rfn_attn_bwd_grouped with d proj delivered as bf16 planes into k-slow
     images (one per encoder, this call's A columns at column ks_col0).  The planes must decode to the f32 values the plain
-    launch writes (to the last bit or one off: separate instantiations), at rows k = b * L + l, and leave the other columns alone; dhproj / dw_part are the same bits."""
+    launch writes (to one rounding: separate instantiations contract 1 - t * t differently), at rows k = b * L + l, and leave the other columns alone; dhproj / dw_part are the same bits."""
     import recurrent_fusion_network_amd._native as N
     G, B, L, A, D, T = 2, 5, 50, 64, 96, 3           # image columns: T steps of A
     g_ = torch.Generator(device='cpu').manual_seed(31)
@@ -218,7 +218,7 @@ def test_attention_backward_writes_the_plane_image_of_its_f32_result(dev):
     for g in range(G):
         s = _decode_ks(imgs[g], K, cols).double().sum(0)             # [k_pad][mp]
         got, want = s[:K, A:2 * A].float(), dp[g].reshape(K, A)
-        # the two instantiations contract the tanh-backward products differently: equal to the last bit or one off
-        assert bool(((got - want).abs() <= 1.2e-7 * want.abs() + 1e-30).all()), float((got - want).abs().max())
+        # the two instantiations contract 1 - t * t differently (fma or not): one rounding of the largest terms apart
+        assert float((got - want).abs().max()) <= 1.2e-7 * float(want.abs().max())
         assert float(s[:, :A].abs().max()) == 0.0 and float(s[:, 2 * A:].abs().max()) == 0.0 and float(s[K:].abs().max()) == 0.0
         assert torch.equal(dhp[g], dhp2[g]) and torch.equal(dwp[g], dwp2[g])
