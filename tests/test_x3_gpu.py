@@ -194,7 +194,7 @@ def test_k_slow_gemm_against_f64(dev, shape, splitk):
 def test_attention_backward_writes_the_plane_image_of_its_f32_result(dev):
     """rfn_attn_bwd_grouped_ks: the same launch as rfn_attn_bwd_grouped with d proj delivered as bf16 planes into k-slow
     images (one per encoder, this call's A columns at column ks_col0).  The planes must decode to the f32 values the plain
-    launch writes (to one rounding: separate instantiations contract 1 - t * t differently), at rows k = b * L + l, and leave the other columns alone; dhproj / dw_part are the same bits."""
+    launch writes (to one rounding: separate instantiations contract 1 - t * t differently), at rows k = b * L + l, and leave the other columns alone; dhproj / dw_part agree to rounding."""
     import recurrent_fusion_network_amd._native as N
     G, B, L, A, D, T = 2, 5, 50, 64, 96, 3           # image columns: T steps of A
     g_ = torch.Generator(device='cpu').manual_seed(31)
@@ -221,4 +221,5 @@ def test_attention_backward_writes_the_plane_image_of_its_f32_result(dev):
         # the two instantiations contract 1 - t * t differently (fma or not): one rounding of the largest terms apart
         assert float((got - want).abs().max()) <= 1.2e-7 * float(want.abs().max())
         assert float(s[:, :A].abs().max()) == 0.0 and float(s[:, 2 * A:].abs().max()) == 0.0 and float(s[K:].abs().max()) == 0.0
-        assert torch.equal(dhp[g], dhp2[g]) and torch.equal(dwp[g], dwp2[g])
+        for u, v in ((dhp[g], dhp2[g]), (dwp[g], dwp2[g])):            # column sums of those values: same caveat
+            assert float((u - v).abs().max()) <= 1e-6 * float(u.abs().max())
