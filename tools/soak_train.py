@@ -14,6 +14,7 @@ import recurrent_fusion_network_amd as R
 ap = argparse.ArgumentParser()
 ap.add_argument('--steps', type=int, default=300)
 ap.add_argument('--recipe', action='store_true')
+ap.add_argument('--gemm', default='exact', choices=['exact', 'bf16x3'])
 a = ap.parse_args()
 dev = torch.device('cuda:0')
 w = dict(HB.WORKLOADS['c3'])
@@ -23,6 +24,9 @@ if a.recipe:
     cfg.drop_prob_lm, cfg.use_label_smoothing = 0.3, 1
 model = R.RecurrentFusionModel(cfg).to(dev)
 HB.seeded_weights_(model, 100)
+if a.gemm == 'bf16x3':
+    import recurrent_fusion_network_amd._native as N
+    model.gemm_flags |= N.GEMM_OPT_BF16X3
 model.train()
 model.ss_prob = 0.25 if a.recipe else 0.0
 crit = R.ReviewNetEnsembleCriterion(cfg)
