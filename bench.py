@@ -513,6 +513,11 @@ def run_train(args, rank, world, dev, R, DP):
                                'frac': round(6 * flops_a / secs_a / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4),
                                'f32_equivalent_tflops': round(flops_a / secs_a / 1e12, 2),
                                'kernel': 'x3_gemm_k, same projection on plane images, %.3f ms per launch' % (secs_a * 1e3)}
+            try:      # HBM-side bytes per launch from the rocprofv3 --pmc passes (profiles/pmc_traffic.json)
+                gb = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json'))).get(args.workload + '_bf16x3')
+                alt['roofline']['traffic'] = None if (gb is None or B != w['B']) else int(gb * 1e9)
+            except Exception:
+                alt['roofline']['traffic'] = None
         model.gemm_flags &= ~N.GEMM_OPT_BF16X3
     if rank != 0:
         return
@@ -554,10 +559,18 @@ def run_train(args, rank, world, dev, R, DP):
             traffic = None if gb is None else int(gb * 1e9)
         except Exception:
             traffic = None
+    traffic_x3 = None
+    if os.path.exists(tfile) and B == w['B']:
+        try:
+            gb = json.load(open(tfile)).get(args.workload + '_bf16x3')
+            traffic_x3 = None if gb is None else int(gb * 1e9)
+        except Exception:
+            traffic_x3 = None
     L0, D0 = w['enc'][0][0], w['enc'][0][1]
     if x3:      # priced in bf16 MFMA FLOP (6 plane products per f32 product) against the bf16 peak
         roof = {'bound': 'mfma', 'achieved': round(6 * achieved, 2), 'peak': BF16_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': round(6 * achieved / BF16_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
+                'frac': round(6 * achieved / BF16_MFMA_PEAK_TFLOPS, 4), 'traffic': traffic_x3,
+                'traffic_unit': 'bytes per launch (2*FETCH_SIZE + WRITE_SIZE)',
                 'f32_equivalent_tflops': round(achieved, 2),
                 'algorithmic_bytes': int(6 * (B * L0 * D0 + 8 * 512 * D0) + 4 * B * L0 * 8 * 512),
                 'kernel': 'x3_gemm_k (grouped att_2_att_h projection of encoder 0 on plane images, %.3f TFLOP of f32 '
