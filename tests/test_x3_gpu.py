@@ -223,3 +223,27 @@ def test_attention_backward_writes_the_plane_image_of_its_f32_result(dev):
         assert float(s[:, :A].abs().max()) == 0.0 and float(s[:, 2 * A:].abs().max()) == 0.0 and float(s[K:].abs().max()) == 0.0
         for u, v in ((dhp[g], dhp2[g]), (dwp[g], dwp2[g])):            # column sums of those values: same caveat
             assert float((u - v).abs().max()) <= 1e-6 * float(u.abs().max())
+
+
+def test_gemm_random_shapes_both_image_kinds(dev):
+    """40 random problems (M, N up to ~900, K up to ~2000, any remainder, 1-5 K slices): fragment-order images and k-slow
+    images of the same operands give the same bits, and both are right against f64."""
+    import random
+    import recurrent_fusion_network_amd._native as N
+    rng = random.Random(5)
+    g = torch.Generator(device='cpu').manual_seed(5)
+    for case in range(40):
+        M, N_ = rng.randint(1, 900), 4 * rng.randint(1, 225)
+        K = rng.choice([1, 7, 31, 32, 33, 64, 100, 257, rng.randint(1, 2000)])
+        steps = (K + 31) // 32
+        splitk = rng.randint(1, min(5, steps))
+        a, b = torch.randn(K, M, generator=g).to(dev), torch.randn(K, N_, generator=g).to(dev)      # both reduction-index-major
+        out_f, out_k = torch.full((M, N_), float('nan'), device=dev), torch.full((M, N_), float('nan'), device=dev)
+        N.x3_gemm(M, N_, K, N.x3_image([a], M, K, k_fast=False), N.x3_image([b], N_, K, k_fast=False), [out_f], splitk=splitk)
+        if M % 4 == 0:
+            N.x3_gemm(M, N_, K, N.x3_image_ks([a], K, M), N.x3_image_ks([b], K, N_), [out_k], splitk=splitk, k_slow=True)
+            assert torch.equal(out_f, out_k), (case, M, N_, K, splitk)
+        ref = a.double().t() @ b.double()
+        mag = a.double().abs().t() @ b.double().abs()
+        err = float(((out_f.double() - ref).abs() / (mag + 1e-30)).max())
+        assert err <= 8 * U, (case, M, N_, K, splitk, err / U)
