@@ -466,8 +466,9 @@ def run_train(args, rank, world, dev, R, DP):
         n = 0
         if args.settle > 0:
             ts = time.perf_counter()
+            keep = None
             while True:
-                step()
+                keep = step()            # held like the timed loop holds it: same allocator pattern (see the warm-up loop)
                 n += 1
                 torch.cuda.synchronize()
                 # every rank leaves after the same step: continue while ANY rank's clock is still inside the window
@@ -479,10 +480,12 @@ def run_train(args, rank, world, dev, R, DP):
     for _ in range(args.warmup):
         step()
     fence()
+    a0 = torch.cuda.memory_stats(dev).get('num_device_alloc', 0) + torch.cuda.memory_stats(dev).get('num_device_free', 0)
     t0, c0 = time.perf_counter(), time.thread_time()
     for _ in range(args.steps):
         loss = step()
     fence()
+    dev_allocs = torch.cuda.memory_stats(dev).get('num_device_alloc', 0) + torch.cuda.memory_stats(dev).get('num_device_free', 0) - a0
     host_cpu = (time.thread_time() - c0) / max(1e-9, time.perf_counter() - t0)   # share of the timed region the launching
     elapsed = DP.max_over_ranks(time.perf_counter() - t0, world, dev)             # thread was on a CPU (1.0 = never descheduled)
     dump_trace('exact' if not x3 else 'bf16x3', args.steps)
@@ -494,17 +497,21 @@ def run_train(args, rank, world, dev, R, DP):
         import recurrent_fusion_network_amd._native as N
         model.gemm_flags |= N.GEMM_OPT_BF16X3
         settle()                         # first use of this mode's workspaces and kernels
+        loss_alt = None
         for _ in range(args.warmup):
-            step()
+            loss_alt = step()
         fence()
+        a1 = torch.cuda.memory_stats(dev).get('num_device_alloc', 0) + torch.cuda.memory_stats(dev).get('num_device_free', 0)
         t1 = time.perf_counter()
         for _ in range(args.steps):
             loss_alt = step()
         fence()
+        alt_allocs = torch.cuda.memory_stats(dev).get('num_device_alloc', 0) + torch.cuda.memory_stats(dev).get('num_device_free', 0) - a1
         alt_elapsed = DP.max_over_ranks(time.perf_counter() - t1, world, dev)
         dump_trace('bf16x3', args.steps)
         alt = {'value': round(global_B * args.steps / alt_elapsed, 2), 'unit': 'captions/s',
                'ms_per_step': round(alt_elapsed / args.steps * 1e3, 3), 'final_loss': round(float(loss_alt.detach()), 4),
+               'device_mallocs_frees_in_timed_region': int(alt_allocs),
                'dtype': 'f32 (the two long products as 3 bf16 planes x 6 MFMA products, f32 accumulate; the rest exact f32)'}
         if rank == 0:
             secs_a, flops_a = time_dominant_kernel(model, att, reps=5)
@@ -534,6 +541,7 @@ def run_train(args, rank, world, dev, R, DP):
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 3), 'higher_is_better': True,
         'scaling': 'strong' if args.strong else 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'settle_s': args.settle, 'settle_steps': settle_n, 'host_thread_cpu_share': round(host_cpu, 3),
+        'device_mallocs_frees_in_timed_region': int(dev_allocs),
         'rccl_ranks': torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
         'dist_backend': torch.distributed.get_backend() if torch.distributed.is_initialized() else None,
         'config': {'workload': '%s: RecurrentFusionModel XE train step (zero_grad+fwd+criterion+bwd+clamp+Adam), '
