@@ -9,7 +9,7 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int SHAPE>
+template <int SHAPE, bool LDSR = false>
 __global__ __launch_bounds__(256) void mfma_loop(const float* __restrict__ in, float* __restrict__ out, int iters,
                                                  unsigned long long* __restrict__ clk) {
     const int gid = blockIdx.x * 256 + threadIdx.x;
@@ -18,6 +18,23 @@ __global__ __launch_bounds__(256) void mfma_loop(const float* __restrict__ in, f
         a[i] = in[(gid * 5 + i) & 0xffff];
         b[i] = in[(gid * 7 + 3 + i) & 0xffff];
     }
+    // LDSR: every iteration re-reads its operands from LDS (4 x ds_read_b128 per lane and 16 / 32 MFMAs: the LDS traffic per
+    // MFMA of the product GEMM's main loop), so the loop runs under the power of LDS + matrix pipe instead of the pipe alone
+    __shared__ __attribute__((aligned(16))) float lds[256 * 16];
+    if constexpr (LDSR) {
+        for (int i = 0; i < 16; ++i) lds[threadIdx.x * 16 + i] = in[(gid * 16 + i) & 0xffff];
+        __syncthreads();
+    }
+    auto reload = [&](int it) {
+        if constexpr (LDSR) {
+            const f32x4* p = reinterpret_cast<const f32x4*>(lds + ((threadIdx.x + it) & 255) * 16);
+            const f32x4 u = p[0], v = p[1];
+            a[0] = u[0]; a[1] = u[1]; a[2] = u[2]; a[3] = u[3];
+            b[0] = v[0]; b[1] = v[1]; b[2] = v[2]; b[3] = v[3];
+            const f32x4 u2 = p[2], v2 = p[3];
+            a[0] += u2[0] * 1e-6f; b[0] += v2[0] * 1e-6f;
+        }
+    };
     float s = 0.f;
     unsigned long long t0, r0, t1, r1;
     if constexpr (SHAPE == 32) {
@@ -27,6 +44,7 @@ __global__ __launch_bounds__(256) void mfma_loop(const float* __restrict__ in, f
         t0 = __builtin_amdgcn_s_memtime();
         r0 = __builtin_amdgcn_s_memrealtime();
         for (int it = 0; it < iters; ++it) {
+            reload(it);
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -45,6 +63,7 @@ __global__ __launch_bounds__(256) void mfma_loop(const float* __restrict__ in, f
         t0 = __builtin_amdgcn_s_memtime();
         r0 = __builtin_amdgcn_s_memrealtime();
         for (int it = 0; it < iters; ++it) {
+            reload(it);
 #pragma unroll
             for (int u = 0; u < 2; ++u)      // 2 x 16 MFMAs of 16x16x4 = the FLOP of 4 x 4 MFMAs of 32x32x2
 #pragma unroll
@@ -81,10 +100,12 @@ int main() {
     const int iters = 20000;
     for (int round = 0; round < 3; ++round)
         for (int blocks : {256, 512, 768})
-            for (int shape : {32, 16}) {
+            for (int shape : {32, 16, 1032, 1016}) {
                 hipEventRecord(e0);
                 if (shape == 32) hipLaunchKernelGGL(mfma_loop<32>, dim3(blocks), dim3(256), 0, 0, in, out, iters, clk);
-                else hipLaunchKernelGGL(mfma_loop<16>, dim3(blocks), dim3(256), 0, 0, in, out, iters, clk);
+                else if (shape == 16) hipLaunchKernelGGL(mfma_loop<16>, dim3(blocks), dim3(256), 0, 0, in, out, iters, clk);
+                else if (shape == 1032) hipLaunchKernelGGL((mfma_loop<32, true>), dim3(blocks), dim3(256), 0, 0, in, out, iters, clk);
+                else hipLaunchKernelGGL((mfma_loop<16, true>), dim3(blocks), dim3(256), 0, 0, in, out, iters, clk);
                 hipEventRecord(e1);
                 hipEventSynchronize(e1);
                 float ms;
@@ -93,7 +114,7 @@ int main() {
                 hipMemcpy(hc, clk, 16, hipMemcpyDeviceToHost);
                 const double flops = (double)blocks * 4 * iters * 16.0 * 32 * 32 * 2 * 2;
                 printf("%s  %d blocks (%d waves/SIMD): %.3f ms  %.1f TFLOP/s  in-kernel clock %.0f MHz\n",
-                       shape == 32 ? "32x32x2" : "16x16x4", blocks, blocks / 256, ms, flops / ms / 1e9,
+                       shape == 32 ? "32x32x2" : shape == 16 ? "16x16x4" : shape == 1032 ? "32x32x2 + LDS reads" : "16x16x4 + LDS reads", blocks, blocks / 256, ms, flops / ms / 1e9,
                        (double)hc[0] / (double)hc[1] * 100.0);
             }
     return 0;
