@@ -153,6 +153,28 @@ def time_dominant_kernel(model, att, reps):
     return e0.elapsed_time(e1) * 1e-3 / reps, flops
 
 
+def source_sha16(rel):
+    import hashlib
+    with open(os.path.join(ROOT, rel), 'rb') as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
+def pmc_traffic(key, same_batch=True):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
+    (profiles/pmc_traffic.json), or None.  Every entry carries the hash of the kernel source it was measured at: a
+    kernel that has changed since reports null instead of a stale figure (re-run tools/run_gemm_pmc.sh / run_x3_pmc.sh
+    and tools/stamp_pmc_traffic.py)."""
+    if not same_batch:
+        return None
+    try:
+        ent = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json'))).get(key)
+        if not isinstance(ent, dict) or ent.get('src_sha16') != source_sha16(ent['src']):
+            return None
+        return int(ent['gb'] * 1e9)
+    except Exception:      # noqa: BLE001
+        return None
+
+
 def cpu_baseline(cfg, sample_B, seed, mode='train'):
     """The CPU oracle (kind "port": a PyTorch-CPU restatement validated against the reference, see oracle/)
     timed on this host on a bounded sample of the same workload at the full model size: one XE train step
@@ -494,37 +516,50 @@ def run_train(args, rank, world, dev, R, DP):
     # beside the headline as out['bf16x3'], never as `value`
     alt = None
     if not x3 and not args.no_alt_line:
+        # The headline above is already measured: nothing in this opt-in leg may lose it.  Every rank runs the leg under
+        # try / finally (failures of this mode are shape-dependent and therefore the same on every rank), the flag is
+        # cleared whatever happens, and the collectives that agree on the outcome sit outside the try.
         import recurrent_fusion_network_amd._native as N
+        alt_err, alt_local, alt_allocs, loss_alt = None, 0.0, 0, None
         model.gemm_flags |= N.GEMM_OPT_BF16X3
-        settle()                         # first use of this mode's workspaces and kernels
-        loss_alt = None
-        for _ in range(args.warmup):
-            loss_alt = step()
-        fence()
-        a1 = torch.cuda.memory_stats(dev).get('num_device_alloc', 0) + torch.cuda.memory_stats(dev).get('num_device_free', 0)
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            loss_alt = step()
-        fence()
-        alt_allocs = torch.cuda.memory_stats(dev).get('num_device_alloc', 0) + torch.cuda.memory_stats(dev).get('num_device_free', 0) - a1
-        alt_elapsed = DP.max_over_ranks(time.perf_counter() - t1, world, dev)
-        dump_trace('bf16x3', args.steps)
-        alt = {'value': round(global_B * args.steps / alt_elapsed, 2), 'unit': 'captions/s',
-               'ms_per_step': round(alt_elapsed / args.steps * 1e3, 3), 'final_loss': round(float(loss_alt.detach()), 4),
-               'device_mallocs_frees_in_timed_region': int(alt_allocs),
-               'dtype': 'f32 (the two long products as 3 bf16 planes x 6 MFMA products, f32 accumulate; the rest exact f32)'}
-        if rank == 0:
-            secs_a, flops_a = time_dominant_kernel(model, att, reps=5)
-            alt['roofline'] = {'bound': 'mfma', 'achieved': round(6 * flops_a / secs_a / 1e12, 2),
-                               'peak': BF16_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                               'frac': round(6 * flops_a / secs_a / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4),
-                               'f32_equivalent_tflops': round(flops_a / secs_a / 1e12, 2),
-                               'kernel': 'x3_gemm_k, same projection on plane images, %.3f ms per launch' % (secs_a * 1e3)}
-            try:      # HBM-side bytes per launch from the rocprofv3 --pmc passes (profiles/pmc_traffic.json)
-                gb = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json'))).get(args.workload + '_bf16x3')
-                alt['roofline']['traffic'] = None if (gb is None or B != w['B']) else int(gb * 1e9)
-            except Exception:
-                alt['roofline']['traffic'] = None
+        try:
+            settle()                         # first use of this mode's workspaces and kernels
+            for _ in range(args.warmup):
+                loss_alt = step()
+            fence()
+            a1 = torch.cuda.memory_stats(dev).get('num_device_alloc', 0) + torch.cuda.memory_stats(dev).get('num_device_free', 0)
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                loss_alt = step()
+            fence()
+            alt_allocs = torch.cuda.memory_stats(dev).get('num_device_alloc', 0) + torch.cuda.memory_stats(dev).get('num_device_free', 0) - a1
+            alt_local = time.perf_counter() - t1
+            final_alt = float(loss_alt.detach())
+        except Exception as e:      # noqa: BLE001  (reported in the line, the exact-f32 headline stands)
+            alt_err = '%s: %s' % (type(e).__name__, e)
+            sync.works.clear()
+            sync.buckets.clear()
+        any_failed = DP.max_over_ranks(1.0 if alt_err else 0.0, world, dev) > 0.0
+        if any_failed:
+            alt = {'error': alt_err or 'another rank failed in bf16x3 mode'}
+        else:
+            alt_elapsed = DP.max_over_ranks(alt_local, world, dev)
+            dump_trace('bf16x3', args.steps)
+            alt = {'value': round(global_B * args.steps / alt_elapsed, 2), 'unit': 'captions/s',
+                   'ms_per_step': round(alt_elapsed / args.steps * 1e3, 3), 'final_loss': round(final_alt, 4),
+                   'device_mallocs_frees_in_timed_region': int(alt_allocs),
+                   'dtype': 'f32 (the two long products as 3 bf16 planes x 6 MFMA products, f32 accumulate; the rest exact f32)'}
+            if rank == 0:
+                try:
+                    secs_a, flops_a = time_dominant_kernel(model, att, reps=5)
+                    alt['roofline'] = {'bound': 'mfma', 'achieved': round(6 * flops_a / secs_a / 1e12, 2),
+                                       'peak': BF16_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                                       'frac': round(6 * flops_a / secs_a / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4),
+                                       'f32_equivalent_tflops': round(flops_a / secs_a / 1e12, 2),
+                                       'kernel': 'x3_gemm_k, same projection on plane images, %.3f ms per launch' % (secs_a * 1e3)}
+                    alt['roofline']['traffic'] = pmc_traffic(args.workload + '_bf16x3', B == w['B'])
+                except Exception as e:      # noqa: BLE001
+                    alt['roofline'] = {'error': '%s: %s' % (type(e).__name__, e)}
         model.gemm_flags &= ~N.GEMM_OPT_BF16X3
     if rank != 0:
         return
@@ -559,21 +594,10 @@ def run_train(args, rank, world, dev, R, DP):
     # roofline of the dominant kernel, timed live with HIP events on the launch stream
     secs, flops = time_dominant_kernel(model, att, reps=5)
     achieved = flops / secs / 1e12
-    traffic = None               # HBM-side bytes per launch of that kernel, from the rocprofv3 --pmc passes
-    tfile = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
-    if os.path.exists(tfile) and B == w['B']:
-        try:
-            gb = json.load(open(tfile)).get(args.workload)
-            traffic = None if gb is None else int(gb * 1e9)
-        except Exception:
-            traffic = None
-    traffic_x3 = None
-    if os.path.exists(tfile) and B == w['B']:
-        try:
-            gb = json.load(open(tfile)).get(args.workload + '_bf16x3')
-            traffic_x3 = None if gb is None else int(gb * 1e9)
-        except Exception:
-            traffic_x3 = None
+    # HBM-side bytes per launch of that kernel, from the rocprofv3 --pmc passes (null when the kernel source has changed
+    # since they were taken)
+    traffic = pmc_traffic(args.workload, B == w['B'])
+    traffic_x3 = pmc_traffic(args.workload + '_bf16x3', B == w['B'])
     L0, D0 = w['enc'][0][0], w['enc'][0][1]
     if x3:      # priced in bf16 MFMA FLOP (6 plane products per f32 product) against the bf16 peak
         roof = {'bound': 'mfma', 'achieved': round(6 * achieved, 2), 'peak': BF16_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',

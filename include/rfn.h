@@ -364,6 +364,15 @@ int rfn_rl_loss(const float* input, int64_t ld_in, const int64_t* seq, int64_t l
                 float* scratch /* B*T floats when loss_out != NULL */, float* loss_out, int accumulate_loss,
                 float* d_input, int64_t ld_din, float* d_logprobs_all, int64_t dlp_sb, int64_t dlp_st,
                 void* stream);
+/* Same, for an autograd host: the upstream gradient is read from a device scalar (d_input and d_logprobs_all are scaled
+ * by gscale_dev[0]; NULL = 1), and logprobs_all / d_logprobs_all hold T_all >= T steps per caption (sample() returns
+ * seq_length + 1 of them, misc/RecurrentFusionModel.py:655-658): rows t in [T, T_all) of d_logprobs_all are written as
+ * zeros by the same launch, so the caller needs neither a zero fill nor a scaling pass over the (B, T_all, V+1) tensor. */
+int rfn_rl_loss_ex(const float* input, int64_t ld_in, const int64_t* seq, int64_t ld_seq, const float* reward,
+                   int64_t ld_rw, const float* logprobs_all, int64_t lp_sb, int64_t lp_st, int B, int T, int T_all, int V1,
+                   float entropy_reg, const float* old_logprobs, int64_t ld_old, int use_ppo, float ppo_clip,
+                   const float* gscale_dev, float* scratch, float* loss_out, int accumulate_loss, float* d_input,
+                   int64_t ld_din, float* d_logprobs_all, int64_t dlp_sb, int64_t dlp_st, void* stream);
 /* nn.MultiLabelMarginLoss, mean reduction (misc/utils.py:186-190), scaled by `scale`:
  * loss_out[0] (+)= scale * MLM(pred, target); dpred (overwritten) = scale * gscale * dMLM/dpred. */
 int rfn_multilabel_margin(const float* pred, int B, int K, const int64_t* target, float scale,

@@ -109,6 +109,7 @@ def _load():
         'rfn_xe_loss_ex': (C.c_int, [P, I, I, I, P, L, P, L, F, F, P, P, P, I, P, P]),
         'rfn_multilabel_margin_grouped': (C.c_int, [I, P, I, I, P, F, F, P, P, P, I, P, P]),
         'rfn_rl_loss': (C.c_int, [P, L, P, L, P, L, P, L, L, I, I, I, F, P, L, I, F, P, P, I, P, L, P, L, L, P]),
+        'rfn_rl_loss_ex': (C.c_int, [P, L, P, L, P, L, P, L, L, I, I, I, I, F, P, L, I, F, P, P, P, I, P, L, P, L, L, P]),
         'rfn_adam_step': (C.c_int, [P, P, P, P, L, F, F, F, F, F, F, F, I, P]),
         'rfn_greedy_pick': (C.c_int, [P, L, I, I, I, P, P, L, P, L, P, P, P]),
         'rfn_multinomial_pick': (C.c_int, [P, L, I, I, F, P, P, F, P, L, P]),

@@ -135,12 +135,15 @@ class _RLFn(torch.autograd.Function):
         old = rest[0] if rest else None
         ent, ppo, clip, B, T, V1 = ctx.args
         d_inp = torch.empty_like(inp)
-        d_lp = torch.zeros_like(lp)                      # rows t >= T do not enter the loss
-        N.check(N.lib.rfn_rl_loss(inp.data_ptr(), T, seq.data_ptr(), seq.stride(0), reward.data_ptr(), reward.stride(0),
-                                  lp.data_ptr(), lp.stride(0), lp.stride(1), B, T, V1, ent, N.ptr(old), T, ppo, clip,
-                                  None, None, 0, d_inp.data_ptr(), T, d_lp.data_ptr(), d_lp.stride(0), d_lp.stride(1),
-                                  N.stream_ptr()), 'rfn_rl_loss (grad)')
-        return None, None, None, None, None, None, d_inp.mul_(g), d_lp.mul_(g)
+        d_lp = torch.empty_like(lp)
+        g = g.contiguous().float()                       # d loss stays on the device: the kernel reads it there
+        # one launch writes every row of d_lp (rows t >= T do not enter the loss: zeros) already scaled by g
+        N.check(N.lib.rfn_rl_loss_ex(inp.data_ptr(), T, seq.data_ptr(), seq.stride(0), reward.data_ptr(),
+                                     reward.stride(0), lp.data_ptr(), lp.stride(0), lp.stride(1), B, T, lp.size(1), V1,
+                                     ent, N.ptr(old), T, ppo, clip, g.data_ptr(), None, None, 0, d_inp.data_ptr(), T,
+                                     d_lp.data_ptr(), d_lp.stride(0), d_lp.stride(1), N.stream_ptr()),
+                'rfn_rl_loss_ex (grad)')
+        return None, None, None, None, None, None, d_inp, d_lp
 
 
 class ReviewNetRewardCriterion(nn.Module):

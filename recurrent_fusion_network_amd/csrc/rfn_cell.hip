@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_k(float* __restrict__ gates, lon
     if (maxout) {  // in_transform = max of the two candidate chunks, no tanh; chunk 4 keeps the selector
         const float a = g[3 * R + j], b2 = g[4 * R + j];
         gg = fmaxf(a, b2);
-        g[4 * R + j] = (a >= b2) ? 1.f : 0.f;
+        g[4 * R + j] = (a > b2) ? 1.f : ((a == b2) ? 0.5f : 0.f);   // a tie splits the gradient, as torch.max(a, b) does
     } else {
         gg = tanhf(g[3 * R + j]);
     }
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_k(float* __restrict__ gates, lon
     g[j] = d_i * ig * (1.0f - ig);
     g[R + j] = d_f * fg * (1.0f - fg);
     g[2 * R + j] = d_o * og * (1.0f - og);
-    if (maxout) {  // the gradient goes to the chunk that won the max
+    if (maxout) {  // the gradient goes to the chunk that won the max (half each on a tie)
         const float sel = g[4 * R + j];
         g[3 * R + j] = d_g * sel;
         g[4 * R + j] = d_g * (1.0f - sel);

@@ -776,8 +776,8 @@ struct X3SplitKsArgs {
     char* img;
 };
 __global__ __launch_bounds__(256) void x3_split_ks_k(const X3SplitKsArgs a) {
-    const int k = blockIdx.y;
-    const int m = (blockIdx.x * 256 + threadIdx.x) * 4;
+    const int k = blockIdx.x;      // the reduction index (B*L rows of the weight-gradient operands) rides on grid.x: no 65535 cap
+    const int m = (blockIdx.y * 256 + threadIdx.x) * 4;
     if (m >= a.mp) return;
     const int g = m / a.cols, c = m - g * a.cols;      // host: cols % 4 == 0, so a group of 4 columns never straddles
     x3_f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -811,7 +811,8 @@ extern "C" int rfn_x3_split_ks(const float* const* srcs_host, int ngroups, int64
     a.mp = (int)x3_rows_pad((long)ngroups * cols);
     a.kpad = (int)x3_k_pad(K);
     a.img = (char*)image;
-    hipLaunchKernelGGL(x3_split_ks_k, dim3((a.mp / 4 + 255) / 256, a.kpad), dim3(256), 0, (hipStream_t)stream, a);
+    if ((a.mp / 4 + 255) / 256 > 65535) return RFN_ERR_SHAPE;
+    hipLaunchKernelGGL(x3_split_ks_k, dim3(a.kpad, (a.mp / 4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
     RFN_CHECK_LAUNCH();
     return RFN_OK;
 }

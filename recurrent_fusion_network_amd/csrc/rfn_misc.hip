@@ -512,11 +512,20 @@ __global__ __launch_bounds__(256) void rl_loss_k(const float* __restrict__ inp, 
                                                  long ld_seq, const float* __restrict__ reward, long ld_rw,
                                                  const float* __restrict__ lp_all, long lp_sb, long lp_st, int T, int V1,
                                                  float entropy_reg, const float* __restrict__ old_lp, long ld_old,
-                                                 int use_ppo, float ppo_clip, float inv_B, float* __restrict__ row_loss,
+                                                 int use_ppo, float ppo_clip, float inv_B_host, float* __restrict__ row_loss,
                                                  float* __restrict__ d_inp, long ld_din, float* __restrict__ d_lp,
-                                                 long dlp_sb, long dlp_st) {
+                                                 long dlp_sb, long dlp_st, int T_all, const float* __restrict__ gdev) {
     __shared__ float red[4];
-    const int r = blockIdx.x, b = r / T, t = r - b * T;
+    // T_all >= T rows per caption are launched; rows t >= T do not enter the loss: their d_logprobs_all row is zero
+    const int r = blockIdx.x, b = r / T_all, t = r - b * T_all;
+    if (t >= T) {
+        if (d_lp) {
+            float* d = d_lp + b * dlp_sb + t * dlp_st;
+            for (int v = threadIdx.x; v < V1; v += 256) d[v] = 0.f;
+        }
+        return;
+    }
+    const float inv_B = gdev ? inv_B_host * gdev[0] : inv_B_host;   // upstream d loss, read on the device (no host sync)
     const float m0 = (seq[b * ld_seq + t] > 0) ? 1.f : 0.f;
     const float mk = (t == 0) ? 1.f : ((seq[b * ld_seq + t - 1] > 0) ? 1.f : 0.f);
     const float* lp = lp_all + b * lp_sb + t * lp_st;
@@ -536,7 +545,7 @@ __global__ __launch_bounds__(256) void rl_loss_k(const float* __restrict__ inp, 
             } else {
                 pol = x * rw;
             }
-            row_loss[r] = -pol * mk + entropy_reg * m0 * e;
+            row_loss[b * T + t] = -pol * mk + entropy_reg * m0 * e;
         }
     }
     if (d_lp) {
@@ -561,25 +570,36 @@ __global__ __launch_bounds__(256) void rl_loss_k(const float* __restrict__ inp, 
         d_inp[b * ld_din + t] = -g * mk * inv_B;
     }
 }
-extern "C" int rfn_rl_loss(const float* input, int64_t ld_in, const int64_t* seq, int64_t ld_seq, const float* reward,
-                           int64_t ld_rw, const float* logprobs_all, int64_t lp_sb, int64_t lp_st, int B, int T, int V1,
-                           float entropy_reg, const float* old_logprobs, int64_t ld_old, int use_ppo, float ppo_clip,
-                           float* scratch, float* loss_out, int accumulate_loss, float* d_input, int64_t ld_din,
-                           float* d_logprobs_all, int64_t dlp_sb, int64_t dlp_st, void* stream) {
-    if (B <= 0 || T <= 0 || V1 <= 0) return RFN_ERR_SHAPE;
+extern "C" int rfn_rl_loss_ex(const float* input, int64_t ld_in, const int64_t* seq, int64_t ld_seq, const float* reward,
+                              int64_t ld_rw, const float* logprobs_all, int64_t lp_sb, int64_t lp_st, int B, int T, int T_all,
+                              int V1, float entropy_reg, const float* old_logprobs, int64_t ld_old, int use_ppo,
+                              float ppo_clip, const float* gscale_dev, float* scratch, float* loss_out, int accumulate_loss,
+                              float* d_input, int64_t ld_din, float* d_logprobs_all, int64_t dlp_sb, int64_t dlp_st,
+                              void* stream) {
+    if (B <= 0 || T <= 0 || V1 <= 0 || T_all < T) return RFN_ERR_SHAPE;
     if (!input || !seq || !reward || !logprobs_all || (loss_out && !scratch) || (use_ppo && !old_logprobs))
         return RFN_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(rl_loss_k, dim3(B * T), dim3(256), 0, st, input, (long)ld_in, seq, (long)ld_seq, reward,
+    const int rows = d_logprobs_all ? T_all : T;      // the extra rows exist only to zero d_logprobs_all[:, T:]
+    hipLaunchKernelGGL(rl_loss_k, dim3(B * rows), dim3(256), 0, st, input, (long)ld_in, seq, (long)ld_seq, reward,
                        (long)ld_rw, logprobs_all, (long)lp_sb, (long)lp_st, T, V1, entropy_reg, old_logprobs,
                        (long)ld_old, use_ppo, ppo_clip, 1.0f / (float)B, loss_out ? scratch : nullptr, d_input,
-                       (long)ld_din, d_logprobs_all, (long)dlp_sb, (long)dlp_st);
+                       (long)ld_din, d_logprobs_all, (long)dlp_sb, (long)dlp_st, rows, gscale_dev);
     RFN_CHECK_LAUNCH();
     if (loss_out) {
         hipLaunchKernelGGL(sum_k, dim3(1), dim3(256), 0, st, scratch, B * T, 1.0f / (float)B, loss_out, accumulate_loss);
         RFN_CHECK_LAUNCH();
     }
     return RFN_OK;
+}
+extern "C" int rfn_rl_loss(const float* input, int64_t ld_in, const int64_t* seq, int64_t ld_seq, const float* reward,
+                           int64_t ld_rw, const float* logprobs_all, int64_t lp_sb, int64_t lp_st, int B, int T, int V1,
+                           float entropy_reg, const float* old_logprobs, int64_t ld_old, int use_ppo, float ppo_clip,
+                           float* scratch, float* loss_out, int accumulate_loss, float* d_input, int64_t ld_din,
+                           float* d_logprobs_all, int64_t dlp_sb, int64_t dlp_st, void* stream) {
+    return rfn_rl_loss_ex(input, ld_in, seq, ld_seq, reward, ld_rw, logprobs_all, lp_sb, lp_st, B, T, T, V1, entropy_reg,
+                          old_logprobs, ld_old, use_ppo, ppo_clip, nullptr, scratch, loss_out, accumulate_loss, d_input,
+                          ld_din, d_logprobs_all, dlp_sb, dlp_st, stream);
 }
 
 // ---- nn.MultiLabelMarginLoss (mean) -----------------------------------------------------------------

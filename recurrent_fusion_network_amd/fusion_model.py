@@ -121,42 +121,54 @@ class _PrefixFn(torch.autograd.Function):
                                      int(train), seed, N.stream_ptr()), 'rfn_prefix_fwd')
         if train:
             ctx.model, ctx.seed, ctx.M, ctx.B, ctx.drop = model, seed, M, B, drop
-            ctx.ws, ctx.fc, ctx.att, ctx.params, ctx.consumed = ws, fc, att, params, False
+            ctx.fc, ctx.att, ctx.params, ctx.consumed, ctx.snapshot = fc, att, params, False, None
+            # the multi-GB workspace is a SAVED tensor, not an attribute: autograd frees it right after a non-retained
+            # backward instead of keeping it for as long as anything references the graph (a trainer's `loss` variable)
+            ctx.save_for_backward(ws)
         return comb, h, c, reason
 
     @staticmethod
     def backward(ctx, d_comb, d_h, d_c, d_reason):
         model, M, B = ctx.model, ctx.M, ctx.B
+        ws, = ctx.saved_tensors
         d = model._dims_for(ctx.drop)
         dev = ctx.fc[0].device
         table = model._param_table(ctx.params, model._prefix_slots)
         flats, by_slot, gtable = model._grad_buffers(model._prefix_buckets, dev)
         cont = lambda t: None if t is None else t.contiguous()  # noqa: E731
         d_comb, d_h, d_c, d_reason = cont(d_comb), cont(d_h), cont(d_c), cont(d_reason)
-        ws_bytes = ctx.ws.numel()
+        ws_bytes = ws.numel()
         att_ptrs = N.ptr_array(ctx.att)
-        if ctx.consumed:
+        if ctx.consumed and ctx.snapshot is not None:
+            ws.copy_(ctx.snapshot)      # model.retain_activations: the activations of the ORIGINAL forward (see below)
+        elif ctx.consumed:
             # backward overwrites activations in place (projections -> their gradients, gates -> gate gradients), so a
             # second backward over the same graph (loss.backward(retain_graph=True) in the PPO loop, train_rl.py:190-201)
-            # first recomputes phase 1 into the workspace: same inputs, same dropout seed
+            # first recomputes phase 1 into the workspace: same inputs, same dropout seed, the weights AS THEY ARE NOW.
+            # If optimizer.step() ran in between (it does in that loop) these are the activations of the updated weights:
+            # a self-consistent gradient at the new weights.  The reference instead backpropagates the activations saved
+            # at the original forward through the updated weights; set model.retain_activations = True for exactly that
+            # (costs one copy of the workspace per retained graph).
             R, T2, K = d.R, d.T2, d.K
             scratch = torch.empty(T2 * B * R + 2 * B * R + (M + 1) * B * K, device=dev)
             o1, o2, o3 = T2 * B * R, T2 * B * R + B * R, T2 * B * R + 2 * B * R
             N.check(N.lib.rfn_prefix_fwd(C.byref(d), B, table, N.ptr_array(ctx.fc), att_ptrs, scratch.data_ptr(),
                                          scratch[o1:].data_ptr(), scratch[o2:].data_ptr(), scratch[o3:].data_ptr(),
-                                         ctx.ws.data_ptr(), ws_bytes, 1, ctx.seed, N.stream_ptr()),
+                                         ws.data_ptr(), ws_bytes, 1, ctx.seed, N.stream_ptr()),
                     'rfn_prefix_fwd (recompute)')
+        elif getattr(model, 'retain_activations', False):
+            ctx.snapshot = ws.clone()
         ctx.consumed = True
         # everything except the per-encoder stage-I weight gradients ...
         N.check(N.lib.rfn_prefix_bwd(C.byref(d), B, table, N.ptr_array(ctx.fc), att_ptrs, N.ptr(d_comb),
-                                     N.ptr(d_h), N.ptr(d_c), N.ptr(d_reason), gtable, ctx.ws.data_ptr(), ws_bytes,
+                                     N.ptr(d_h), N.ptr(d_c), N.ptr(d_reason), gtable, ws.data_ptr(), ws_bytes,
                                      ctx.seed, 1, N.stream_ptr()), 'rfn_prefix_bwd')
         model._bucket_done('core', flats['core'])
         # ... then one encoder at a time, so a data-parallel host overlaps bucket i's all-reduce with the
         # GEMMs of encoder i+1 (the largest of backward)
         for i in range(M):
             for part, tag in ((1, 'a'), (2, 'b')):
-                N.check(N.lib.rfn_prefix_bwd_wgrad(C.byref(d), B, att_ptrs, gtable, ctx.ws.data_ptr(), ws_bytes, i,
+                N.check(N.lib.rfn_prefix_bwd_wgrad(C.byref(d), B, att_ptrs, gtable, ws.data_ptr(), ws_bytes, i,
                                                    part, N.stream_ptr()), 'rfn_prefix_bwd_wgrad')
                 model._bucket_done('enc%d%s' % (i, tag), flats['enc%d%s' % (i, tag)])
         return (None, None, None, None, None) + (None,) * (2 * M) + (None,) * len(ctx.params)
@@ -207,15 +219,15 @@ class _DecoderFn(torch.autograd.Function):
                                           int(train), seed, N.stream_ptr()), 'rfn_decoder_fwd')
         if train:
             ctx.model, ctx.seed, ctx.B, ctx.S, ctx.drop = model, seed, B, S, drop
-            ctx.ws, ctx.ids, ctx.params, ctx.consumed = ws, ids, params, False
-            ctx.save_for_backward(comb, h0, c0, log_prob)
+            ctx.ids, ctx.params, ctx.consumed, ctx.snapshot = ids, params, False, None
+            ctx.save_for_backward(comb, h0, c0, log_prob, ws)     # ws: freed with the graph (see _PrefixFn.forward)
         ctx.mark_non_differentiable(ids)
         return log_prob, ids
 
     @staticmethod
     def backward(ctx, d_log_prob, _d_ids=None):
         model, B, S = ctx.model, ctx.B, ctx.S
-        comb, h0, c0, log_prob = ctx.saved_tensors
+        comb, h0, c0, log_prob, ws = ctx.saved_tensors
         d = model._dims_for(ctx.drop)
         dev = comb.device
         table = model._param_table(ctx.params, model._decoder_slots)
@@ -224,16 +236,23 @@ class _DecoderFn(torch.autograd.Function):
         d_comb = torch.empty_like(comb)
         d_h0 = torch.empty_like(h0)
         d_c0 = torch.empty_like(c0)
-        if ctx.consumed:     # second backward over the same graph: recompute phase 2 first (see _PrefixFn.backward)
+        if ctx.consumed and ctx.snapshot is not None:
+            ws.copy_(ctx.snapshot)
+        elif ctx.consumed:
+            # second backward over the same graph: recompute phase 2 first (see _PrefixFn.backward), log-probs included,
+            # so the pass differentiated is self-consistent at the current weights
+            log_prob = torch.empty_like(log_prob)
             N.check(N.lib.rfn_decoder_fwd(C.byref(d), B, S, table, comb.data_ptr(), h0.data_ptr(), c0.data_ptr(),
-                                          ctx.ids.data_ptr(), ctx.ids.stride(0), torch.empty_like(log_prob).data_ptr(),
-                                          ctx.ws.data_ptr(), ctx.ws.numel(), 1, ctx.seed, N.stream_ptr()),
+                                          ctx.ids.data_ptr(), ctx.ids.stride(0), log_prob.data_ptr(),
+                                          ws.data_ptr(), ws.numel(), 1, ctx.seed, N.stream_ptr()),
                     'rfn_decoder_fwd (recompute)')
+        elif getattr(model, 'retain_activations', False):
+            ctx.snapshot = ws.clone()
         ctx.consumed = True
         N.check(N.lib.rfn_decoder_bwd(C.byref(d), B, S, table, comb.data_ptr(), h0.data_ptr(), c0.data_ptr(),
                                       ctx.ids.data_ptr(), ctx.ids.stride(0), log_prob.data_ptr(),
                                       d_log_prob.data_ptr(), d_comb.data_ptr(), d_h0.data_ptr(), d_c0.data_ptr(),
-                                      gtable, ctx.ws.data_ptr(), ctx.ws.numel(), ctx.seed, N.stream_ptr()),
+                                      gtable, ws.data_ptr(), ws.numel(), ctx.seed, N.stream_ptr()),
                 'rfn_decoder_bwd')
         model._bucket_done('decoder', flats['decoder'])
         return (None, None, None, None, None, d_comb, d_h0, d_c0, None, None) + (None,) * len(ctx.params)
@@ -319,6 +338,11 @@ class RecurrentFusionModel(nn.Module):
         # the very same objects (unchanged `_version`) as the previous call's, with unchanged weights and no active
         # dropout, reuses that call's stage-I/II outputs instead of recomputing them.
         self.reuse_prefix = False
+        # Opt-in for loops that call loss.backward(retain_graph=True) repeatedly with optimizer steps in between (PPO,
+        # train_rl.py:190-201): keep a copy of the activations backward consumes, so later passes differentiate the
+        # ORIGINAL forward's activations through the current weights, as the reference does.  Off: they are recomputed
+        # at the current weights.
+        self.retain_activations = False
         self._prefix_cache = None
         self._weights_epoch = 0          # bumped by FusedClampAdam.step (it writes parameters behind autograd's back)
         self._last_flat_grads = {}

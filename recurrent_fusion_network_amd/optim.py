@@ -73,6 +73,15 @@ class FusedClampAdam:
                             for name, st in self.flat.items()}}
 
     def load_state_dict(self, sd):
+        """Accepts this class's own format and the ``torch.optim.Adam`` format the reference's checkpoints hold
+        (``optimizer_<id>.pth``, train.py:86-88: ``{'state': {index: {'step', 'exp_avg', 'exp_avg_sq'}}, 'param_groups':
+        [...]}`` with ``index`` = position in ``model.parameters()``, which is the reference's order: the module
+        registers its parameters in the same sequence)."""
+        if 'state' in sd and 'param_groups' in sd:
+            return self._load_torch_adam(sd)
+        if 'buckets' not in sd:
+            raise N.RfnError('unrecognised optimizer state: expected FusedClampAdam\'s {buckets, step_count, hyper} or '
+                             'torch.optim.Adam\'s {state, param_groups}, got keys %s' % sorted(sd))
         if set(sd['buckets']) != set(self.flat):
             raise N.RfnError('optimizer state has buckets %s, the model has %s' % (sorted(sd['buckets']), sorted(self.flat)))
         for name, st in self.flat.items():
@@ -84,6 +93,46 @@ class FusedClampAdam:
         self.step_count = int(sd['step_count'])
         for k, v in sd.get('hyper', {}).items():
             self.param_groups[0][k] = tuple(v) if k == 'betas' else v
+
+    def _load_torch_adam(self, sd):
+        groups = sd['param_groups']
+        order = [i for g in groups for i in g['params']]
+        params = list(self.model.parameters())
+        if len(order) != len(params):
+            raise N.RfnError('torch.optim.Adam state covers %d parameters, the model has %d' % (len(order), len(params)))
+        where = {}      # id(parameter) -> (bucket, offset)
+        for name in self.model.bucket_names():
+            ps, offs, _ = self.model.bucket_layout(name)
+            for p, o in zip(ps, offs):
+                where[id(p)] = (name, o)
+        steps = set()
+        for st in self.flat.values():
+            st['m'].zero_()
+            st['v'].zero_()
+        for pos, key in enumerate(order):
+            ent = sd['state'].get(key)
+            if ent is None:         # a parameter Adam never stepped: moments stay zero
+                continue
+            p = params[pos]
+            if tuple(ent['exp_avg'].shape) != tuple(p.shape):
+                raise N.RfnError('optimizer state %s has shape %s, parameter %d has %s'
+                                 % (key, tuple(ent['exp_avg'].shape), pos, tuple(p.shape)))
+            name, o = where[id(p)]
+            n = p.numel()
+            self.flat[name]['m'][o:o + n].copy_(ent['exp_avg'].reshape(-1))
+            self.flat[name]['v'][o:o + n].copy_(ent['exp_avg_sq'].reshape(-1))
+            steps.add(int(ent['step']))
+        if len(steps) > 1:
+            raise N.RfnError('torch.optim.Adam state has per-parameter step counts %s; the fused update keeps one' % sorted(steps))
+        self.step_count = steps.pop() if steps else 0
+        g0 = groups[0]
+        if g0.get('amsgrad', False):
+            raise N.RfnError('amsgrad state is not supported by the fused update')
+        for k in ('lr', 'eps', 'weight_decay'):
+            if k in g0:
+                self.param_groups[0][k] = g0[k]
+        if 'betas' in g0:
+            self.param_groups[0]['betas'] = tuple(g0['betas'])
 
     # ---- the update ------------------------------------------------------------------------------------
     def step(self, grad_scale=1.0):

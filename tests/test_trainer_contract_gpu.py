@@ -124,3 +124,89 @@ def test_optimizer_param_groups_and_state_round_trip(dev, tmp_path):
     p2 = dict(m2.named_parameters())
     for k, p in m1.named_parameters():
         assert torch.equal(p.detach(), p2[k].detach()), k
+
+
+def test_optimizer_resumes_from_a_torch_adam_checkpoint(dev, tmp_path):
+    """A checkpoint directory written by the reference holds torch.optim.Adam state (train.py:86-88,232-233:
+    {'state': {index: step / exp_avg / exp_avg_sq}, 'param_groups'}), indexed by position in model.parameters().
+    FusedClampAdam.load_state_dict scatters it into its flat moments; unknown formats fail by name."""
+    import recurrent_fusion_network_amd as R
+    cfg, spec, P, batch, gold = load_case('tiny0')
+    fc, att, labels, masks, top = to_dev(batch, dev)
+    crit = R.ReviewNetEnsembleCriterion(cfg)
+    kw = dict(lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5)
+
+    def run(model, opt, steps, fused):
+        for _ in range(steps):
+            opt.zero_grad()
+            _loss(model, crit, fc, att, labels, masks, top).backward()
+            if not fused:
+                R.clip_gradient(opt, 1.0)                     # misc/utils.py:292-296
+            opt.step()
+
+    m1 = build(cfg, P, dev, train=True)
+    o1 = torch.optim.Adam(m1.parameters(), **kw)             # the reference's optimizer (train.py:69-71)
+    run(m1, o1, 2, False)
+    torch.save(o1.state_dict(), str(tmp_path / 'optimizer_ref.pth'))
+    torch.save(m1.state_dict(), str(tmp_path / 'model_ref.pth'))
+    run(m1, o1, 2, False)
+    m2 = build(cfg, torch.load(str(tmp_path / 'model_ref.pth')), dev, train=True)
+    o2 = R.FusedClampAdam(m2, lr=1.0, grad_clip=1.0)         # hyper-parameters come from the checkpoint
+    o2.load_state_dict(torch.load(str(tmp_path / 'optimizer_ref.pth')))
+    assert o2.step_count == 2 and o2.lr == 5e-4 and o2.weight_decay == 1e-5
+    run(m2, o2, 2, True)
+    p2 = dict(m2.named_parameters())
+    for k, p in m1.named_parameters():
+        # two more Adam steps from the same moments: equal up to the rounding of the two implementations, amplified where
+        # |g| is tiny against sqrt(v) (see DESIGN 6 on the first Adam step)
+        assert maxerr(p.detach(), p2[k].detach().cpu()) < 2e-5, k
+    with pytest.raises(R._native.RfnError):
+        o2.load_state_dict({'something': 1})
+
+
+def test_retained_graph_after_a_weight_update_matches_the_reference_semantics(dev):
+    """PPO loop (train_rl.py:190-201): loss.backward(retain_graph=True), optimizer.step(), then backward AGAIN over the
+    same graph.  The reference (and the oracle, an ordinary autograd graph) differentiates the activations saved at the
+    original forward through the weights as they are now.  model.retain_activations = True gives exactly that; the
+    default recomputes the activations at the new weights (self-consistent, documented in fusion_model.py)."""
+    import recurrent_fusion_network_amd as R
+    from oracle import rfn_oracle as O
+    cfg, spec, P, batch, gold = load_case('mid')
+    fc, att, labels, masks, top = batch
+    lr = 0.05
+
+    # oracle: an in-place update through .data leaves the saved tensors' version alone, as PyTorch 0.3.1 optimizers did
+    Pg = {k: v.detach().clone().requires_grad_(True) for k, v in P.items()}
+    lp, heads = O.forward(cfg, Pg, fc, att, labels)
+    loss = O.xe_criterion(cfg, lp, labels[:, 1:], masks[:, 1:], heads, top, 1.0)
+    loss.backward(retain_graph=True)
+    for v in Pg.values():
+        v.data.add_(v.grad, alpha=-lr)
+        v.grad = None
+    loss.backward(retain_graph=True)
+    want = {k: v.grad for k, v in Pg.items()}
+
+    def second_pass(retain):
+        model = build(cfg, P, dev, train=True)
+        model.retain_activations = retain
+        crit = R.ReviewNetEnsembleCriterion(cfg)
+        l_ = _loss(model, crit, *to_dev(batch, dev))
+        l_.backward(retain_graph=True)
+        first = {k: p.grad.clone() for k, p in model.named_parameters()}
+        with torch.no_grad():
+            for p in model.parameters():
+                p.data.add_(p.grad, alpha=-lr)
+                p.grad = None
+        model._last_flat_grads.clear()
+        l_.backward(retain_graph=True)
+        return first, {k: p.grad.clone() for k, p in model.named_parameters()}
+
+    first, got = second_pass(True)
+    for k, w in want.items():
+        assert maxerr(got[k], w) <= 1e-5 + 1e-3 * float(w.abs().max()), k
+    # logit.weight's gradient is dlogits^T h: activations and saved log-probs only -> unchanged by the update, bit for bit
+    assert torch.equal(got['logit.weight'], first['logit.weight'])
+    _, recomputed = second_pass(False)
+    assert not torch.equal(recomputed['logit.weight'], first['logit.weight'])
+    worst = max(float((recomputed[k].cpu() - w).abs().max()) / (1e-5 + 1e-3 * float(w.abs().max())) for k, w in want.items())
+    assert worst > 1.0          # the recompute path is a different (self-consistent) gradient: the flag matters

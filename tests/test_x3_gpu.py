@@ -172,6 +172,18 @@ def test_k_slow_image_is_an_exact_split_in_the_documented_layout(dev):
     assert float(pl[K:].abs().max()) == 0.0 and float(pl[:, 3 * cols:].abs().max()) == 0.0
 
 
+def test_k_slow_image_with_more_than_65535_reduction_rows(dev):
+    """K = B*L of the weight-gradient operands exceeds HIP's 65535 cap on gridDim.y from B = 335 at L = 196 (bench.py
+    --batch 512): the split kernel carries k on grid.x."""
+    import recurrent_fusion_network_amd._native as N
+    K, cols = 70000, 8
+    m = torch.randn(K, cols, generator=torch.Generator(device='cpu').manual_seed(3)).to(dev)
+    img = N.x3_image_ks([m], K, cols)
+    pl = _decode_ks(img, K, cols).double().sum(0)
+    assert torch.equal(pl[:K, :cols].float(), m)
+    assert float(pl[K:].abs().max()) == 0.0 and float(pl[:, cols:].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize('shape,splitk', [((300, 520, 70), 1), ((512, 260, 5000), 3), ((256, 256, 32), 1), ((40, 2300, 333), 2)])
 def test_k_slow_gemm_against_f64(dev, shape, splitk):
     """C = A^T B with both operands stored reduction-index-major ([K][M], [K][N]): the weight-gradient orientation.  The MFMA
