@@ -262,6 +262,18 @@ int rfn_attn_small_bwd(int ngroups, const float* const* proj, int64_t proj_sb, i
                        int64_t dproj_sl, int accumulate_dproj, float* const* dhproj, float* const* dw_part,
                        float* const* datt_seq, void* stream);
 
+/* Dropout masks of the path (nn.Dropout of the three cells: misc/RecurrentFusionModel.py:70,
+ * misc/LSTMSoftMultiAttentionFeatArrayNoInputCore.py:69, misc/LSTMSoftAttentionCore.py:98).  A mask is never stored:
+ * unit j of batch row b of one cell call is kept iff philox4x32-10(key = seed, counter = (b * R + j, offset)) >= p, with
+ * `seed` the 64-bit seed the caller hands to rfn_prefix_fwd / rfn_decoder_fwd / rfn_decoder_step and `offset` the call
+ * site: stage-I cell (step t, encoder i) -> t * M + i (p = drop_fusion); stage-II cell t -> RFN_DROP_OFFSET_STAGE2 + t
+ * (p = drop_reason); decoder step s -> RFN_DROP_OFFSET_DECODER + s (p = drop_lm).  Forward and backward regenerate it.
+ * rfn_dropout_mask writes the keep mask of one call site (n = B * R values, 1.0f = kept, 0.0f = dropped) so that a
+ * test can hand the product's own masks to the CPU oracle. */
+#define RFN_DROP_OFFSET_STAGE2 (1ull << 20)
+#define RFN_DROP_OFFSET_DECODER (1ull << 21)
+int rfn_dropout_mask(uint64_t seed, uint64_t offset, int64_t n, float drop_p, float* keep_out, void* stream);
+
 /* LSTM gate epilogue shared by the three cells (misc/RecurrentFusionModel.py:55-73,
  * misc/LSTMSoftMultiAttentionFeatArrayNoInputCore.py:54-72, misc/LSTMSoftAttentionCore.py:83-101):
  * gates[b, 0:4R] = [in | forget | out | g] pre-activations on entry, activations on exit;

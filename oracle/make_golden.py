@@ -2,7 +2,7 @@
 """Generate golden vectors by RUNNING THE REFERENCE in the build container.
 
 Usage (build container only; /root/reference does not exist on the GPU box):
-    python oracle/make_golden.py [--only tiny0,tiny1,mid,c2,c3,c5,evalmid]
+    python oracle/make_golden.py [--only tiny0,tiny1,mid,c2,c3,c5,evalmid,tiny0_drop,tinymax_drop,mid_drop]
 
 Imports the reference's RecurrentFusionModel / criteria from /root/reference, loads the
 documented seeded weight stream (oracle.rfn_oracle.seeded_params), runs forward / greedy sample /
@@ -425,6 +425,102 @@ def generate_decode(name, RefModel, ref_utils, outdir):
         name, loss.item(), g[0].size(1), beam, b[0].size(1), float(out['rl_loss']), path, os.path.getsize(path) / 1024))
 
 
+DROP_PROBS = dict(drop_prob_fusion=0.1, drop_prob_reason=0.2, drop_prob_lm=0.3)
+DROP_TIERS = ('tiny0', 'tinymax', 'mid')
+
+
+def generate_dropout(name, RefModel, ref_utils, outdir):
+    """Training-mode parity: the reference in train() mode with drop_prob_fusion / _reason / _lm =
+    0.1 / 0.2 / 0.3 and forward hooks on every nn.Dropout it owns, capturing each call's keep mask in call order
+    (misc/RecurrentFusionModel.py:70, misc/LSTMSoftMultiAttentionFeatArrayNoInputCore.py:69,
+    misc/LSTMSoftAttentionCore.py:98).  The oracle run with exactly those masks must reproduce log-probs, reason heads,
+    loss and every gradient; masks and results are stored as `<name>_drop.npz`."""
+    spec = dict(CONFIGS[name])
+    spec['extra'] = dict(spec.get('extra', {}), **DROP_PROBS)
+    cfg = cfg_of(spec)
+    torch.manual_seed(0)
+    model = RefModel(cfg)
+    P = O.seeded_params(cfg, spec['seed'])
+    model.load_state_dict(P)
+    model.train()
+    model.ss_prob = 0.0
+    fc, att, labels, masks, top = batch_of(cfg, spec)
+    M, T1, T2 = len(spec['feats']), spec['T1'], spec['T2']
+    calls = dict(fusion={}, review={}, decoder=[])
+
+    def capture(store, key):
+        def hook(mod, inp, outp):
+            keep = (outp != 0) | (inp[0] == 0)        # a kept unit is scaled, never zeroed (an exact 0 input: either way)
+            scaled = inp[0] * (keep.to(inp[0].dtype) * (1.0 / (1.0 - mod.p)))
+            assert float((scaled - outp).abs().max()) <= 1e-6 * max(1.0, float(outp.abs().max())), 'not inverted dropout'
+            if key is None:
+                store.append(keep.clone())
+            else:
+                assert key not in store, 'dropout site called twice'
+                store[key] = keep.clone()
+        return hook
+
+    hooks = []
+    for t in range(T1):
+        for i in range(M):
+            cell = model.review_steps_individual[t].lstm[i]
+            assert abs(cell.dropout.p - cfg.drop_prob_fusion) < 1e-12
+            hooks.append(cell.dropout.register_forward_hook(capture(calls['fusion'], (t, i))))
+        # FeatArrayFusionNoInputCore owns a second nn.Dropout (:99) that its forward never calls
+        hooks.append(model.review_steps_individual[t].dropout.register_forward_hook(
+            lambda *a: (_ for _ in ()).throw(AssertionError('FeatArrayFusionNoInputCore.dropout was called'))))
+    for t in range(T2):
+        assert abs(model.review_steps[t].dropout.p - cfg.drop_prob_reason) < 1e-12
+        hooks.append(model.review_steps[t].dropout.register_forward_hook(capture(calls['review'], t)))
+    assert abs(model.decoder.dropout.p - cfg.drop_prob_lm) < 1e-12
+    hooks.append(model.decoder.dropout.register_forward_hook(capture(calls['decoder'], None)))
+
+    crit = ref_utils.ReviewNetEnsembleCriterion(cfg)
+    torch.manual_seed(500 + spec['seed'])
+    model.zero_grad()
+    log_prob, top_pred = model(fc, att, labels)
+    loss = crit(log_prob, labels[:, 1:], masks[:, 1:], top_pred, top, 1.0)
+    loss.backward()
+    for h in hooks:
+        h.remove()
+    S = log_prob.size(1)
+    assert len(calls['fusion']) == T1 * M and len(calls['review']) == T2 and len(calls['decoder']) == S
+    drop = O.make_drop(cfg, [[calls['fusion'][(t, i)] for i in range(M)] for t in range(T1)],
+                       [calls['review'][t] for t in range(T2)], calls['decoder'])
+    grads = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+    o_lp, o_rp = O.forward(cfg, P, fc, att, labels, drop=drop)
+    e1 = close(o_lp, log_prob, 2e-5, 'log_prob (dropout)')
+    for a, b in zip(o_rp, top_pred):
+        close(a, b, 2e-5, 'reason_pred (dropout)')
+    o_loss, o_grads = O.train_step_loss_and_grads(cfg, P, fc, att, labels, masks, top, 1.0, drop=drop)
+    close(o_loss, loss, 1e-4, 'xe loss (dropout)')
+    for k in grads:
+        close(o_grads[k], grads[k], 2e-5 + 1e-4 * float(grads[k].abs().max()), 'grad (dropout) ' + k)
+    # the masks matter: the eval-mode oracle is far from these numbers
+    assert float((O.forward(cfg, P, fc, att, labels)[0] - log_prob).abs().max()) > 1e-3
+    full = name.startswith('tiny')
+    out = dict(weights_digest=digest([P[k] for k in sorted(P)]), inputs_digest=digest(fc + att), labels=labels.numpy(),
+               masks=masks.numpy(), top_words=top.numpy(),
+               drop_probs=np.array([cfg.drop_prob_fusion, cfg.drop_prob_reason, cfg.drop_prob_lm]),
+               keep_fusion=np.stack([np.stack([calls['fusion'][(t, i)].numpy() for i in range(M)]) for t in range(T1)]),
+               keep_review=np.stack([calls['review'][t].numpy() for t in range(T2)]),
+               keep_decoder=np.stack([m.numpy() for m in calls['decoder']]),
+               log_prob=log_prob.detach().numpy(), xe_loss=np.float64(loss.item()))
+    for j, r in enumerate(top_pred):
+        out['reason_pred_%d' % j] = r.detach().numpy()
+    for k in sorted(grads):
+        n, sl = grad_summary(k, grads[k])
+        out['gradnorm/' + k] = n
+        out['gradslice/' + k] = sl
+        if full:
+            out['grad/' + k] = grads[k].numpy()
+    path = os.path.join(outdir, name + '_drop.npz')
+    np.savez_compressed(path, **out)
+    kept = [float(np.mean(out[k])) for k in ('keep_fusion', 'keep_review', 'keep_decoder')]
+    print('%-12s log_prob err %.2e  xe %.6f  keep rates %.3f %.3f %.3f -> %s (%.1f KB)' % (
+        name + '_drop', e1, loss.item(), kept[0], kept[1], kept[2], path, os.path.getsize(path) / 1024))
+
+
 SHOWTELL = dict(fc=2048, R=512, V=9487, B=4, S=16, seed=11, max_words=9)   # BASELINE config 1
 
 
@@ -489,7 +585,7 @@ def generate_showtell(outdir):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--only', default='tiny0,tiny1,tinymax,odd,mid,c2,c3,c5,evalmid,showtell')
+    ap.add_argument('--only', default='tiny0,tiny1,tinymax,odd,mid,c2,c3,c5,evalmid,showtell,tiny0_drop,tinymax_drop,mid_drop')
     ap.add_argument('--out', default=os.path.join(ROOT, 'tests', 'golden'))
     args = ap.parse_args()
     torch.set_num_threads(8)
@@ -498,6 +594,9 @@ def main():
     for name in args.only.split(','):
         if name == 'showtell':
             generate_showtell(args.out)
+            continue
+        if name.endswith('_drop'):
+            generate_dropout(name[:-5], RefModel, ref_utils, args.out)
             continue
         if 'decode' in CONFIGS[name]:
             generate_decode(name, RefModel, ref_utils, args.out)

@@ -152,6 +152,17 @@ def attention(pre_h: Tensor, att_seq: Tensor, P: Dict[str, Tensor], prefix: str)
     return z, alpha, scores
 
 
+def apply_dropout(next_h: Tensor, keep: Tensor = None, p: float = 0.0) -> Tensor:
+    """nn.Dropout in training mode with the Bernoulli draw given explicitly (misc/RecurrentFusionModel.py:70,
+    misc/LSTMSoftMultiAttentionFeatArrayNoInputCore.py:69, misc/LSTMSoftAttentionCore.py:98): kept units are scaled by
+    1 / (1 - p), dropped ones are 0.  It acts on next_h only: the recurrent h, every consumer of the cell output (reason
+    heads, thought vectors, logit layer, the concatenated H) see the POST-dropout value; next_c is never dropped.
+    ``keep`` None = eval mode."""
+    if keep is None:
+        return next_h
+    return next_h * (keep.to(next_h.dtype) * (1.0 / (1.0 - p)))
+
+
 def lstm_update(sums: Tensor, pre_c: Tensor, R: int, maxout: int = 0):
     """Gate epilogue shared by the three cells (misc/RecurrentFusionModel.py:55-68):
     chunk order [in | forget | out | g], NOT cuDNN's."""
@@ -166,30 +177,34 @@ def lstm_update(sums: Tensor, pre_c: Tensor, R: int, maxout: int = 0):
     return next_h, next_c
 
 
-def fusion_cell(H: Tensor, att_feat: Tensor, h: Tensor, c: Tensor, P, prefix: str, R: int):
-    """Stage-I cell (misc/RecurrentFusionModel.py:47-74), dropout p=0."""
+def fusion_cell(H: Tensor, att_feat: Tensor, h: Tensor, c: Tensor, P, prefix: str, R: int, keep: Tensor = None,
+                p: float = 0.0):
+    """Stage-I cell (misc/RecurrentFusionModel.py:47-74); ``keep``: this call's dropout mask (None = eval)."""
     z, alpha, _ = attention(h, att_feat, P, prefix + 'att_model.')
     sums = (H @ P[prefix + 'H2h.weight'].t() + P[prefix + 'H2h.bias']
             + z @ P[prefix + 'z2h.weight'].t() + P[prefix + 'z2h.bias'])          # :53
     nh, nc = lstm_update(sums, c, R, 0)
+    nh = apply_dropout(nh, keep, p)                                               # :70
     return nh, nc, dict(z=z, alpha=alpha, sums=sums)
 
 
-def fusion_step(att_feats: List[Tensor], hs: List[Tensor], cs: List[Tensor], P, t: int, R: int):
+def fusion_step(att_feats: List[Tensor], hs: List[Tensor], cs: List[Tensor], P, t: int, R: int, drop=None):
     """One stage-I step over all encoders (misc/RecurrentFusionModel.py:101-114): H is built from
-    the PREVIOUS step's hidden states before any cell runs."""
+    the PREVIOUS step's (post-dropout) hidden states before any cell runs."""
     H = torch.cat(hs, 1)                                                          # :102-107
     nh, nc = [], []
     for i in range(len(hs)):
         a, b, _ = fusion_cell(H, att_feats[i], hs[i], cs[i], P,
-                              'review_steps_individual.%d.lstm.%d.' % (t, i), R)
+                              'review_steps_individual.%d.lstm.%d.' % (t, i), R,
+                              None if drop is None else drop['fusion'][t][i], 0.0 if drop is None else drop['p_fusion'])
         nh.append(a)
         nc.append(b)
     return nh, nc
 
 
-def review_cell(thoughts: List[Tensor], h: Tensor, c: Tensor, P, t: int, R: int, maxout: int = 0):
-    """Stage-II cell (misc/LSTMSoftMultiAttentionFeatArrayNoInputCore.py:41-73), dropout p=0."""
+def review_cell(thoughts: List[Tensor], h: Tensor, c: Tensor, P, t: int, R: int, maxout: int = 0, keep: Tensor = None,
+                drop_p: float = 0.0):
+    """Stage-II cell (misc/LSTMSoftMultiAttentionFeatArrayNoInputCore.py:41-73); ``keep``: dropout mask (None = eval)."""
     p = 'review_steps.%d.' % t
     sums = h @ P[p + 'h2h.weight'].t() + P[p + 'h2h.bias']                        # :50
     aux = []
@@ -198,17 +213,29 @@ def review_cell(thoughts: List[Tensor], h: Tensor, c: Tensor, P, t: int, R: int,
         sums = sums + z @ P[p + 'z_2_h.%d.weight' % i].t() + P[p + 'z_2_h.%d.bias' % i]   # :51-52
         aux.append(dict(z=z, alpha=alpha))
     nh, nc = lstm_update(sums, c, R, maxout)
+    nh = apply_dropout(nh, keep, drop_p)                                          # :69
     return nh, nc, dict(sums=sums, att=aux)
 
 
-def decoder_cell(xt: Tensor, comb: Tensor, h: Tensor, c: Tensor, P, R: int, maxout: int = 0):
-    """Decoder cell (misc/LSTMSoftAttentionCore.py:60-102), dropout p=0."""
+def decoder_cell(xt: Tensor, comb: Tensor, h: Tensor, c: Tensor, P, R: int, maxout: int = 0, keep: Tensor = None,
+                 p: float = 0.0):
+    """Decoder cell (misc/LSTMSoftAttentionCore.py:60-102); ``keep``: dropout mask (None = eval)."""
     z, alpha, _ = attention(h, comb, P, 'decoder.')                               # :64-79
     sums = (xt @ P['decoder.i2h.weight'].t() + P['decoder.i2h.bias']
             + h @ P['decoder.h2h.weight'].t() + P['decoder.h2h.bias']
             + z @ P['decoder.z2h.weight'].t() + P['decoder.z2h.bias'])            # :81
     nh, nc = lstm_update(sums, c, R, maxout)
+    nh = apply_dropout(nh, keep, p)                                               # :98
     return nh, nc, dict(z=z, alpha=alpha, sums=sums)
+
+
+def make_drop(cfg, fusion, review, decoder):
+    """Training-mode dropout with explicit masks: ``fusion[t][i]``, ``review[t]``, ``decoder[s]`` are the (B, R) keep
+    masks (bool / 0-1) of the stage-I cell (t, i), the stage-II cell t and the decoder step s, in the order the
+    reference's nn.Dropout layers are called; probabilities: stage I ``drop_prob_fusion``
+    (misc/RecurrentFusionModel.py:160), stage II ``drop_prob_reason`` (:172), decoder ``drop_prob_lm`` (:183)."""
+    return dict(fusion=fusion, review=review, decoder=decoder, p_fusion=float(cfg.drop_prob_fusion),
+                p_reason=float(cfg.drop_prob_reason), p_lm=float(cfg.drop_prob_lm))
 
 
 # --------------------------------------------------------------------------- #
@@ -224,7 +251,7 @@ def init_state(cfg, P, fc_feats):
     return hs, cs
 
 
-def thought_vectors(cfg, P, att_feats, hs, cs, want_aux: bool = False):
+def thought_vectors(cfg, P, att_feats, hs, cs, want_aux: bool = False, drop=None):
     """Stages I+II (misc/RecurrentFusionModel.py:283-331, same code at :210-255).
     Returns (thought_vectors_comb (B,T2,R), reason_pred list[M+1] of (B,K), (h, c))."""
     M, R = len(cfg.feat_array_info), cfg.rnn_size
@@ -232,7 +259,7 @@ def thought_vectors(cfg, P, att_feats, hs, cs, want_aux: bool = False):
     outs = [[] for _ in range(M)]
     reason = [[] for _ in range(M)]
     for t in range(T1):                                                           # :287-291
-        hs, cs = fusion_step(att_feats, hs, cs, P, t, R)
+        hs, cs = fusion_step(att_feats, hs, cs, P, t, R, drop)
         for j in range(M):
             outs[j].append(hs[j])
             reason[j].append(hs[j] @ P['reason_linear_individual.%d.weight' % j].t()
@@ -245,7 +272,8 @@ def thought_vectors(cfg, P, att_feats, hs, cs, want_aux: bool = False):
     c = sum(cs) / M
     comb, reason_c = [], []
     for t in range(T2):                                                           # :315-318
-        h, c, _ = review_cell(thoughts, h, c, P, t, R, cfg.review_maxout)
+        h, c, _ = review_cell(thoughts, h, c, P, t, R, cfg.review_maxout,
+                              None if drop is None else drop['review'][t], 0.0 if drop is None else drop['p_reason'])
         comb.append(h)
         reason_c.append(h @ P['reason_linear.weight'].t() + P['reason_linear.bias'])
     comb_t = torch.stack(comb).transpose(0, 1).contiguous()                       # (B,T2,R)
@@ -255,22 +283,24 @@ def thought_vectors(cfg, P, att_feats, hs, cs, want_aux: bool = False):
     return comb_t, reason_pred, (h, c)
 
 
-def one_time_step(cfg, P, xt, comb, h, c):
-    """misc/RecurrentFusionModel.py:345-350: returns PRE-softmax logits."""
-    h, c, _ = decoder_cell(xt, comb, h, c, P, cfg.rnn_size, cfg.maxout)
+def one_time_step(cfg, P, xt, comb, h, c, keep=None, p: float = 0.0):
+    """misc/RecurrentFusionModel.py:345-350: returns PRE-softmax logits (of the post-dropout h)."""
+    h, c, _ = decoder_cell(xt, comb, h, c, P, cfg.rnn_size, cfg.maxout, keep, p)
     return h @ P['logit.weight'].t() + P['logit.bias'], h, c
 
 
-def forward(cfg, P, fc_feats, att_feats, seq: Tensor):
-    """Teacher-forced XE pass (misc/RecurrentFusionModel.py:198-281) with ss_prob = 0."""
+def forward(cfg, P, fc_feats, att_feats, seq: Tensor, drop=None):
+    """Teacher-forced XE pass (misc/RecurrentFusionModel.py:198-281) with ss_prob = 0.  ``drop`` (make_drop): training
+    mode with the given dropout masks; None: eval mode."""
     hs, cs = init_state(cfg, P, fc_feats)
-    comb, reason_pred, (h, c) = thought_vectors(cfg, P, att_feats, hs, cs)
+    comb, reason_pred, (h, c) = thought_vectors(cfg, P, att_feats, hs, cs, drop=drop)
     outputs = []
     for i in range(seq.size(1)):                                                  # :259
         if i >= 1 and int(seq[:, i].sum()) == 0:                                  # :274
             break
         xt = P['embed.weight'][seq[:, i]]                                         # :276
-        logits, h, c = one_time_step(cfg, P, xt, comb, h, c)
+        logits, h, c = one_time_step(cfg, P, xt, comb, h, c, None if drop is None else drop['decoder'][i],
+                                     0.0 if drop is None else drop['p_lm'])
         outputs.append(torch.log_softmax(logits, dim=1))                          # :278
     return torch.stack(outputs, 1).contiguous(), reason_pred                      # :281
 
@@ -481,11 +511,11 @@ def clip_and_adam(params: Dict[str, Tensor], grads: Dict[str, Tensor], state: di
 
 
 def train_step_loss_and_grads(cfg, P: Dict[str, Tensor], fc, att, labels, masks, top_words,
-                              reason_weight: float = 1.0):
+                              reason_weight: float = 1.0, drop=None):
     """The reference's timed region minus the optimiser (train.py:143-160): forward, criterion,
     backward.  Returns (loss, grads dict)."""
     Pg = {k: v.detach().clone().requires_grad_(True) for k, v in P.items()}
-    log_prob, top_pred = forward(cfg, Pg, fc, att, labels)
+    log_prob, top_pred = forward(cfg, Pg, fc, att, labels, drop=drop)
     loss = xe_criterion(cfg, log_prob, labels[:, 1:], masks[:, 1:], top_pred, top_words, reason_weight)
     loss.backward()
     grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in Pg.items()}

@@ -144,3 +144,19 @@ extern "C" int rfn_lstm_bwd(float* gates, int64_t ldg, const float* c_prev, int6
     return rfn_lstm_bwd_grouped(gates, ldg, c_prev, ldcp, c_next, ldcn, dh, lddh, dc_next, lddcn, dc_prev, lddcp, B, R,
                                 maxout, drop_p, seed, offset, 1, 0, 0, 0, 0, stream);
 }
+
+// keep mask of one dropout call site, as lstm_fwd_k / lstm_bwd_k regenerate it (rfn.h: rfn_dropout_mask)
+__global__ __launch_bounds__(256) void dropout_mask_k(uint64_t seed, uint64_t offset, long n, float drop_p,
+                                                      float* __restrict__ keep) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n) return;
+    keep[idx] = (drop_p > 0.f && rfn_philox_uniform(seed, offset, (uint64_t)idx) < drop_p) ? 0.f : 1.f;
+}
+extern "C" int rfn_dropout_mask(uint64_t seed, uint64_t offset, int64_t n, float drop_p, float* keep_out, void* stream) {
+    if (n <= 0 || drop_p < 0.f || drop_p >= 1.f) return RFN_ERR_SHAPE;
+    if (!keep_out) return RFN_ERR_ARG;
+    hipLaunchKernelGGL(dropout_mask_k, dim3(rfn_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, seed, offset, (long)n,
+                       drop_p, keep_out);
+    RFN_CHECK_LAUNCH();
+    return RFN_OK;
+}

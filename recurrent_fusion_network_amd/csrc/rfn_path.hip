@@ -341,7 +341,7 @@ DecoderLayout decoder_layout(const rfn_dims* d, int B, int S, int train) {
     return L;
 }
 
-const uint64_t OFF_STAGE2 = 1u << 20, OFF_DECODER = 1u << 21;
+const uint64_t OFF_STAGE2 = RFN_DROP_OFFSET_STAGE2, OFF_DECODER = RFN_DROP_OFFSET_DECODER;   // rfn.h: rfn_dropout_mask
 
 }  // namespace
 

@@ -54,6 +54,27 @@ def load_case(name):
     return cfg, spec, P, (fc, att, labels, masks, top), gold
 
 
+def load_drop_case(name):
+    """Training-mode tier `<name>_drop` (oracle/make_golden.py generate_dropout): the base tier's weights and inputs
+    with drop_prob_fusion / _reason / _lm = 0.1 / 0.2 / 0.3, plus the keep masks the reference's own nn.Dropout layers
+    drew and the results it produced with them.  -> (cfg, spec, P, batch, gold, drop) with drop = O.make_drop(...)."""
+    from oracle import make_golden as G
+    from oracle import rfn_oracle as O
+    spec = dict(G.CONFIGS[name])
+    spec['extra'] = dict(spec.get('extra', {}), **G.DROP_PROBS)
+    cfg = G.cfg_of(spec)
+    P = O.seeded_params(cfg, spec['seed'])
+    fc, att, labels, masks, top = G.batch_of(cfg, spec)
+    gold = np.load(os.path.join(GOLDEN_DIR, name + '_drop.npz'))
+    assert abs(G.digest([P[k] for k in sorted(P)]) - float(gold['weights_digest'])) <= 1e-6 * abs(float(gold['weights_digest']))
+    assert abs(G.digest(fc + att) - float(gold['inputs_digest'])) <= 1e-6 * abs(float(gold['inputs_digest']))
+    assert np.array_equal(labels.numpy(), gold['labels'])
+    assert np.allclose(gold['drop_probs'], [cfg.drop_prob_fusion, cfg.drop_prob_reason, cfg.drop_prob_lm])
+    kf, kr, kd = (torch.from_numpy(gold[k]) for k in ('keep_fusion', 'keep_review', 'keep_decoder'))
+    drop = O.make_drop(cfg, [[kf[t, i] for i in range(kf.size(1))] for t in range(kf.size(0))], list(kr), list(kd))
+    return cfg, spec, P, (fc, att, labels, masks, top), gold, drop
+
+
 @pytest.fixture(scope='session')
 def dev():
     return torch.device('cuda:0')

@@ -33,6 +33,35 @@ def test_forward_loss_and_every_gradient(name):
     assert abs(float(ls) - float(gold['xe_loss_ls'])) < 1e-4
 
 
+@pytest.mark.parametrize('name', ['tiny0', 'tinymax', 'mid'])
+def test_training_mode_with_the_references_own_dropout_masks(name):
+    """Dropout-mode pin: the reference was run in train() mode with drop_prob_fusion / _reason / _lm =
+    0.1 / 0.2 / 0.3 and every nn.Dropout call's keep mask was captured by a forward hook.  The oracle with those masks
+    must give the reference's log-probs, reason heads, loss and every gradient: which probability each stage uses, that
+    every consumer sees the POST-dropout h while c is never dropped, the 1 / (1 - p) scale."""
+    from conftest import load_drop_case
+    from oracle import rfn_oracle as O
+    cfg, spec, P, batch, gold, drop = load_drop_case(name)
+    fc, att, labels, masks, top = batch
+    log_prob, reason = O.forward(cfg, P, fc, att, labels, drop=drop)
+    assert maxerr(log_prob, gold['log_prob']) < 2e-5
+    for j, r in enumerate(reason):
+        assert maxerr(r, gold['reason_pred_%d' % j]) < 2e-5
+    loss, grads = O.train_step_loss_and_grads(cfg, P, fc, att, labels, masks, top, 1.0, drop=drop)
+    assert abs(float(loss.detach()) - float(gold['xe_loss'])) < 1e-4
+    for k, g in grads.items():
+        gn = float(gold['gradnorm/' + k])
+        assert abs(float(g.double().norm()) - gn) <= 1e-6 + 1e-3 * gn, k
+        if name.startswith('tiny'):
+            assert maxerr(g, gold['grad/' + k]) < 2e-5 + 1e-4 * float(np.abs(gold['grad/' + k]).max()), k
+    # each stage's keep rate is its own probability's (not a shared one): 0.9 / 0.8 / 0.7 within sampling noise
+    for key, p_ in (('keep_fusion', 0.1), ('keep_review', 0.2), ('keep_decoder', 0.3)):
+        n = gold[key].size
+        assert abs(float(gold[key].mean()) - (1 - p_)) < 4 * (p_ * (1 - p_) / n) ** 0.5 + 1e-3, key
+    # a wrong wiring is visible: the eval-mode pass, or the masks with c dropped too, are far from the reference
+    assert maxerr(O.forward(cfg, P, fc, att, labels)[0], gold['log_prob']) > 1e-3
+
+
 def test_early_break_on_all_zero_column():
     """tiny0 has captions of <= 3 words with seq_length 5: the loop must stop at the first all-zero column
     (misc/RecurrentFusionModel.py:274), so fewer than seq_length+1 steps are produced."""
