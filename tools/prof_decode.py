@@ -1,5 +1,5 @@
 import os, sys
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench as HB
 import recurrent_fusion_network_amd as R
