@@ -262,6 +262,64 @@ int rfn_attn_small_bwd(int ngroups, const float* const* proj, int64_t proj_sb, i
                        int64_t dproj_sl, int accumulate_dproj, float* const* dhproj, float* const* dw_part,
                        float* const* datt_seq, void* stream);
 
+/* ---- row-panel GEMM of the recurrences (csrc/rfn_cellgemm.hip) ------------------------------------------------------
+ * One launch computes up to RFN_CELL_MAXOUT outputs over the same M (= batch) rows, each with its own destination,
+ * weights and K segments:  C_o[M, N_o] (+)= sum_s A_os[M, K_os] * op(B_os) + sum_s bias_os.  Segments are rfn_gemm_seg
+ * with a_kfast = 1; b_kfast = 1: B is an nn.Linear weight [N][K] (forward products, K1-K2 / K5 / K8 / K9 of SURVEY.md
+ * 2.2); b_kfast = 0: B is [K][N] (dX = dY . W of the backward recurrences).  The K range of an output tile is cut across
+ * the waves of ONE block and the partial tiles are added in LDS in wave order: deterministic, no scratch, and an
+ * element's k order depends only on K.
+ * epilogue RFN_CELL_EPI_STORE: plain store / accumulate (16-B coalesced).
+ * epilogue RFN_CELL_EPI_LSTM (b_kfast = 1, N = 4R): C is the gate buffer (B, 4R) [in | forget | out | g]; the sums
+ *   (+ C when accumulate: e.g. i2h(x) + h2h(h) produced earlier) go through the LSTM gate math of rfn_lstm_fwd inside
+ *   the same launch: activations written back to C, c_next = f c_prev + i g, h_next = dropout(o tanh c_next) with the
+ *   mask of (seed, drop_offset) (rfn_dropout_mask).  Replaces misc/RecurrentFusionModel.py:53-73,
+ *   misc/LSTMSoftMultiAttentionFeatArrayNoInputCore.py:50-72, misc/LSTMSoftAttentionCore.py:81-101 after the attention.
+ * epilogue RFN_CELL_EPI_LSTM_BWD (b_kfast = 0, N = R, one output): the product is the recurrent part of d h of an
+ *   EARLIER cell call (the one the backward sweep processes next); the launch finishes that gradient,
+ *   dh = product (+ C when accumulate) + dh_ext, and runs rfn_lstm_bwd of that call on it: `gates` holds its activations
+ *   on entry and its gate gradients on exit, c_prev / c_next are its cell states, dc_next (may be NULL, may alias
+ *   dc_prev) the incoming d c, dc_prev the outgoing one, (seed, drop_offset) its dropout mask.  C (may be NULL unless
+ *   accumulate) receives dh.  Replaces the axpby + rfn_lstm_bwd pair at the head of every backward step.
+ * Requirements (rfn_cell_gemm_supported; otherwise RFN_ERR_UNSUPPORTED and the caller uses rfn_gemm_f32 + rfn_lstm_*):
+ * every K and N a multiple of 32, 16-B aligned operands with leading dimensions that are multiples of 4, R a multiple
+ * of 8 for the gate epilogue; any M.  `variant` 0 lets the library pick the tile from the column and K counts alone --
+ * never from M, so a row's arithmetic does not depend on the batch it sits in (1..3 force one: tests, tools). */
+#define RFN_CELL_MAXOUT 10
+#define RFN_CELL_MAXSEG 8
+#define RFN_CELL_EPI_STORE 0
+#define RFN_CELL_EPI_LSTM 1
+#define RFN_CELL_EPI_LSTM_BWD 2
+typedef struct rfn_cell_out {
+    float* C;
+    int64_t ldc;
+    int32_t N;
+    int32_t accumulate;
+    int32_t nseg;
+    int32_t epilogue;            /* the same for every output of a launch */
+    rfn_gemm_seg seg[RFN_CELL_MAXSEG];
+    /* RFN_CELL_EPI_LSTM and _LSTM_BWD */
+    const float* c_prev;         /* (M, R); forward: may alias c_next */
+    int64_t ldcp;
+    float* c_next;               /* forward: written; backward: read */
+    int64_t ldcn;
+    float* h_next;               /* forward only */
+    int64_t ldh;
+    uint64_t drop_offset;
+    /* RFN_CELL_EPI_LSTM_BWD only */
+    float* gates;                /* (M, 4R) activations in, gate gradients out */
+    int64_t ldg;
+    const float* dh_ext;         /* (M, R) gradient of that call's h from outside the recurrence, may be NULL */
+    int64_t lddh;
+    const float* dc_next;        /* may be NULL */
+    int64_t lddcn;
+    float* dc_prev;
+    int64_t lddcp;
+} rfn_cell_out;
+int rfn_cell_gemm_supported(int M, int nout, const rfn_cell_out* outs_host, int R);
+int rfn_cell_gemm(int M, int nout, const rfn_cell_out* outs_host, int R, float drop_p, uint64_t seed, int variant,
+                  void* stream);
+
 /* Dropout masks of the path (nn.Dropout of the three cells: misc/RecurrentFusionModel.py:70,
  * misc/LSTMSoftMultiAttentionFeatArrayNoInputCore.py:69, misc/LSTMSoftAttentionCore.py:98).  A mask is never stored:
  * unit j of batch row b of one cell call is kept iff philox4x32-10(key = seed, counter = (b * R + j, offset)) >= p, with

@@ -47,6 +47,20 @@ class GemmProblem(C.Structure):
                 ('a_colsum', C.c_void_p), ('seg', GemmSeg * RFN_GEMM_MAXSEG)]
 
 
+RFN_CELL_MAXOUT = 10
+RFN_CELL_MAXSEG = 8
+CELL_EPI_STORE, CELL_EPI_LSTM, CELL_EPI_LSTM_BWD = 0, 1, 2
+
+
+class CellOut(C.Structure):
+    _fields_ = [('C', C.c_void_p), ('ldc', C.c_int64), ('N', C.c_int32), ('accumulate', C.c_int32), ('nseg', C.c_int32),
+                ('epilogue', C.c_int32), ('seg', GemmSeg * RFN_CELL_MAXSEG), ('c_prev', C.c_void_p), ('ldcp', C.c_int64),
+                ('c_next', C.c_void_p), ('ldcn', C.c_int64), ('h_next', C.c_void_p), ('ldh', C.c_int64),
+                ('drop_offset', C.c_uint64), ('gates', C.c_void_p), ('ldg', C.c_int64), ('dh_ext', C.c_void_p),
+                ('lddh', C.c_int64), ('dc_next', C.c_void_p), ('lddcn', C.c_int64), ('dc_prev', C.c_void_p),
+                ('lddcp', C.c_int64)]
+
+
 def _load():
     if not os.path.exists(LIB_PATH):
         raise RfnError(
@@ -89,6 +103,8 @@ def _load():
         'rfn_attn_small_fwd': (C.c_int, [I, P, L, L, P, P, P, P, L, L, I, I, I, I, P, P, L, P]),
         'rfn_attn_small_bwd': (C.c_int, [I, P, L, L, P, P, P, P, L, L, P, L, I, I, I, I, P, L, L, I, P, P, P, P]),
         'rfn_dropout_mask': (C.c_int, [U64, U64, L, F, P, P]),
+        'rfn_cell_gemm_supported': (C.c_int, [I, I, C.POINTER(CellOut), I]),
+        'rfn_cell_gemm': (C.c_int, [I, I, C.POINTER(CellOut), I, F, U64, I, P]),
         'rfn_lstm_fwd': (C.c_int, [P, L, P, L, P, L, P, L, I, I, I, F, U64, U64, P]),
         'rfn_lstm_bwd': (C.c_int, [P, L, P, L, P, L, P, L, P, L, P, L, I, I, I, F, U64, U64, P]),
         'rfn_lstm_fwd_grouped': (C.c_int, [P, L, P, L, P, L, P, L, I, I, I, F, U64, U64, I, L, L, L, L, P]),
@@ -218,6 +234,34 @@ def gemm(M, N, problems, accumulate=False, ws=None, flags=0):
             sg.K, sg.bias = K, ptr(bias)
     check(lib.rfn_gemm_f32_opt(M, N, len(problems), arr, int(accumulate), ptr(ws), 0 if ws is None else ws.numel(),
                                int(flags), stream_ptr()), 'rfn_gemm_f32_opt')
+
+
+def cell_gemm(M, outs, R=0, drop_p=0.0, seed=0, variant=0):
+    """Row-panel GEMM of the recurrences (rfn_cell_gemm).  outs: list of dicts with C, ldc, N, accumulate, segs =
+    [(A, lda, B, ldb, b_kfast, K, bias), ...] and, for the LSTM gate epilogue, lstm = (c_prev, ldcp, c_next, ldcn, h_next,
+    ldh, drop_offset); for the gate-gradient epilogue lstm_bwd = (gates, ldg, c_prev, ldcp, c_next, ldcn, dh_ext, lddh,
+    dc_next, lddcn, dc_prev, lddcp, drop_offset) and C may be None."""
+    arr = (CellOut * len(outs))()
+    for o, spec in enumerate(outs):
+        t = arr[o]
+        t.C, t.ldc, t.N, t.accumulate = ptr(spec['C']), spec['ldc'], spec['N'], int(spec.get('accumulate', 0))
+        t.nseg = len(spec['segs'])
+        t.epilogue = CELL_EPI_LSTM if 'lstm' in spec else (CELL_EPI_LSTM_BWD if 'lstm_bwd' in spec else CELL_EPI_STORE)
+        for s, (A, lda, B, ldb, bk, K, bias) in enumerate(spec['segs']):
+            sg = t.seg[s]
+            sg.A, sg.lda, sg.a_kfast = A.data_ptr(), lda, 1
+            sg.B, sg.ldb, sg.b_kfast = B.data_ptr(), ldb, int(bk)
+            sg.K, sg.bias = K, ptr(bias)
+        if 'lstm' in spec:
+            cp, ldcp, cn, ldcn, hn, ldh, off = spec['lstm']
+            t.c_prev, t.ldcp, t.c_next, t.ldcn, t.h_next, t.ldh, t.drop_offset = (cp.data_ptr(), ldcp, cn.data_ptr(), ldcn,
+                                                                                 hn.data_ptr(), ldh, off)
+        if 'lstm_bwd' in spec:
+            g, ldg, cp, ldcp, cn, ldcn, dhe, lddh, dcn, lddcn, dcp, lddcp, off = spec['lstm_bwd']
+            t.gates, t.ldg, t.c_prev, t.ldcp, t.c_next, t.ldcn = g.data_ptr(), ldg, cp.data_ptr(), ldcp, cn.data_ptr(), ldcn
+            t.dh_ext, t.lddh, t.dc_next, t.lddcn, t.dc_prev, t.lddcp, t.drop_offset = (ptr(dhe), lddh, ptr(dcn), lddcn,
+                                                                                       dcp.data_ptr(), lddcp, off)
+    check(lib.rfn_cell_gemm(M, len(outs), arr, R, drop_p, seed, variant, stream_ptr()), 'rfn_cell_gemm')
 
 
 def x3_image(srcs, rows, K, k_fast=True, ld=None) -> torch.Tensor:

@@ -193,6 +193,47 @@ int gemm_groups_split_cols(int M, int N, int n, const rfn_gemm_problem* p, int a
     return gemm_groups(M, N - Na, n, rest, acc, gx);
 }
 
+// ---------------------------------------------------------------------------------------------
+// fused per-step products of the recurrences (csrc/rfn_cellgemm.hip): several outputs per launch, K cut across the
+// waves of a block, LSTM forward / backward epilogues.  cell_lin(): Y = X W^T + b;  cell_dx(): dX = dY W.
+// ---------------------------------------------------------------------------------------------
+rfn_cell_out cell_out(float* C, long ldc, int N, int accumulate) {
+    rfn_cell_out o;
+    memset(&o, 0, sizeof(o));
+    o.C = C; o.ldc = ldc; o.N = N; o.accumulate = accumulate; o.epilogue = RFN_CELL_EPI_STORE;
+    return o;
+}
+void cell_lin(rfn_cell_out& o, const float* X, long ldx, const float* W, long ldw, int K, const float* bias) {
+    if (o.nseg < RFN_CELL_MAXSEG) o.seg[o.nseg] = seg_lin(X, ldx, W, ldw, K, bias);
+    ++o.nseg;     // an overflow makes rfn_cell_gemm_supported() say no
+}
+void cell_dx(rfn_cell_out& o, const float* dY, long lddy, const float* W, long ldw, int N) {
+    if (o.nseg < RFN_CELL_MAXSEG) o.seg[o.nseg] = seg_dx(dY, lddy, W, ldw, N);
+    ++o.nseg;
+}
+void cell_lstm(rfn_cell_out& o, const float* c_prev, long ldcp, float* c_next, long ldcn, float* h_next, long ldh,
+               uint64_t drop_offset) {
+    o.epilogue = RFN_CELL_EPI_LSTM;
+    o.c_prev = c_prev; o.ldcp = ldcp; o.c_next = c_next; o.ldcn = ldcn; o.h_next = h_next; o.ldh = ldh;
+    o.drop_offset = drop_offset;
+}
+void cell_lstm_bwd(rfn_cell_out& o, float* gates, long ldg, const float* c_prev, long ldcp, const float* c_next, long ldcn,
+                   const float* dh_ext, long lddh, const float* dc_next, long lddcn, float* dc_prev, long lddcp,
+                   uint64_t drop_offset) {
+    o.epilogue = RFN_CELL_EPI_LSTM_BWD;
+    o.gates = gates; o.ldg = ldg; o.c_prev = c_prev; o.ldcp = ldcp; o.c_next = const_cast<float*>(c_next); o.ldcn = ldcn;
+    o.dh_ext = dh_ext; o.lddh = lddh; o.dc_next = dc_next; o.lddcn = lddcn; o.dc_prev = dc_prev; o.lddcp = lddcp;
+    o.drop_offset = drop_offset;
+}
+bool cell_ok(int B, int n, const rfn_cell_out* outs, int R) {
+    for (int i = 0; i < n; ++i)
+        if (outs[i].nseg > RFN_CELL_MAXSEG) return false;
+    return n <= RFN_CELL_MAXOUT && rfn_cell_gemm_supported(B, n, outs, R) != 0;
+}
+int cell_run(int B, int n, const rfn_cell_out* outs, int R, float drop_p, uint64_t seed, void* st) {
+    return rfn_cell_gemm(B, n, outs, R, drop_p, seed, 0, st);
+}
+
 int copy_f32(float* dst, const float* src, size_t n, void* st) {
     if (hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)st) != hipSuccess)
         return RFN_ERR_LAUNCH;
@@ -638,9 +679,26 @@ static int prefix_fwd_impl(const rfn_dims* d, int B, const float* const* prm, co
         float* al = W + Lo.al2 + (long)t * M * B * T1;
         float* z = W + Lo.z2 + (long)t * M * BR;
         float* g = W + Lo.g2 + (long)t * B * G2;
-        for (int i = 0; i < M; ++i)
-            pr[i] = prob1(hp + (long)i * B * A, A, seg_lin(hc, R, prm[P.s2(t, i, 4)], R, R, prm[P.s2(t, i, 5)]));
-        RFN_TRY(gemm_groups(B, A, M, pr, 0, gx));
+        // Fused form (3 launches): K1 = every h_2_att_h_i(h) and h2h(h) in one launch (they share h); the M attentions;
+        // K3 = sum_i z_2_h_i(z_i) accumulated onto the gates with the LSTM update as its epilogue.
+        rfn_cell_out k1[RFN_MAX_ENC + 1], k3;
+        for (int i = 0; i < M; ++i) {
+            k1[i] = cell_out(hp + (long)i * B * A, A, A, 0);
+            cell_lin(k1[i], hc, R, prm[P.s2(t, i, 4)], R, R, prm[P.s2(t, i, 5)]);
+        }
+        k1[M] = cell_out(g, G2, G2, 0);
+        cell_lin(k1[M], hc, R, prm[P.s2_hh_w(t)], R, R, prm[P.s2_hh_b(t)]);
+        k3 = cell_out(g, G2, G2, 1);
+        for (int i = 0; i < M; ++i) cell_lin(k3, z + i * BR, R, prm[P.s2(t, i, 0)], R, R, prm[P.s2(t, i, 1)]);
+        cell_lstm(k3, cc, R, cn, R, hn, R, OFF_STAGE2 + (uint64_t)t);
+        const bool fused = !d->review_maxout && cell_ok(B, M + 1, k1, R) && cell_ok(B, 1, &k3, R);
+        if (fused) {
+            RFN_TRY(cell_run(B, M + 1, k1, R, 0.f, 0, st));
+        } else {
+            for (int i = 0; i < M; ++i)
+                pr[i] = prob1(hp + (long)i * B * A, A, seg_lin(hc, R, prm[P.s2(t, i, 4)], R, R, prm[P.s2(t, i, 5)]));
+            RFN_TRY(gemm_groups(B, A, M, pr, 0, gx));
+        }
         segs[0] = seg_lin(hc, R, prm[P.s2_hh_w(t)], R, R, prm[P.s2_hh_b(t)]);
         {   // attention of all M encoders over the T1 thoughts: one fused launch
             const float *a_p[RFN_MAX_ENC], *a_hp[RFN_MAX_ENC], *a_w[RFN_MAX_ENC], *a_b[RFN_MAX_ENC], *a_x[RFN_MAX_ENC];
@@ -658,9 +716,13 @@ static int prefix_fwd_impl(const rfn_dims* d, int B, const float* const* prm, co
             RFN_TRY(rfn_attn_small_fwd(M, a_p, (long)T2 * A, (long)B * T2 * A, a_hp, a_w, a_b, a_x, MR, BMR, B, T1, A,
                                        R, a_al, a_z, R, st));
         }
-        RFN_TRY(gemm_segs(B, G2, M + 1, segs, g, G2, 0, gx));
-        RFN_TRY(rfn_lstm_fwd(g, G2, cc, R, cn, R, hn, R, B, R, d->review_maxout, d->drop_reason, seed,
-                             OFF_STAGE2 + (uint64_t)t, st));
+        if (fused) {
+            RFN_TRY(cell_run(B, 1, &k3, R, d->drop_reason, seed, st));
+        } else {
+            RFN_TRY(gemm_segs(B, G2, M + 1, segs, g, G2, 0, gx));
+            RFN_TRY(rfn_lstm_fwd(g, G2, cc, R, cn, R, hn, R, B, R, d->review_maxout, d->drop_reason, seed,
+                                 OFF_STAGE2 + (uint64_t)t, st));
+        }
     }
     RFN_TRY(gemm1(T2 * B, K, seg_lin(h2 + BR, R, prm[P.r_w()], R, R, prm[P.r_b()]), rmat, K, 0, gx));
     RFN_TRY(rfn_max_over_steps_fwd(rmat, T2, B, K, reason_pred + (long)M * B * K, rarg + (long)M * B * K, st));
@@ -733,24 +795,60 @@ extern "C" int rfn_prefix_bwd(const rfn_dims* d, int B, const float* const* prm,
     RFN_TRY(zero_f32(dHs, (size_t)(T1 + 1) * BMR, st));
 
     // ---- stage II backward ------------------------------------------------------------------------
+    // Fused form of a step (3 launches): Kb1 = dh_rec and every dz_i = dgates . [W_hh | W_z_i] in one launch; the M
+    // attention backwards; Kb2 = dh_rec += sum_i dhp_i . W_h_i whose epilogue completes d h of step t-1 (+ its external
+    // share dh2e[t-1]) and runs that step's LSTM backward.
+    bool fused2 = !d->review_maxout;
+    {
+        rfn_cell_out t1[RFN_MAX_ENC + 1], t2;
+        float* g0 = W + Lo.g2;
+        t1[0] = cell_out(dhrec, R, R, 0);
+        cell_dx(t1[0], g0, G2, prm[P.s2_hh_w(0)], R, G2);
+        for (int i = 0; i < M; ++i) {
+            t1[1 + i] = cell_out(dz2 + i * BR, R, R, 0);
+            cell_dx(t1[1 + i], g0, G2, prm[P.s2(0, i, 0)], R, G2);
+        }
+        t2 = cell_out(dhrec, R, R, 1);
+        for (int i = 0; i < M; ++i) cell_dx(t2, W + Lo.dhp2 + i * BA, A, prm[P.s2(0, i, 4)], R, A);
+        rfn_cell_out t3 = t2;
+        cell_lstm_bwd(t3, g0, G2, c2, R, c2 + BR, R, dh2e, R, dc2, R, dc2, R, OFF_STAGE2);
+        fused2 = fused2 && cell_ok(B, M + 1, t1, R) && cell_ok(B, 1, &t2, R) && cell_ok(B, 1, &t3, R);
+    }
+    if (fused2) {   // LSTM backward of the last step: only the external gradients (thoughts, reason head, decoder state)
+        float* dht = dh2e + (T2 - 1) * BR;
+        if (d_h) RFN_TRY(rfn_axpby_2d(1.f, d_h, R, 1.f, dht, R, B, R, st));
+        RFN_TRY(rfn_lstm_bwd(W + Lo.g2 + (long)(T2 - 1) * B * G2, G2, c2 + (T2 - 1) * BR, R, c2 + T2 * BR, R, dht, R, d_c, R, dc2, R,
+                             B, R, 0, d->drop_reason, seed, OFF_STAGE2 + (uint64_t)(T2 - 1), st));
+    }
     for (int t = T2 - 1; t >= 0; --t) {
         float* hp = W + Lo.hp2 + (long)t * M * BA;
         float* dhp = W + Lo.dhp2 + (long)t * M * BA;
         float* al = W + Lo.al2 + (long)t * M * B * T1;
         float* g = W + Lo.g2 + (long)t * B * G2;
         float* dht = dh2e + t * BR;  // total dh of h2[t+1]
-        if (t == T2 - 1) {
-            if (d_h) RFN_TRY(rfn_axpby_2d(1.f, d_h, R, 1.f, dht, R, B, R, st));
+        if (!fused2) {
+            if (t == T2 - 1) {
+                if (d_h) RFN_TRY(rfn_axpby_2d(1.f, d_h, R, 1.f, dht, R, B, R, st));
+            } else {
+                RFN_TRY(rfn_axpby_2d(1.f, dhrec, R, 1.f, dht, R, B, R, st));
+            }
+            const float* dcn = (t == T2 - 1) ? d_c : dc2;
+            RFN_TRY(rfn_lstm_bwd(g, G2, c2 + t * BR, R, c2 + (t + 1) * BR, R, dht, R, dcn, R, dc2, R, B, R, d->review_maxout,
+                                 d->drop_reason, seed, OFF_STAGE2 + (uint64_t)t, st));
+            // dh_rec = dgates . W_hh ; dz_i = dgates . W_z_i   (same shape: one grouped launch)
+            pr[0] = prob1(dhrec, R, seg_dx(g, G2, prm[P.s2_hh_w(t)], R, G2));
+            for (int i = 0; i < M; ++i) pr[1 + i] = prob1(dz2 + i * BR, R, seg_dx(g, G2, prm[P.s2(t, i, 0)], R, G2));
+            RFN_TRY(gemm_groups(B, R, M + 1, pr, 0, gx));
         } else {
-            RFN_TRY(rfn_axpby_2d(1.f, dhrec, R, 1.f, dht, R, B, R, st));
+            rfn_cell_out kb1[RFN_MAX_ENC + 1];
+            kb1[0] = cell_out(dhrec, R, R, 0);
+            cell_dx(kb1[0], g, G2, prm[P.s2_hh_w(t)], R, G2);
+            for (int i = 0; i < M; ++i) {
+                kb1[1 + i] = cell_out(dz2 + i * BR, R, R, 0);
+                cell_dx(kb1[1 + i], g, G2, prm[P.s2(t, i, 0)], R, G2);
+            }
+            RFN_TRY(cell_run(B, M + 1, kb1, R, 0.f, 0, st));
         }
-        const float* dcn = (t == T2 - 1) ? d_c : dc2;
-        RFN_TRY(rfn_lstm_bwd(g, G2, c2 + t * BR, R, c2 + (t + 1) * BR, R, dht, R, dcn, R, dc2, R, B, R, d->review_maxout,
-                             d->drop_reason, seed, OFF_STAGE2 + (uint64_t)t, st));
-        // dh_rec = dgates . W_hh ; dz_i = dgates . W_z_i   (same shape: one grouped launch)
-        pr[0] = prob1(dhrec, R, seg_dx(g, G2, prm[P.s2_hh_w(t)], R, G2));
-        for (int i = 0; i < M; ++i) pr[1 + i] = prob1(dz2 + i * BR, R, seg_dx(g, G2, prm[P.s2(t, i, 0)], R, G2));
-        RFN_TRY(gemm_groups(B, R, M + 1, pr, 0, gx));
         {   // whole attention backward of the M encoders in one fused launch (dP overwrites P in place)
             const float *a_p[RFN_MAX_ENC], *a_hp[RFN_MAX_ENC], *a_w[RFN_MAX_ENC], *a_al[RFN_MAX_ENC], *a_x[RFN_MAX_ENC],
                 *a_dz[RFN_MAX_ENC];
@@ -771,7 +869,16 @@ extern "C" int rfn_prefix_bwd(const rfn_dims* d, int B, const float* const* prm,
             RFN_TRY(rfn_attn_small_bwd(M, a_p, (long)T2 * A, (long)B * T2 * A, a_hp, a_w, a_al, a_x, MR, BMR, a_dz, R,
                                        B, T1, A, R, a_dp, (long)T2 * A, (long)B * T2 * A, 0, a_dhp, a_dw, a_dx, st));
         }
-        RFN_TRY(gemm_segs(B, R, M, segs, dhrec, R, 1, gx));
+        if (!fused2) {
+            RFN_TRY(gemm_segs(B, R, M, segs, dhrec, R, 1, gx));
+        } else {
+            rfn_cell_out kb2 = cell_out(dhrec, R, R, 1);
+            for (int i = 0; i < M; ++i) cell_dx(kb2, dhp + i * BA, A, prm[P.s2(t, i, 4)], R, A);
+            if (t > 0)
+                cell_lstm_bwd(kb2, W + Lo.g2 + (long)(t - 1) * B * G2, G2, c2 + (t - 1) * BR, R, c2 + t * BR, R, dh2e + (t - 1) * BR, R,
+                              dc2, R, dc2, R, OFF_STAGE2 + (uint64_t)(t - 1));
+            RFN_TRY(cell_run(B, 1, &kb2, R, d->drop_reason, seed, st));
+        }
     }
     // weight gradients of stage II, grouped over steps; every bias gradient rides on the GEMM that streams
     // the same dY (h2h.b = z_2_h[i].b = colsum(dgates); h_2_att_h.b = att_2_att_h.b = colsum over (b) resp. (l,b))
@@ -1047,6 +1154,41 @@ extern "C" size_t rfn_decoder_ws_bytes(const rfn_dims* d, int B, int S, int trai
     return decoder_layout(d, B, S, train).total * sizeof(float);
 }
 
+// One decoder cell call on given buffers (g already holds i2h(x)): h_2_att_h(h), attention over the fused thoughts,
+// h2h(h) + z2h(z) accumulated onto the gates, LSTM update with the dropout mask of (seed, step).  Shared by the batched,
+// the step-wise and the free-running pass, so the three are bit-identical by construction.
+// Fused form (3 launches): K1 = h_2_att_h(h) and g += h2h(h) in one launch (they share h); the attention; K3 =
+// g += z2h(z) with the LSTM update as its epilogue.  h_next / c_next may alias h / c (free-running step).
+static int decoder_cell_core(const rfn_dims* d, int B, const float* const* prm, const float* comb, const float* cproj,
+                             const float* h, const float* c, float* h_next, float* c_next, float* hp, float* al, float* z,
+                             float* g, const GemmCtx& gx, uint64_t seed, int step, void* st) {
+    const PIdx P(d);
+    const int R = d->R, A = d->A, T2 = d->T2;
+    const int GD = gate_width(d->decoder_maxout, R);
+    const long BR = (long)B * R, BA = (long)B * A;
+    rfn_cell_out k1[2], k3;
+    k1[0] = cell_out(hp, A, A, 0);
+    cell_lin(k1[0], h, R, prm[P.dec(8)], R, R, prm[P.dec(9)]);
+    k1[1] = cell_out(g, GD, GD, 1);
+    cell_lin(k1[1], h, R, prm[P.dec(2)], R, R, prm[P.dec(3)]);
+    k3 = cell_out(g, GD, GD, 1);
+    cell_lin(k3, z, R, prm[P.dec(4)], R, R, prm[P.dec(5)]);
+    cell_lstm(k3, c, R, c_next, R, h_next, R, OFF_DECODER + (uint64_t)step);
+    if (!d->decoder_maxout && cell_ok(B, 2, k1, R) && cell_ok(B, 1, &k3, R)) {
+        RFN_TRY(cell_run(B, 2, k1, R, 0.f, 0, st));
+        RFN_TRY(attn1_fwd(cproj, A, BA, hp, prm[P.dec(10)], prm[P.dec(11)], comb, R, BR, B, T2, A, R, al, z, R, st));
+        return cell_run(B, 1, &k3, R, d->drop_lm, seed, st);
+    }
+    RFN_TRY(gemm1(B, A, seg_lin(h, R, prm[P.dec(8)], R, R, prm[P.dec(9)]), hp, A, 0, gx));
+    RFN_TRY(attn1_fwd(cproj, A, BA, hp, prm[P.dec(10)], prm[P.dec(11)], comb, R, BR, B, T2, A, R, al, z, R, st));
+    rfn_gemm_seg segs[2];
+    segs[0] = seg_lin(h, R, prm[P.dec(2)], R, R, prm[P.dec(3)]);
+    segs[1] = seg_lin(z, R, prm[P.dec(4)], R, R, prm[P.dec(5)]);
+    RFN_TRY(gemm_segs(B, GD, 2, segs, g, GD, 1, gx));
+    return rfn_lstm_fwd(g, GD, c, R, c_next, R, h_next, R, B, R, d->decoder_maxout, d->drop_lm, seed,
+                        OFF_DECODER + (uint64_t)step, st);
+}
+
 // The decoder cell of step s on the training workspace (gd[s] already holds i2h(x_s)): h_2_att_h, attention over the
 // fused thoughts, h2h + z2h accumulated onto the gates, LSTM epilogue with the dropout mask of (seed, s).
 static int decoder_fwd_cell(const rfn_dims* d, int B, int s, const float* const* prm, const float* comb, float* W,
@@ -1062,14 +1204,8 @@ static int decoder_fwd_cell(const rfn_dims* d, int B, int s, const float* const*
     float* al = W + Lo.ald + (long)s * B * T2;
     float* z = W + Lo.zd + s * BR;
     float* g = W + Lo.gd + (long)s * B * GD;
-    RFN_TRY(gemm1(B, A, seg_lin(hc, R, prm[P.dec(8)], R, R, prm[P.dec(9)]), hp, A, 0, gx));
-    RFN_TRY(attn1_fwd(W + Lo.Pd, A, BA, hp, prm[P.dec(10)], prm[P.dec(11)], comb, R, BR, B, T2, A, R, al, z, R, st));
-    rfn_gemm_seg segs[2];
-    segs[0] = seg_lin(hc, R, prm[P.dec(2)], R, R, prm[P.dec(3)]);
-    segs[1] = seg_lin(z, R, prm[P.dec(4)], R, R, prm[P.dec(5)]);
-    RFN_TRY(gemm_segs(B, GD, 2, segs, g, GD, 1, gx));
-    return rfn_lstm_fwd(g, GD, cd + s * BR, R, cd + (s + 1) * BR, R, hd + (s + 1) * BR, R, B, R, d->decoder_maxout,
-                        d->drop_lm, seed, OFF_DECODER + (uint64_t)s, st);
+    return decoder_cell_core(d, B, prm, comb, W + Lo.Pd, hc, cd + s * BR, hd + (s + 1) * BR, cd + (s + 1) * BR, hp, al, z, g,
+                             gx, seed, s, st);
 }
 
 // Loop-invariant part of phase 2: projection of the fused thoughts (applied once instead of every step) and the
@@ -1183,17 +1319,53 @@ extern "C" int rfn_decoder_bwd(const rfn_dims* d, int B, int S, const float* con
     RFN_TRY(zero_f32(d_comb, (size_t)T2 * BR, st));
     RFN_TRY(zero_f32(dPd, (size_t)T2 * BA, st));
     rfn_gemm_problem pr[2];
+    // Fused form of a backward step (3 launches): Kb1 = [dh_rec | dz] = dgates . [W_hh | W_z] in one launch (they share the
+    // gate gradients); the attention backward; Kb2 = dh_rec += dhp . W_h whose epilogue completes d h of step s-1
+    // (+ the logit layer's share dhe[s-1]) and runs that step's LSTM backward -- the next thing the sweep needs.
+    bool fused = !d->decoder_maxout;
+    {
+        rfn_cell_out t1[2], t2;
+        t1[0] = cell_out(dhrec, R, R, 0);
+        cell_dx(t1[0], gd, GD, prm[P.dec(2)], R, GD);
+        t1[1] = cell_out(dz, R, R, 0);
+        cell_dx(t1[1], gd, GD, prm[P.dec(4)], R, GD);
+        t2 = cell_out(dhrec, R, R, 1);
+        cell_dx(t2, W + Lo.dhpd, A, prm[P.dec(8)], R, A);
+        rfn_cell_out t3 = t2;
+        cell_lstm_bwd(t3, gd, GD, cd, R, cd + BR, R, dhe, R, dc, R, dc, R, OFF_DECODER);
+        fused = fused && cell_ok(B, 2, t1, R) && cell_ok(B, 1, &t2, R) && cell_ok(B, 1, &t3, R);
+    }
+    if (fused)   // LSTM backward of the last step: nothing recurrent flows into it
+        RFN_TRY(rfn_lstm_bwd(gd + (long)(S - 1) * B * GD, GD, cd + (S - 1) * BR, R, cd + S * BR, R, dhe + (S - 1) * BR, R, nullptr,
+                             R, dc, R, B, R, 0, d->drop_lm, seed, OFF_DECODER + (uint64_t)(S - 1), st));
     for (int s = S - 1; s >= 0; --s) {
         float* g = gd + (long)s * B * GD;
         float* dht = dhe + s * BR;
+        float* al = W + Lo.ald + (long)s * B * T2;
+        float* dhp = W + Lo.dhpd + s * BA;
+        if (fused) {
+            rfn_cell_out kb1[2], kb2;
+            kb1[0] = cell_out(dhrec, R, R, 0);
+            cell_dx(kb1[0], g, GD, prm[P.dec(2)], R, GD);
+            kb1[1] = cell_out(dz, R, R, 0);
+            cell_dx(kb1[1], g, GD, prm[P.dec(4)], R, GD);
+            RFN_TRY(cell_run(B, 2, kb1, R, 0.f, 0, st));
+            RFN_TRY(attn1_bwd(W + Lo.Pd, A, BA, W + Lo.hpd + s * BA, prm[P.dec(10)], al, comb, R, BR, dz, R, B, T2, A, R,
+                              dPd, A, BA, 1, dhp, W + Lo.dwp + s * BA, d_comb, st));
+            kb2 = cell_out(dhrec, R, R, 1);
+            cell_dx(kb2, dhp, A, prm[P.dec(8)], R, A);
+            if (s > 0)
+                cell_lstm_bwd(kb2, gd + (long)(s - 1) * B * GD, GD, cd + (s - 1) * BR, R, cd + s * BR, R, dhe + (s - 1) * BR, R,
+                              dc, R, dc, R, OFF_DECODER + (uint64_t)(s - 1));
+            RFN_TRY(cell_run(B, 1, &kb2, R, d->drop_lm, seed, st));
+            continue;
+        }
         if (s < S - 1) RFN_TRY(rfn_axpby_2d(1.f, dhrec, R, 1.f, dht, R, B, R, st));
         RFN_TRY(rfn_lstm_bwd(g, GD, cd + s * BR, R, cd + (s + 1) * BR, R, dht, R, (s < S - 1) ? dc : nullptr, R, dc,
                              R, B, R, d->decoder_maxout, d->drop_lm, seed, OFF_DECODER + (uint64_t)s, st));
         pr[0] = prob1(dhrec, R, seg_dx(g, GD, prm[P.dec(2)], R, GD));
         pr[1] = prob1(dz, R, seg_dx(g, GD, prm[P.dec(4)], R, GD));
         RFN_TRY(gemm_groups(B, R, 2, pr, 0, gx));
-        float* al = W + Lo.ald + (long)s * B * T2;
-        float* dhp = W + Lo.dhpd + s * BA;
         RFN_TRY(attn1_bwd(W + Lo.Pd, A, BA, W + Lo.hpd + s * BA, prm[P.dec(10)], al, comb, R, BR, dz, R, B, T2, A, R,
                           dPd, A, BA, 1, dhp, W + Lo.dwp + s * BA, d_comb, st));
         RFN_TRY(gemm1(B, R, seg_dx(dhp, A, prm[P.dec(8)], R, A), dhrec, R, 1, gx));
@@ -1258,7 +1430,6 @@ static int decoder_step_impl(const rfn_dims* d, int B, const float* const* prm, 
     const PIdx P(d);
     const int R = d->R, A = d->A, E = d->E, T2 = d->T2, V1 = d->V1;
     const int GD = gate_width(d->decoder_maxout, R);
-    const long BR = (long)B * R, BA = (long)B * A;
     Bump b;
     float* W = (float*)ws;
     const GemmCtx gx{st, W + b.take(STEP_GEMM_WS_FLOATS), STEP_GEMM_WS_FLOATS * sizeof(float), d->gemm_flags};  // split-K scratch
@@ -1272,13 +1443,7 @@ static int decoder_step_impl(const rfn_dims* d, int B, const float* const* prm, 
     if (!xt) RFN_TRY(rfn_embed_fwd(prm[P.embed()], E, V1, ids, B, 1, 0, B, x, E, st));
     RFN_TRY(gemm1(B, GD, xt ? seg_lin(xt, ld_xt, prm[P.dec(0)], E, E, prm[P.dec(1)]) : seg_lin(x, E, prm[P.dec(0)], E, E, prm[P.dec(1)]),
                   g, GD, 0, gx_whole));
-    RFN_TRY(gemm1(B, A, seg_lin(h, R, prm[P.dec(8)], R, R, prm[P.dec(9)]), hp, A, 0, gx));
-    RFN_TRY(attn1_fwd(cproj, A, BA, hp, prm[P.dec(10)], prm[P.dec(11)], comb, R, BR, B, T2, A, R, al, z, R, st));
-    rfn_gemm_seg segs[2];
-    segs[0] = seg_lin(h, R, prm[P.dec(2)], R, R, prm[P.dec(3)]);
-    segs[1] = seg_lin(z, R, prm[P.dec(4)], R, R, prm[P.dec(5)]);
-    RFN_TRY(gemm_segs(B, GD, 2, segs, g, GD, 1, gx));
-    RFN_TRY(rfn_lstm_fwd(g, GD, c, R, c, R, h, R, B, R, d->decoder_maxout, d->drop_lm, seed, OFF_DECODER + (uint64_t)step, st));
+    RFN_TRY(decoder_cell_core(d, B, prm, comb, cproj, h, c, h, c, hp, al, z, g, gx, seed, step, st));
     if (logits || logp) {
         RFN_TRY(gemm_logits(B, V1, h, R, prm[P.logit_w()], prm[P.logit_b()], lg, gx_whole));
         if (logp) {
