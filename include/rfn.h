@@ -132,8 +132,20 @@ int rfn_gemm_f32_ws(int M, int N, int ngroups, const rfn_gemm_problem* problems_
 #define RFN_GEMM_OPT_NO_DMA 2u
 #define RFN_GEMM_OPT_BF16X3 4u
 #define RFN_GEMM_OPT_BF16X3_ANY_SIZE 8u
+/* (rfn_dims.gemm_flags only) A/B hook: the split-K GEMMs of the path finish inside their launch (rfn_gemm_f32_tk, below)
+ * instead of through rfn_gemm_reduce_k.  Bit-identical results; MEASURED SLOWER on MI355X (C3 step 65.6 -> 68.9 ms, C2
+ * 5.4 -> 6.6 ms: every K-range block pays an agent-scope release = a write-back of its XCD's L2 before its ticket), which
+ * is what the MI355X guide reports for split-K seams kept inside a launch.  Off by default. */
+#define RFN_GEMM_OPT_SPLITK_IN_KERNEL 16u
 int rfn_gemm_f32_opt(int M, int N, int ngroups, const rfn_gemm_problem* problems_host, int accumulate,
                      void* ws, size_t ws_bytes, unsigned flags, void* stream);
+/* Same, with split-K finished INSIDE the launch: `tickets` points to n_tickets int32 counters that are ZERO on entry
+ * (the library leaves them zero: a caller zeroes them once per workspace and keeps them for its GEMMs).  The K ranges of
+ * an output tile draw tickets on the tile's counter; the last one to arrive adds the partial tiles in K-range order
+ * (the order the separate reduce kernel uses: bit-identical results) -- no second launch.  Launches with more output
+ * tiles than counters use the separate reduce kernel. */
+int rfn_gemm_f32_tk(int M, int N, int ngroups, const rfn_gemm_problem* problems_host, int accumulate, void* ws,
+                    size_t ws_bytes, unsigned flags, int32_t* tickets, int n_tickets, void* stream);
 
 /* ---- f32 GEMM on the bf16 matrix cores (csrc/rfn_gemm_x3.hip) -------------------------------------------------------
  * Replaces, when RFN_GEMM_OPT_BF16X3 is set, the two nn.Linear products the reference spends most of its time in:

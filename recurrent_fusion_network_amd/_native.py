@@ -21,6 +21,7 @@ GEMM_OPT_LDS_LEAN = 1
 GEMM_OPT_NO_DMA = 2
 GEMM_OPT_BF16X3 = 4
 GEMM_OPT_BF16X3_ANY_SIZE = 8
+GEMM_OPT_SPLITK_IN_KERNEL = 16
 
 
 class RfnError(RuntimeError):
@@ -79,6 +80,7 @@ def _load():
         'rfn_gemm_f32': (C.c_int, [I, I, I, C.POINTER(GemmProblem), I, P]),
         'rfn_gemm_f32_ws': (C.c_int, [I, I, I, C.POINTER(GemmProblem), I, P, SZ, P]),
         'rfn_gemm_f32_opt': (C.c_int, [I, I, I, C.POINTER(GemmProblem), I, P, SZ, C.c_uint, P]),
+        'rfn_gemm_f32_tk': (C.c_int, [I, I, I, C.POINTER(GemmProblem), I, P, SZ, C.c_uint, P, I, P]),
         'rfn_x3_image_bytes': (SZ, [I, I]),
         'rfn_x3_split': (C.c_int, [P, I, L, I, I, I, P, P]),
         'rfn_x3_gemm': (C.c_int, [I, I, I, P, P, I, I, P, P, L, I, I, P, P]),
@@ -219,9 +221,10 @@ def param_shape(d: Dims, idx: int):
 
 
 # ---- thin helpers over the primitive operators (used by the model shell and by the tests) ---------
-def gemm(M, N, problems, accumulate=False, ws=None, flags=0):
+def gemm(M, N, problems, accumulate=False, ws=None, flags=0, tickets=None):
     """problems: list of (C, ldc, [(A, lda, a_kfast, B, ldb, b_kfast, K, bias), ...][, a_colsum]).
-    ws: optional uint8 scratch tensor enabling split-K for skinny problems; flags: GEMM_OPT_* bits."""
+    ws: optional uint8 scratch tensor enabling split-K for skinny problems; flags: GEMM_OPT_* bits; tickets: optional
+    zeroed int32 tensor -> split-K is finished inside the launch (rfn_gemm_f32_tk)."""
     arr = (GemmProblem * len(problems))()
     for g, prob in enumerate(problems):
         Ct, ldc, segs = prob[:3]
@@ -232,8 +235,14 @@ def gemm(M, N, problems, accumulate=False, ws=None, flags=0):
             sg.A, sg.lda, sg.a_kfast = A.data_ptr(), lda, int(ak)
             sg.B, sg.ldb, sg.b_kfast = B.data_ptr(), ldb, int(bk)
             sg.K, sg.bias = K, ptr(bias)
-    check(lib.rfn_gemm_f32_opt(M, N, len(problems), arr, int(accumulate), ptr(ws), 0 if ws is None else ws.numel(),
-                               int(flags), stream_ptr()), 'rfn_gemm_f32_opt')
+    check(lib.rfn_gemm_f32_tk(M, N, len(problems), arr, int(accumulate), ptr(ws), 0 if ws is None else ws.numel(),
+                              int(flags), ptr(tickets), 0 if tickets is None else tickets.numel(), stream_ptr()),
+          'rfn_gemm_f32_tk')
+
+
+def cell_gemm_args(outs):
+    """The rfn_cell_out array of `outs` (see cell_gemm); keep the tensors alive while it is used."""
+    return _cell_outs(outs)
 
 
 def cell_gemm(M, outs, R=0, drop_p=0.0, seed=0, variant=0):
@@ -241,6 +250,10 @@ def cell_gemm(M, outs, R=0, drop_p=0.0, seed=0, variant=0):
     [(A, lda, B, ldb, b_kfast, K, bias), ...] and, for the LSTM gate epilogue, lstm = (c_prev, ldcp, c_next, ldcn, h_next,
     ldh, drop_offset); for the gate-gradient epilogue lstm_bwd = (gates, ldg, c_prev, ldcp, c_next, ldcn, dh_ext, lddh,
     dc_next, lddcn, dc_prev, lddcp, drop_offset) and C may be None."""
+    check(lib.rfn_cell_gemm(M, len(outs), _cell_outs(outs), R, drop_p, seed, variant, stream_ptr()), 'rfn_cell_gemm')
+
+
+def _cell_outs(outs):
     arr = (CellOut * len(outs))()
     for o, spec in enumerate(outs):
         t = arr[o]
@@ -261,7 +274,7 @@ def cell_gemm(M, outs, R=0, drop_p=0.0, seed=0, variant=0):
             t.gates, t.ldg, t.c_prev, t.ldcp, t.c_next, t.ldcn = g.data_ptr(), ldg, cp.data_ptr(), ldcp, cn.data_ptr(), ldcn
             t.dh_ext, t.lddh, t.dc_next, t.lddcn, t.dc_prev, t.lddcp, t.drop_offset = (ptr(dhe), lddh, ptr(dcn), lddcn,
                                                                                        dcp.data_ptr(), lddcp, off)
-    check(lib.rfn_cell_gemm(M, len(outs), arr, R, drop_p, seed, variant, stream_ptr()), 'rfn_cell_gemm')
+    return arr
 
 
 def x3_image(srcs, rows, K, k_fast=True, ld=None) -> torch.Tensor:

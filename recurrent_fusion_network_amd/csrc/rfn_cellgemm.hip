@@ -35,7 +35,7 @@ typedef __attribute__((address_space(3))) void cg_lds_void;
 typedef const __attribute__((address_space(1))) void cg_gbl_void;
 
 #define CG_MAXSEG 24
-#define CG_SLOTS 3
+#define CG_MAX_SLOTS 6            /* ring slots are a launch parameter: as many as LDS allows for the blocks a CU hosts */
 #define CG_BN 32                   /* tile width: 8 units x 4 gates in the gate epilogue */
 enum { CG_EPI_STORE = 0, CG_EPI_LSTM = 1, CG_EPI_LSTM_BWD = 2 };
 
@@ -64,7 +64,7 @@ struct CgOut {
 struct CgArgs {
     int M, nout, R, tiles_m;
     float drop_p;
-    int pad;
+    int slots;
     unsigned long long seed;
     CgOut out[RFN_CELL_MAXOUT];
     CgSeg seg[CG_MAXSEG];
@@ -105,7 +105,8 @@ __global__ __launch_bounds__(64 * (BM / 32) * WK) void cell_gemm_k(const CgArgs 
     constexpr int RPP = 64 / CPR;    // rows per piece
     constexpr int KG = BK / 8;       // k-groups per K step
     static_assert(KG % WK == 0 && (BK == 32 || BK == 64), "unsupported K step");
-    static_assert(WK * BM * BN <= CG_SLOTS * SLOT_FL, "the partial tiles reuse the ring");
+    static_assert(WK * BM * BN <= 2 * SLOT_FL, "the partial tiles reuse the ring (at least two slots)");
+    static_assert(NIW * (CG_MAX_SLOTS - 1) <= 63, "vmcnt is a 6-bit counter");
     static_assert((EPI == CG_EPI_LSTM) ? BKF : true, "the gate epilogue belongs to forward products");
     static_assert((EPI == CG_EPI_LSTM_BWD) ? !BKF : true, "the gate-gradient epilogue belongs to dX products");
     constexpr int U = BN / 4;                       // units per tile of the gate epilogue
@@ -196,15 +197,8 @@ __global__ __launch_bounds__(64 * (BM / 32) * WK) void cell_gemm_k(const CgArgs 
         }
     };
 
-    int issued = 0;
-#pragma unroll
-    for (int s = 0; s < CG_SLOTS - 1; ++s)
-        if (s < total_iters) {
-            issue(s);
-            ++issued;
-        }
-
-    // ---- everything the epilogue reads from global memory is requested now and lands under the K loop -----------------
+    // ---- everything the epilogue reads from global memory is requested first (oldest in the vector-memory queue: the
+    // counted waits of the K loop then never wait for more than the K step they need) and lands under the loop -----------
     cg_f32x4 e_prev[NV], e_bias[NV];                       // store epilogue
     float g_prev[NP][4], g_bias[NP][4], g_cprev[NP];       // gate epilogue
     float b_in[(EPI == CG_EPI_LSTM_BWD) ? NE : 1][9];      // gate-gradient epilogue: prev dh, dh_ext, i f o g, c_prev, c_next, dc_next
@@ -268,12 +262,28 @@ __global__ __launch_bounds__(64 * (BM / 32) * WK) void cell_gemm_k(const CgArgs 
         }
     }
 
+    // Ring of SL slots, SL - 1 K steps in flight: a step is a few hundred matrix-pipe cycles but a microsecond of L2 / fabric
+    // latency under load, so the ring is as deep as the LDS of the blocks sharing a CU allows (host: cg_dispatch).
+    const int SL = a.slots;
+    int issued = 0;
+    for (int s = 0; s < SL - 1 && s < total_iters; ++s) {
+        issue(s);
+        ++issued;
+    }
+
     const int swa = swz(l31), swb = swz(l31);   // tile rows are l31 + multiples of 32
-    int cur = 0, fill = CG_SLOTS - 1;
+    int cur = 0, fill = SL - 1;
     for (int it = 0; it < total_iters; ++it) {
-        if (issued - it - 1 >= 1) cg_wait_vmcnt<NIW>();   // this wave's pieces of step `it` have landed, one younger step may fly
-        else cg_wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();                     // ... everyone's have, and slot (it - 1) % SLOTS is free
+        // this wave's pieces of step `it` have landed; the `younger` steps issued after it stay in flight
+        switch (issued - it - 1) {
+            case 0: cg_wait_vmcnt<0>(); break;
+            case 1: cg_wait_vmcnt<NIW>(); break;
+            case 2: cg_wait_vmcnt<2 * NIW>(); break;
+            case 3: cg_wait_vmcnt<3 * NIW>(); break;
+            case 4: cg_wait_vmcnt<4 * NIW>(); break;
+            default: cg_wait_vmcnt<5 * NIW>(); break;
+        }
+        __builtin_amdgcn_s_barrier();                     // ... everyone's have, and slot (it - 1) % SL is free
         if (issued < total_iters) {
             issue(fill);
             ++issued;
@@ -297,8 +307,8 @@ __global__ __launch_bounds__(64 * (BM / 32) * WK) void cell_gemm_k(const CgArgs 
 #pragma unroll
             for (int c = 0; c < 4; ++c) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c], bf[c], acc, 0, 0, 0);
         }
-        cur = (cur + 1 == CG_SLOTS) ? 0 : cur + 1;
-        fill = (fill + 1 == CG_SLOTS) ? 0 : fill + 1;
+        cur = (cur + 1 == SL) ? 0 : cur + 1;
+        fill = (fill + 1 == SL) ? 0 : fill + 1;
     }
 
     // ---- the WK partial tiles meet in LDS (the ring is free: every DMA has been waited for) ----------------------------
@@ -398,31 +408,56 @@ struct CgDevState {
     bool set[16] = {};
 };
 template <int BM, int BK, int WK, bool BKF, int EPI>
-static int cg_launch(CgArgs& a, int blocks, hipStream_t st) {
+static int cg_launch(CgArgs& a, int blocks, int max_iters, int force_slots, hipStream_t st) {
     auto k = cell_gemm_k<BM, BK, WK, BKF, EPI>;
-    constexpr size_t lds = (size_t)CG_SLOTS * (BM + CG_BN) * BK * sizeof(float);
+    constexpr size_t slot = (size_t)(BM + CG_BN) * BK * sizeof(float);
     static CgDevState ds;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return RFN_ERR_LAUNCH;
     if (!ds.set[dev & 15]) {
-        if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(CG_MAX_SLOTS * slot)) !=
+            hipSuccess)
             return RFN_ERR_LAUNCH;
         ds.set[dev & 15] = true;
     }
-    hipLaunchKernelGGL(k, dim3(blocks), dim3(64 * (BM / 32) * WK), lds, st, a);
+    // Ring depth 3 (two K steps in flight).  Measured on MI355X (tools/bench_cellgemm.py --slots 2,3,4,6): 2 and 3 slots tie,
+    // deeper rings LOSE 10-40 % -- the kernel is bound by the rate of the L2 -> LDS path at 8 flops per operand byte, not by
+    // its latency, and what helps is more co-resident blocks per CU (each with its own barrier), i.e. LESS LDS per block.
+    (void)blocks;
+    int slots = 3;
+    if (force_slots > 0) slots = force_slots;   // tools only
+    if (slots > CG_MAX_SLOTS) slots = CG_MAX_SLOTS;
+    if (slots > max_iters + 1) slots = max_iters + 1;
+    if (slots < 2) slots = 2;
+    a.slots = slots;
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(64 * (BM / 32) * WK), slots * slot, st, a);
     RFN_CHECK_LAUNCH();
     return RFN_OK;
 }
 
 // Tile variants: 1 = 64 rows, K step 32, 2 K-waves; 2 = 64 rows, K step 64, 4 K-waves; 3 = 32 rows, K step 64, 4 K-waves.
-// variant 0: chosen here FROM THE COLUMN AND K COUNTS ONLY (never from M: a row's arithmetic must not depend on its batch).
+// variant 0: the K step / K-wave count -- which fix the k order of every output element -- are chosen FROM THE K COUNTS
+// ONLY, so a row's arithmetic never depends on the batch it sits in (variants 2 and 3 give bit-identical results).
 template <bool BKF, int EPI>
 static int cg_dispatch(CgArgs& a, const rfn_cell_out* outs, int variant, hipStream_t st) {
+    const int force_slots = (variant >> 4) & 15;   // tools: bits 4-7 of `variant` force the ring depth
+    variant &= 15;
     bool k64 = true;
-    for (int s = 0; s < a.out[a.nout - 1].seg0 + a.out[a.nout - 1].nseg; ++s) k64 = k64 && (a.seg[s].K % 64 == 0);
+    int max_iters = 0;
+    for (int o = 0; o < a.nout; ++o) {
+        int it = 0;
+        for (int s = 0; s < a.out[o].nseg; ++s) {
+            k64 = k64 && (a.seg[a.out[o].seg0 + s].K % 64 == 0);
+            it += a.seg[a.out[o].seg0 + s].K;
+        }
+        max_iters = it > max_iters ? it : max_iters;
+    }
+    // 32-row tiles whenever the K step of 64 applies: measured fastest at every per-step shape of the path (B = 64 ... 640),
+    // because they put two to three independent blocks on a CU (profiles/r03_cellgemm.md)
     if (variant == 0) variant = k64 ? 3 : 1;
     if ((variant == 2 || variant == 3) && !k64) return RFN_ERR_SHAPE;
     const int bm = (variant == 3) ? 32 : 64;
+    max_iters /= (variant == 1) ? 32 : 64;
     a.tiles_m = rfn_cdiv(a.M, bm);
     int t0 = 0;
     for (int o = 0; o < a.nout; ++o) {
@@ -432,9 +467,9 @@ static int cg_dispatch(CgArgs& a, const rfn_cell_out* outs, int variant, hipStre
     }
     (void)outs;
     switch (variant) {
-        case 1: return cg_launch<64, 32, 2, BKF, EPI>(a, t0, st);
-        case 2: return cg_launch<64, 64, 4, BKF, EPI>(a, t0, st);
-        case 3: return cg_launch<32, 64, 4, BKF, EPI>(a, t0, st);
+        case 1: return cg_launch<64, 32, 2, BKF, EPI>(a, t0, max_iters, force_slots, st);
+        case 2: return cg_launch<64, 64, 4, BKF, EPI>(a, t0, max_iters, force_slots, st);
+        case 3: return cg_launch<32, 64, 4, BKF, EPI>(a, t0, max_iters, force_slots, st);
         default: return RFN_ERR_SHAPE;
     }
 }

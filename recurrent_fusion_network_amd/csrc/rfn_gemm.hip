@@ -133,8 +133,97 @@ struct GemmArgs {
     int tail_main_blocks;   // > 0: blocks past this id process HALF-height tiles (see rfn_gemm_kernel)
     int tail_idx_main;      // first per-XCD tile index of the tail round
     float* part;  // [ngroups][splitk][M][N]
+    int* tickets; // non-NULL: one zeroed counter per output tile; the last K range to arrive finishes the tile in-kernel
+    int n_tickets;
     rfn_gemm_problem g[RFN_GEMM_MAXGROUP];
 };
+
+// ---- split-K finished inside the GEMM launch ------------------------------------------------------------------------
+// Every K-range block has written its raw partial tile (and partial bias-gradient sums).  One agent-scope release per
+// block, one ticket per block on the tile's counter; the block that draws the last ticket makes one agent-scope acquire
+// and adds the slabs IN K-RANGE ORDER -- the order rfn_gemm_reduce_k uses, whoever arrives last -- plus bias / previous C.
+// The counter is left at zero for the next launch.  (MI355X guide, 'Projection GEMM at M = 256' item 2: plain slab
+// stores -> every wave's vmcnt(0) -> barrier -> lane 0 release fence -> vmcnt(0) -> relaxed agent fetch_add; reducer:
+// lane 0 acquire fence -> vmcnt(0) -> barrier -> plain loads.  Correct for any placement of the blocks on XCDs / CUs.)
+template <int BM, int BN, bool VEC, int THREADS>
+__device__ __forceinline__ void gemm_finish_splitk(const GemmArgs& args, const rfn_gemm_problem& P, const int grp,
+                                                   const int tile_id, const int row0, const int col0,
+                                                   const bool colsum_tile, float* flag_lds) {
+    const int tid = threadIdx.x;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int t = __hip_atomic_fetch_add(args.tickets + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *reinterpret_cast<volatile int*>(flag_lds) = t;
+    }
+    __syncthreads();
+    const int ticket = *reinterpret_cast<volatile int*>(flag_lds);
+    if (ticket != args.splitk - 1) return;
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __hip_atomic_store(args.tickets + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int M = args.M, N = args.N, splitk = args.splitk;
+    const long MN = (long)M * N;
+    const float* part = args.part + (long)grp * splitk * MN;
+    if constexpr (VEC) {   // N % 4 == 0, 16-B aligned C / bias are not guaranteed: only the slabs are read 16 B wide
+        constexpr int C4 = BN / 4;
+        for (int idx = tid; idx < BM * C4; idx += THREADS) {
+            const int r = idx / C4, c4 = idx - r * C4, row = row0 + r, col = col0 + 4 * c4;
+            if (row >= M || col >= N) continue;
+            const float* p = part + (long)row * N + col;
+            if (col + 4 <= N && (N & 3) == 0) {
+                f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+                for (int k = 0; k < splitk; ++k) sum += *reinterpret_cast<const f32x4*>(p + k * MN);
+                float* c = P.C + (long)row * P.ldc + col;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = sum[e];
+                    for (int sg = 0; sg < P.nseg; ++sg)
+                        if (P.seg[sg].bias) v += P.seg[sg].bias[col + e];
+                    c[e] = args.accumulate ? c[e] + v : v;
+                }
+            } else {
+                for (int e = 0; e < 4 && col + e < N; ++e) {
+                    float v = 0.f;
+                    for (int k = 0; k < splitk; ++k) v += p[k * MN + e];
+                    for (int sg = 0; sg < P.nseg; ++sg)
+                        if (P.seg[sg].bias) v += P.seg[sg].bias[col + e];
+                    float* c = P.C + (long)row * P.ldc + col + e;
+                    *c = args.accumulate ? *c + v : v;
+                }
+            }
+        }
+    } else {
+        for (int idx = tid; idx < BM * BN; idx += THREADS) {
+            const int r = idx / BN, cc = idx - r * BN, row = row0 + r, col = col0 + cc;
+            if (row >= M || col >= N) continue;
+            const float* p = part + (long)row * N + col;
+            float v = 0.f;
+            for (int k = 0; k < splitk; ++k) v += p[k * MN];
+            for (int sg = 0; sg < P.nseg; ++sg)
+                if (P.seg[sg].bias) v += P.seg[sg].bias[col];
+            float* c = P.C + (long)row * P.ldc + col;
+            *c = args.accumulate ? *c + v : v;
+        }
+    }
+    if (colsum_tile && P.a_colsum) {   // the bias-gradient rider of this row tile: partial column sums of every K range, in order
+        for (int r = tid; r < BM; r += THREADS) {
+            const int row = row0 + r;
+            if (row >= M) continue;
+            const float* cs = args.part + (long)args.ngroups * splitk * MN + (long)grp * splitk * M + row;
+            float v = 0.f;
+            for (int k = 0; k < splitk; ++k) v += cs[(long)k * M];
+            float* o = P.a_colsum + row;
+            *o = args.accumulate ? *o + v : v;
+        }
+    }
+}
+
 
 // ---- staging of one ROWS x BK operand tile ---------------------------------------------------
 // [row][k] tiles have BK+4 floats per row: 36 and 68 both put the 16 rows of a ds_read_b128 lane group on 16
@@ -509,6 +598,9 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& args, const int grp, c
                     if (row < M) part[(long)row * N + col] = acc[i][j][r];
                 }
         }
+        if (args.tickets)
+            gemm_finish_splitk<BM, BN, VEC, THREADS>(args, P, grp, (grp * args.tiles_m + row0 / BM) * args.tiles_n + tn, row0, col0,
+                                                     !AK && tn == 0, smem);
         return;
     }
 
@@ -782,6 +874,9 @@ __device__ __forceinline__ void gemm_tile_dma(const GemmArgs& args, const int gr
             }
         }
     }
+    if (raw && args.tickets)
+        gemm_finish_splitk<BM, BN, true, GEMM_THREADS>(args, P, grp, (grp * args.tiles_m + row0 / BM) * args.tiles_n + col0 / BN,
+                                                       row0, col0, false, smem);
 }
 
 // ---- block -> (group, tile_m, tile_n): bijective XCD remap, then 8-row bands --------------------------------------
@@ -906,7 +1001,9 @@ static int device_cus() {
 
 template <int BM, int BN, bool AK, bool BKF, bool VEC, int STAGES, int BK, bool FAST = false, int THREADS = GEMM_THREADS,
           int DMA = 0>
-static int launch_cfg(const GemmArgs& a, hipStream_t st) {
+static int launch_cfg(const GemmArgs& a_in, hipStream_t st) {
+    GemmArgs a = a_in;
+    if (a.splitk <= 1 || (long)a.ngroups * a.tiles_m * a.tiles_n > a.n_tickets) a.tickets = nullptr;   // separate reduce launch
     using StA = Stage<BM, AK, VEC, BK, THREADS>;
     using StB = Stage<BN, BKF, VEC, BK, THREADS>;
     size_t lds = DMA > 0 ? (size_t)DMA * (BM + BN) * BK * sizeof(float)
@@ -944,7 +1041,7 @@ static int launch_cfg(const GemmArgs& a, hipStream_t st) {
         hipLaunchKernelGGL(k, dim3(nblk), dim3(THREADS), lds, st, a);
         RFN_CHECK_LAUNCH();
     }
-    if (a.splitk > 1) {
+    if (a.splitk > 1 && !a.tickets) {
         bool colsum = false;
         for (int g = 0; g < a.ngroups; ++g) colsum = colsum || (a.g[g].a_colsum != nullptr);
         const int cs_blocks = (colsum && !AK) ? rfn_cdiv(a.M, 256) : 0;
@@ -1082,6 +1179,11 @@ extern "C" int rfn_gemm_f32_ws(int M, int N, int ngroups, const rfn_gemm_problem
 
 extern "C" int rfn_gemm_f32_opt(int M, int N, int ngroups, const rfn_gemm_problem* problems, int accumulate,
                                 void* ws, size_t ws_bytes, unsigned flags, void* stream) {
+    return rfn_gemm_f32_tk(M, N, ngroups, problems, accumulate, ws, ws_bytes, flags, nullptr, 0, stream);
+}
+
+extern "C" int rfn_gemm_f32_tk(int M, int N, int ngroups, const rfn_gemm_problem* problems, int accumulate, void* ws,
+                               size_t ws_bytes, unsigned flags, int32_t* tickets, int n_tickets, void* stream) {
     if (M <= 0 || N <= 0) return RFN_OK;
     if (ngroups < 1 || ngroups > RFN_GEMM_MAXGROUP || !problems) return RFN_ERR_SHAPE;
     GemmArgs a;
@@ -1093,6 +1195,8 @@ extern "C" int rfn_gemm_f32_opt(int M, int N, int ngroups, const rfn_gemm_proble
     a.tail_main_blocks = 0;
     a.tail_idx_main = 0;
     a.flags = flags;
+    a.tickets = (tickets && n_tickets > 0) ? (int*)tickets : nullptr;
+    a.n_tickets = a.tickets ? n_tickets : 0;
     a.part = (ws && ws_bytes >= (1u << 20) && rfn_aligned16(ws)) ? (float*)ws : nullptr;
     a.ws_mib = (int)(ws_bytes >> 20);
     const int ak = problems[0].seg[0].a_kfast, bk = problems[0].seg[0].b_kfast;

@@ -104,7 +104,10 @@ struct GemmCtx {
     float* ws;
     size_t ws_bytes;
     unsigned flags;   // RFN_GEMM_OPT_* bits of the phase (rfn_dims.gemm_flags)
+    int32_t* tickets = nullptr;   // zeroed split-K tile counters of the phase's workspace (rfn_gemm_f32_tk), or NULL
+    int n_tickets = 0;
 };
+const int GEMM_TICKETS = 16384;   // 64 KB of counters per workspace: every split launch of the path has fewer output tiles
 rfn_gemm_problem prob1(float* C, long ldc, const rfn_gemm_seg& s) {
     rfn_gemm_problem p;
     memset(&p, 0, sizeof(p));
@@ -120,12 +123,12 @@ rfn_gemm_problem prob_dw(float* dW, long ldw, float* db, const float* dY, long l
 }
 int gemm1(int M, int N, const rfn_gemm_seg& s, float* C, long ldc, int acc, const GemmCtx& gx) {
     rfn_gemm_problem p = prob1(C, ldc, s);
-    return rfn_gemm_f32_opt(M, N, 1, &p, acc, gx.ws, gx.ws_bytes, gx.flags, gx.st);
+    return rfn_gemm_f32_tk(M, N, 1, &p, acc, gx.ws, gx.ws_bytes, gx.flags, gx.tickets, gx.n_tickets, gx.st);
 }
 int gemm_dw(int N, int K, float* dW, long ldw, float* db, const float* dY, long lddy, const float* X, long ldx,
             int rows, const GemmCtx& gx) {
     rfn_gemm_problem p = prob_dw(dW, ldw, db, dY, lddy, X, ldx, rows);
-    return rfn_gemm_f32_opt(N, K, 1, &p, 0, gx.ws, gx.ws_bytes, gx.flags, gx.st);
+    return rfn_gemm_f32_tk(N, K, 1, &p, 0, gx.ws, gx.ws_bytes, gx.flags, gx.tickets, gx.n_tickets, gx.st);
 }
 // The vocabulary (V+1 = 9488 at the headline size) is not a multiple of the 128-wide tile: the three logit-layer GEMMs
 // are issued as an aligned main part that takes the unchecked fast path plus a thin remainder (< 128 columns / rows /
@@ -158,7 +161,7 @@ int gemm_segs(int M, int N, int nseg, const rfn_gemm_seg* segs, float* C, long l
         p.C = C; p.ldc = ldc;
         p.nseg = (nseg - s0 < RFN_GEMM_MAXSEG) ? nseg - s0 : RFN_GEMM_MAXSEG;
         for (int s = 0; s < p.nseg; ++s) p.seg[s] = segs[s0 + s];
-        RFN_TRY(rfn_gemm_f32_opt(M, N, 1, &p, (s0 > 0) ? 1 : acc, gx.ws, gx.ws_bytes, gx.flags, gx.st));
+        RFN_TRY(rfn_gemm_f32_tk(M, N, 1, &p, (s0 > 0) ? 1 : acc, gx.ws, gx.ws_bytes, gx.flags, gx.tickets, gx.n_tickets, gx.st));
     }
     return RFN_OK;
 }
@@ -166,7 +169,7 @@ int gemm_segs(int M, int N, int nseg, const rfn_gemm_seg* segs, float* C, long l
 int gemm_groups(int M, int N, int n, const rfn_gemm_problem* p, int acc, const GemmCtx& gx) {
     for (int g0 = 0; g0 < n; g0 += RFN_GEMM_MAXGROUP) {
         const int ng = (n - g0 < RFN_GEMM_MAXGROUP) ? n - g0 : RFN_GEMM_MAXGROUP;
-        RFN_TRY(rfn_gemm_f32_opt(M, N, ng, p + g0, acc, gx.ws, gx.ws_bytes, gx.flags, gx.st));
+        RFN_TRY(rfn_gemm_f32_tk(M, N, ng, p + g0, acc, gx.ws, gx.ws_bytes, gx.flags, gx.tickets, gx.n_tickets, gx.st));
     }
     return RFN_OK;
 }
@@ -269,6 +272,7 @@ struct PrefixLayout {
     size_t Hs, Cs, hp1, g1, rmat, rarg, h2, c2, hp2, al2, z2, g2;
     size_t dHs, dC, dal, dwp, dhp1, dh2e, dhrec, dc2, dz2, dhp2;
     size_t gws;
+    size_t tk;      // split-K tile counters (GEMM_TICKETS int32), zeroed at the head of every entry point that splits
     size_t x3;      // plane images + split-K partials of the bf16-plane GEMMs (RFN_GEMM_OPT_BF16X3), 0 floats otherwise
     size_t x3p[RFN_MAX_ENC];   // train: encoder i's dP1 as a k-slow plane image (all T1 steps), kept from the backward
                                // recurrence to its weight-gradient GEMM
@@ -324,6 +328,7 @@ PrefixLayout prefix_layout(const rfn_dims* d, int B, int train) {
     L.z2 = b.take(T2 * M * Bz * R);
     L.g2 = b.take(T2 * Bz * G2);
     L.gws = b.take(GEMM_WS_FLOATS);
+    L.tk = b.take(GEMM_TICKETS);
     L.x3 = b.take(x3_scratch_floats(d, B, train));
     if (train)
         for (int i = 0; i < d->M; ++i)
@@ -348,7 +353,7 @@ PrefixLayout prefix_layout(const rfn_dims* d, int B, int train) {
 struct DecoderLayout {
     size_t Pd, xs, gd, hd, cd, hpd, ald, zd, logits;
     size_t dhe, dhrec, dc, dz, dal, dwp, dhpd, dPd, dxs;
-    size_t gws;
+    size_t gws, tk;
     size_t total;
 };
 DecoderLayout decoder_layout(const rfn_dims* d, int B, int S, int train) {
@@ -367,6 +372,7 @@ DecoderLayout decoder_layout(const rfn_dims* d, int B, int S, int train) {
     L.zd = b.take(Sz * Bz * R);
     L.logits = b.take(Sz * Bz * V1);  // logits in forward, dlogits in backward
     L.gws = b.take(GEMM_WS_FLOATS);
+    L.tk = b.take(GEMM_TICKETS);
     if (train) {
         L.dhe = b.take(Sz * Bz * R);
         L.dhrec = b.take(Bz * R);
@@ -534,7 +540,10 @@ static int prefix_fwd_impl(const rfn_dims* d, int B, const float* const* prm, co
     const int G2 = gate_width(d->review_maxout, R);
     const long MR = (long)M * R, BMR = (long)B * MR, BR = (long)B * R;
     float* W = (float*)ws;
-    const GemmCtx gx{st, W + Lo.gws, GEMM_WS_FLOATS * sizeof(float), d->gemm_flags};
+    const bool tk_on = (d->gemm_flags & RFN_GEMM_OPT_SPLITK_IN_KERNEL) != 0;   // measured slower: off unless asked for (rfn.h)
+    const GemmCtx gx{st, W + Lo.gws, GEMM_WS_FLOATS * sizeof(float), d->gemm_flags, tk_on ? (int32_t*)(W + Lo.tk) : nullptr,
+                     tk_on ? GEMM_TICKETS : 0};
+    if (tk_on) RFN_TRY(zero_f32(W + Lo.tk, GEMM_TICKETS, st));   // tile counters: zero on entry, every launch leaves them zero
     float* Hs = W + Lo.Hs;
     float* Cs = W + Lo.Cs;
     int32_t* rarg = (int32_t*)(W + Lo.rarg);
@@ -764,7 +773,10 @@ extern "C" int rfn_prefix_bwd(const rfn_dims* d, int B, const float* const* prm,
     const int G2 = gate_width(d->review_maxout, R);
     const long MR = (long)M * R, BMR = (long)B * MR, BR = (long)B * R, BA = (long)B * A;
     float* W = (float*)ws;
-    const GemmCtx gx{st, W + Lo.gws, GEMM_WS_FLOATS * sizeof(float), d->gemm_flags};
+    const bool tk_on = (d->gemm_flags & RFN_GEMM_OPT_SPLITK_IN_KERNEL) != 0;   // measured slower: off unless asked for (rfn.h)
+    const GemmCtx gx{st, W + Lo.gws, GEMM_WS_FLOATS * sizeof(float), d->gemm_flags, tk_on ? (int32_t*)(W + Lo.tk) : nullptr,
+                     tk_on ? GEMM_TICKETS : 0};
+    if (tk_on) RFN_TRY(zero_f32(W + Lo.tk, GEMM_TICKETS, st));   // tile counters: zero on entry, every launch leaves them zero
     float* Hs = W + Lo.Hs;
     float* Cs = W + Lo.Cs;
     float* h2 = W + Lo.h2;
@@ -1052,7 +1064,9 @@ extern "C" int rfn_prefix_bwd_wgrad(const rfn_dims* d, int B, const float* const
     if (T1 > 64) return RFN_ERR_SHAPE;
     const long MR = (long)M * R, BMR = (long)B * MR, BA = (long)B * A;
     float* W = (float*)ws;
-    const GemmCtx gx{st, W + Lo.gws, GEMM_WS_FLOATS * sizeof(float), d->gemm_flags};
+    const bool tk_on = (d->gemm_flags & RFN_GEMM_OPT_SPLITK_IN_KERNEL) != 0;
+    const GemmCtx gx{st, W + Lo.gws, GEMM_WS_FLOATS * sizeof(float), d->gemm_flags, tk_on ? (int32_t*)(W + Lo.tk) : nullptr,
+                     tk_on ? GEMM_TICKETS : 0};
     const float* Hs = W + Lo.Hs;
     rfn_gemm_problem pr[64];
     const long Li = d->L[i], Di = d->D[i];
@@ -1302,7 +1316,10 @@ extern "C" int rfn_decoder_bwd(const rfn_dims* d, int B, int S, const float* con
     const int GD = gate_width(d->decoder_maxout, R);
     const long BR = (long)B * R, BA = (long)B * A;
     float* W = (float*)ws;
-    const GemmCtx gx{st, W + Lo.gws, GEMM_WS_FLOATS * sizeof(float), d->gemm_flags};
+    const bool tk_on = (d->gemm_flags & RFN_GEMM_OPT_SPLITK_IN_KERNEL) != 0;   // measured slower: off unless asked for (rfn.h)
+    const GemmCtx gx{st, W + Lo.gws, GEMM_WS_FLOATS * sizeof(float), d->gemm_flags, tk_on ? (int32_t*)(W + Lo.tk) : nullptr,
+                     tk_on ? GEMM_TICKETS : 0};
+    if (tk_on) RFN_TRY(zero_f32(W + Lo.tk, GEMM_TICKETS, st));   // tile counters: zero on entry, every launch leaves them zero
     float* hd = W + Lo.hd;
     float* cd = W + Lo.cd;
     float* gd = W + Lo.gd;

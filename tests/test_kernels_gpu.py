@@ -169,6 +169,35 @@ def test_gemm_weight_gradient_split_k_keeps_the_bias_rider(dev, rows, Nn, K, gro
         assert torch.equal(p[0], dW) and torch.equal(p[3], db)
 
 
+@pytest.mark.parametrize('rows,Nn,K,groups', [(4352, 512, 512, 1), (2048, 2048, 96, 3), (300, 200, 52, 2), (50176, 512, 256, 2)])
+def test_gemm_split_k_finished_in_kernel_keeps_the_bias_rider(dev, rows, Nn, K, groups):
+    """rfn_gemm_f32_tk on weight gradients (reduction over `rows`, a_colsum rider): the last K range to arrive sums the
+    partial tiles and the partial column sums in K-range order -- same bits as the separate reduce kernel, repeated
+    launches on the same counters (left at zero each time), also under accumulate."""
+    n = N()
+    ws = torch.empty(48 << 20, dtype=torch.uint8, device=dev)
+    tickets = torch.zeros(16384, dtype=torch.int32, device=dev)
+    dY = [rnd(rows, Nn, seed=10 + g).to(dev) for g in range(groups)]
+    X = [rnd(rows, K, seed=20 + g).to(dev) for g in range(groups)]
+
+    def run(tk, acc):
+        dW = [torch.full((Nn, K), 0.5, device=dev) for _ in range(groups)]
+        db = [torch.full((Nn,), 0.25, device=dev) for _ in range(groups)]
+        probs = [(dW[g], K, [(dY[g], Nn, 0, X[g], K, 0, rows, None)], db[g]) for g in range(groups)]
+        n.gemm(Nn, K, probs, accumulate=acc, ws=ws, tickets=tk)
+        return dW, db
+
+    for acc in (False, True):
+        ref_w, ref_b = run(None, acc)
+        for rep in range(3):
+            got_w, got_b = run(tickets, acc)
+            assert int(tickets.abs().sum()) == 0
+            for g in range(groups):
+                assert torch.equal(got_w[g], ref_w[g]) and torch.equal(got_b[g], ref_b[g]), (acc, rep, g)
+    want = dY[0].double().t() @ X[0].double()
+    assert maxerr(ref_w[0] - 0.5, want) < 1e-5 + 3e-6 * rows
+
+
 def test_gemm_half_height_tail_round(dev):
     """Big NT launches whose tile count leaves the last round at most half full process that round as half-height
     tiles inside the same launch (rfn_gemm.hip, TAIL): 3200 tiles = 400 per XCD = 4 full rounds of 96 + 16, a ragged
@@ -812,6 +841,8 @@ def test_gemm_randomized_shapes_layouts_segments_groups(dev):
     n = N()
     rng = random.Random(1234)
     ws = torch.empty(48 << 20, dtype=torch.uint8, device=dev)
+    ws2 = torch.empty(48 << 20, dtype=torch.uint8, device=dev)
+    tickets = torch.zeros(16384, dtype=torch.int32, device=dev)
     g = torch.Generator().manual_seed(99)
     dims_m = [1, 3, 64, 100, 128, 256, 300, 1024]
     dims_n = [1, 20, 51, 64, 128, 130, 512, 2048]
@@ -852,7 +883,15 @@ def test_gemm_randomized_shapes_layouts_segments_groups(dev):
             Cd = Cfull.to(dev)
             problems.append((Cd, ldc, segs))
             refs.append((ref, Cfull))
+        # the same launch with split-K finished inside the kernel (rfn_gemm_f32_tk): bit-identical, counters left at zero
+        if use_ws:
+            twin = [(Cfull.to(dev), ldc, segs) for (Cd, ldc, segs), (ref, Cfull) in zip(problems, refs)]
+            n.gemm(M, Nn, twin, accumulate=acc, ws=ws2, tickets=tickets)
+            assert int(tickets.abs().sum()) == 0, 'a tile counter was left non-zero'
         n.gemm(M, Nn, problems, accumulate=acc, ws=ws if use_ws else None)
+        if use_ws:
+            for (Cd, _, _), (Ct, _, _) in zip(problems, twin):
+                assert torch.equal(Cd, Ct), (case, 'in-kernel split-K finish differs from the reduce kernel')
         for (Cd, ldc, segs), (ref, Cfull) in zip(problems, refs):
             ktot = sum(s_[6] for s_ in segs)
             tol = 1e-5 + 3e-6 * ktot * 3.0

@@ -31,6 +31,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--reps', type=int, default=200)
     ap.add_argument('--floor', action='store_true')
+    ap.add_argument('--slots', type=lambda x: [int(v) for v in x.split(',')], default=[2, 3, 4, 6])
     a = ap.parse_args()
     g = torch.Generator(device=dev).manual_seed(1)
     rnd = lambda *s: torch.randn(*s, device=dev, generator=g) * 0.1  # noqa: E731
@@ -79,12 +80,13 @@ def main():
                 N.check(N.lib.rfn_lstm_fwd(o['C'].data_ptr(), 4 * R, cp.data_ptr(), R, cn.data_ptr(), R, hn.data_ptr(), R, M, R,
                                            0, 0.0, 0, 0, N.stream_ptr()))
         line += ' old %6.1f us |' % timeit(old, a.reps)
-        for v in (0, 1, 2, 3):
-            try:
-                t = timeit(lambda: N.cell_gemm(M, outs, R=R, variant=v), a.reps)
-                line += ' v%d %5.1f' % (v, t)
-            except N.RfnError:
-                line += ' v%d   -- ' % v
+        arr, st = N.cell_gemm_args(outs), N.stream_ptr()
+        for v in [0] + [t + 16 * sl for t in (1, 2, 3) for sl in a.slots]:
+            if N.lib.rfn_cell_gemm(M, len(outs), arr, R, 0.0, 0, v, st) != 0:
+                line += ' v%d/%d   -- ' % (v & 15, v >> 4)
+                continue
+            t = timeit(lambda: N.lib.rfn_cell_gemm(M, len(outs), arr, R, 0.0, 0, v, st), a.reps)
+            line += ' v%d/%d %5.1f' % (v & 15, v >> 4, t)
         print(line, flush=True)
 
 
