@@ -146,6 +146,21 @@ int rfn_gemm_f32_opt(int M, int N, int ngroups, const rfn_gemm_problem* problems
  * tiles than counters use the separate reduce kernel. */
 int rfn_gemm_f32_tk(int M, int N, int ngroups, const rfn_gemm_problem* problems_host, int accumulate, void* ws,
                     size_t ws_bytes, unsigned flags, int32_t* tickets, int n_tickets, void* stream);
+/* Gate GEMM + LSTM update in one call (stage I: misc/RecurrentFusionModel.py:53-73): gates_g[M, 4R] = sum_s A_s W_s^T + b
+ * for ngroups cells (problems_host[g].C = cell g's gate buffer, equally spaced), then rfn_lstm_fwd_grouped on them.  When
+ * the product is cut along K the update rides on the fixed-order reduce (one launch less); results are those of
+ * rfn_gemm_f32_ws followed by rfn_lstm_fwd_grouped either way. */
+typedef struct rfn_gemm_lstm {
+    const float* c_prev;   /* cell g at c_prev + g * gs_cprev, (M, R) with row stride ldcp; likewise c_next, h_next */
+    float* c_next;
+    float* h_next;
+    int64_t ldcp, ldcn, ldh, gs_cprev, gs_cnext, gs_h;
+    float drop_p;
+    int32_t pad_;
+    uint64_t seed, offset; /* dropout stream of cell g: (seed, offset + g) */
+} rfn_gemm_lstm;
+int rfn_gemm_f32_lstm(int M, int R, int ngroups, const rfn_gemm_problem* problems_host, void* ws, size_t ws_bytes,
+                      unsigned flags, const rfn_gemm_lstm* lstm, void* stream);
 
 /* ---- f32 GEMM on the bf16 matrix cores (csrc/rfn_gemm_x3.hip) -------------------------------------------------------
  * Replaces, when RFN_GEMM_OPT_BF16X3 is set, the two nn.Linear products the reference spends most of its time in:

@@ -43,6 +43,12 @@ class GemmSeg(C.Structure):
                 ('pad_', C.c_int32)]
 
 
+class GemmLstm(C.Structure):
+    _fields_ = [('c_prev', C.c_void_p), ('c_next', C.c_void_p), ('h_next', C.c_void_p), ('ldcp', C.c_int64), ('ldcn', C.c_int64),
+                ('ldh', C.c_int64), ('gs_cprev', C.c_int64), ('gs_cnext', C.c_int64), ('gs_h', C.c_int64), ('drop_p', C.c_float),
+                ('pad_', C.c_int32), ('seed', C.c_uint64), ('offset', C.c_uint64)]
+
+
 class GemmProblem(C.Structure):
     _fields_ = [('C', C.c_void_p), ('ldc', C.c_int64), ('nseg', C.c_int32), ('pad_', C.c_int32),
                 ('a_colsum', C.c_void_p), ('seg', GemmSeg * RFN_GEMM_MAXSEG)]
@@ -81,6 +87,7 @@ def _load():
         'rfn_gemm_f32_ws': (C.c_int, [I, I, I, C.POINTER(GemmProblem), I, P, SZ, P]),
         'rfn_gemm_f32_opt': (C.c_int, [I, I, I, C.POINTER(GemmProblem), I, P, SZ, C.c_uint, P]),
         'rfn_gemm_f32_tk': (C.c_int, [I, I, I, C.POINTER(GemmProblem), I, P, SZ, C.c_uint, P, I, P]),
+        'rfn_gemm_f32_lstm': (C.c_int, [I, I, I, C.POINTER(GemmProblem), P, SZ, C.c_uint, C.POINTER(GemmLstm), P]),
         'rfn_x3_image_bytes': (SZ, [I, I]),
         'rfn_x3_split': (C.c_int, [P, I, L, I, I, I, P, P]),
         'rfn_x3_gemm': (C.c_int, [I, I, I, P, P, I, I, P, P, L, I, I, P, P]),

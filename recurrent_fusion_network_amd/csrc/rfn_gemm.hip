@@ -25,6 +25,8 @@
 //     B column-panel run on one XCD's L2 at the same time; the last, partly filled round of a big launch runs as
 //     half-height tiles.
 //   * options travel with the call (rfn_gemm_f32_opt flags); no environment variable is read.
+#include <string.h>
+
 #include "rfn_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -135,6 +137,7 @@ struct GemmArgs {
     float* part;  // [ngroups][splitk][M][N]
     int* tickets; // non-NULL: one zeroed counter per output tile; the last K range to arrive finishes the tile in-kernel
     int n_tickets;
+    rfn_gemm_lstm lstm;   // lstm.c_next != NULL: C is a gate buffer (M, 4R) and the split-K reduce ends in the LSTM update
     rfn_gemm_problem g[RFN_GEMM_MAXGROUP];
 };
 
@@ -963,6 +966,61 @@ __global__ __launch_bounds__(256) void rfn_gemm_reduce_k(const GemmArgs args) {
     *c = args.accumulate ? *c + s : s;
 }
 
+// The same fixed-order reduce for a gate GEMM (N = 4R, gate chunks [in | forget | out | g]) followed by the LSTM update of
+// rfn_cell.hip lstm_fwd_k in the same thread: one thread per (row, unit) adds the K-range partials of its four gates in
+// order, the biases, applies the gate math and writes the activations back into C, c_next and the (dropout-masked)
+// h_next.  Group g = cell g of a stage-I step: its state pointers advance by the gs_* strides, its dropout stream is
+// offset + g.  (misc/RecurrentFusionModel.py:53-73)
+__device__ __forceinline__ float gemm_philox_uniform(uint64_t seed, uint64_t offset, uint64_t idx) {
+    uint32_t c0 = (uint32_t)idx, c1 = (uint32_t)(idx >> 32), c2 = (uint32_t)offset, c3 = (uint32_t)(offset >> 32);
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return (float)(c0 >> 8) * (1.0f / 16777216.0f);
+}
+__global__ __launch_bounds__(256) void rfn_gemm_reduce_lstm_k(const GemmArgs args) {
+    const int R = args.N / 4, M = args.M;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)M * R) return;
+    const int grp = blockIdx.y;
+    const rfn_gemm_problem& P = args.g[grp];
+    const rfn_gemm_lstm& L = args.lstm;
+    const int row = (int)(idx / R), j = (int)(idx - (long)row * R);
+    const long MN = (long)M * args.N;
+    const float* part = args.part + (long)grp * args.splitk * MN + (long)row * args.N + j;
+    float pre[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        float s = 0.f;
+        for (int k = 0; k < args.splitk; ++k) s += part[k * MN + g * R];
+        for (int sg = 0; sg < P.nseg; ++sg)
+            if (P.seg[sg].bias) s += P.seg[sg].bias[g * R + j];
+        pre[g] = s;
+    }
+    float* G = P.C + (long)row * P.ldc;
+    const float ig = rfn_sigmoid(pre[0]), fg = rfn_sigmoid(pre[1]), og = rfn_sigmoid(pre[2]);
+    const float gg = tanhf(pre[3]);
+    G[j] = ig;
+    G[R + j] = fg;
+    G[2 * R + j] = og;
+    G[3 * R + j] = gg;
+    const float c = fg * L.c_prev[grp * L.gs_cprev + (long)row * L.ldcp + j] + ig * gg;
+    L.c_next[grp * L.gs_cnext + (long)row * L.ldcn + j] = c;
+    float hv = og * tanhf(c);
+    if (L.drop_p > 0.f) {
+        const float u = gemm_philox_uniform(L.seed, L.offset + (uint64_t)grp, (uint64_t)idx);
+        hv = (u >= L.drop_p) ? hv * (1.0f / (1.0f - L.drop_p)) : 0.f;
+    }
+    L.h_next[grp * L.gs_h + (long)row * L.ldh + j] = hv;
+}
+
 // Per-device launch state of one kernel instantiation: the dynamic-LDS opt-in has been made and the number of blocks
 // a CU hosts is known.  Indexed by device ordinal, so a host that drives several GPUs from one process gets each
 // device's own answer; the entries are write-once (a race repeats the same calls and stores the same values).
@@ -1003,7 +1061,7 @@ template <int BM, int BN, bool AK, bool BKF, bool VEC, int STAGES, int BK, bool 
           int DMA = 0>
 static int launch_cfg(const GemmArgs& a_in, hipStream_t st) {
     GemmArgs a = a_in;
-    if (a.splitk <= 1 || (long)a.ngroups * a.tiles_m * a.tiles_n > a.n_tickets) a.tickets = nullptr;   // separate reduce launch
+    if (a.splitk <= 1 || (long)a.ngroups * a.tiles_m * a.tiles_n > a.n_tickets || a.lstm.c_next) a.tickets = nullptr;   // separate reduce launch
     using StA = Stage<BM, AK, VEC, BK, THREADS>;
     using StB = Stage<BN, BKF, VEC, BK, THREADS>;
     size_t lds = DMA > 0 ? (size_t)DMA * (BM + BN) * BK * sizeof(float)
@@ -1045,8 +1103,11 @@ static int launch_cfg(const GemmArgs& a_in, hipStream_t st) {
         bool colsum = false;
         for (int g = 0; g < a.ngroups; ++g) colsum = colsum || (a.g[g].a_colsum != nullptr);
         const int cs_blocks = (colsum && !AK) ? rfn_cdiv(a.M, 256) : 0;
-        hipLaunchKernelGGL(rfn_gemm_reduce_k, dim3(rfn_cdiv((long)a.M * a.N, 256) + cs_blocks, a.ngroups), dim3(256), 0,
-                           st, a);
+        if (a.lstm.c_next)
+            hipLaunchKernelGGL(rfn_gemm_reduce_lstm_k, dim3(rfn_cdiv((long)a.M * (a.N / 4), 256), a.ngroups), dim3(256), 0, st, a);
+        else
+            hipLaunchKernelGGL(rfn_gemm_reduce_k, dim3(rfn_cdiv((long)a.M * a.N, 256) + cs_blocks, a.ngroups), dim3(256), 0,
+                               st, a);
         RFN_CHECK_LAUNCH();
     }
     return RFN_OK;
@@ -1182,8 +1243,28 @@ extern "C" int rfn_gemm_f32_opt(int M, int N, int ngroups, const rfn_gemm_proble
     return rfn_gemm_f32_tk(M, N, ngroups, problems, accumulate, ws, ws_bytes, flags, nullptr, 0, stream);
 }
 
+static int gemm_entry(int M, int N, int ngroups, const rfn_gemm_problem* problems, int accumulate, void* ws,
+                      size_t ws_bytes, unsigned flags, int32_t* tickets, int n_tickets, const rfn_gemm_lstm* lstm,
+                      void* stream);
+
 extern "C" int rfn_gemm_f32_tk(int M, int N, int ngroups, const rfn_gemm_problem* problems, int accumulate, void* ws,
                                size_t ws_bytes, unsigned flags, int32_t* tickets, int n_tickets, void* stream) {
+    return gemm_entry(M, N, ngroups, problems, accumulate, ws, ws_bytes, flags, tickets, n_tickets, nullptr, stream);
+}
+
+// Gate GEMM + LSTM update: gates[M, 4R] = sum_s A_s W_s^T + b (rfn_gemm_f32 semantics, no accumulate), then the update of
+// rfn_lstm_fwd_grouped on it.  When the product is cut along K the update rides on the fixed-order reduce (one launch
+// less, the gate pre-activations never travel to HBM and back); otherwise it is the separate element-wise launch.
+extern "C" int rfn_gemm_f32_lstm(int M, int R, int ngroups, const rfn_gemm_problem* problems, void* ws, size_t ws_bytes,
+                                 unsigned flags, const rfn_gemm_lstm* lstm, void* stream) {
+    if (!lstm || !lstm->c_prev || !lstm->c_next || !lstm->h_next || R < 1) return RFN_ERR_ARG;
+    if (lstm->drop_p < 0.f || lstm->drop_p >= 1.f) return RFN_ERR_SHAPE;
+    return gemm_entry(M, 4 * R, ngroups, problems, 0, ws, ws_bytes, flags, nullptr, 0, lstm, stream);
+}
+
+static int gemm_entry(int M, int N, int ngroups, const rfn_gemm_problem* problems, int accumulate, void* ws,
+                      size_t ws_bytes, unsigned flags, int32_t* tickets, int n_tickets, const rfn_gemm_lstm* lstm,
+                      void* stream) {
     if (M <= 0 || N <= 0) return RFN_OK;
     if (ngroups < 1 || ngroups > RFN_GEMM_MAXGROUP || !problems) return RFN_ERR_SHAPE;
     GemmArgs a;
@@ -1197,6 +1278,8 @@ extern "C" int rfn_gemm_f32_tk(int M, int N, int ngroups, const rfn_gemm_problem
     a.flags = flags;
     a.tickets = (tickets && n_tickets > 0) ? (int*)tickets : nullptr;
     a.n_tickets = a.tickets ? n_tickets : 0;
+    memset(&a.lstm, 0, sizeof(a.lstm));
+    if (lstm) a.lstm = *lstm;
     a.part = (ws && ws_bytes >= (1u << 20) && rfn_aligned16(ws)) ? (float*)ws : nullptr;
     a.ws_mib = (int)(ws_bytes >> 20);
     const int ak = problems[0].seg[0].a_kfast, bk = problems[0].seg[0].b_kfast;
@@ -1216,11 +1299,17 @@ extern "C" int rfn_gemm_f32_tk(int M, int N, int ngroups, const rfn_gemm_problem
         a.g[g] = p;
     }
     hipStream_t st = (hipStream_t)stream;
-#define RFN_DISPATCH(AKV, BKV)                                              \
-    return vec ? launch_tile<AKV, BKV, true>(a, st) : launch_tile<AKV, BKV, false>(a, st)
+    int rc;
+#define RFN_DISPATCH(AKV, BKV) rc = vec ? launch_tile<AKV, BKV, true>(a, st) : launch_tile<AKV, BKV, false>(a, st)
     if (ak && bk) { RFN_DISPATCH(true, true); }
-    if (ak && !bk) { RFN_DISPATCH(true, false); }
-    if (!ak && bk) { RFN_DISPATCH(false, true); }
-    RFN_DISPATCH(false, false);
+    else if (ak && !bk) { RFN_DISPATCH(true, false); }
+    else if (!ak && bk) { RFN_DISPATCH(false, true); }
+    else { RFN_DISPATCH(false, false); }
 #undef RFN_DISPATCH
+    if (rc != RFN_OK || !lstm || a.splitk > 1) return rc;     // launch_tile records its split in a.splitk
+    // unsplit product: the gate pre-activations are in C, the update is the element-wise launch
+    return rfn_lstm_fwd_grouped(problems[0].C, problems[0].ldc, lstm->c_prev, lstm->ldcp, lstm->c_next, lstm->ldcn, lstm->h_next,
+                                lstm->ldh, M, N / 4, 0, lstm->drop_p, lstm->seed, lstm->offset, ngroups,
+                                ngroups > 1 ? (int64_t)(problems[1].C - problems[0].C) : 0, lstm->gs_cprev, lstm->gs_cnext,
+                                lstm->gs_h, stream);
 }

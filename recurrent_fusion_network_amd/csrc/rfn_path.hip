@@ -556,10 +556,18 @@ static int prefix_fwd_impl(const rfn_dims* d, int B, const float* const* prm, co
             RFN_TRY(rfn_axpby_2d(1.f, init_c[i], R, 0.f, Cs + i * R, MR, B, R, st));
         }
     } else {
+        rfn_cell_out k0[RFN_MAX_ENC];
         for (int i = 0; i < M; ++i) {
             if (!fc[i]) return RFN_ERR_ARG;
-            RFN_TRY(gemm1(B, R, seg_lin(fc[i], d->F[i], prm[P.fc_w(i)], d->F[i], d->F[i], prm[P.fc_b(i)]), Hs + i * R,
-                          MR, 0, gx));
+            k0[i] = cell_out(Hs + i * R, MR, R, 0);
+            cell_lin(k0[i], fc[i], d->F[i], prm[P.fc_w(i)], d->F[i], d->F[i], prm[P.fc_b(i)]);
+        }
+        if (cell_ok(B, M, k0, R)) {   // the M fc2h products in one launch
+            RFN_TRY(cell_run(B, M, k0, R, 0.f, 0, st));
+        } else {
+            for (int i = 0; i < M; ++i)
+                RFN_TRY(gemm1(B, R, seg_lin(fc[i], d->F[i], prm[P.fc_w(i)], d->F[i], d->F[i], prm[P.fc_b(i)]), Hs + i * R,
+                              MR, 0, gx));
         }
         RFN_TRY(copy_f32(Cs, Hs, BMR, st));
     }
@@ -602,10 +610,21 @@ static int prefix_fwd_impl(const rfn_dims* d, int B, const float* const* prm, co
         float* Cn = Cs + (t + 1) * BMR;
         float* hp = W + Lo.hp1 + (long)t * M * B * A;
         float* g = W + Lo.g1 + (long)t * M * B * 4 * R;
-        for (int i = 0; i < M; ++i)
-            pr[i] = prob1(hp + (long)i * B * A, A,
-                          seg_lin(Hc + i * R, MR, prm[P.s1(t, i, 2)], R, R, prm[P.s1(t, i, 3)]));
-        RFN_TRY(gemm_groups(B, A, M, pr, 0, gx));
+        {   // h_2_att_h of the M cells: one launch, encoder i's own h = column block i of H
+            rfn_cell_out k1[RFN_MAX_ENC];
+            for (int i = 0; i < M; ++i) {
+                k1[i] = cell_out(hp + (long)i * B * A, A, A, 0);
+                cell_lin(k1[i], Hc + i * R, MR, prm[P.s1(t, i, 2)], R, R, prm[P.s1(t, i, 3)]);
+            }
+            if (cell_ok(B, M, k1, R)) {
+                RFN_TRY(cell_run(B, M, k1, R, 0.f, 0, st));
+            } else {
+                for (int i = 0; i < M; ++i)
+                    pr[i] = prob1(hp + (long)i * B * A, A,
+                                  seg_lin(Hc + i * R, MR, prm[P.s1(t, i, 2)], R, R, prm[P.s1(t, i, 3)]));
+                RFN_TRY(gemm_groups(B, A, M, pr, 0, gx));
+            }
+        }
         // attention of the M encoders: one grouped pair of launches when they share (L, D), else one pair each.
         // Raw scores land in the (idle) split-K scratch; the context kernel normalises them on the fly.
         bool same_ld = M > 1;
@@ -645,10 +664,15 @@ static int prefix_fwd_impl(const rfn_dims* d, int B, const float* const* prm, co
             p.seg[0] = seg_lin(Hc, MR, prm[P.s1(t, i, 6)], MR, (int)MR, prm[P.s1(t, i, 7)]);
             p.seg[1] = seg_lin(z, Di, prm[P.s1(t, i, 8)], Di, (int)Di, prm[P.s1(t, i, 9)]);
         }
-        RFN_TRY(gemm_groups(B, 4 * R, M, pr, 0, gx));
-        // the M cells of this step in one launch: encoder i's state is column block i of the (B, M*R) rows
-        RFN_TRY(rfn_lstm_fwd_grouped(g, 4 * R, Cc, MR, Cn, MR, Hn, MR, B, R, 0, d->drop_fusion, seed,
-                                     (uint64_t)(t * M), M, (long)B * 4 * R, R, R, R, st));
+        // gate GEMM of the M cells (grouped) with the LSTM update riding on its split-K reduce: encoder i's state is column
+        // block i of the (B, M*R) rows
+        rfn_gemm_lstm lu;
+        memset(&lu, 0, sizeof(lu));
+        lu.c_prev = Cc; lu.c_next = Cn; lu.h_next = Hn;
+        lu.ldcp = lu.ldcn = lu.ldh = MR;
+        lu.gs_cprev = lu.gs_cnext = lu.gs_h = R;
+        lu.drop_p = d->drop_fusion; lu.seed = seed; lu.offset = (uint64_t)(t * M);
+        RFN_TRY(rfn_gemm_f32_lstm(B, R, M, pr, gx.ws, gx.ws_bytes, gx.flags, &lu, st));
     }
 
     // reason heads of stage I: max over steps of reason_linear_individual (:217, :229)
@@ -1026,7 +1050,15 @@ extern "C" int rfn_prefix_bwd(const rfn_dims* d, int B, const float* const* prm,
             }
             pr[i] = prob1(dHc + i * R, MR, seg_dx(dhp + i * BA, A, prm[P.s1(t, i, 2)], R, A));
         }
-        RFN_TRY(gemm_groups(B, R, M, pr, 1, gx));
+        {
+            rfn_cell_out kb[RFN_MAX_ENC];
+            for (int i = 0; i < M; ++i) {
+                kb[i] = cell_out(dHc + i * R, MR, R, 1);
+                cell_dx(kb[i], dhp + i * BA, A, prm[P.s1(t, i, 2)], R, A);
+            }
+            if (cell_ok(B, M, kb, R)) RFN_TRY(cell_run(B, M, kb, R, 0.f, 0, st));
+            else RFN_TRY(gemm_groups(B, R, M, pr, 1, gx));
+        }
     }
     // c0 = h0.clone() (:206): dh0 += dc0 ; fc2h gradients
     RFN_TRY(rfn_axpby_2d(1.f, dC, MR, 1.f, dHs, MR, B, (int)MR, st));
