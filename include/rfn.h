@@ -500,6 +500,12 @@ int rfn_greedy_pick(const float* logp, int64_t ldl, int B, int V1, int t, int64_
                     int64_t* seq_out, int64_t ld_seq, float* lp_out, int64_t ld_lp,
                     const int32_t* unf_prev, int32_t* unf_out, void* stream);
 
+/* The same bookkeeping for a token chosen elsewhere (given != NULL, e.g. a multinomial draw; may alias next_ids):
+ * it = given[b], lp_out[b] = logp[b, it], unf / seq / next_ids as above.  given == NULL: rfn_greedy_pick. */
+int rfn_pick_record(const float* logp, int64_t ldl, int B, int V1, int t, const int64_t* given, int64_t* next_ids,
+                    int64_t* seq_out, int64_t ld_seq, float* lp_out, int64_t ld_lp, const int32_t* unf_prev,
+                    int32_t* unf_out, void* stream);
+
 /* multinomial pick of sample() (misc/RecurrentFusionModel.py:623-631) and of scheduled sampling (:260-270), on the
  * device: ids[b] = inverse-CDF draw from p[v] ~ exp(logp[b,v] * inv_temperature) with the caller's uniform u[b] in
  * [0,1) -- a deterministic function of (logp, u).  With coin != NULL only rows with coin[b] < keep_prob are redrawn,
@@ -613,6 +619,42 @@ int rfn_decoder_step_embedded(const rfn_dims* d, int B, const float* const* para
                               const float* cproj, const float* xt, int64_t ld_xt, float* h, float* c,
                               float* logits, float* logp, int64_t ld_logp, void* ws, size_t ws_bytes,
                               uint64_t seed, int step, void* stream);
+
+/* ---- whole decode loops queued by ONE call: the device-resident decoder loop (SURVEY.md 8b "decoder_loop") ------------
+ * Each is the sequence of per-step launches its host loop would issue (embedding K10, decoder cell a5, logit +
+ * log-softmax K11, the pick / beam bookkeeping between steps) with the host removed from the loop: nothing is read back,
+ * nothing is decided on the host between steps, results are bit for bit those of the step-by-step calls.
+ * They are NOT one persistent kernel, on purpose: a decoder step is three dependent all-to-all products, and on MI355X a
+ * grid-wide barrier inside a launch (4-7 us) costs more than the kernel boundary it replaces (1.5-2 us) -- the same
+ * trade the in-launch split-K finish lost when it was measured (RFN_GEMM_OPT_SPLITK_IN_KERNEL); DESIGN.md section 13.
+ *
+ * rfn_decoder_loop: sample() free-running decode (misc/RecurrentFusionModel.py:616-653), `steps` = seq_length + 1 steps.
+ *   mode 0 greedy (argmax of the previous step's log-probs, first maximum), mode 1 multinomial (inverse-CDF draw with the
+ *   caller's uniforms u[(t-1) * B + b], temperature 1 / inv_temperature).  h, c: decoder state in / out (B, R).
+ *   logp_all[b * ld_b + t * ld_t + v]: log-probs of step t.  seq / seq_lp (B, steps - 1) with row strides ld_seq / ld_lp:
+ *   token (0 once the row has finished) and its log-prob per step, as :647-649.  unf (steps, B) int32: unfinished flags
+ *   per step (row 0 unused), for the caller's single early-exit read-back (:645).  ids: B int64 of scratch (last fed
+ *   tokens).  ws: rfn_decoder_step_ws_bytes. */
+int rfn_decoder_loop(const rfn_dims* d, int B, int steps, const float* const* params, const float* comb,
+                     const float* cproj, float* h, float* c, int mode, float inv_temperature, const float* u,
+                     float* logp_all, int64_t ld_b, int64_t ld_t, int64_t* seq, int64_t ld_seq, float* seq_lp,
+                     int64_t ld_lp, int32_t* unf, int64_t* ids, void* ws, size_t ws_bytes, uint64_t seed, void* stream);
+/* rfn_decoder_fwd_sampled: the step-wise TRAINING decoder with draws between the steps (scheduled sampling :260-270 with
+ *   probability ss_prob; ss_prob = 1: the multinomial sample() with grad, train_rl.py:160) = rfn_decoder_fwd_begin + S x
+ *   (rfn_multinomial_pick, rfn_decoder_fwd_step).  ids (B, S) in / out (column 0 = BOS is never redrawn); u_draw, u_coin
+ *   (S, B) uniforms in [0, 1) (row 0 unused).  Leaves the workspace ready for rfn_decoder_bwd. */
+int rfn_decoder_fwd_sampled(const rfn_dims* d, int B, int S, const float* const* params, const float* comb,
+                            const float* h0, const float* c0, int64_t* ids, int64_t ld_ids, float ss_prob,
+                            float inv_temperature, const float* u_draw, const float* u_coin, float* log_prob, void* ws,
+                            size_t ws_bytes, int train, uint64_t seed, void* stream);
+/* rfn_beam_loop: sample_beam's search (:451-531) for NB images x W beams: S x (rfn_beam_step, two rfn_gather_rows,
+ *   rfn_decoder_step on the NB * W rows).  h / c (NB * W, R) in / out, h_alt / c_alt same-size scratch, logp (NB * W, V+1)
+ *   scratch; the beam / done arrays as rfn_beam_step (zero-initialised by the caller; active = 1). */
+int rfn_beam_loop(const rfn_dims* d, int NB, int W, int S, const float* const* params, const float* comb,
+                  const float* cproj, float* h, float* c, float* h_alt, float* c_alt, float* logp, int64_t* beam_seq,
+                  float* beam_lp, float* beam_sum, int32_t* order, int64_t* ids, int64_t* done_seq, float* done_lp,
+                  float* done_p, int32_t* done_n, int32_t* active, int max_done, void* ws, size_t ws_bytes, uint64_t seed,
+                  void* stream);
 
 #ifdef __cplusplus
 }

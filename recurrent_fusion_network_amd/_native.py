@@ -151,6 +151,10 @@ def _load():
         'rfn_decoder_fwd_begin': (C.c_int, [DP, I, I, P, P, P, P, P, SZ, I, P]),
         'rfn_decoder_fwd_step': (C.c_int, [DP, I, I, I, P, P, P, L, P, P, SZ, I, U64, P]),
         'rfn_decoder_bwd': (C.c_int, [DP, I, I, P, P, P, P, P, L, P, P, P, P, P, P, P, SZ, U64, P]),
+        'rfn_pick_record': (C.c_int, [P, L, I, I, I, P, P, P, L, P, L, P, P, P]),
+        'rfn_decoder_loop': (C.c_int, [DP, I, I, P, P, P, P, P, I, F, P, P, L, L, P, L, P, L, P, P, P, SZ, U64, P]),
+        'rfn_decoder_fwd_sampled': (C.c_int, [DP, I, I, P, P, P, P, P, L, F, F, P, P, P, P, SZ, I, U64, P]),
+        'rfn_beam_loop': (C.c_int, [DP, I, I, I] + [P] * 18 + [I, P, SZ, U64, P]),
         'rfn_decoder_step_ws_bytes': (SZ, [DP, I]),
         'rfn_decoder_prepare': (C.c_int, [DP, I, P, P, P, P]),
         'rfn_decoder_step': (C.c_int, [DP, I, P, P, P, P, P, P, P, P, L, P, SZ, U64, I, P]),

@@ -663,13 +663,17 @@ struct Dma {
     // this lane's 32-bit byte offset, fixed for the whole K loop (one per wave-instruction).  The DMA instruction then
     // takes its address as SGPR pair + one VGPR: half the address-register traffic of a 64-bit per-lane pointer and
     // no per-lane pointer arithmetic in the loop (the host checks that the operand spans < 4 GiB).
-    __device__ __forceinline__ static void init_offs(uint32_t (&o)[NI], long ld, int row0, int wave, int lane) {
+    // nrows: valid rows of a [row][k] operand.  Rows of an edge tile that lie past it fetch the last valid row instead
+    // (their products are computed and never stored), so ragged row / column counts need no masked loads.
+    __device__ __forceinline__ static void init_offs(uint32_t (&o)[NI], long ld, int row0, int wave, int lane, int nrows) {
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
             const int n = wave * NI + j;
             if constexpr (KFAST) {
                 const int row = n * RPI + lane / CPR;
-                o[j] = (uint32_t)(((long)(row0 + row) * ld + 4 * ((lane % CPR) ^ swz(row))) * 4);
+                int gr = row0 + row;
+                gr = gr < nrows ? gr : nrows - 1;
+                o[j] = (uint32_t)(((long)gr * ld + 4 * ((lane % CPR) ^ swz(row))) * 4);
             } else {
                 o[j] = (uint32_t)(((long)(n * KPI + lane / RQ) * ld + row0 + 4 * (lane % RQ)) * 4);
             }
@@ -761,8 +765,8 @@ __device__ __forceinline__ void gemm_tile_dma(const GemmArgs& args, const int gr
         if (seg < P.nseg) {
             const rfn_gemm_seg& sg = P.seg[seg];
             segK = sg.K;
-            DA::init_offs(oa, sg.lda, row0, wave, lane);
-            DB::init_offs(ob, sg.ldb, col0, wave, lane);
+            DA::init_offs(oa, sg.lda, row0, wave, lane, args.M);
+            DB::init_offs(ob, sg.ldb, col0, wave, lane, args.N);
             stepA = (AK ? (long)BK : (long)BK * sg.lda) * 4;
             stepB = (BKF ? (long)BK : (long)BK * sg.ldb) * 4;
             baseA = (const char*)sg.A + (long)(k0 / BK) * stepA;
@@ -850,6 +854,30 @@ __device__ __forceinline__ void gemm_tile_dma(const GemmArgs& args, const int gr
     const uint32_t lane_off = (uint32_t)(wm * (BM / 2) + 4 * h) * ld4 + (uint32_t)(wn * (BN / 2) + l31) * 4u;
     const bool raw = splitk > 1;   // raw partial tile; rfn_gemm_reduce_k adds the bias / previous C in a fixed order
     const bool accumulate = !raw && args.accumulate;
+    if (row0 + BM > M || col0 + BN > N) {
+        // edge tile of a ragged problem (both operands [row][k]: the out-of-range rows were clamped at the source): the
+        // same values, bounds-checked stores
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int col = col0 + wn * (BN / 2) + j * 32 + l31;
+            if (col >= N) continue;
+            float bsum = 0.f;
+            if (!raw)
+                for (int s = 0; s < P.nseg; ++s)
+                    if (P.seg[s].bias) bsum += P.seg[s].bias[col];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = row0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (row >= M) continue;
+                    float* c = raw ? args.part + ((long)grp * splitk + ks) * (long)M * N + (long)row * N + col
+                                   : P.C + (long)row * P.ldc + col;
+                    const float v = acc[i][j][r] + bsum;
+                    *c = accumulate ? v + *c : v;
+                }
+        }
+    } else {
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         float bsum = 0.f;
@@ -876,6 +904,7 @@ __device__ __forceinline__ void gemm_tile_dma(const GemmArgs& args, const int gr
                     *reinterpret_cast<float*>(tile + (sub + (uint32_t)((r & 3) + 8 * (r >> 2)) * ld4)) = acc[i][j][r] + bsum;
             }
         }
+    }
     }
     if (raw && args.tickets)
         gemm_finish_splitk<BM, BN, true, GEMM_THREADS>(args, P, grp, (grp * args.tiles_m + row0 / BM) * args.tiles_n + col0 / BN,
@@ -1149,10 +1178,14 @@ static int launch_tile(GemmArgs& a, hipStream_t st) {
         constexpr int ST = (AK && BKF) ? GEMM_NT_STAGES : GEMM_XX_STAGES;
 #if GEMM_FAST_PATH
         if constexpr (VEC) {
-            bool fast = (a.M % GEMM_BIG_BM == 0) && (a.N % GEMM_BIG_BN == 0);
+            bool kdiv = true;
             for (int g = 0; g < a.ngroups; ++g)
                 for (int s = 0; s < a.g[g].nseg; ++s)
-                    fast = fast && a.g[g].seg[s].K > 0 && (a.g[g].seg[s].K % GEMM_BIG_BK == 0);
+                    kdiv = kdiv && a.g[g].seg[s].K > 0 && (a.g[g].seg[s].K % GEMM_BIG_BK == 0);
+            const bool fast = kdiv && (a.M % GEMM_BIG_BM == 0) && (a.N % GEMM_BIG_BN == 0);
+            // the LDS-DMA kernel also takes ragged row / column counts when both operands are [row][k] (edge tiles clamp
+            // their source rows and bounds-check their stores): the vocabulary (9488) needs no remainder launch
+            const bool dma_ok = fast || (kdiv && AK && BKF);
 #if GEMM_ONE_WAVE
             if (fast && (a.M % 64 == 0) && (a.N % 64 == 0)) {   // experiment: barrier-free single-wave 64x64 blocks
                 a.tiles_m = a.M / 64;
@@ -1173,7 +1206,7 @@ static int launch_tile(GemmArgs& a, hipStream_t st) {
                 }
             for (int g = 0; g < a.ngroups; ++g)   // ... and one output tile as tile base + 32-bit byte offset
                 span32 = span32 && a.g[g].ldc >= 0 && (double)a.g[g].ldc * 4 * GEMM_BIG_BM < 4.0e9 && (double)a.N * 4 * GEMM_BIG_BM < 4.0e9;
-            if (fast && span32 && !colsum && !(a.flags & RFN_GEMM_OPT_NO_DMA)) {
+            if (dma_ok && span32 && !colsum && !(a.flags & RFN_GEMM_OPT_NO_DMA)) {
                 constexpr int SL = (AK && BKF) ? GEMM_DMA_SLOTS_NT : GEMM_DMA_SLOTS_XX;
                 constexpr int DBK = (AK && BKF) ? GEMM_DMA_BK : GEMM_DMA_BK_XX;
                 // lean: 16-deep K steps, two slots = 32 KB of LDS per block (64 KB per CU at the two blocks per CU of a
@@ -1212,7 +1245,7 @@ static int launch_tile(GemmArgs& a, hipStream_t st) {
     // with GEMM_SMALL_DMA_SLOTS slots the whole K range of the block is in flight after the first wait.  Bit-identical
     // (same k order per output element).
     if constexpr (VEC) {
-        bool ok = (a.M % 64 == 0) && (a.N % 64 == 0) && !colsum && !(a.flags & RFN_GEMM_OPT_NO_DMA);
+        bool ok = ((AK && BKF) || ((a.M % 64 == 0) && (a.N % 64 == 0))) && !colsum && !(a.flags & RFN_GEMM_OPT_NO_DMA);
         for (int g = 0; g < a.ngroups && ok; ++g) {
             ok = ok && a.g[g].ldc >= 0 && (double)a.g[g].ldc * 4 * 64 < 4.0e9;
             for (int s = 0; s < a.g[g].nseg; ++s) {

@@ -845,11 +845,25 @@ extern "C" int rfn_multinomial_pick(const float* logp, int64_t ldl, int B, int V
 __global__ __launch_bounds__(256) void greedy_pick_k(const float* __restrict__ logp, long ldl, int V1, int t,
                                                      int64_t* __restrict__ next_ids, int64_t* __restrict__ seq_out,
                                                      long ld_seq, float* __restrict__ lp_out, long ld_lp,
-                                                     const int32_t* unf_prev, int32_t* unf_out) {
+                                                     const int32_t* unf_prev, int32_t* unf_out,
+                                                     const int64_t* given /* may alias next_ids */) {
     __shared__ float vs[4];
     __shared__ int is[4];
     const int b = blockIdx.x;
     const float* x = logp + b * ldl;
+    if (given) {   // the token was drawn elsewhere (multinomial): record its log-prob and the finished flags only
+        if (threadIdx.x == 0) {
+            long it = given[b];
+            if (it < 0 || it >= V1) it = 0;
+            int unf = (t == 1) ? 1 : unf_prev[b];
+            unf = unf && (it > 0);
+            unf_out[b] = unf;
+            next_ids[b] = it;
+            seq_out[b * ld_seq] = unf ? it : 0;
+            lp_out[b * ld_lp] = x[it];
+        }
+        return;
+    }
     float m = -INFINITY;
     int mi = 0x7fffffff;
     for (int v = threadIdx.x; v < V1; v += 256) {
@@ -888,13 +902,18 @@ __global__ __launch_bounds__(256) void greedy_pick_k(const float* __restrict__ l
         lp_out[b * ld_lp] = m;
     }
 }
-extern "C" int rfn_greedy_pick(const float* logp, int64_t ldl, int B, int V1, int t, int64_t* next_ids,
-                               int64_t* seq_out, int64_t ld_seq, float* lp_out, int64_t ld_lp,
+extern "C" int rfn_pick_record(const float* logp, int64_t ldl, int B, int V1, int t, const int64_t* given,
+                               int64_t* next_ids, int64_t* seq_out, int64_t ld_seq, float* lp_out, int64_t ld_lp,
                                const int32_t* unf_prev, int32_t* unf_out, void* stream) {
     if (B <= 0 || V1 <= 0 || t < 1) return RFN_ERR_SHAPE;
     if (!logp || !next_ids || !seq_out || !lp_out || !unf_out || (t > 1 && !unf_prev)) return RFN_ERR_ARG;
-    hipLaunchKernelGGL(greedy_pick_k, dim3(B), dim3(256), 0, (hipStream_t)stream, logp, (long)ldl, V1, t, next_ids,
-                       seq_out, (long)ld_seq, lp_out, (long)ld_lp, unf_prev, unf_out);
+    hipLaunchKernelGGL(greedy_pick_k, dim3(B), dim3(given ? 64 : 256), 0, (hipStream_t)stream, logp, (long)ldl, V1, t, next_ids,
+                       seq_out, (long)ld_seq, lp_out, (long)ld_lp, unf_prev, unf_out, given);
     RFN_CHECK_LAUNCH();
     return RFN_OK;
+}
+extern "C" int rfn_greedy_pick(const float* logp, int64_t ldl, int B, int V1, int t, int64_t* next_ids,
+                               int64_t* seq_out, int64_t ld_seq, float* lp_out, int64_t ld_lp,
+                               const int32_t* unf_prev, int32_t* unf_out, void* stream) {
+    return rfn_pick_record(logp, ldl, B, V1, t, nullptr, next_ids, seq_out, ld_seq, lp_out, ld_lp, unf_prev, unf_out, stream);
 }

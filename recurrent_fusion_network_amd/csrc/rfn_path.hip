@@ -136,8 +136,10 @@ int gemm_dw(int N, int K, float* dW, long ldw, float* db, const float* dY, long 
 // which adds the remainder's partial product last.
 static inline int aligned_part(int n) { return (n / 128) * 128; }
 int gemm_logits(int rows, int V1, const float* h, int R, const float* Wl, const float* bl, float* C, const GemmCtx& gx) {
+    // both operands are [row][k]: the LDS-DMA kernel takes the ragged vocabulary in one launch (edge tiles clamp their
+    // source rows); only a hidden size that is not a whole K step keeps the main + remainder split
     const int Va = aligned_part(V1);
-    if (Va == V1 || Va == 0) return gemm1(rows, V1, seg_lin(h, R, Wl, R, R, bl), C, V1, 0, gx);
+    if (Va == V1 || Va == 0 || R % 32 == 0) return gemm1(rows, V1, seg_lin(h, R, Wl, R, R, bl), C, V1, 0, gx);
     RFN_TRY(gemm1(rows, Va, seg_lin(h, R, Wl, R, R, bl), C, V1, 0, gx));
     return gemm1(rows, V1 - Va, seg_lin(h, R, Wl + (long)Va * R, R, R, bl + Va), C + Va, V1, 0, gx);
 }
@@ -1518,4 +1520,92 @@ extern "C" int rfn_decoder_step_embedded(const rfn_dims* d, int B, const float* 
     if (!xt) return RFN_ERR_ARG;
     return decoder_step_impl(d, B, prm, comb, cproj, nullptr, xt, ld_xt, h, c, logits, logp, ld_logp, ws, ws_bytes,
                              seed, step, st);
+}
+
+// =============================================================================================
+// whole decode loops queued by one call (no host work between steps)
+// =============================================================================================
+// sample() free-running decode (misc/RecurrentFusionModel.py:616-653): step t = 0 feeds BOS; step t >= 1 feeds the token
+// picked from step t-1's distribution (mode 0: argmax; mode 1: inverse-CDF draw with the caller's uniform u[t-1][b]).
+// Every step is rfn_decoder_step (embedding K10, cell a5, logit + log-softmax K11) on the same buffers, so the result is
+// bit for bit what the step-by-step host loop gives -- only the host is gone from the loop.  `unf` keeps one row of
+// unfinished flags per step so that the caller applies the reference's early exit (:645) with ONE read-back afterwards.
+extern "C" int rfn_decoder_loop(const rfn_dims* d, int B, int steps, const float* const* prm, const float* comb,
+                                const float* cproj, float* h, float* c, int mode, float inv_temperature, const float* u,
+                                float* logp_all, int64_t ld_b, int64_t ld_t, int64_t* seq, int64_t ld_seq, float* seq_lp,
+                                int64_t ld_lp, int32_t* unf, int64_t* ids, void* ws, size_t ws_bytes, uint64_t seed,
+                                void* st) {
+    RFN_TRY(check_dims(d));
+    if (B < 1 || steps < 1 || (mode != 0 && mode != 1)) return RFN_ERR_SHAPE;
+    if (!prm || !comb || !cproj || !h || !c || !logp_all || !seq || !seq_lp || !unf || !ids || !ws) return RFN_ERR_ARG;
+    if (mode == 1 && !u) return RFN_ERR_ARG;
+    const int V1 = d->V1;
+    if (hipMemsetAsync(ids, 0, (size_t)B * sizeof(int64_t), (hipStream_t)st) != hipSuccess) return RFN_ERR_LAUNCH;   // BOS
+    for (int t = 0; t < steps; ++t) {
+        if (t >= 1) {
+            const float* prev = logp_all + (long)(t - 1) * ld_t;
+            if (mode == 1)   // the draw first: the greedy-pick kernel below then records ITS log-prob and finished flags
+                RFN_TRY(rfn_multinomial_pick(prev, ld_b, B, V1, inv_temperature, u + (long)(t - 1) * B, nullptr, 1.f, ids, 1, st));
+            RFN_TRY(rfn_pick_record(prev, ld_b, B, V1, t, mode == 1 ? ids : nullptr, ids, seq + (t - 1), ld_seq, seq_lp + (t - 1),
+                                    ld_lp, t > 1 ? unf + (long)(t - 1) * B : nullptr, unf + (long)t * B, st));
+        }
+        RFN_TRY(rfn_decoder_step(d, B, prm, comb, cproj, ids, h, c, nullptr, logp_all + (long)t * ld_t, ld_b, ws, ws_bytes, seed, t,
+                                 st));
+    }
+    return RFN_OK;
+}
+
+// The step-wise training decoder with draws between the steps (scheduled sampling :260-270, multinomial sample() with
+// grad :623-631), queued by one call: begin, then for every step s >= 1 rows whose coin u_coin[s][b] < ss_prob get a
+// token drawn from step s-1's distribution (uniform u_draw[s][b]), then rfn_decoder_fwd_step.  Leaves workspace, ids and
+// log_prob exactly as the host loop over rfn_multinomial_pick / rfn_decoder_fwd_step does.
+extern "C" int rfn_decoder_fwd_sampled(const rfn_dims* d, int B, int S, const float* const* prm, const float* comb,
+                                       const float* h0, const float* c0, int64_t* ids, int64_t ld_ids, float ss_prob,
+                                       float inv_temperature, const float* u_draw, const float* u_coin, float* log_prob,
+                                       void* ws, size_t ws_bytes, int train, uint64_t seed, void* st) {
+    RFN_TRY(check_dims(d));
+    if (B < 1 || S < 1) return RFN_ERR_SHAPE;
+    if (!prm || !comb || !h0 || !c0 || !ids || !u_draw || !u_coin || !log_prob || !ws) return RFN_ERR_ARG;
+    RFN_TRY(rfn_decoder_fwd_begin(d, B, S, prm, comb, h0, c0, ws, ws_bytes, train, st));
+    const long ld_b = (long)S * d->V1;
+    for (int s = 0; s < S; ++s) {
+        if (s >= 1)
+            RFN_TRY(rfn_multinomial_pick(log_prob + (long)(s - 1) * d->V1, ld_b, B, d->V1, inv_temperature, u_draw + (long)s * B,
+                                         u_coin + (long)s * B, ss_prob, ids + s, ld_ids, st));
+        RFN_TRY(rfn_decoder_fwd_step(d, B, S, s, prm, comb, ids + s, ld_ids, log_prob, ws, ws_bytes, train, seed, st));
+    }
+    return RFN_OK;
+}
+
+// sample_beam's search (misc/RecurrentFusionModel.py:451-531) for all images at once, queued by one call: per step the
+// device-side bookkeeping (rfn_beam_step), the re-gather of the recurrent state rows and one decoder step on the
+// NB * W beam rows.  h / c are ping-ponged with h_alt / c_alt; on return the live state is in h / c again.
+extern "C" int rfn_beam_loop(const rfn_dims* d, int NB, int W, int S, const float* const* prm, const float* comb,
+                             const float* cproj, float* h, float* c, float* h_alt, float* c_alt, float* logp,
+                             int64_t* beam_seq, float* beam_lp, float* beam_sum, int32_t* order, int64_t* ids,
+                             int64_t* done_seq, float* done_lp, float* done_p, int32_t* done_n, int32_t* active, int max_done,
+                             void* ws, size_t ws_bytes, uint64_t seed, void* st) {
+    RFN_TRY(check_dims(d));
+    if (NB < 1 || W < 1 || S < 1) return RFN_ERR_SHAPE;
+    if (!prm || !comb || !cproj || !h || !c || !h_alt || !c_alt || !logp || !ids || !order || !ws) return RFN_ERR_ARG;
+    const int rows = NB * W, V1 = d->V1, R = d->R;
+    float *hc = h, *cc = c, *ha = h_alt, *ca = c_alt;
+    if (hipMemsetAsync(ids, 0, (size_t)rows * sizeof(int64_t), (hipStream_t)st) != hipSuccess) return RFN_ERR_LAUNCH;
+    for (int t = 0; t <= S; ++t) {
+        if (t >= 1) {
+            RFN_TRY(rfn_beam_step(logp, V1, V1, W, S, t, NB, max_done, beam_seq, beam_lp, beam_sum, order, ids, done_seq, done_lp,
+                                  done_p, done_n, active, st));
+            if (t == S) break;   // the reference still runs one more decoder step whose output is never used
+            RFN_TRY(rfn_gather_rows(hc, ha, order, rows, R, st));
+            RFN_TRY(rfn_gather_rows(cc, ca, order, rows, R, st));
+            float* x = hc; hc = ha; ha = x;
+            x = cc; cc = ca; ca = x;
+        }
+        RFN_TRY(rfn_decoder_step(d, rows, prm, comb, cproj, ids, hc, cc, nullptr, logp, V1, ws, ws_bytes, seed, t, st));
+    }
+    if (hc != h) {   // an odd number of swaps: bring the live state home
+        RFN_TRY(copy_f32(h, hc, (size_t)rows * R, st));
+        RFN_TRY(copy_f32(c, cc, (size_t)rows * R, st));
+    }
+    return RFN_OK;
 }

@@ -198,19 +198,12 @@ class _DecoderFn(torch.autograd.Function):
         log_prob = torch.empty(B, S, d.V1, device=dev)
         if ss_prob > 0.0 and S > 1:
             ids = ids.clone()
-            st = N.stream_ptr()
-            N.check(N.lib.rfn_decoder_fwd_begin(C.byref(d), B, S, table, comb.data_ptr(), h0.data_ptr(), c0.data_ptr(),
-                                                ws.data_ptr(), ws_bytes, int(train), st), 'rfn_decoder_fwd_begin')
-            for s in range(S):
-                if s >= 1:   # rows whose coin says so get a token drawn from the previous step's distribution
-                    r = torch.rand(2, B, device=dev)
-                    prev = log_prob[:, s - 1]
-                    N.check(N.lib.rfn_multinomial_pick(prev.data_ptr(), prev.stride(0), B, d.V1, inv_temp,
-                                                       r[0].data_ptr(), r[1].data_ptr(), ss_prob, ids[:, s].data_ptr(),
-                                                       ids.stride(0), st), 'rfn_multinomial_pick')
-                N.check(N.lib.rfn_decoder_fwd_step(C.byref(d), B, S, s, table, comb.data_ptr(), ids[:, s].data_ptr(),
-                                                   ids.stride(0), log_prob.data_ptr(), ws.data_ptr(), ws_bytes,
-                                                   int(train), seed, st), 'rfn_decoder_fwd_step')
+            # one call queues begin + S x (draw, step): the host is off the critical path (uniforms drawn up front)
+            r = torch.rand(2, S, B, device=dev)
+            N.check(N.lib.rfn_decoder_fwd_sampled(C.byref(d), B, S, table, comb.data_ptr(), h0.data_ptr(), c0.data_ptr(),
+                                                  ids.data_ptr(), ids.stride(0), float(ss_prob), float(inv_temp),
+                                                  r[0].data_ptr(), r[1].data_ptr(), log_prob.data_ptr(), ws.data_ptr(),
+                                                  ws_bytes, int(train), seed, N.stream_ptr()), 'rfn_decoder_fwd_sampled')
             if getattr(model, '_trace_ss', False):
                 model._ss_ids = ids.clone()      # test hook: the token matrix the pass ended up feeding
         else:
@@ -635,22 +628,19 @@ class RecurrentFusionModel(nn.Module):
             if getattr(self, '_trace_ss', False):
                 self._sample_ids = raw[:, :t_stop].clone()       # test hook: the tokens the pass fed
             return seq[:, :n_seq], seq_lp, logp.contiguous(), reason_pred
-        with torch.no_grad():      # greedy: free-running steps with the argmax pick on the device
+        with torch.no_grad():      # greedy: the whole free-running loop (pick, embed, cell, logit, log-softmax) in one call
             stepper = _Stepper(self, comb.detach(), h.detach().clone(), c.detach().clone(), train, seed)
             logp_all = torch.empty(B, S + 1, V1, device=dev)
             seq = torch.zeros(B, S, dtype=torch.long, device=dev)
             seq_lp = torch.zeros(B, S, device=dev)
             unf = torch.zeros(S + 1, B, dtype=torch.int32, device=dev)
-            it = torch.zeros(B, dtype=torch.long, device=dev)
-            for t in range(S + 1):
-                if t >= 1:
-                    prev = logp_all[:, t - 1]
-                    N.check(N.lib.rfn_greedy_pick(prev.data_ptr(), prev.stride(0), B, V1, t, it.data_ptr(),
-                                                  seq[:, t - 1].data_ptr(), seq.stride(0),
-                                                  seq_lp[:, t - 1].data_ptr(), seq_lp.stride(0),
-                                                  unf[t - 1].data_ptr() if t > 1 else None, unf[t].data_ptr(),
-                                                  N.stream_ptr()), 'rfn_greedy_pick')
-                stepper.step(it, out=logp_all[:, t])
+            it = torch.empty(B, dtype=torch.long, device=dev)
+            N.check(N.lib.rfn_decoder_loop(C.byref(stepper.d), B, S + 1, stepper.table, stepper.comb.data_ptr(),
+                                           stepper.cproj.data_ptr(), stepper.h.data_ptr(), stepper.c.data_ptr(), 0, 1.0, None,
+                                           logp_all.data_ptr(), logp_all.stride(0), logp_all.stride(1), seq.data_ptr(),
+                                           seq.stride(0), seq_lp.data_ptr(), seq_lp.stride(0), unf.data_ptr(), it.data_ptr(),
+                                           stepper.ws.data_ptr(), stepper.ws_bytes, stepper.seed, N.stream_ptr()),
+                    'rfn_decoder_loop')
             # the reference's early exit (:645): stop at the first t >= 1 with no unfinished row
             alive = unf[1:].sum(1).tolist()
         t_stop = next((t for t in range(1, S + 1) if alive[t - 1] == 0), S + 1)
@@ -691,22 +681,13 @@ class RecurrentFusionModel(nn.Module):
             active = torch.ones(B, dtype=torch.int32, device=dev)
             logp = torch.empty(rows, V1, device=dev)
             h_alt, c_alt = torch.empty_like(stepper.h), torch.empty_like(stepper.c)
-            R = self.rnn_size
-            for t in range(S + 1):
-                if t >= 1:
-                    N.check(N.lib.rfn_beam_step(logp.data_ptr(), V1, V1, W, S, t, B, max_done, bs.data_ptr(),
-                                                bl.data_ptr(), bsum.data_ptr(), order.data_ptr(), ids.data_ptr(),
-                                                done_seq.data_ptr(), done_lp.data_ptr(), done_p.data_ptr(),
-                                                done_n.data_ptr(), active.data_ptr(), N.stream_ptr()),
-                            'rfn_beam_step')
-                    if t == S:
-                        break    # the reference still runs one more decoder step whose output is never used
-                    st = N.stream_ptr()
-                    N.check(N.lib.rfn_gather_rows(stepper.h.data_ptr(), h_alt.data_ptr(), order.data_ptr(), rows, R, st))
-                    N.check(N.lib.rfn_gather_rows(stepper.c.data_ptr(), c_alt.data_ptr(), order.data_ptr(), rows, R, st))
-                    stepper.h, h_alt = h_alt, stepper.h
-                    stepper.c, c_alt = c_alt, stepper.c
-                stepper.step(ids, out=logp)
+            # the whole search in one call: S x (bookkeeping, state re-gather, decoder step on the B * W rows)
+            N.check(N.lib.rfn_beam_loop(C.byref(stepper.d), B, W, S, stepper.table, stepper.comb.data_ptr(),
+                                        stepper.cproj.data_ptr(), stepper.h.data_ptr(), stepper.c.data_ptr(), h_alt.data_ptr(),
+                                        c_alt.data_ptr(), logp.data_ptr(), bs.data_ptr(), bl.data_ptr(), bsum.data_ptr(),
+                                        order.data_ptr(), ids.data_ptr(), done_seq.data_ptr(), done_lp.data_ptr(),
+                                        done_p.data_ptr(), done_n.data_ptr(), active.data_ptr(), max_done,
+                                        stepper.ws.data_ptr(), stepper.ws_bytes, stepper.seed, N.stream_ptr()), 'rfn_beam_loop')
             n_done = done_n.cpu().numpy()
             d_seq, d_lp, d_p = done_seq.cpu().numpy(), done_lp.cpu().numpy(), done_p.cpu().numpy()
         # done beams sorted by -p, stably, as the reference's sorted(..., key=-p) (:529) -- for all images at once
@@ -716,19 +697,42 @@ class RecurrentFusionModel(nn.Module):
         l_all = torch.from_numpy(np.take_along_axis(d_lp, rank[:, :, None], axis=1))
         p_all = np.take_along_axis(d_p, rank, axis=1)
         seq, seq_lp = s_all[:, 0].contiguous(), l_all[:, 0].contiguous()          # (B, S): best done beam per image
-        top_seq, top_prob, reason_batch = [], [], []
-        self.done_beams = []
+        counts = n_done.tolist()
+        probs = p_all.tolist()
+        top_seq = [s_all[k, :n] for k, n in enumerate(counts)]
+        top_prob = [probs[k][:n] for k, n in enumerate(counts)]
+        # self.done_beams[k] = the reference's list of {'seq', 'logps', 'p'} dicts, sorted by -p.  Thousands of small
+        # tensor views: built on first access (an eval loop that only reads the returned captions never pays for it)
+        self.done_beams = _LazyDoneBeams(s_all, l_all, probs, counts)
         heads = reason.unsqueeze(2).expand(-1, -1, W, -1)                          # (M+1, B, W, K) broadcast view
-        for k in range(B):
-            n = int(n_done[k])
-            s_k, l_k, p_k = s_all[k, :n], l_all[k, :n], p_all[k, :n].tolist()
-            self.done_beams.append([{'seq': a, 'logps': b_, 'p': c_}
-                                    for a, b_, c_ in zip(s_k.unbind(0), l_k.unbind(0), p_k)])
-            top_seq.append(s_k)
-            top_prob.append(p_k)
-            reason_batch.append([heads[j, k] for j in range(self.num_feat_array + 1)])
+        reason_batch = [list(t.unbind(0)) for t in heads.unbind(1)]
         return seq.to(dev), seq_lp.to(dev), top_seq, top_prob, reason_batch
 
+
+class _LazyDoneBeams(list):
+    """`model.done_beams` of sample_beam (misc/RecurrentFusionModel.py:529-531): a list (one entry per image) of lists of
+    {'seq': (S,) int64, 'logps': (S,) float, 'p': float}, best first.  Behaves as that list; the per-beam dicts of image k
+    are materialised when entry k is first read."""
+
+    def __init__(self, s_all, l_all, probs, counts):
+        super().__init__([None] * len(counts))
+        self._src = (s_all, l_all, probs, counts)
+
+    def _fill(self, k):
+        s_all, l_all, probs, counts = self._src
+        n = counts[k]
+        got = [{'seq': a, 'logps': b_, 'p': c_} for a, b_, c_ in zip(s_all[k, :n].unbind(0), l_all[k, :n].unbind(0), probs[k][:n])]
+        list.__setitem__(self, k, got)
+        return got
+
+    def __getitem__(self, k):
+        if isinstance(k, slice):
+            return [self[i] for i in range(*k.indices(len(self)))]
+        got = list.__getitem__(self, k)
+        return self._fill(k if k >= 0 else len(self) + k) if got is None else got
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
 
 
 class _Stepper:
