@@ -526,6 +526,15 @@ int rfn_beam_step(const float* logp, int64_t ldl, int V1, int W, int S, int t, i
                   int64_t* beam_seq, float* beam_lp, float* beam_sum, int32_t* order, int64_t* next_ids,
                   int64_t* done_seq, float* done_lp, float* done_p, int32_t* done_n, int32_t* active,
                   void* stream);
+/* The same step fed with every beam row's W best log-probs and tokens (rfn_log_softmax_topk, (NB * W, W) each) instead
+ * of the full rows -- all the reference ever reads of them (:463-466). */
+int rfn_beam_step_topk(const float* topv, const int32_t* topi, int V1, int W, int S, int t, int NB, int max_done,
+                       int64_t* beam_seq, float* beam_lp, float* beam_sum, int32_t* order, int64_t* next_ids,
+                       int64_t* done_seq, float* done_lp, float* done_p, int32_t* done_n, int32_t* active, void* stream);
+/* log-softmax of every row + its W <= 16 best entries, ordered (value descending, token ascending) as a descending
+ * sort lists them; the log-prob bits are those rfn_log_softmax_fwd writes, which are not materialised here. */
+int rfn_log_softmax_topk(const float* logits, int64_t ldl, int rows, int V1, int W, float* topv, int32_t* topi,
+                         void* stream);
 /* dst[r,:] = src[order[r],:]  (src != dst) */
 int rfn_gather_rows(const float* src, float* dst, const int32_t* order, int rows, int R, void* stream);
 
@@ -648,8 +657,9 @@ int rfn_decoder_fwd_sampled(const rfn_dims* d, int B, int S, const float* const*
                             float inv_temperature, const float* u_draw, const float* u_coin, float* log_prob, void* ws,
                             size_t ws_bytes, int train, uint64_t seed, void* stream);
 /* rfn_beam_loop: sample_beam's search (:451-531) for NB images x W beams: S x (rfn_beam_step, two rfn_gather_rows,
- *   rfn_decoder_step on the NB * W rows).  h / c (NB * W, R) in / out, h_alt / c_alt same-size scratch, logp (NB * W, V+1)
- *   scratch; the beam / done arrays as rfn_beam_step (zero-initialised by the caller; active = 1). */
+ *   rfn_decoder_step on the NB * W rows, ending in rfn_log_softmax_topk instead of the full log-softmax).  h / c
+ *   (NB * W, R) in / out, h_alt / c_alt same-size scratch, logp: 2 * NB * W * W floats of scratch (the rows' top-W lists);
+ *   the beam / done arrays as rfn_beam_step (zero-initialised by the caller; active = 1). */
 int rfn_beam_loop(const rfn_dims* d, int NB, int W, int S, const float* const* params, const float* comb,
                   const float* cproj, float* h, float* c, float* h_alt, float* c_alt, float* logp, int64_t* beam_seq,
                   float* beam_lp, float* beam_sum, int32_t* order, int64_t* ids, int64_t* done_seq, float* done_lp,

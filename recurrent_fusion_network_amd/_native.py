@@ -141,6 +141,8 @@ def _load():
         'rfn_multinomial_pick': (C.c_int, [P, L, I, I, F, P, P, F, P, L, P]),
         'rfn_beam_step': (C.c_int, [P, L, I, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P]),
         'rfn_gather_rows': (C.c_int, [P, P, P, I, I, P]),
+        'rfn_beam_step_topk': (C.c_int, [P, P, I, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P]),
+        'rfn_log_softmax_topk': (C.c_int, [P, L, I, I, I, P, P, P]),
         'rfn_prefix_ws_bytes': (SZ, [DP, I, I]),
         'rfn_prefix_fwd': (C.c_int, [DP, I, P, P, P, P, P, P, P, P, SZ, I, U64, P]),
         'rfn_prefix_fwd_from_state': (C.c_int, [DP, I, P, P, P, P, P, P, P, P, P, SZ, P]),

@@ -30,7 +30,8 @@ __global__ __launch_bounds__(BEAM_THREADS) void beam_step_k(
     const float* __restrict__ logp, long ldl, int V1, int W, int S, int t, int NB, int MAXD, int64_t* __restrict__ bs,
     float* __restrict__ bl, float* __restrict__ bsum, int32_t* __restrict__ order, int64_t* __restrict__ nxt,
     int64_t* __restrict__ done_seq, float* __restrict__ done_lp, float* __restrict__ done_p,
-    int32_t* __restrict__ done_n, int32_t* __restrict__ active) {
+    int32_t* __restrict__ done_n, int32_t* __restrict__ active, const float* __restrict__ topv,
+    const int32_t* __restrict__ topi) {
     __shared__ float ys[BEAM_MAX_W][BEAM_MAX_W];
     __shared__ int ix[BEAM_MAX_W][BEAM_MAX_W];
     __shared__ float wys[BEAM_WAVES][BEAM_MAX_W];
@@ -54,7 +55,9 @@ __global__ __launch_bounds__(BEAM_THREADS) void beam_step_k(
     const int live_rows = (t == 1) ? 1 : W;
     const int wpr = BEAM_WAVES / live_rows;          // waves per row (>= 1: W <= 16)
     const int q = wave / wpr, part = wave - q * wpr;
-    if (q < live_rows) {
+    if (topv) {
+        // the rows' top-W lists were produced with their log-softmax (rfn_log_softmax_topk): same values, same order
+    } else if (q < live_rows) {
         const float* row = logp + (long)(k * W + q) * ldl;
         const int chunk = (V1 + wpr - 1) / wpr;
         const int v0 = part * chunk, v1 = min(V1, v0 + chunk);
@@ -109,13 +112,19 @@ __global__ __launch_bounds__(BEAM_THREADS) void beam_step_k(
         }
     }
     // ---- snapshot of the beams before this step (forks read the OLD columns, :488-489) ----------------------
-    for (int i = tid; i < (t - 1) * W; i += BEAM_THREADS) {
+    for (int i = tid; i < (t - 1) * W; i += (int)blockDim.x) {
         const int s = i / W, w = i - s * W;
         prev_seq[s][w] = (int)bs[((long)s * NB + k) * W + w];
         prev_lp[s][w] = bl[((long)s * NB + k) * W + w];
     }
     __syncthreads();
-    if (tid < live_rows) {                           // merge the row's wave lists (each already sorted)
+    if (topv) {
+        if (tid < live_rows * cols) {
+            const int qq = tid / cols, c = tid - qq * cols;
+            ys[qq][c] = topv[(long)(k * W + qq) * W + c];
+            ix[qq][c] = topi[(long)(k * W + qq) * W + c];
+        }
+    } else if (tid < live_rows) {                    // merge the row's wave lists (each already sorted)
         int pos[BEAM_WAVES];
         for (int p = 0; p < wpr; ++p) pos[p] = 0;
         for (int c = 0; c < cols; ++c) {
@@ -184,7 +193,7 @@ __global__ __launch_bounds__(BEAM_THREADS) void beam_step_k(
         return;
     }
     // ---- phase 2b (all threads): forked columns and done beams ---------------------------------------------------
-    for (int i = tid; i < nnew * S; i += BEAM_THREADS) {
+    for (int i = tid; i < nnew * S; i += (int)blockDim.x) {
         const int vix = i / S, s = i - vix * S;
         const int ci = sel_ci[vix], qq = cand_q[ci];
         int64_t tok;
@@ -224,20 +233,21 @@ __global__ __launch_bounds__(BEAM_THREADS) void beam_step_k(
     }
 }
 
-extern "C" int rfn_beam_step(const float* logp, int64_t ldl, int V1, int W, int S, int t, int NB, int max_done,
-                             int64_t* beam_seq, float* beam_lp, float* beam_sum, int32_t* order, int64_t* next_ids,
-                             int64_t* done_seq, float* done_lp, float* done_p, int32_t* done_n, int32_t* active,
-                             void* stream) {
+static int beam_step_launch(const float* logp, int64_t ldl, const float* topv, const int32_t* topi, int V1, int W, int S, int t,
+                            int NB, int max_done, int64_t* beam_seq, float* beam_lp, float* beam_sum, int32_t* order,
+                            int64_t* next_ids, int64_t* done_seq, float* done_lp, float* done_p, int32_t* done_n,
+                            int32_t* active, void* stream) {
     if (W < 1 || W > BEAM_MAX_W || S < 1 || S > 32 || t < 1 || t > S || NB < 1 || V1 < 1 || max_done < 1)
         return RFN_ERR_SHAPE;
-    if (!logp || !beam_seq || !beam_lp || !beam_sum || !order || !next_ids || !done_seq || !done_lp || !done_p ||
-        !done_n || !active)
+    if ((!logp && !(topv && topi)) || !beam_seq || !beam_lp || !beam_sum || !order || !next_ids || !done_seq || !done_lp ||
+        !done_p || !done_n || !active)
         return RFN_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
+    const int threads = topv ? 256 : BEAM_THREADS;      // without the row scan the block only does the bookkeeping
 #define BEAM_LAUNCH(LWV)                                                                                             \
-    hipLaunchKernelGGL(beam_step_k<LWV>, dim3(NB), dim3(BEAM_THREADS), 0, st, logp, (long)ldl, V1, W, S, t, NB,       \
+    hipLaunchKernelGGL(beam_step_k<LWV>, dim3(NB), dim3(threads), 0, st, logp, (long)ldl, V1, W, S, t, NB,            \
                        max_done, beam_seq, beam_lp, beam_sum, order, next_ids, done_seq, done_lp, done_p, done_n,     \
-                       active)
+                       active, topv, topi)
     if (W <= 2) BEAM_LAUNCH(2);
     else if (W <= 4) BEAM_LAUNCH(4);
     else if (W <= 8) BEAM_LAUNCH(8);
@@ -245,6 +255,23 @@ extern "C" int rfn_beam_step(const float* logp, int64_t ldl, int V1, int W, int 
 #undef BEAM_LAUNCH
     RFN_CHECK_LAUNCH();
     return RFN_OK;
+}
+extern "C" int rfn_beam_step(const float* logp, int64_t ldl, int V1, int W, int S, int t, int NB, int max_done,
+                             int64_t* beam_seq, float* beam_lp, float* beam_sum, int32_t* order, int64_t* next_ids,
+                             int64_t* done_seq, float* done_lp, float* done_p, int32_t* done_n, int32_t* active,
+                             void* stream) {
+    if (!logp) return RFN_ERR_ARG;
+    return beam_step_launch(logp, ldl, nullptr, nullptr, V1, W, S, t, NB, max_done, beam_seq, beam_lp, beam_sum, order, next_ids,
+                            done_seq, done_lp, done_p, done_n, active, stream);
+}
+// The same step fed with every beam row's W best log-probs (rfn_log_softmax_topk) instead of the full rows.
+extern "C" int rfn_beam_step_topk(const float* topv, const int32_t* topi, int V1, int W, int S, int t, int NB, int max_done,
+                                  int64_t* beam_seq, float* beam_lp, float* beam_sum, int32_t* order, int64_t* next_ids,
+                                  int64_t* done_seq, float* done_lp, float* done_p, int32_t* done_n, int32_t* active,
+                                  void* stream) {
+    if (!topv || !topi) return RFN_ERR_ARG;
+    return beam_step_launch(nullptr, 0, topv, topi, V1, W, S, t, NB, max_done, beam_seq, beam_lp, beam_sum, order, next_ids,
+                            done_seq, done_lp, done_p, done_n, active, stream);
 }
 
 // dst[r, :] = src[order[r], :]  -- recurrent-state re-gather of the forked beams (:499-501)

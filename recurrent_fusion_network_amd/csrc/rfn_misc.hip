@@ -229,6 +229,39 @@ extern "C" int rfn_embed_bwd(const float* dout, int64_t ldo, const int64_t* ids,
 }
 
 // ---- log-softmax over the vocabulary --------------------------------------------------------------
+// One block per row.  Rows of up to 256 x 4 x LSM_R4 = 10240 logits (16-B aligned, V1 % 4 == 0) are read ONCE, 16 B per
+// lane, and held in registers for the max, the sum and the output pass; other rows take the three-pass scalar form.
+// log_softmax_row() is shared by the plain kernel and by the top-k kernel of the beam search, so both produce the same
+// log-prob bits for a row.
+typedef float lsm_f32x4 __attribute__((ext_vector_type(4)));
+#define LSM_R4 10
+template <bool VEC>
+__device__ __forceinline__ float log_softmax_row(const float* __restrict__ x, int V1, lsm_f32x4 (&xr)[LSM_R4], float* red) {
+    float m = -INFINITY, s = 0.f;
+    if constexpr (VEC) {
+        const int n4 = V1 >> 2;
+#pragma unroll
+        for (int j = 0; j < LSM_R4; ++j) {
+            const int i = threadIdx.x + 256 * j;
+            xr[j] = lsm_f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            if (i < n4) xr[j] = *reinterpret_cast<const lsm_f32x4*>(x + 4 * i);
+        }
+#pragma unroll
+        for (int j = 0; j < LSM_R4; ++j) m = fmaxf(m, fmaxf(fmaxf(xr[j][0], xr[j][1]), fmaxf(xr[j][2], xr[j][3])));
+        m = block_max_256(m, red);
+#pragma unroll
+        for (int j = 0; j < LSM_R4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s += expf(xr[j][e] - m);      // exp(-inf) = 0 for the padding lanes
+    } else {
+        for (int v = threadIdx.x; v < V1; v += 256) m = fmaxf(m, x[v]);
+        m = block_max_256(m, red);
+        for (int v = threadIdx.x; v < V1; v += 256) s += expf(x[v] - m);
+    }
+    s = block_sum_256(s, red);
+    return m + logf(s);
+}
+template <bool VEC>
 __global__ __launch_bounds__(256) void log_softmax_fwd_k(const float* __restrict__ logits, long ldl, int V1,
                                                          int inner, long s_inner, long s_outer,
                                                          float* __restrict__ out) {
@@ -236,21 +269,142 @@ __global__ __launch_bounds__(256) void log_softmax_fwd_k(const float* __restrict
     const int r = blockIdx.x;
     const float* x = logits + r * ldl;
     float* o = out + (long)(r % inner) * s_inner + (long)(r / inner) * s_outer;
-    float m = -INFINITY;
-    for (int v = threadIdx.x; v < V1; v += 256) m = fmaxf(m, x[v]);
-    m = block_max_256(m, red);
-    float s = 0.f;
-    for (int v = threadIdx.x; v < V1; v += 256) s += expf(x[v] - m);
-    s = block_sum_256(s, red);
-    const float lse = m + logf(s);
-    for (int v = threadIdx.x; v < V1; v += 256) o[v] = x[v] - lse;
+    lsm_f32x4 xr[LSM_R4];
+    const float lse = log_softmax_row<VEC>(x, V1, xr, red);
+    if constexpr (VEC) {
+        const int n4 = V1 >> 2;
+#pragma unroll
+        for (int j = 0; j < LSM_R4; ++j) {
+            const int i = threadIdx.x + 256 * j;
+            if (i < n4) *reinterpret_cast<lsm_f32x4*>(o + 4 * i) = xr[j] - lse;
+        }
+    } else {
+        for (int v = threadIdx.x; v < V1; v += 256) o[v] = x[v] - lse;
+    }
+}
+static bool lsm_vec_ok(const float* logits, int64_t ldl, int V1, const float* out, int64_t s_inner, int64_t s_outer) {
+    return V1 % 4 == 0 && V1 <= 256 * 4 * LSM_R4 && ldl % 4 == 0 && rfn_aligned16(logits) &&
+           (!out || (rfn_aligned16(out) && s_inner % 4 == 0 && s_outer % 4 == 0));
 }
 extern "C" int rfn_log_softmax_fwd(const float* logits, int64_t ldl, int rows, int V1, int inner,
                                    int64_t out_s_inner, int64_t out_s_outer, float* out, void* stream) {
     if (rows <= 0 || V1 <= 0 || inner <= 0) return RFN_ERR_SHAPE;
     if (!logits || !out) return RFN_ERR_ARG;
-    hipLaunchKernelGGL(log_softmax_fwd_k, dim3(rows), dim3(256), 0, (hipStream_t)stream, logits, (long)ldl, V1,
-                       inner, (long)out_s_inner, (long)out_s_outer, out);
+    if (lsm_vec_ok(logits, ldl, V1, out, out_s_inner, out_s_outer))
+        hipLaunchKernelGGL(log_softmax_fwd_k<true>, dim3(rows), dim3(256), 0, (hipStream_t)stream, logits, (long)ldl, V1,
+                           inner, (long)out_s_inner, (long)out_s_outer, out);
+    else
+        hipLaunchKernelGGL(log_softmax_fwd_k<false>, dim3(rows), dim3(256), 0, (hipStream_t)stream, logits, (long)ldl, V1,
+                           inner, (long)out_s_inner, (long)out_s_outer, out);
+    RFN_CHECK_LAUNCH();
+    return RFN_OK;
+}
+
+// ---- log-softmax + top-W of every row, without materialising the log-probs (beam search) ---------------------------------
+// sample_beam only ever looks at the W best log-probs of a beam row (misc/RecurrentFusionModel.py:463-466: a full sort, of
+// which columns 0 .. beam_size-1 are read).  topv[r, c] / topi[r, c], c < W: the c-th largest log-prob of row r and its
+// token, ordered (value descending, token ascending) -- the order the reference's descending sort lists them -- computed
+// from the same log-prob bits rfn_log_softmax_fwd writes.  W <= 16.
+#define LSM_TOPW 16
+__device__ __forceinline__ bool lsm_before(float x, int i, float y, int j) { return x > y || (x == y && i < j); }
+template <bool VEC, int LW>
+__global__ __launch_bounds__(256) void log_softmax_topk_k(const float* __restrict__ logits, long ldl, int V1, int W,
+                                                          float* __restrict__ topv, int* __restrict__ topi) {
+    __shared__ float red[4];
+    __shared__ float wv[4][LSM_TOPW];
+    __shared__ int wi[4][LSM_TOPW];
+    const int r = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* x = logits + r * ldl;
+    lsm_f32x4 xr[LSM_R4];
+    const float lse = log_softmax_row<VEC>(x, V1, xr, red);
+    float tv[LW];
+    int ti[LW];
+#pragma unroll
+    for (int j = 0; j < LW; ++j) {
+        tv[j] = -INFINITY;
+        ti[j] = 0x7fffffff;
+    }
+    auto offer = [&](float lp, int v) {      // sorted insert by compare-exchange down the list (ascending v per thread)
+        if (lsm_before(lp, v, tv[LW - 1], ti[LW - 1])) {
+#pragma unroll
+            for (int j = 0; j < LW; ++j) {
+                const bool fwd = lsm_before(lp, v, tv[j], ti[j]);
+                const float ov = tv[j];
+                const int oi = ti[j];
+                tv[j] = fwd ? lp : ov;
+                ti[j] = fwd ? v : oi;
+                lp = fwd ? ov : lp;
+                v = fwd ? oi : v;
+            }
+        }
+    };
+    if constexpr (VEC) {
+        const int n4 = V1 >> 2;
+#pragma unroll
+        for (int j = 0; j < LSM_R4; ++j) {
+            const int i = threadIdx.x + 256 * j;
+            if (i < n4) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) offer(xr[j][e] - lse, 4 * i + e);
+            }
+        }
+    } else {
+        for (int v = threadIdx.x; v < V1; v += 256) offer(x[v] - lse, v);
+    }
+    const int cols = min(W, V1);
+    for (int c = 0; c < cols; ++c) {             // wave merge: pop the best head `cols` times
+        float best = tv[0];
+        int bi = ti[0];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ob = __shfl_xor(best, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (lsm_before(ob, oi, best, bi)) {
+                best = ob;
+                bi = oi;
+            }
+        }
+        if (ti[0] == bi && bi != 0x7fffffff) {
+#pragma unroll
+            for (int j = 0; j + 1 < LW; ++j) {
+                tv[j] = tv[j + 1];
+                ti[j] = ti[j + 1];
+            }
+            tv[LW - 1] = -INFINITY;
+            ti[LW - 1] = 0x7fffffff;
+        }
+        if (lane == 0) {
+            wv[wave][c] = best;
+            wi[wave][c] = bi;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {                      // merge the four waves' sorted lists
+        int pos[4] = {0, 0, 0, 0};
+        for (int c = 0; c < cols; ++c) {
+            int bp = -1;
+            for (int p = 0; p < 4; ++p) {
+                if (pos[p] >= cols || wi[p][pos[p]] == 0x7fffffff) continue;
+                if (bp < 0 || lsm_before(wv[p][pos[p]], wi[p][pos[p]], wv[bp][pos[bp]], wi[bp][pos[bp]])) bp = p;
+            }
+            topv[(long)r * W + c] = wv[bp][pos[bp]];
+            topi[(long)r * W + c] = wi[bp][pos[bp]];
+            ++pos[bp];
+        }
+    }
+}
+extern "C" int rfn_log_softmax_topk(const float* logits, int64_t ldl, int rows, int V1, int W, float* topv, int32_t* topi,
+                                    void* stream) {
+    if (rows <= 0 || V1 <= 0 || W < 1 || W > LSM_TOPW) return RFN_ERR_SHAPE;
+    if (!logits || !topv || !topi) return RFN_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const bool vec = lsm_vec_ok(logits, ldl, V1, nullptr, 0, 0);
+#define LSM_LAUNCH(VECV, LWV)                                                                                              \
+    hipLaunchKernelGGL((log_softmax_topk_k<VECV, LWV>), dim3(rows), dim3(256), 0, st, logits, (long)ldl, V1, W, topv, topi)
+    if (W <= 4) { if (vec) LSM_LAUNCH(true, 4); else LSM_LAUNCH(false, 4); }
+    else if (W <= 8) { if (vec) LSM_LAUNCH(true, 8); else LSM_LAUNCH(false, 8); }
+    else { if (vec) LSM_LAUNCH(true, 16); else LSM_LAUNCH(false, 16); }
+#undef LSM_LAUNCH
     RFN_CHECK_LAUNCH();
     return RFN_OK;
 }

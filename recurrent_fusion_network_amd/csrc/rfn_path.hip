@@ -1472,7 +1472,7 @@ extern "C" int rfn_decoder_prepare(const rfn_dims* d, int B, const float* const*
 static int decoder_step_impl(const rfn_dims* d, int B, const float* const* prm, const float* comb, const float* cproj,
                              const int64_t* ids, const float* xt, int64_t ld_xt, float* h, float* c, float* logits,
                              float* logp, int64_t ld_logp, void* ws, size_t ws_bytes, uint64_t seed, int step,
-                             void* st) {
+                             void* st, float* topv = nullptr, int32_t* topi = nullptr, int topw = 0) {
     RFN_TRY(check_dims(d));
     if (B < 1 || step < 0) return RFN_ERR_SHAPE;
     if (!prm || !comb || !cproj || (!ids && !xt) || !h || !c || !ws) return RFN_ERR_ARG;
@@ -1495,12 +1495,13 @@ static int decoder_step_impl(const rfn_dims* d, int B, const float* const* prm, 
     RFN_TRY(gemm1(B, GD, xt ? seg_lin(xt, ld_xt, prm[P.dec(0)], E, E, prm[P.dec(1)]) : seg_lin(x, E, prm[P.dec(0)], E, E, prm[P.dec(1)]),
                   g, GD, 0, gx_whole));
     RFN_TRY(decoder_cell_core(d, B, prm, comb, cproj, h, c, h, c, hp, al, z, g, gx, seed, step, st));
-    if (logits || logp) {
+    if (logits || logp || topv) {
         RFN_TRY(gemm_logits(B, V1, h, R, prm[P.logit_w()], prm[P.logit_b()], lg, gx_whole));
         if (logp) {
             if (ld_logp < V1) return RFN_ERR_SHAPE;
             RFN_TRY(rfn_log_softmax_fwd(lg, V1, B, V1, B, ld_logp, 0, logp, st));
         }
+        if (topv) RFN_TRY(rfn_log_softmax_topk(lg, V1, B, V1, topw, topv, topi, st));   // beam search: W best per row, no full rows
     }
     return RFN_OK;
 }
@@ -1585,23 +1586,29 @@ extern "C" int rfn_beam_loop(const rfn_dims* d, int NB, int W, int S, const floa
                              int64_t* beam_seq, float* beam_lp, float* beam_sum, int32_t* order, int64_t* ids,
                              int64_t* done_seq, float* done_lp, float* done_p, int32_t* done_n, int32_t* active, int max_done,
                              void* ws, size_t ws_bytes, uint64_t seed, void* st) {
+    // `logp` holds, per beam row, its W best log-probs and their tokens (2 * W values): the search never looks at more
+    // (:463-466), so the full (rows, V+1) log-prob matrix is neither written nor read back
     RFN_TRY(check_dims(d));
     if (NB < 1 || W < 1 || S < 1) return RFN_ERR_SHAPE;
     if (!prm || !comb || !cproj || !h || !c || !h_alt || !c_alt || !logp || !ids || !order || !ws) return RFN_ERR_ARG;
     const int rows = NB * W, V1 = d->V1, R = d->R;
+    if (W > 16) return RFN_ERR_SHAPE;
+    float* topv = logp;
+    int32_t* topi = (int32_t*)(logp + (size_t)rows * W);
     float *hc = h, *cc = c, *ha = h_alt, *ca = c_alt;
     if (hipMemsetAsync(ids, 0, (size_t)rows * sizeof(int64_t), (hipStream_t)st) != hipSuccess) return RFN_ERR_LAUNCH;
     for (int t = 0; t <= S; ++t) {
         if (t >= 1) {
-            RFN_TRY(rfn_beam_step(logp, V1, V1, W, S, t, NB, max_done, beam_seq, beam_lp, beam_sum, order, ids, done_seq, done_lp,
-                                  done_p, done_n, active, st));
+            RFN_TRY(rfn_beam_step_topk(topv, topi, V1, W, S, t, NB, max_done, beam_seq, beam_lp, beam_sum, order, ids, done_seq,
+                                       done_lp, done_p, done_n, active, st));
             if (t == S) break;   // the reference still runs one more decoder step whose output is never used
             RFN_TRY(rfn_gather_rows(hc, ha, order, rows, R, st));
             RFN_TRY(rfn_gather_rows(cc, ca, order, rows, R, st));
             float* x = hc; hc = ha; ha = x;
             x = cc; cc = ca; ca = x;
         }
-        RFN_TRY(rfn_decoder_step(d, rows, prm, comb, cproj, ids, hc, cc, nullptr, logp, V1, ws, ws_bytes, seed, t, st));
+        RFN_TRY(decoder_step_impl(d, rows, prm, comb, cproj, ids, nullptr, 0, hc, cc, nullptr, nullptr, 0, ws, ws_bytes, seed, t, st,
+                                  topv, topi, W));
     }
     if (hc != h) {   // an odd number of swaps: bring the live state home
         RFN_TRY(copy_f32(h, hc, (size_t)rows * R, st));

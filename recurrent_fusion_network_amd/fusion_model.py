@@ -679,7 +679,7 @@ class RecurrentFusionModel(nn.Module):
             done_p = torch.zeros(B, max_done, device=dev)
             done_n = torch.zeros(B, dtype=torch.int32, device=dev)
             active = torch.ones(B, dtype=torch.int32, device=dev)
-            logp = torch.empty(rows, V1, device=dev)
+            logp = torch.empty(2 * rows * W, device=dev)           # the rows' top-W lists (rfn_beam_loop)
             h_alt, c_alt = torch.empty_like(stepper.h), torch.empty_like(stepper.c)
             # the whole search in one call: S x (bookkeeping, state re-gather, decoder step on the B * W rows)
             N.check(N.lib.rfn_beam_loop(C.byref(stepper.d), B, W, S, stepper.table, stepper.comb.data_ptr(),

@@ -833,6 +833,53 @@ def test_beam_step_kernel_matches_python_bookkeeping(dev, W, V1, S, ties):
             assert abs(float(dp[k, j]) - rp) < 1e-5
 
 
+@pytest.mark.parametrize('W,V1,rows,ties', [(5, 9488, 37, False), (3, 301, 12, True), (16, 9488, 6, False), (8, 50, 9, True),
+                                             (5, 10, 4, False)])
+def test_log_softmax_topk_and_the_beam_step_it_feeds(dev, W, V1, rows, ties):
+    """rfn_log_softmax_topk: the W best entries of every row of log_softmax(logits), ordered (value descending, token
+    ascending), from the same log-prob bits rfn_log_softmax_fwd writes -- and rfn_beam_step_topk on those lists does exactly
+    what rfn_beam_step does on the full rows (vectorised and scalar row forms, ties, W up to 16, W > V+1)."""
+    n = N()
+    st = n.stream_ptr()
+    g = torch.Generator().manual_seed(W * 1000 + V1)
+    logits = torch.randn(rows, V1, generator=g) * 3.0
+    if ties:
+        logits = torch.round(logits)
+    lg = logits.to(dev)
+    lp = torch.empty(rows, V1, device=dev)
+    n.check(n.lib.rfn_log_softmax_fwd(lg.data_ptr(), V1, rows, V1, rows, V1, 0, lp.data_ptr(), st))
+    assert maxerr(lp, torch.log_softmax(logits.double(), 1)) < 2e-6
+    topv = torch.full((rows, W), float('nan'), device=dev)
+    topi = torch.full((rows, W), -1, dtype=torch.int32, device=dev)
+    n.check(n.lib.rfn_log_softmax_topk(lg.data_ptr(), V1, rows, V1, W, topv.data_ptr(), topi.data_ptr(), st))
+    cols = min(W, V1)
+    # reference order: stable sort of the log-prob bits, descending (ties keep the lower token first)
+    order = torch.sort(lp.cpu(), dim=1, descending=True, stable=True).indices[:, :cols]
+    assert torch.equal(topi[:, :cols].cpu().long(), order)
+    assert torch.equal(topv[:, :cols].cpu(), lp.cpu().gather(1, order))
+    # one beam step from the lists == one beam step from the rows (NB images x W beams need rows == NB * W)
+    NB = rows // W
+    if NB < 1:
+        return
+    S, MAXD = 4, W * 4
+
+    def fresh():
+        return dict(bs=torch.zeros(S, NB, W, dtype=torch.long, device=dev), bl=torch.zeros(S, NB, W, device=dev),
+                    bsum=torch.zeros(NB, W, device=dev), order=torch.zeros(NB * W, dtype=torch.int32, device=dev),
+                    ids=torch.zeros(NB * W, dtype=torch.long, device=dev),
+                    dseq=torch.zeros(NB, MAXD, S, dtype=torch.long, device=dev), dlp=torch.zeros(NB, MAXD, S, device=dev),
+                    dp=torch.zeros(NB, MAXD, device=dev), dn=torch.zeros(NB, dtype=torch.int32, device=dev),
+                    act=torch.ones(NB, dtype=torch.int32, device=dev))
+    a, b = fresh(), fresh()
+    for t in (1, 2, 3):
+        n.check(n.lib.rfn_beam_step(lp.data_ptr(), V1, V1, W, S, t, NB, MAXD, *[a[k].data_ptr() for k in
+                                    ('bs', 'bl', 'bsum', 'order', 'ids', 'dseq', 'dlp', 'dp', 'dn', 'act')], st))
+        n.check(n.lib.rfn_beam_step_topk(topv.data_ptr(), topi.data_ptr(), V1, W, S, t, NB, MAXD, *[b[k].data_ptr() for k in
+                                         ('bs', 'bl', 'bsum', 'order', 'ids', 'dseq', 'dlp', 'dp', 'dn', 'act')], st))
+        for k in a:
+            assert torch.equal(a[k], b[k]), (t, k)
+
+
 def test_gemm_randomized_shapes_layouts_segments_groups(dev):
     """60 random problems: all operand layouts, ragged / tiny / large dims, 1-4 K segments of different lengths
     (different per group), 1-5 groups, bias on some segments, accumulate, padded ldc/lda/ldb, split-K scratch on
