@@ -317,6 +317,54 @@ __global__ __launch_bounds__(256) void log_softmax_topk_k(const float* __restric
     const float* x = logits + r * ldl;
     lsm_f32x4 xr[LSM_R4];
     const float lse = log_softmax_row<VEC>(x, V1, xr, red);
+    const int cols = min(W, V1);
+    // Threshold first: the `cols`-th largest of the 256 threads' LOCAL maxima is a lower bound of the row's `cols`-th largest
+    // log-prob (those maxima are distinct elements of the row), so only entries >= it can make the list -- a handful per
+    // row instead of every entry going through a sorted insert.
+    float lm = -INFINITY;
+    if constexpr (VEC) {
+#pragma unroll
+        for (int j = 0; j < LSM_R4; ++j) lm = fmaxf(lm, fmaxf(fmaxf(xr[j][0], xr[j][1]), fmaxf(xr[j][2], xr[j][3])));
+    } else {
+        for (int v = threadIdx.x; v < V1; v += 256) lm = fmaxf(lm, x[v]);
+    }
+    lm -= lse;      // x - lse is monotone in x: the maximum of the log-probs is the log-prob of the maximum
+    {
+        float mine = lm;
+        for (int c = 0; c < cols; ++c) {         // wave: pop the largest local maximum `cols` times
+            float best = mine;
+            int bl_ = lane;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ob = __shfl_xor(best, o, 64);
+                const int ol = __shfl_xor(bl_, o, 64);
+                if (ob > best || (ob == best && ol < bl_)) {
+                    best = ob;
+                    bl_ = ol;
+                }
+            }
+            if (lane == bl_) mine = -INFINITY;
+            if (lane == 0) wv[wave][c] = best;
+        }
+    }
+    __syncthreads();
+    float thr;
+    {
+        int pos[4] = {0, 0, 0, 0};
+        thr = -INFINITY;
+        for (int c = 0; c < cols; ++c) {         // every thread merges the four sorted lists redundantly (cols <= 16)
+            int bp = 0;
+            float bv = -INFINITY;
+            for (int p = 0; p < 4; ++p)
+                if (pos[p] < cols && wv[p][pos[p]] > bv) {
+                    bv = wv[p][pos[p]];
+                    bp = p;
+                }
+            thr = bv;
+            ++pos[bp];
+        }
+    }
+    __syncthreads();                             // wv is reused by the merge below
     float tv[LW];
     int ti[LW];
 #pragma unroll
@@ -325,7 +373,7 @@ __global__ __launch_bounds__(256) void log_softmax_topk_k(const float* __restric
         ti[j] = 0x7fffffff;
     }
     auto offer = [&](float lp, int v) {      // sorted insert by compare-exchange down the list (ascending v per thread)
-        if (lsm_before(lp, v, tv[LW - 1], ti[LW - 1])) {
+        if (lp >= thr && lsm_before(lp, v, tv[LW - 1], ti[LW - 1])) {
 #pragma unroll
             for (int j = 0; j < LW; ++j) {
                 const bool fwd = lsm_before(lp, v, tv[j], ti[j]);
@@ -351,7 +399,6 @@ __global__ __launch_bounds__(256) void log_softmax_topk_k(const float* __restric
     } else {
         for (int v = threadIdx.x; v < V1; v += 256) offer(x[v] - lse, v);
     }
-    const int cols = min(W, V1);
     for (int c = 0; c < cols; ++c) {             // wave merge: pop the best head `cols` times
         float best = tv[0];
         int bi = ti[0];

@@ -9,16 +9,18 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _random_case(seed):
+def _random_case(seed, x3=False):
+    """x3: shapes the bf16-plane GEMM accepts (att_hid_size a multiple of its 256-wide output groups, feature widths
+    multiples of 4), everything else as random as before -- so RFN_GEMM_OPT_BF16X3 | _ANY_SIZE really takes it."""
     from oracle import rfn_oracle as O
-    rng = np.random.default_rng(seed)
+    rng = np.random.default_rng(seed + (5000 if x3 else 0))
     M = int(rng.integers(1, 5))
-    info = [dict(att_num=int(rng.integers(1, 41)), att_feat_size=int(rng.integers(4, 71)),
+    info = [dict(att_num=int(rng.integers(1, 41)), att_feat_size=int(rng.integers(1, 18)) * 4 if x3 else int(rng.integers(4, 71)),
                  fc_feat_size=int(rng.integers(4, 51))) for _ in range(M)]
     extra = dict(review_maxout=int(rng.integers(0, 2)), maxout=int(rng.integers(0, 2)),
                  use_label_smoothing=int(rng.integers(0, 2)), label_smoothing_epsilon=0.1)
     cfg = O.make_cfg(info, vocab_size=int(rng.integers(20, 121)), rnn_size=int(rng.integers(8, 41)),
-                     input_encoding_size=int(rng.integers(8, 41)), att_hid_size=int(rng.integers(8, 41)),
+                     input_encoding_size=int(rng.integers(8, 41)), att_hid_size=256 if x3 else int(rng.integers(8, 41)),
                      num_review_steps_0=int(rng.integers(1, 7)), num_review_steps=int(rng.integers(1, 7)),
                      top_words_count=int(rng.integers(5, 31)), seq_length=int(rng.integers(2, 9)), **extra)
     B = int(rng.integers(1, 7))
@@ -32,13 +34,19 @@ def _random_case(seed):
     return O, cfg, P, (fc, att, labels, masks, top)
 
 
+@pytest.mark.parametrize('gemm', ['exact', 'bf16x3'])
 @pytest.mark.parametrize('seed', range(24))
-def test_random_configuration_matches_oracle(dev, seed):
+def test_random_configuration_matches_oracle(dev, seed, gemm):
+    """gemm = bf16x3: the same 24 seeds on shapes the plane GEMM takes, with RFN_GEMM_OPT_BF16X3 | _ANY_SIZE: same bars
+    against the oracle as the exact path, greedy ids included."""
     import recurrent_fusion_network_amd as R
-    O, cfg, P, (fc, att, labels, masks, top) = _random_case(seed)
+    O, cfg, P, (fc, att, labels, masks, top) = _random_case(seed, x3=(gemm == 'bf16x3'))
     model = R.RecurrentFusionModel(cfg)
     model.load_state_dict(P)
     model = model.to(dev).eval()
+    if gemm == 'bf16x3':
+        import recurrent_fusion_network_amd._native as N
+        model.gemm_flags |= N.GEMM_OPT_BF16X3 | N.GEMM_OPT_BF16X3_ANY_SIZE
     d = lambda ts: [t.to(dev) for t in ts]  # noqa: E731
     lp, reason = model(d(fc), d(att), labels.to(dev))
     crit = R.ReviewNetEnsembleCriterion(cfg)
