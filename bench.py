@@ -232,6 +232,12 @@ def parse_args(argv=None):
                          "(the 'bf16x3' object of the JSON line; `value` is always the exact-f32 measurement)")
     ap.add_argument('--cpu-sample', type=int, default=CPU_SAMPLE_B, help='captions in the CPU-baseline sample')
     ap.add_argument('--micro-batches', type=int, default=-1, help='override model.micro_batches (-1: model default)')
+    ap.add_argument('--lds-lean', action='store_true',
+                    help='force RFN_GEMM_OPT_LDS_LEAN (GradSync sets it by itself when world > 1): the big-tile configuration '
+                         'of a data-parallel run on one rank')
+    ap.add_argument('--digest', action='store_true',
+                    help="add config.digest: a hash of the loss bits and of every parameter bucket's float64 sum / sum of "
+                         'squares after the timed steps -- two runs that agree bit for bit print the same digest')
     ap.add_argument('--selftest-launch', action='store_true',
                     help='launcher / rendezvous check without a GPU: ranks meet, reduce a timing, rank 0 prints the line')
     args = ap.parse_args(argv)
@@ -436,6 +442,9 @@ def run_train(args, rank, world, dev, R, DP):
     if x3:
         import recurrent_fusion_network_amd._native as N
         model.gemm_flags |= N.GEMM_OPT_BF16X3
+    if args.lds_lean:
+        import recurrent_fusion_network_amd._native as N
+        model.gemm_flags |= N.GEMM_OPT_LDS_LEAN
     if args.micro_batches >= 0 and hasattr(model, 'micro_batches'):
         model.micro_batches = args.micro_batches
     crit = R.ReviewNetEnsembleCriterion(cfg)
@@ -512,6 +521,15 @@ def run_train(args, rank, world, dev, R, DP):
     elapsed = DP.max_over_ranks(time.perf_counter() - t0, world, dev)             # thread was on a CPU (1.0 = never descheduled)
     dump_trace('exact' if not x3 else 'bf16x3', args.steps)
     final_loss = float(loss.detach())
+    digest = None
+    if args.digest:
+        import hashlib
+        import struct
+        hsh = hashlib.sha256(struct.pack('<f', final_loss))
+        for name in model.bucket_names():
+            flat = opt.flat[name]['p'].double()
+            hsh.update(struct.pack('<dd', float(flat.sum()), float((flat * flat).sum())))
+        digest = hsh.hexdigest()[:16]
     # the same W + K steps once more with the two long products on the bf16 matrix cores: reported
     # beside the headline as out['bf16x3'], never as `value`
     alt = None
@@ -585,7 +603,7 @@ def run_train(args, rank, world, dev, R, DP):
                    'captions_per_gpu': B, 'global_batch': global_B,
                    'parallelism': 'dp%d (batch sharded, RCCL all-reduce of grads)' % world if world > 1 else 'single GPU',
                    'micro_batches': int(getattr(model, 'micro_batches', 1) or 1),
-                   'final_loss': round(final_loss, 4)},
+                   'final_loss': round(final_loss, 4), 'gemm_flags': int(model.gemm_flags), 'digest': digest},
     }
     if x3:
         out['dtype'] = 'f32 (the two long products as 3 bf16 planes x 6 MFMA products, f32 accumulate; the rest exact f32)'

@@ -74,3 +74,26 @@ def test_single_gpu_line_has_roofline_and_cpu_baseline():
     assert out['n_gpus'] == 1 and out['rccl_ranks'] == 1
     assert set(out['roofline']) >= {'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'}
     assert out['cpu_baseline']['kind'] == 'port' and out['cpu_baseline']['value'] > 0
+
+
+@pytest.mark.gpu
+def test_one_rank_rccl_group_with_lean_tiles_is_bit_equal_to_the_plain_step():
+    """DP readiness on one GPU: the full train step of bench.py inside a 1-rank RCCL process group
+    (RFN_FORCE_DIST=1: every bucket goes through an asynchronous nccl all-reduce) with the big-tile GEMMs in the lean LDS
+    configuration a data-parallel run uses (RFN_GEMM_OPT_LDS_LEAN) ends in the same bits as the plain single-process
+    step: same loss, same parameters after two optimizer steps (config.digest)."""
+    base = [sys.executable, os.path.join(ROOT, 'bench.py'), '--batch', '32', '--steps', '2', '--warmup', '1', '--settle', '0',
+            '--no-cpu-baseline', '--no-alt-line', '--digest']
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.pop('RFN_FORCE_DIST', None)
+    plain = subprocess.run(base, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert plain.returncode == 0, plain.stderr[-2000:]
+    a = json.loads([l for l in plain.stdout.splitlines() if l.startswith('{"metric"')][-1])
+    env_d = dict(env, RFN_FORCE_DIST='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(29500 + os.getpid() % 1000))
+    dist = subprocess.run(base + ['--lds-lean'], env=env_d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                          timeout=900)
+    assert dist.returncode == 0, dist.stderr[-2000:]
+    b = json.loads([l for l in dist.stdout.splitlines() if l.startswith('{"metric"')][-1])
+    assert a['rccl_ranks'] == 1 and a['dist_backend'] is None and a['config']['gemm_flags'] == 0
+    assert b['rccl_ranks'] == 1 and b['dist_backend'] == 'nccl' and b['config']['gemm_flags'] & 1
+    assert a['config']['digest'] and a['config']['digest'] == b['config']['digest'], (a['config'], b['config'])

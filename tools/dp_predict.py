@@ -1,0 +1,63 @@
+"""Predicted data-parallel step times from single-GPU shard measurements (profiles/r03_shards.jsonl: bench.py --batch B on
+one MI355X) -- so that the first real multi-GPU run has numbers to be compared with.
+
+Model.  A rank's step = its shard's compute time (measured) + the part of the gradient exchange that is still running
+when backward ends.  The exchange is one ring all-reduce per bucket, issued in the order backward finishes the buckets
+(decoder, core, then enc_i a / enc_i b per encoder); bucket b of S_b bytes takes 2 (N-1)/N S_b / BW on the RCCL stream,
+buckets queue behind each other, and a bucket cannot start before backward has produced it.  Ready times are taken as
+fractions of the measured step (from the phase trace of the C3 step, profiles/r03_phases.txt: backward starts at 46 % of
+the step, decoder bucket at 53 %, core at 60 %, encoder i's big bucket (a) at 60 % + i * 9.1 % + 0.5 %, its small bucket
+(b) at 60 % + (i + 1) * 9.1 %, clamp+Adam is the last 3.5 %) -- the fractions hold within a few points down to B = 32
+because every phase scales with the batch except Adam.  BW: 153 GB/s = one xGMI link (a single ring, the pessimistic
+end), 7 x 153 GB/s = all links of the fully connected node (the optimistic end).
+
+    python tools/dp_predict.py [profiles/r03_shards.jsonl]
+"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, 'profiles', 'r03_shards.jsonl')
+meas = {}
+for ln in open(path):
+    d = json.loads(ln)
+    meas[d['config']['captions_per_gpu']] = (d['ms_per_step'], d['bf16x3']['ms_per_step'])
+
+MB = 1e6
+BUCKETS = [('decoder', 54 * MB, 0.53), ('core', 262 * MB, 0.60)]
+for i in range(4):
+    BUCKETS.append(('enc%da' % i, 277 * MB, 0.60 + i * 0.09125 + 0.005))
+    BUCKETS.append(('enc%db' % i, 34 * MB, 0.60 + (i + 1) * 0.09125))
+ADAM = 0.035          # share of the step after the last bucket is produced
+TOTAL = sum(b[1] for b in BUCKETS)
+
+
+def step_ms(compute_ms, n, bw):
+    """compute_ms: measured single-GPU step of the shard; returns (step, exposed) in ms."""
+    if n == 1:
+        return compute_ms, 0.0
+    t_done = 0.0
+    for _, size, frac in BUCKETS:
+        ready = frac * compute_ms
+        t_done = max(t_done, ready) + 2.0 * (n - 1) / n * size / bw * 1e3
+    bwd_end = (1.0 - ADAM) * compute_ms
+    exposed = max(0.0, t_done - bwd_end)
+    return compute_ms + exposed, exposed
+
+
+print('gradient exchange per step: %.2f GB in %d buckets; ring all-reduce moves 2 (N-1)/N of that per GPU' % (TOTAL / 1e9, len(BUCKETS)))
+print()
+print('| N | scaling | captions / rank | shard step, exact / bf16x3 (measured, ms) | step at 153 GB/s (exact / x3) | step at 1071 GB/s (exact / x3) | captions/s at 1071 GB/s (exact) |')
+print('|---|---|---|---|---|---|---|')
+for n in (1, 2, 4, 8):
+    for kind in ('weak', 'strong'):
+        b = 256 if kind == 'weak' else 256 // n
+        if b not in meas or (n == 1 and kind == 'strong'):
+            continue
+        ex, x3 = meas[b]
+        lo = [step_ms(t, n, 153e9) for t in (ex, x3)]
+        hi = [step_ms(t, n, 7 * 153e9) for t in (ex, x3)]
+        print('| %d | %s | %d | %.1f / %.1f | %.1f / %.1f (exposed %.1f / %.1f) | %.1f / %.1f (exposed %.1f / %.1f) | %.0f |' % (
+            n, kind, b, ex, x3, lo[0][0], lo[1][0], lo[0][1], lo[1][1], hi[0][0], hi[1][0], hi[0][1], hi[1][1],
+            n * b / hi[0][0] * 1e3))
