@@ -144,10 +144,17 @@ int gemm_logits(int rows, int V1, const float* h, int R, const float* Wl, const 
     return gemm1(rows, V1 - Va, seg_lin(h, R, Wl + (long)Va * R, R, R, bl + Va), C + Va, V1, 0, gx);
 }
 int gemm_logits_dw(int V1, int R, float* dW, float* db, const float* dlg, const float* h, int rows, const GemmCtx& gx) {
+    // The bias gradient (column sums of the 165 MB dlogits) comes from its own streaming pass (~35 us) instead of riding
+    // on the GEMM: without the rider the 42-GFLOP weight gradient takes the LDS-DMA kernel (0.55 -> 0.33 ms at C3).
+    const bool big = (double)rows * V1 * R >= 2e9 && db;
+    if (big) {
+        RFN_TRY(rfn_colsum_f32(dlg, V1, rows, V1, db, 0, gx.st));
+        db = nullptr;
+    }
     const int Va = aligned_part(V1);
     if (Va == V1 || Va == 0) return gemm_dw(V1, R, dW, R, db, dlg, V1, h, R, rows, gx);
     RFN_TRY(gemm_dw(Va, R, dW, R, db, dlg, V1, h, R, rows, gx));
-    return gemm_dw(V1 - Va, R, dW + (long)Va * R, R, db + Va, dlg + Va, V1, h, R, rows, gx);
+    return gemm_dw(V1 - Va, R, dW + (long)Va * R, R, db ? db + Va : nullptr, dlg + Va, V1, h, R, rows, gx);
 }
 int gemm_logits_dx(int rows, int R, int V1, const float* dlg, const float* Wl, float* dh, const GemmCtx& gx) {
     const int Va = aligned_part(V1);
