@@ -274,6 +274,7 @@ struct Bump {
 
 const size_t GEMM_WS_FLOATS = (size_t)12 << 20;  // 48 MiB of split-K partial tiles
 const int FUSED_ATTN_BWD_MIN_B = 96;   // below this the (L/64, B) grid of the split dalpha kernel fills the chip better
+const long FUSED_ATTN_BWD_SMALL_MAP = 32768;   // ... unless the map (L x D) is so small that launches, not bytes, are the cost
 const size_t STEP_GEMM_WS_FLOATS = GEMM_WS_FLOATS;   // the free-running step makes the same split-K choices as the teacher-forced pass
 
 struct PrefixLayout {
@@ -1001,7 +1002,8 @@ extern "C" int rfn_prefix_bwd(const rfn_dims* d, int B, const float* const* prm,
         }
         bool same_ld = same_d && M > 1;
         for (int i = 1; i < M; ++i) same_ld = same_ld && d->L[i] == d->L[0];
-        const bool grouped_bwd = same_ld && B >= FUSED_ATTN_BWD_MIN_B;
+        const bool grouped_bwd = same_ld && (B >= FUSED_ATTN_BWD_MIN_B ||
+                                             (!x3_takes(d, B, 0) && (long)d->L[0] * d->D[0] <= FUSED_ATTN_BWD_SMALL_MAP));
         if (grouped_bwd) {   // all encoders' attention backward of this step: one launch
             const long L0 = d->L[0], D0 = d->D[0];
             const float *a_p[RFN_MAX_ENC], *a_hp[RFN_MAX_ENC], *a_w[RFN_MAX_ENC], *a_al[RFN_MAX_ENC], *a_dz[RFN_MAX_ENC];
@@ -1046,7 +1048,7 @@ extern "C" int rfn_prefix_bwd(const rfn_dims* d, int B, const float* const* prm,
                 float* dwo = dwp + ((long)t * M + i) * BA;
                 RFN_TRY(rfn_attn_bwd_grouped_ks(1, &p1c, Li * A, (long)A, &hpc, &wc, &alc, &att[i], Li * Di, Di, &dzc, Di, B,
                                                 (int)Li, A, (int)Di, &img, x3_row_pad(T1 * A), t * A, &dhpo, &dwo, st));
-            } else if (B >= FUSED_ATTN_BWD_MIN_B) {   // one block per row fills the chip: dalpha stays in LDS, one launch
+            } else if (B >= FUSED_ATTN_BWD_MIN_B || (!x3_takes(d, B, i) && Li * Di <= FUSED_ATTN_BWD_SMALL_MAP)) {   // dalpha stays in LDS, one launch
                 RFN_TRY(rfn_attn_bwd(p1, Li * A, (long)A, hp + i * BA, prm[P.s1(t, i, 4)],
                                      W + Lo.al1[i] + (long)t * B * Li, att[i], Li * Di, Di, dz, Di, B, (int)Li, A,
                                      (int)Di, p1, Li * A, (long)A, 0, dhp + i * BA,

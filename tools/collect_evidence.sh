@@ -1,6 +1,7 @@
 #!/bin/bash
-# Round evidence in one GPU-box call: the bench line, rocprofv3 kernel-trace summaries of both GEMM modes, the secondary
-# lines.  Outputs under gpurun_out/ev/ (copy what is to be judged into profiles/).   bash tools/collect_evidence.sh
+# Round evidence in one GPU-box call: the bench line, rocprofv3 kernel-trace summaries of both GEMM modes, phase tables,
+# dominant launches, the secondary lines, the PMC passes of the dominant GEMM.  Outputs under gpurun_out/ev/ (copy what is
+# to be judged into profiles/).   bash tools/collect_evidence.sh
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/ev
 mkdir -p $O
@@ -10,15 +11,20 @@ python bench.py 2> $O/bench.err | tail -1 > $O/bench.json
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $O/exact -o t --output-format csv -- python3 $R/bench.py --no-cpu-baseline --no-alt-line > $O/exact.log 2>&1
 rocprofv3 --kernel-trace --stats -d $O/x3 -o t --output-format csv -- python3 $R/bench.py --no-cpu-baseline --gemm bf16x3 > $O/x3.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/c2 -o t --output-format csv -- python3 $R/bench.py --workload c2 --no-cpu-baseline --no-alt-line > $O/c2.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/dec -o t --output-format csv -- python3 $R/tools/prof_decode.py > $O/dec.log 2>&1
 cd $R
 python tools/trace_phases.py $O/exact/t_kernel_trace.csv --top 8 > $O/phases_exact.txt
 python tools/trace_phases.py $O/x3/t_kernel_trace.csv --top 8 > $O/phases_x3.txt
 python tools/dominant_launches.py $O/exact/t_kernel_trace.csv > $O/dominant_exact.csv
 python tools/dominant_launches.py $O/x3/t_kernel_trace.csv > $O/dominant_x3.csv
+python tools/step_launches.py $O/exact/t_kernel_trace.csv > $O/step_launches_exact.txt
+python tools/step_launches.py $O/c2/t_kernel_trace.csv > $O/step_launches_c2.txt
 : > $O/secondary.jsonl
 for args in "--workload c2" "--workload c3het" "--recipe" "--label-smoothing" "--workload c5"; do
   python bench.py --no-cpu-baseline $args 2>/dev/null | tail -1 >> $O/secondary.jsonl
 done
 python bench.py --no-cpu-baseline --workload c5 --gemm bf16x3 2>/dev/null | tail -1 >> $O/secondary.jsonl
-rm -f $O/exact/t_kernel_trace.csv $O/x3/t_kernel_trace.csv    # tens of MB; the summaries stay
+bash tools/run_gemm_pmc.sh r03 "" all > $O/pmc_gemm.txt 2>&1
+rm -f $O/exact/t_kernel_trace.csv $O/x3/t_kernel_trace.csv $O/c2/t_kernel_trace.csv $O/dec/t_kernel_trace.csv    # tens of MB; the summaries stay
 ls -la $O

@@ -3,6 +3,7 @@
 //   TN: its weight gradient                              (M=512, N=2048, K=50176, 8 groups)
 // Built several times with -DGEMM_* knobs by tools/run_gemm_bench.sh; prints TFLOP/s per variant.
 #include "../recurrent_fusion_network_amd/csrc/rfn_gemm.hip"
+#include "../recurrent_fusion_network_amd/csrc/rfn_cell.hip"   // rfn_gemm_f32_lstm falls back to rfn_lstm_fwd_grouped
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>

@@ -1,6 +1,7 @@
 // Diagnostic: the skinny per-step GEMMs of the recurrence (M = batch = 256), timed back to back with cold-ish
 // weights (a different weight matrix per call, as in the path).  Variants via -DGEMM_SMALL_* knobs.
 #include "../recurrent_fusion_network_amd/csrc/rfn_gemm.hip"
+#include "../recurrent_fusion_network_amd/csrc/rfn_cell.hip"   // rfn_gemm_f32_lstm falls back to rfn_lstm_fwd_grouped
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
