@@ -688,51 +688,87 @@ class RecurrentFusionModel(nn.Module):
                                         order.data_ptr(), ids.data_ptr(), done_seq.data_ptr(), done_lp.data_ptr(),
                                         done_p.data_ptr(), done_n.data_ptr(), active.data_ptr(), max_done,
                                         stepper.ws.data_ptr(), stepper.ws_bytes, stepper.seed, N.stream_ptr()), 'rfn_beam_loop')
-            n_done = done_n.cpu().numpy()
-            d_seq, d_lp, d_p = done_seq.cpu().numpy(), done_lp.cpu().numpy(), done_p.cpu().numpy()
-        # done beams sorted by -p, stably, as the reference's sorted(..., key=-p) (:529) -- for all images at once
-        key = np.where(np.arange(max_done)[None, :] < n_done[:, None], -d_p, np.inf)
-        rank = np.argsort(key, axis=1, kind='stable')
-        s_all = torch.from_numpy(np.take_along_axis(d_seq, rank[:, :, None], axis=1))
-        l_all = torch.from_numpy(np.take_along_axis(d_lp, rank[:, :, None], axis=1))
-        p_all = np.take_along_axis(d_p, rank, axis=1)
-        seq, seq_lp = s_all[:, 0].contiguous(), l_all[:, 0].contiguous()          # (B, S): best done beam per image
-        counts = n_done.tolist()
-        probs = p_all.tolist()
-        top_seq = [s_all[k, :n] for k, n in enumerate(counts)]
-        top_prob = [probs[k][:n] for k, n in enumerate(counts)]
-        # self.done_beams[k] = the reference's list of {'seq', 'logps', 'p'} dicts, sorted by -p.  Thousands of small
-        # tensor views: built on first access (an eval loop that only reads the returned captions never pays for it)
-        self.done_beams = _LazyDoneBeams(s_all, l_all, probs, counts)
-        heads = reason.unsqueeze(2).expand(-1, -1, W, -1)                          # (M+1, B, W, K) broadcast view
-        reason_batch = [list(t.unbind(0)) for t in heads.unbind(1)]
-        return seq.to(dev), seq_lp.to(dev), top_seq, top_prob, reason_batch
+            # done beams sorted by -p, stably, as the reference's sorted(..., key=-p) (:529) -- on the device, for all
+            # images at once: the call returns with everything queued and nothing read back, so the host's next batch
+            # (and its stage-I/II GEMMs) starts while this one is still decoding
+            key = torch.where(torch.arange(max_done, device=dev)[None, :] < done_n[:, None], -done_p,
+                              torch.full_like(done_p, float('inf')))
+            rank = torch.sort(key, dim=1, stable=True).indices
+            pick = rank[:, :, None].expand(-1, -1, S)
+            s_all, l_all, p_all = done_seq.gather(1, pick), done_lp.gather(1, pick), done_p.gather(1, rank)
+            seq, seq_lp = s_all[:, 0].contiguous(), l_all[:, 0].contiguous()       # (B, S): best done beam per image
+            heads = reason.unsqueeze(2).expand(-1, -1, W, -1)                       # (M+1, B, W, K) broadcast view
+        # The per-image Python structures (top_seq, top_prob, reason_pred_batch, self.done_beams: thousands of small
+        # objects) need the done counts on the host: they are lists that fill themselves on first access, so a loop that
+        # only consumes the returned captions never waits for them.
+        src = _BeamResults(s_all, l_all, p_all, done_n)
+        top_seq = _LazyList(B, lambda: src.top_seq())
+        top_prob = _LazyList(B, lambda: src.top_prob())
+        self.done_beams = _LazyList(B, lambda: src.done_beams())
+        reason_batch = _LazyList(B, lambda: [list(t.unbind(0)) for t in heads.unbind(1)])
+        return seq, seq_lp, top_seq, top_prob, reason_batch
 
 
-class _LazyDoneBeams(list):
-    """`model.done_beams` of sample_beam (misc/RecurrentFusionModel.py:529-531): a list (one entry per image) of lists of
-    {'seq': (S,) int64, 'logps': (S,) float, 'p': float}, best first.  Behaves as that list; the per-beam dicts of image k
-    are materialised when entry k is first read."""
+class _BeamResults:
+    """Host copies of the sorted done beams, fetched once, on demand."""
 
-    def __init__(self, s_all, l_all, probs, counts):
-        super().__init__([None] * len(counts))
-        self._src = (s_all, l_all, probs, counts)
+    def __init__(self, s_all, l_all, p_all, done_n):
+        self._dev = (s_all, l_all, p_all, done_n)
+        self._host = None
 
-    def _fill(self, k):
-        s_all, l_all, probs, counts = self._src
-        n = counts[k]
-        got = [{'seq': a, 'logps': b_, 'p': c_} for a, b_, c_ in zip(s_all[k, :n].unbind(0), l_all[k, :n].unbind(0), probs[k][:n])]
-        list.__setitem__(self, k, got)
-        return got
+    def host(self):
+        if self._host is None:
+            s_all, l_all, p_all, done_n = self._dev
+            self._host = (s_all.cpu(), l_all.cpu(), p_all.cpu().tolist(), done_n.cpu().tolist())
+        return self._host
+
+    def top_seq(self):
+        s_all, _, _, counts = self.host()
+        return [s_all[k, :n] for k, n in enumerate(counts)]
+
+    def top_prob(self):
+        _, _, probs, counts = self.host()
+        return [probs[k][:n] for k, n in enumerate(counts)]
+
+    def done_beams(self):
+        """misc/RecurrentFusionModel.py:529-531: per image the list of {'seq', 'logps', 'p'} dicts, best first."""
+        s_all, l_all, probs, counts = self.host()
+        return [[{'seq': a, 'logps': b_, 'p': c_} for a, b_, c_ in zip(s_all[k, :n].unbind(0), l_all[k, :n].unbind(0), probs[k][:n])]
+                for k, n in enumerate(counts)]
+
+
+class _LazyList(list):
+    """A list of known length whose entries are produced (all at once) by `fill()` the first time any of them is read:
+    indexing, slicing, iteration, comparison and printing see the filled list."""
+
+    def __init__(self, n, fill):
+        super().__init__([None] * n)
+        self._fill = fill
+
+    def _ensure(self):
+        if self._fill is not None:
+            fill, self._fill = self._fill, None
+            list.__setitem__(self, slice(None), fill())
 
     def __getitem__(self, k):
-        if isinstance(k, slice):
-            return [self[i] for i in range(*k.indices(len(self)))]
-        got = list.__getitem__(self, k)
-        return self._fill(k if k >= 0 else len(self) + k) if got is None else got
+        self._ensure()
+        return list.__getitem__(self, k)
 
     def __iter__(self):
-        return (self[i] for i in range(len(self)))
+        self._ensure()
+        return list.__iter__(self)
+
+    def __repr__(self):
+        self._ensure()
+        return list.__repr__(self)
+
+    def __eq__(self, other):
+        self._ensure()
+        return list.__eq__(self, other)
+
+    def __contains__(self, x):
+        self._ensure()
+        return list.__contains__(self, x)
 
 
 class _Stepper:
