@@ -137,6 +137,8 @@ int rfn_gemm_f32_ws(int M, int N, int ngroups, const rfn_gemm_problem* problems_
  * 5.4 -> 6.6 ms: every K-range block pays an agent-scope release = a write-back of its XCD's L2 before its ticket), which
  * is what the MI355X guide reports for split-K seams kept inside a launch.  Off by default. */
 #define RFN_GEMM_OPT_SPLITK_IN_KERNEL 16u
+/* Diagnostics (tools/split_probe.py): bits 8-12 force the K split of a medium big-tile product (1 = unsplit). */
+#define RFN_GEMM_OPT_FORCE_SPLIT(n) (((unsigned)(n) & 31u) << 8)
 int rfn_gemm_f32_opt(int M, int N, int ngroups, const rfn_gemm_problem* problems_host, int accumulate,
                      void* ws, size_t ws_bytes, unsigned flags, void* stream);
 /* Same, with split-K finished INSIDE the launch: `tickets` points to n_tickets int32 counters that are ZERO on entry

@@ -1160,15 +1160,26 @@ static int launch_tile(GemmArgs& a, hipStream_t st) {
     int big_split = 1;
     const long medium_max = GEMM_MEDIUM_MAX;
     if (big <= medium_max && a.part && big >= 16 && flops >= GEMM_MEDIUM_MIN_FLOPS) {
-        const long target = (AK && BKF) ? GEMM_MEDIUM_TARGET_NT : 512;   // 768 (three NT blocks per CU) measured worse
-        long want = (target + big - 1) / big;
-        if (want > iters32 / 8) want = iters32 / 8;
-        if (want > 16) want = 16;
+        // K split from a cost model of the launch (tools/split_probe.py, profiles/r03_split_probe.md): two blocks share a CU
+        // (512 slots); a block that has its CU to itself runs a K step in ~2.5 us, two co-resident blocks take ~4.3 us
+        // each, a partly filled round after a full one lands in between.  A split whose blocks spill just past a whole
+        // round (136 tiles x 4 = 544) pays a nearly empty extra round: the old "smallest split reaching 512 blocks" rule
+        // did exactly that for the logit dX product (517 -> 430 us at s = 3).
         const long cap = (long)a.ws_mib * (1 << 18) / (((long)a.M * a.N + a.M) * a.ngroups);
-        if (want > cap) want = cap;
-        if (want >= 2) big_split = (int)want;
+        const double part_us = (double)a.M * a.N * a.ngroups * 8.0 / 6.0e6;   // one partial written + read (mostly from L2 / MALL)
+        long want = 1;
+        double best = 1e30;
+        for (long s = 1; s <= 16 && s <= cap && (s == 1 || s <= iters32 / 8); ++s) {
+            const long nb = big * s, full = nb / 512, rem = nb % 512;
+            double t = (full * 4.3 + (rem == 0 ? 0.0 : rem > 256 ? 4.3 : full ? 3.3 : 2.5)) * (double)((iters32 + s - 1) / s);
+            if (s > 1) t += 6.0 + s * part_us;
+            if (t < best - 0.5) { best = t; want = s; }
+        }
+        const long forced = (a.flags >> 8) & 31;   // RFN_GEMM_OPT_FORCE_SPLIT(n): tools/split_probe.py
+        if (forced >= 1 && forced <= cap && forced <= iters32) want = forced;
+        big_split = (want >= 2) ? (int)want : 1;
     }
-    if (big >= 384 || big_split > 1) {
+    if (big >= 384 || big_split > 1 || (((a.flags >> 8) & 31) == 1 && big >= 16)) {
         a.splitk = big_split;
         a.tiles_m = rfn_cdiv(a.M, GEMM_BIG_BM);
         a.tiles_n = rfn_cdiv(a.N, GEMM_BIG_BN);
