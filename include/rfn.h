@@ -208,6 +208,11 @@ int rfn_colsum_f32(const float* X, int64_t ldx, int rows, int cols, float* out, 
 /* the same for `ngroups` matrices X + g*group_stride, each into its own outs_host[g] (one launch) */
 int rfn_colsum_grouped_f32(const float* X, int64_t group_stride, int64_t ldx, int rows, int cols,
                            float* const* outs_host, int ngroups, void* stream);
+/* the same, every sum also written to outs2_host[g] where that is not NULL (two parameters that enter one pre-activation
+ * share one bias gradient: H2h.bias / z2h.bias, LSTMFusionNoInputCore.py:42; att_2_att_h.bias / h_2_att_h.bias,
+ * AttentionModelCore.py:36-38) */
+int rfn_colsum_grouped2_f32(const float* X, int64_t group_stride, int64_t ldx, int rows, int cols,
+                            float* const* outs_host, float* const* outs2_host, int ngroups, void* stream);
 
 /* outs_host[g][0..n) = value for `ngroups` small device buffers in one launch */
 int rfn_fill_small_f32(float* const* outs_host, int ngroups, int n, float value, void* stream);

@@ -98,6 +98,7 @@ def _load():
         'rfn_x3_splitk_for': (C.c_int, [I, I, I]),
         'rfn_colsum_f32': (C.c_int, [P, L, I, I, P, I, P]),
         'rfn_colsum_grouped_f32': (C.c_int, [P, L, L, I, I, P, I, P]),
+        'rfn_colsum_grouped2_f32': (C.c_int, [P, L, L, I, I, P, P, I, P]),
         'rfn_fill_small_f32': (C.c_int, [P, I, I, F, P]),
         'rfn_copy_small_f32': (C.c_int, [P, P, I, I, P]),
         'rfn_attn_scores_fwd': (C.c_int, [P, L, L, P, P, P, I, I, I, P, P]),

@@ -76,8 +76,9 @@ struct ColsumOuts { float* out[64]; };
 // 64 columns x 16 row-lanes per block: a thread sums every 16th row of its column, the 16 partial sums are added in a
 // fixed order through LDS (deterministic).
 #define CSG_LANES 16
+struct ColsumOuts2 { float* out[64]; float* out2[64]; };
 __global__ __launch_bounds__(64 * CSG_LANES) void colsum_grouped_k(const float* __restrict__ X, long gstride, long ldx,
-                                                                  int rows, int cols, const ColsumOuts outs) {
+                                                                  int rows, int cols, const ColsumOuts2 outs) {
     __shared__ float red[CSG_LANES][64];
     const float* Xg = X + blockIdx.y * gstride;
     const int l = threadIdx.x & 63, c = blockIdx.x * 64 + l, rl = threadIdx.x >> 6;
@@ -91,24 +92,30 @@ __global__ __launch_bounds__(64 * CSG_LANES) void colsum_grouped_k(const float* 
 #pragma unroll
         for (int k = 0; k < CSG_LANES; ++k) t += red[k][l];
         outs.out[blockIdx.y][c] = t;
+        if (outs.out2[blockIdx.y]) outs.out2[blockIdx.y][c] = t;
     }
 }
-extern "C" int rfn_colsum_grouped_f32(const float* X, int64_t group_stride, int64_t ldx, int rows, int cols,
-                                      float* const* outs, int ngroups, void* stream) {
+extern "C" int rfn_colsum_grouped2_f32(const float* X, int64_t group_stride, int64_t ldx, int rows, int cols,
+                                       float* const* outs, float* const* outs2, int ngroups, void* stream) {
     if (rows < 0 || cols <= 0 || ngroups < 1) return RFN_ERR_SHAPE;
     if (!X || !outs) return RFN_ERR_ARG;
     for (int g0 = 0; g0 < ngroups; g0 += 64) {
-        ColsumOuts o;
+        ColsumOuts2 o;
         const int ng = ngroups - g0 < 64 ? ngroups - g0 : 64;
         for (int g = 0; g < ng; ++g) {
             if (!outs[g0 + g]) return RFN_ERR_ARG;
             o.out[g] = outs[g0 + g];
+            o.out2[g] = outs2 ? outs2[g0 + g] : nullptr;
         }
         hipLaunchKernelGGL(colsum_grouped_k, dim3(rfn_cdiv(cols, 64), ng), dim3(64 * CSG_LANES), 0, (hipStream_t)stream,
                            X + (long)g0 * group_stride, (long)group_stride, (long)ldx, rows, cols, o);
         RFN_CHECK_LAUNCH();
     }
     return RFN_OK;
+}
+extern "C" int rfn_colsum_grouped_f32(const float* X, int64_t group_stride, int64_t ldx, int rows, int cols,
+                                      float* const* outs, int ngroups, void* stream) {
+    return rfn_colsum_grouped2_f32(X, group_stride, ldx, rows, cols, outs, nullptr, ngroups, stream);
 }
 
 // out[g][0..n) = value for up to 64 small buffers per launch (the exactly-zero att_h_2_out.bias gradients)
@@ -176,7 +183,8 @@ extern "C" int rfn_embed_fwd(const float* W, int E, int64_t V1, const int64_t* i
 }
 // One block per vocabulary row.  The token list is scanned 64 rows at a time: every lane tests one row,
 // a ballot gives the matching rows, and they are added in ascending row order -- deterministic, no float
-// atomics, and ~rows/64 iterations per block instead of a serial scan.
+// atomics, and ~rows/64 ballots per block instead of a serial scan.
+#define EMB_UNROLL 8
 template <bool VEC>
 __global__ __launch_bounds__(128) void embed_bwd_k(const float* __restrict__ dout, long ldo,
                                                    const int64_t* __restrict__ ids, int inner, long si, long so,
@@ -189,20 +197,27 @@ __global__ __launch_bounds__(128) void embed_bwd_k(const float* __restrict__ dou
         float acc[W];
 #pragma unroll
         for (int k = 0; k < W; ++k) acc[k] = 0.f;
-        for (int base = 0; base < rows; base += 64) {
-            const int r = base + lane;
-            long id = -1;
-            if (r < rows) id = ids[(long)(r % inner) * si + (long)(r / inner) * so];
-            unsigned long long m = __ballot(id == v);
-            while (m) {
-                const int rr = base + __builtin_ctzll(m);
-                m &= m - 1;
-                if (e < E) {
-                    if constexpr (VEC) {
-                        const float4 x = *reinterpret_cast<const float4*>(dout + rr * ldo + e);
-                        acc[0] += x.x; acc[1] += x.y; acc[2] += x.z; acc[3] += x.w;
-                    } else {
-                        acc[0] += dout[rr * ldo + e];
+        for (int base = 0; base < rows; base += 64 * EMB_UNROLL) {
+            long id[EMB_UNROLL];       // EMB_UNROLL id loads in flight per lane: the scan is bound by their latency
+#pragma unroll
+            for (int u = 0; u < EMB_UNROLL; ++u) {
+                const int r = base + 64 * u + lane;
+                id[u] = -1;
+                if (r < rows) id[u] = ids[(long)(r % inner) * si + (long)(r / inner) * so];
+            }
+#pragma unroll
+            for (int u = 0; u < EMB_UNROLL; ++u) {
+                unsigned long long m = __ballot(id[u] == v);
+                while (m) {
+                    const int rr = base + 64 * u + __builtin_ctzll(m);
+                    m &= m - 1;
+                    if (e < E) {
+                        if constexpr (VEC) {
+                            const float4 x = *reinterpret_cast<const float4*>(dout + rr * ldo + e);
+                            acc[0] += x.x; acc[1] += x.y; acc[2] += x.z; acc[3] += x.w;
+                        } else {
+                            acc[0] += dout[rr * ldo + e];
+                        }
                     }
                 }
             }
@@ -455,6 +470,9 @@ extern "C" int rfn_log_softmax_topk(const float* logits, int64_t ldl, int rows, 
     RFN_CHECK_LAUNCH();
     return RFN_OK;
 }
+// d logits = g - softmax * sum(g), one block per row.  VEC: rows of up to 10240 logits (16-B aligned, V1 % 4 == 0) keep g in
+// registers between the sum and the update: one read of g and of the log-probs, one write, 16 B per lane.
+template <bool VEC>
 __global__ __launch_bounds__(256) void log_softmax_bwd_k(const float* __restrict__ g, const float* __restrict__ logp,
                                                          int V1, int inner, long s_inner, long s_outer,
                                                          float* __restrict__ dlogits, long ldd) {
@@ -463,18 +481,53 @@ __global__ __launch_bounds__(256) void log_softmax_bwd_k(const float* __restrict
     const long off = (long)(r % inner) * s_inner + (long)(r / inner) * s_outer;
     const float* gr = g + off;
     const float* lp = logp + off;
-    float s = 0.f;
-    for (int v = threadIdx.x; v < V1; v += 256) s += gr[v];
-    s = block_sum_256(s, red);
     float* d = dlogits + r * ldd;
-    for (int v = threadIdx.x; v < V1; v += 256) d[v] = gr[v] - expf(lp[v]) * s;
+    if constexpr (VEC) {
+        const int n4 = V1 >> 2;
+        lsm_f32x4 gv[LSM_R4], lv[LSM_R4];
+#pragma unroll
+        for (int j = 0; j < LSM_R4; ++j) {
+            const int i = threadIdx.x + 256 * j;
+            gv[j] = lsm_f32x4{0.f, 0.f, 0.f, 0.f};
+            lv[j] = lsm_f32x4{0.f, 0.f, 0.f, 0.f};
+            if (i < n4) {
+                gv[j] = *reinterpret_cast<const lsm_f32x4*>(gr + 4 * i);
+                lv[j] = __builtin_nontemporal_load(reinterpret_cast<const lsm_f32x4*>(lp + 4 * i));
+            }
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < LSM_R4; ++j) s += (gv[j][0] + gv[j][1]) + (gv[j][2] + gv[j][3]);
+        s = block_sum_256(s, red);
+#pragma unroll
+        for (int j = 0; j < LSM_R4; ++j) {
+            const int i = threadIdx.x + 256 * j;
+            if (i < n4) {
+                lsm_f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = gv[j][e] - expf(lv[j][e]) * s;
+                *reinterpret_cast<lsm_f32x4*>(d + 4 * i) = o;
+            }
+        }
+    } else {
+        float s = 0.f;
+        for (int v = threadIdx.x; v < V1; v += 256) s += gr[v];
+        s = block_sum_256(s, red);
+        for (int v = threadIdx.x; v < V1; v += 256) d[v] = gr[v] - expf(lp[v]) * s;
+    }
 }
 extern "C" int rfn_log_softmax_bwd(const float* g, const float* logp, int rows, int V1, int inner, int64_t s_inner,
                                    int64_t s_outer, float* dlogits, int64_t ldd, void* stream) {
     if (rows <= 0 || V1 <= 0 || inner <= 0) return RFN_ERR_SHAPE;
     if (!g || !logp || !dlogits) return RFN_ERR_ARG;
-    hipLaunchKernelGGL(log_softmax_bwd_k, dim3(rows), dim3(256), 0, (hipStream_t)stream, g, logp, V1, inner,
-                       (long)s_inner, (long)s_outer, dlogits, (long)ldd);
+    const bool vec = V1 % 4 == 0 && V1 <= 256 * 4 * LSM_R4 && s_inner % 4 == 0 && s_outer % 4 == 0 && ldd % 4 == 0 &&
+                     rfn_aligned16(g) && rfn_aligned16(logp) && rfn_aligned16(dlogits);
+    if (vec)
+        hipLaunchKernelGGL(log_softmax_bwd_k<true>, dim3(rows), dim3(256), 0, (hipStream_t)stream, g, logp, V1, inner,
+                           (long)s_inner, (long)s_outer, dlogits, (long)ldd);
+    else
+        hipLaunchKernelGGL(log_softmax_bwd_k<false>, dim3(rows), dim3(256), 0, (hipStream_t)stream, g, logp, V1, inner,
+                           (long)s_inner, (long)s_outer, dlogits, (long)ldd);
     RFN_CHECK_LAUNCH();
     return RFN_OK;
 }

@@ -19,6 +19,7 @@
 // No allocation, no synchronisation, no global state: buffers come from the caller's workspace.
 #include <stdio.h>
 #include <string.h>
+#include <initializer_list>
 
 #include "rfn_common.h"
 
@@ -246,6 +247,44 @@ int cell_run(int B, int n, const rfn_cell_out* outs, int R, float drop_p, uint64
     return rfn_cell_gemm(B, n, outs, R, drop_p, seed, 0, st);
 }
 
+// Up to MEM_BATCH copies / zero fills of f32 buffers in ONE launch (src == NULL: zero).  The path's bookkeeping moves (initial
+// states into the workspace, gradient slabs zeroed before they are accumulated into) come in twos and threes; each was a
+// hipMemcpyAsync / hipMemsetAsync of its own, i.e. a ~5 us launch in the dependent chain.
+const int MEM_BATCH = 4;
+struct MemOp { float* dst; const float* src; long n; };
+struct MemOps { MemOp op[MEM_BATCH]; };
+__global__ __launch_bounds__(256) void mem_batch_k(const MemOps o) {
+    const MemOp m = o.op[blockIdx.y];
+    const long stride = (long)gridDim.x * 256, i0 = (long)blockIdx.x * 256 + threadIdx.x;
+    const bool v4 = (((uintptr_t)m.dst | (uintptr_t)m.src) & 15) == 0;
+    const long n4 = v4 ? m.n >> 2 : 0;
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    if (m.src) {
+        for (long i = i0; i < n4; i += stride) reinterpret_cast<f4*>(m.dst)[i] = reinterpret_cast<const f4*>(m.src)[i];
+        for (long i = 4 * n4 + i0; i < m.n; i += stride) m.dst[i] = m.src[i];
+    } else {
+        for (long i = i0; i < n4; i += stride) reinterpret_cast<f4*>(m.dst)[i] = f4{0.f, 0.f, 0.f, 0.f};
+        for (long i = 4 * n4 + i0; i < m.n; i += stride) m.dst[i] = 0.f;
+    }
+}
+int mem_batch(std::initializer_list<MemOp> ops, void* st) {
+    MemOps o;
+    int n = 0;
+    long big = 0;
+    for (const MemOp& m : ops) {
+        if (!m.dst || m.n <= 0) continue;
+        if (n == MEM_BATCH) return RFN_ERR_SHAPE;
+        o.op[n++] = m;
+        big = m.n > big ? m.n : big;
+    }
+    if (!n) return RFN_OK;
+    for (int i = n; i < MEM_BATCH; ++i) o.op[i] = MemOp{nullptr, nullptr, 0};
+    long blocks = (big / 4 + 255) / 256;
+    blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+    hipLaunchKernelGGL(mem_batch_k, dim3((unsigned)blocks, n), dim3(256), 0, (hipStream_t)st, o);
+    RFN_CHECK_LAUNCH();
+    return RFN_OK;
+}
 int copy_f32(float* dst, const float* src, size_t n, void* st) {
     if (hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)st) != hipSuccess)
         return RFN_ERR_LAUNCH;
@@ -770,10 +809,7 @@ static int prefix_fwd_impl(const rfn_dims* d, int B, const float* const* prm, co
     RFN_TRY(gemm1(T2 * B, K, seg_lin(h2 + BR, R, prm[P.r_w()], R, R, prm[P.r_b()]), rmat, K, 0, gx));
     RFN_TRY(rfn_max_over_steps_fwd(rmat, T2, B, K, reason_pred + (long)M * B * K, rarg + (long)M * B * K, st));
 
-    if (comb) RFN_TRY(copy_f32(comb, h2 + BR, (size_t)T2 * BR, st));
-    if (h_out) RFN_TRY(copy_f32(h_out, h2 + (long)T2 * BR, BR, st));
-    if (c_out) RFN_TRY(copy_f32(c_out, c2 + (long)T2 * BR, BR, st));
-    return RFN_OK;
+    return mem_batch({{comb, h2 + BR, (long)T2 * BR}, {h_out, h2 + (long)T2 * BR, BR}, {c_out, c2 + (long)T2 * BR, BR}}, st);
 }
 
 extern "C" int rfn_prefix_fwd(const rfn_dims* d, int B, const float* const* prm, const float* const* fc,
@@ -832,13 +868,12 @@ extern "C" int rfn_prefix_bwd(const rfn_dims* d, int B, const float* const* prm,
     // ---- reason head of stage II (:244, :253) -------------------------------------------------
     RFN_TRY(rfn_max_over_steps_bwd(d_reason ? d_reason + (long)M * B * K : nullptr, rarg + (long)M * B * K, T2, B, K,
                                    rmat, st));
-    if (d_comb) RFN_TRY(copy_f32(dh2e, d_comb, (size_t)T2 * BR, st));
-    else RFN_TRY(zero_f32(dh2e, (size_t)T2 * BR, st));
+    // d thoughts from the decoder (or zero) into the slab the reason head accumulates onto; d H of stage I zeroed
+    RFN_TRY(mem_batch({{dh2e, d_comb, (long)T2 * BR}, {dHs, nullptr, (long)(T1 + 1) * BMR}}, st));
     RFN_TRY(gemm1(T2 * B, R, seg_dx(rmat, K, prm[P.r_w()], R, K), dh2e, R, 1, gx));
     RFN_TRY(gemm_dw(K, R, grd[P.r_w()], R, grd[P.r_b()], rmat, K, h2 + BR, R, T2 * B, gx));
 
-    // gradient w.r.t. the stage-I hidden states: thoughts (through stage II) + reason heads + mean
-    RFN_TRY(zero_f32(dHs, (size_t)(T1 + 1) * BMR, st));
+    // gradient w.r.t. the stage-I hidden states (zeroed above): thoughts (through stage II) + reason heads + mean
 
     // ---- stage II backward ------------------------------------------------------------------------
     // Fused form of a step (3 launches): Kb1 = dh_rec and every dz_i = dgates . [W_hh | W_z_i] in one launch; the M
@@ -1114,8 +1149,8 @@ extern "C" int rfn_prefix_bwd_wgrad(const rfn_dims* d, int B, const float* const
     rfn_gemm_problem pr[64];
     const long Li = d->L[i], Di = d->D[i];
     // att_2_att_h.bias and h_2_att_h.bias enter the same pre-activation (AttentionModelCore.py:36-38), so their
-    // gradients are the same vector: it is produced once in part A and copied; the long att_2_att_h GEMM carries no
-    // bias-gradient rider.
+    // gradients are the same vector: the column-sum launch of part A writes it to both; the long att_2_att_h GEMM
+    // carries no bias-gradient rider.
     auto part_b = [&]() -> int {   // the dominant att_2_att_h gradient (small bucket, long GEMM)
         if (x3_takes(d, B, i)) {
             // bf16-plane GEMM: dW[t] = dP1[t]^T . att.  Both operands are reduction-index-major in memory ((b,l) rows), so
@@ -1158,10 +1193,17 @@ extern "C" int rfn_prefix_bwd_wgrad(const rfn_dims* d, int B, const float* const
     // one gradient, like h_2_att_h.bias and att_2_att_h.bias.
     float* outs[64];
     const float* g1i = W + Lo.g1 + (long)i * B * 4 * R;           // (t, i) slab = g1i + t * M*B*4R
-    for (int t = 0; t < T1; ++t) outs[t] = grd[P.s1(t, i, 7)];
-    RFN_TRY(rfn_colsum_grouped_f32(g1i, (long)M * B * 4 * R, 4 * R, B, 4 * R, outs, T1, st));
-    for (int t = 0; t < T1; ++t) outs[t] = grd[P.s1(t, i, 3)];
-    RFN_TRY(rfn_colsum_grouped_f32(W + Lo.dhp1 + (long)i * BA, (long)M * BA, A, B, A, outs, T1, st));
+    float* outs2[64];
+    for (int t = 0; t < T1; ++t) {
+        outs[t] = grd[P.s1(t, i, 7)];
+        outs2[t] = grd[P.s1(t, i, 9)];     // z2h.bias = H2h.bias gradient
+    }
+    RFN_TRY(rfn_colsum_grouped2_f32(g1i, (long)M * B * 4 * R, 4 * R, B, 4 * R, outs, outs2, T1, st));
+    for (int t = 0; t < T1; ++t) {
+        outs[t] = grd[P.s1(t, i, 3)];
+        outs2[t] = grd[P.s1(t, i, 1)];     // att_2_att_h.bias = h_2_att_h.bias gradient
+    }
+    RFN_TRY(rfn_colsum_grouped2_f32(W + Lo.dhp1 + (long)i * BA, (long)M * BA, A, B, A, outs, outs2, T1, st));
     for (int t = 0; t < T1; ++t)
         pr[t] = prob_dw(grd[P.s1(t, i, 6)], MR, nullptr, g1i + (long)t * M * B * 4 * R, 4 * R, Hs + t * BMR, MR, B);
     RFN_TRY(gemm_groups(4 * R, (int)MR, T1, pr, 0, gx));
@@ -1172,20 +1214,6 @@ extern "C" int rfn_prefix_bwd_wgrad(const rfn_dims* d, int B, const float* const
     for (int t = 0; t < T1; ++t)
         pr[t] = prob_dw(grd[P.s1(t, i, 2)], R, nullptr, W + Lo.dhp1 + ((long)t * M + i) * BA, A, Hs + t * BMR + i * R, MR, B);
     RFN_TRY(gemm_groups(A, R, T1, pr, 0, gx));
-    {   // z2h.bias = H2h.bias and att_2_att_h.bias = h_2_att_h.bias gradients (before the large bucket is announced)
-        float* cdst[64];
-        const float* csrc[64];
-        for (int t = 0; t < T1; ++t) {
-            cdst[t] = grd[P.s1(t, i, 9)];
-            csrc[t] = grd[P.s1(t, i, 7)];
-        }
-        RFN_TRY(rfn_copy_small_f32(cdst, csrc, T1, 4 * R, st));
-        for (int t = 0; t < T1; ++t) {
-            cdst[t] = grd[P.s1(t, i, 1)];
-            csrc[t] = grd[P.s1(t, i, 3)];
-        }
-        RFN_TRY(rfn_copy_small_f32(cdst, csrc, T1, A, st));
-    }
     if (parts & 2) RFN_TRY(part_b());
     return RFN_OK;
 }
@@ -1277,8 +1305,7 @@ static int decoder_fwd_begin(const rfn_dims* d, int B, const float* const* prm, 
     const int R = d->R, A = d->A, T2 = d->T2;
     const GemmCtx gx_whole{st, nullptr, 0, d->gemm_flags};
     RFN_TRY(gemm1(T2 * B, A, seg_lin(comb, R, prm[P.dec(6)], R, R, prm[P.dec(7)]), W + Lo.Pd, A, 0, gx_whole));
-    RFN_TRY(copy_f32(W + Lo.hd, h0, (size_t)B * R, st));
-    return copy_f32(W + Lo.cd, c0, (size_t)B * R, st);
+    return mem_batch({{W + Lo.hd, h0, (long)B * R}, {W + Lo.cd, c0, (long)B * R}}, st);
 }
 
 extern "C" int rfn_decoder_fwd(const rfn_dims* d, int B, int S, const float* const* prm, const float* comb,
@@ -1376,8 +1403,7 @@ extern "C" int rfn_decoder_bwd(const rfn_dims* d, int B, int S, const float* con
     RFN_TRY(rfn_log_softmax_bwd(d_log_prob, log_prob, S * B, V1, B, (long)S * V1, V1, dlg, V1, st));
     RFN_TRY(gemm_logits_dw(V1, R, grd[P.logit_w()], grd[P.logit_b()], dlg, hd + BR, S * B, gx));
     RFN_TRY(gemm_logits_dx(S * B, R, V1, dlg, prm[P.logit_w()], dhe, gx));
-    RFN_TRY(zero_f32(d_comb, (size_t)T2 * BR, st));
-    RFN_TRY(zero_f32(dPd, (size_t)T2 * BA, st));
+    RFN_TRY(mem_batch({{d_comb, nullptr, (long)T2 * BR}, {dPd, nullptr, (long)T2 * BA}}, st));
     rfn_gemm_problem pr[2];
     // Fused form of a backward step (3 launches): Kb1 = [dh_rec | dz] = dgates . [W_hh | W_z] in one launch (they share the
     // gate gradients); the attention backward; Kb2 = dh_rec += dhp . W_h whose epilogue completes d h of step s-1
@@ -1430,9 +1456,7 @@ extern "C" int rfn_decoder_bwd(const rfn_dims* d, int B, int S, const float* con
                           dPd, A, BA, 1, dhp, W + Lo.dwp + s * BA, d_comb, st));
         RFN_TRY(gemm1(B, R, seg_dx(dhp, A, prm[P.dec(8)], R, A), dhrec, R, 1, gx));
     }
-    RFN_TRY(copy_f32(d_h0, dhrec, BR, st));
-    RFN_TRY(copy_f32(d_c0, dc, BR, st));
-    RFN_TRY(zero_f32(grd[P.dec(11)], 1, st));
+    RFN_TRY(mem_batch({{d_h0, dhrec, BR}, {d_c0, dc, BR}, {grd[P.dec(11)], nullptr, 1}}, st));
     // attention projection of the fused thoughts (shared by all steps)
     RFN_TRY(gemm1(T2 * B, R, seg_dx(dPd, A, prm[P.dec(6)], R, A), d_comb, R, 1, gx));
     RFN_TRY(gemm_dw(A, R, grd[P.dec(6)], R, grd[P.dec(7)], dPd, A, comb, R, T2 * B, gx));
@@ -1620,8 +1644,7 @@ extern "C" int rfn_beam_loop(const rfn_dims* d, int NB, int W, int S, const floa
                                   topv, topi, W));
     }
     if (hc != h) {   // an odd number of swaps: bring the live state home
-        RFN_TRY(copy_f32(h, hc, (size_t)rows * R, st));
-        RFN_TRY(copy_f32(c, cc, (size_t)rows * R, st));
+        RFN_TRY(mem_batch({{h, hc, (long)rows * R}, {c, cc, (long)rows * R}}, st));
     }
     return RFN_OK;
 }
