@@ -968,31 +968,51 @@ __global__ __launch_bounds__(THREADS, (THREADS == 64) ? 1 : (DMA ? GEMM_DMA_MIN_
 
 // C = sum_ks part[g][ks] + sum_s bias_s (+ C): fixed summation order, one thread per output element.  The blocks
 // past the C range finish the a_colsum rider the same way (partial column sums of every K range, in order).
+// K ranges are read four at a time (the loads of a group are independent and in flight together; the adds keep the
+// k order) and, when rows are whole float4s, four columns per thread: the launch is latency-bound, not bandwidth-bound.
+template <bool VEC>
 __global__ __launch_bounds__(256) void rfn_gemm_reduce_k(const GemmArgs args) {
+    constexpr int W = VEC ? 4 : 1;
+    typedef float vec_t __attribute__((ext_vector_type(W)));
     const long MN = (long)args.M * args.N;
     const int grp = blockIdx.y;
     const rfn_gemm_problem& P = args.g[grp];
-    const int c_blocks = (int)((MN + 255) / 256);
+    const int splitk = args.splitk;
+    const int c_blocks = (int)((MN / W + 255) / 256);
     if ((int)blockIdx.x >= c_blocks) {
         const int row = ((int)blockIdx.x - c_blocks) * 256 + threadIdx.x;
         if (row >= args.M || !P.a_colsum) return;
-        const float* cs = args.part + (long)args.ngroups * args.splitk * MN + (long)grp * args.splitk * args.M + row;
+        const float* cs = args.part + (long)args.ngroups * splitk * MN + (long)grp * splitk * args.M + row;
         float s = 0.f;
-        for (int k = 0; k < args.splitk; ++k) s += cs[(long)k * args.M];
+        for (int k = 0; k < splitk; ++k) s += cs[(long)k * args.M];
         float* o = P.a_colsum + row;
         *o = args.accumulate ? *o + s : s;
         return;
     }
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * W;
     if (i >= MN) return;
     const int row = (int)(i / args.N), col = (int)(i - (long)row * args.N);
-    const float* part = args.part + (long)grp * args.splitk * MN + i;
-    float s = 0.f;
-    for (int k = 0; k < args.splitk; ++k) s += part[k * MN];
-    for (int sg = 0; sg < P.nseg; ++sg)
-        if (P.seg[sg].bias) s += P.seg[sg].bias[col];
+    const float* part = args.part + (long)grp * splitk * MN + i;
     float* c = P.C + (long)row * P.ldc + col;
-    *c = args.accumulate ? *c + s : s;
+    vec_t prev;
+    if (args.accumulate) prev = *reinterpret_cast<const vec_t*>(c);
+    vec_t s;
+#pragma unroll
+    for (int e = 0; e < W; ++e) s[e] = 0.f;
+    for (int k0 = 0; k0 < splitk; k0 += 4) {
+        vec_t v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = k0 + u < splitk ? k0 + u : splitk - 1;
+            v[u] = *reinterpret_cast<const vec_t*>(part + k * MN);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (k0 + u < splitk) s += v[u];
+    }
+    for (int sg = 0; sg < P.nseg; ++sg)
+        if (P.seg[sg].bias) s += *reinterpret_cast<const vec_t*>(P.seg[sg].bias + col);
+    *reinterpret_cast<vec_t*>(c) = args.accumulate ? prev + s : s;
 }
 
 // The same fixed-order reduce for a gate GEMM (N = 4R, gate chunks [in | forget | out | g]) followed by the LSTM update of
@@ -1028,7 +1048,17 @@ __global__ __launch_bounds__(256) void rfn_gemm_reduce_lstm_k(const GemmArgs arg
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         float s = 0.f;
-        for (int k = 0; k < args.splitk; ++k) s += part[k * MN + g * R];
+        for (int k0 = 0; k0 < args.splitk; k0 += 4) {   // four K ranges' loads in flight, added in k order
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = k0 + u < args.splitk ? k0 + u : args.splitk - 1;
+                v[u] = part[k * MN + g * R];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (k0 + u < args.splitk) s += v[u];
+        }
         for (int sg = 0; sg < P.nseg; ++sg)
             if (P.seg[sg].bias) s += P.seg[sg].bias[g * R + j];
         pre[g] = s;
@@ -1134,9 +1164,19 @@ static int launch_cfg(const GemmArgs& a_in, hipStream_t st) {
         const int cs_blocks = (colsum && !AK) ? rfn_cdiv(a.M, 256) : 0;
         if (a.lstm.c_next)
             hipLaunchKernelGGL(rfn_gemm_reduce_lstm_k, dim3(rfn_cdiv((long)a.M * (a.N / 4), 256), a.ngroups), dim3(256), 0, st, a);
-        else
-            hipLaunchKernelGGL(rfn_gemm_reduce_k, dim3(rfn_cdiv((long)a.M * a.N, 256) + cs_blocks, a.ngroups), dim3(256), 0,
-                               st, a);
+        else {
+            bool v4 = (a.N % 4 == 0);   // whole float4s per row: four columns per thread
+            for (int g = 0; g < a.ngroups && v4; ++g) {
+                v4 = v4 && rfn_aligned16(a.g[g].C) && (a.g[g].ldc % 4 == 0);
+                for (int sg = 0; sg < a.g[g].nseg; ++sg) v4 = v4 && (!a.g[g].seg[sg].bias || rfn_aligned16(a.g[g].seg[sg].bias));
+            }
+            if (v4)
+                hipLaunchKernelGGL(rfn_gemm_reduce_k<true>, dim3(rfn_cdiv((long)a.M * a.N / 4, 256) + cs_blocks, a.ngroups),
+                                   dim3(256), 0, st, a);
+            else
+                hipLaunchKernelGGL(rfn_gemm_reduce_k<false>, dim3(rfn_cdiv((long)a.M * a.N, 256) + cs_blocks, a.ngroups),
+                                   dim3(256), 0, st, a);
+        }
         RFN_CHECK_LAUNCH();
     }
     return RFN_OK;

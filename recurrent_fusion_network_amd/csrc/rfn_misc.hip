@@ -181,50 +181,90 @@ extern "C" int rfn_embed_fwd(const float* W, int E, int64_t V1, const int64_t* i
     RFN_CHECK_LAUNCH();
     return RFN_OK;
 }
-// One block per vocabulary row.  The token list is scanned 64 rows at a time: every lane tests one row,
-// a ballot gives the matching rows, and they are added in ascending row order -- deterministic, no float
-// atomics, and ~rows/64 ballots per block instead of a serial scan.
-#define EMB_UNROLL 8
+// One wave per vocabulary row.  The token list is scanned 64 entries at a time: every lane tests one entry, a ballot gives
+// the matches, the matching rows are queued in LDS in scan order, and the queue is drained EMB_DEPTH rows at a time -- their
+// loads in flight together, added in queue order: deterministic, no float atomics.  A hot token (BOS feeds step 0 of every
+// caption: B matches) used to be one serial chain of dependent loads, the long pole of the launch (147 us at B = 256).
+// The scan walks the ids in MEMORY order when the rows form a whole (inner x rows/inner) rectangle (time-major rows
+// r = t*B + b read ids[b][t]), otherwise in row order; either way the order is a function of the shape only.
+#define EMB_UNROLL 4
+#define EMB_CH 2      /* chunks of 64 x W floats per lane: E = 512 is covered by one wave */
+#define EMB_QCAP 512  /* queued rows before a drain (>= 64 * EMB_UNROLL) */
+#define EMB_DEPTH 8
 template <bool VEC>
-__global__ __launch_bounds__(128) void embed_bwd_k(const float* __restrict__ dout, long ldo,
-                                                   const int64_t* __restrict__ ids, int inner, long si, long so,
-                                                   int rows, int E, float* __restrict__ dW) {
+__global__ __launch_bounds__(64) void embed_bwd_k(const float* __restrict__ dout, long ldo,
+                                                  const int64_t* __restrict__ ids, int inner, long si, long so,
+                                                  int rows, int E, float* __restrict__ dW) {
     constexpr int W = VEC ? 4 : 1;
+    typedef float vec_t __attribute__((ext_vector_type(W)));
+    __shared__ int queue[EMB_QCAP];
     const long v = blockIdx.x;
-    const int lane = threadIdx.x & 63;
-    for (int e0 = 0; e0 < E; e0 += 128 * W) {
-        const int e = e0 + threadIdx.x * W;
-        float acc[W];
+    const int lane = threadIdx.x;
+    // scan index q -> (hi, lo) = (q / mod, q % mod), carried along (q advances by 64: no division in the loop)
+    const bool mem_order = rows % inner == 0;
+    const int mod = mem_order ? rows / inner : inner;
+    const long s_hi = mem_order ? si : so, s_lo = mem_order ? so : si;
+    const int step_q = 64 / mod, step_r = 64 - step_q * mod;
+    for (int e0 = 0; e0 < E; e0 += 64 * W * EMB_CH) {
+        vec_t acc[EMB_CH];
 #pragma unroll
-        for (int k = 0; k < W; ++k) acc[k] = 0.f;
-        for (int base = 0; base < rows; base += 64 * EMB_UNROLL) {
-            long id[EMB_UNROLL];       // EMB_UNROLL id loads in flight per lane: the scan is bound by their latency
+        for (int c = 0; c < EMB_CH; ++c)
 #pragma unroll
-            for (int u = 0; u < EMB_UNROLL; ++u) {
-                const int r = base + 64 * u + lane;
-                id[u] = -1;
-                if (r < rows) id[u] = ids[(long)(r % inner) * si + (long)(r / inner) * so];
-            }
+            for (int k = 0; k < W; ++k) acc[c][k] = 0.f;
+        int nq = 0;                                   // queued rows (uniform)
+        auto drain = [&]() {                          // adds queue[0 .. nq) in order
+            __syncthreads();
+            for (int i0 = 0; i0 < nq; i0 += EMB_DEPTH) {
+                vec_t x[EMB_DEPTH][EMB_CH];
 #pragma unroll
-            for (int u = 0; u < EMB_UNROLL; ++u) {
-                unsigned long long m = __ballot(id[u] == v);
-                while (m) {
-                    const int rr = base + 64 * u + __builtin_ctzll(m);
-                    m &= m - 1;
-                    if (e < E) {
-                        if constexpr (VEC) {
-                            const float4 x = *reinterpret_cast<const float4*>(dout + rr * ldo + e);
-                            acc[0] += x.x; acc[1] += x.y; acc[2] += x.z; acc[3] += x.w;
-                        } else {
-                            acc[0] += dout[rr * ldo + e];
-                        }
+                for (int j = 0; j < EMB_DEPTH; ++j) {
+                    const long rr = queue[i0 + j < nq ? i0 + j : nq - 1];
+#pragma unroll
+                    for (int c = 0; c < EMB_CH; ++c) {
+                        const int e = e0 + (c * 64 + lane) * W;
+#pragma unroll
+                        for (int k = 0; k < W; ++k) x[j][c][k] = 0.f;
+                        if (e < E) x[j][c] = *reinterpret_cast<const vec_t*>(dout + rr * ldo + e);
                     }
                 }
+#pragma unroll
+                for (int j = 0; j < EMB_DEPTH; ++j)
+                    if (i0 + j < nq) {
+#pragma unroll
+                        for (int c = 0; c < EMB_CH; ++c) acc[c] += x[j][c];
+                    }
+            }
+            nq = 0;
+            __syncthreads();
+        };
+        int hi = lane / mod, lo = lane - hi * mod;
+        for (int base = 0; base < rows; base += 64 * EMB_UNROLL) {
+            long id[EMB_UNROLL];
+            int row[EMB_UNROLL];
+#pragma unroll
+            for (int u = 0; u < EMB_UNROLL; ++u) {
+                const int q = base + 64 * u + lane;
+                id[u] = -1;
+                if (q < rows) id[u] = ids[hi * s_hi + lo * s_lo];
+                row[u] = mem_order ? lo * inner + hi : q;      // the row of d out this entry belongs to
+                lo += step_r;
+                hi += step_q;
+                if (lo >= mod) { lo -= mod; ++hi; }
+            }
+            if (nq + 64 * EMB_UNROLL > EMB_QCAP) drain();
+#pragma unroll
+            for (int u = 0; u < EMB_UNROLL; ++u) {
+                const bool hit = id[u] == v;
+                const unsigned long long m = __ballot(hit);
+                if (hit) queue[nq + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = row[u];
+                nq += __builtin_popcountll(m);
             }
         }
-        if (e < E) {
+        drain();
 #pragma unroll
-            for (int k = 0; k < W; ++k) dW[v * E + e + k] = acc[k];
+        for (int c = 0; c < EMB_CH; ++c) {
+            const int e = e0 + (c * 64 + lane) * W;
+            if (e < E) *reinterpret_cast<vec_t*>(dW + v * E + e) = acc[c];
         }
     }
 }
@@ -232,12 +272,12 @@ extern "C" int rfn_embed_bwd(const float* dout, int64_t ldo, const int64_t* ids,
                              int64_t ids_s_outer, int rows, int E, int64_t V1, float* dW, void* stream) {
     if (rows < 0 || E <= 0 || V1 <= 0 || inner <= 0) return RFN_ERR_SHAPE;
     if (!dout || !ids || !dW) return RFN_ERR_ARG;
-    const bool vec = (E % 4 == 0) && (ldo % 4 == 0) && rfn_aligned16(dout);
+    const bool vec = (E % 4 == 0) && (ldo % 4 == 0) && rfn_aligned16(dout) && rfn_aligned16(dW);
     if (vec)
-        hipLaunchKernelGGL(embed_bwd_k<true>, dim3((unsigned)V1), dim3(128), 0, (hipStream_t)stream, dout, (long)ldo,
+        hipLaunchKernelGGL(embed_bwd_k<true>, dim3((unsigned)V1), dim3(64), 0, (hipStream_t)stream, dout, (long)ldo,
                            ids, inner, (long)ids_s_inner, (long)ids_s_outer, rows, E, dW);
     else
-        hipLaunchKernelGGL(embed_bwd_k<false>, dim3((unsigned)V1), dim3(128), 0, (hipStream_t)stream, dout,
+        hipLaunchKernelGGL(embed_bwd_k<false>, dim3((unsigned)V1), dim3(64), 0, (hipStream_t)stream, dout,
                            (long)ldo, ids, inner, (long)ids_s_inner, (long)ids_s_outer, rows, E, dW);
     RFN_CHECK_LAUNCH();
     return RFN_OK;
