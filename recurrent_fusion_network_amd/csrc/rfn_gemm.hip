@@ -50,7 +50,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define GEMM_MEDIUM_MIN_FLOPS 6e9 /* per launch; below this the 64x64 tile + split-K stays */
 #endif
 #ifndef GEMM_MEDIUM_MAX
-#define GEMM_MEDIUM_MAX 383   /* up to this many 128x128 tiles a problem is cut along K on big tiles; above, unsplit */
+#define GEMM_MEDIUM_MAX 1023  /* below two full rounds of 128x128 tiles (512 slots each) the K split is priced by the cost model; above, unsplit */
 #endif
 #ifndef GEMM_SPLIT_MIN_ITERS
 #define GEMM_SPLIT_MIN_ITERS 4 /* K iterations every split block keeps at least */
@@ -1198,28 +1198,33 @@ static int launch_tile(GemmArgs& a, hipStream_t st) {
     // Medium problems (the heavier per-step GEMMs: M = batch, a few GF): the 128x128 tile is ~1.5x more efficient
     // than 64x64 but yields too few tiles, so cut K across blocks to reach ~2 blocks per CU.
     int big_split = 1;
+    bool big_unsplit = false;
     const long medium_max = GEMM_MEDIUM_MAX;
     if (big <= medium_max && a.part && big >= 16 && flops >= GEMM_MEDIUM_MIN_FLOPS) {
-        // K split from a cost model of the launch (tools/split_probe.py, profiles/r03_split_probe.md): two blocks share a CU
-        // (512 slots); a block that has its CU to itself runs a K step in ~2.5 us, two co-resident blocks take ~4.3 us
-        // each, a partly filled round after a full one lands in between.  A split whose blocks spill just past a whole
-        // round (136 tiles x 4 = 544) pays a nearly empty extra round: the old "smallest split reaching 512 blocks" rule
-        // did exactly that for the logit dX product (517 -> 430 us at s = 3).
+        // K split from a cost model of the launch (tools/split_probe.py, profiles/r03_split_probe.md).  Blocks are handed
+        // out in rounds of 512 (two per CU, 64 per XCD); a round costs its blocks' K steps at ~3.9 us per 32-deep step,
+        // however full it is -- except a last round of <= 256 blocks (one per CU: a lone block has the matrix pipe to
+        // itself, ~0.6 of the time).  A split whose blocks spill just past a whole round (136 tiles x 4 = 544) pays for
+        // a nearly empty round: the old "smallest split reaching 512 blocks" rule did exactly that for the logit dX
+        // product (517 -> 430 us at s = 3), and an unsplit 384-tile weight gradient ran 1.9 ms instead of 1.45.
         const long cap = (long)a.ws_mib * (1 << 18) / (((long)a.M * a.N + a.M) * a.ngroups);
-        const double part_us = (double)a.M * a.N * a.ngroups * 8.0 / 6.0e6;   // one partial written + read (mostly from L2 / MALL)
+        const double part_us = (double)a.M * a.N * a.ngroups * 4.0 / 4.0e6;   // one partial tile set read back by the reduce
         long want = 1;
         double best = 1e30;
         for (long s = 1; s <= 16 && s <= cap && (s == 1 || s <= iters32 / 8); ++s) {
             const long nb = big * s, full = nb / 512, rem = nb % 512;
-            double t = (full * 4.3 + (rem == 0 ? 0.0 : rem > 256 ? 4.3 : full ? 3.3 : 2.5)) * (double)((iters32 + s - 1) / s);
+            double t = 3.9 * ((double)full + (rem == 0 ? 0.0 : rem > 256 ? 1.0 : 0.6)) * (double)((iters32 + s - 1) / s);
             if (s > 1) t += 6.0 + s * part_us;
-            if (t < best - 0.5) { best = t; want = s; }
+            if (t < best * 0.97) { best = t; want = s; }   // a deeper split has to buy 3 %
         }
         const long forced = (a.flags >> 8) & 31;   // RFN_GEMM_OPT_FORCE_SPLIT(n): tools/split_probe.py
         if (forced >= 1 && forced <= cap && forced <= iters32) want = forced;
         big_split = (want >= 2) ? (int)want : 1;
+        // unsplit by choice (a split was allowed and priced higher): still the big tile; unsplit because no split is
+        // allowed (short K, no workspace): the 64 x 64 path below with its own K cut, as before
+        big_unsplit = want == 1 && ((cap >= 2 && iters32 / 8 >= 2) || forced == 1);
     }
-    if (big >= 384 || big_split > 1 || (((a.flags >> 8) & 31) == 1 && big >= 16)) {
+    if (big >= 384 || big_split > 1 || big_unsplit) {
         a.splitk = big_split;
         a.tiles_m = rfn_cdiv(a.M, GEMM_BIG_BM);
         a.tiles_n = rfn_cdiv(a.N, GEMM_BIG_BN);

@@ -311,7 +311,7 @@ struct Bump {
     }
 };
 
-const size_t GEMM_WS_FLOATS = (size_t)12 << 20;  // 48 MiB of split-K partial tiles
+const size_t GEMM_WS_FLOATS = (size_t)64 << 20;  // 256 MiB of split-K partial tiles (a 4096 x 2208 weight gradient cut 8 ways)
 const int FUSED_ATTN_BWD_MIN_B = 96;   // below this the (L/64, B) grid of the split dalpha kernel fills the chip better
 const long FUSED_ATTN_BWD_SMALL_MAP = 32768;   // ... unless the map (L x D) is so small that launches, not bytes, are the cost
 const size_t STEP_GEMM_WS_FLOATS = GEMM_WS_FLOATS;   // the free-running step makes the same split-K choices as the teacher-forced pass

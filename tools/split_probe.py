@@ -1,5 +1,5 @@
 """K-split choice of the medium big-tile GEMMs: time per forced split (RFN_GEMM_OPT_FORCE_SPLIT) next to the
-library's own choice, at the shapes the train step launches.   python tools/split_probe.py [c3|c2]"""
+library's own choice, at the shapes the train step launches.   python tools/split_probe.py [c3|c2|het]"""
 import os
 import sys
 
@@ -17,6 +17,11 @@ SHAPES = {
         ('i2h fwd 4352x2048 K=512 NT', 4352, 2048, [512], 1, 1, 1),
         ('decoder dW 2048x512 K=4352 TN', 2048, 512, [4352], 0, 0, 1),
         ('decoder dW 2048x2048 K=4352 TN', 2048, 2048, [4352], 0, 0, 1),
+    ],
+    'het': [
+        ('enc1 dW 4096x1536 K=16384 TN', 4096, 1536, [16384], 0, 0, 1),
+        ('enc3 dW 4096x2176 K=12544 TN', 4096, 2176, [12544], 0, 0, 1),
+        ('enc2 dW 4096x1280 K=16384 TN', 4096, 1280, [16384], 0, 0, 1),
     ],
     'c2': [
         ('logit dX   1088x512 K=9488 NN', 1088, 512, [9488], 1, 0, 1),
@@ -60,7 +65,7 @@ def run(name, M, N, Ks, ak, bk, ng, ws):
 
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else 'c3'
-    ws = torch.empty(48 << 20, dtype=torch.uint8, device='cuda')
+    ws = torch.empty(int(os.environ.get("PROBE_WS_MIB", "256")) << 20, dtype=torch.uint8, device='cuda')
     for sh in SHAPES[which]:
         run(*sh, ws)
 

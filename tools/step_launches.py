@@ -14,7 +14,7 @@ rows.sort(key=lambda r: int(r['Start_Timestamp']))
 
 
 def short(n):
-    return re.sub(r'\(.*', '', n).replace('void ', '').replace('rfn_gemm_kernel', 'gemm')[:78]
+    return re.sub(r'\(.*', '', n.replace('(anonymous namespace)::', '')).replace('void ', '').replace('rfn_gemm_kernel', 'gemm')[:78]
 
 
 ev = [(int(r['Start_Timestamp']), int(r['End_Timestamp']), short(r['Kernel_Name']),

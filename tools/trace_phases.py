@@ -14,7 +14,7 @@ import re
 
 
 def short(name):
-    name = re.sub(r'\(.*', '', name).replace('void ', '')
+    name = re.sub(r'\(.*', '', name.replace('(anonymous namespace)::', '')).replace('void ', '')
     name = name.replace('rfn_gemm_kernel', 'gemm')
     return name[:64]
 
