@@ -86,7 +86,8 @@ def test_workspace_queries_scale_with_the_batch():
     a = N.lib.rfn_prefix_ws_bytes(C.byref(d), 64, 1)
     b = N.lib.rfn_prefix_ws_bytes(C.byref(d), 256, 1)
     inf = N.lib.rfn_prefix_ws_bytes(C.byref(d), 256, 0)
-    assert 3.5 < b / a <= 4.05 and inf < b
+    fixed = 256 << 20            # the split-K scratch (GEMM_WS_FLOATS) does not grow with the batch
+    assert 3.5 < (b - fixed) / (a - fixed) <= 4.05 and inf < b
     # the hoisted projections dominate: 4 encoders x (256*196) x (8*512) floats = 3.29 GB
     assert b > 4 * 256 * 196 * 8 * 512 * 4
     assert N.lib.rfn_decoder_ws_bytes(C.byref(d), 256, 17, 1) > N.lib.rfn_decoder_ws_bytes(C.byref(d), 256, 17, 0) > 0
