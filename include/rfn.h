@@ -264,6 +264,19 @@ int rfn_attn_bwd(const float* proj, int64_t proj_sb, int64_t proj_sl, const floa
                  const float* alpha, const float* att_seq, int64_t sb, int64_t sl, const float* dz, int64_t lddz,
                  int B, int L, int A, int D, float* dproj, int64_t dproj_sb, int64_t dproj_sl,
                  int accumulate_dproj, float* dhproj, float* dw_part, void* stream);
+/* rfn_attn_fwd_grouped / rfn_attn_bwd_grouped for encoders whose feature maps differ in (L_g, D_g) -- the reference ships
+ * 196 x 2048, 64 x 1536, 64 x 1280 and 49 x 2208 maps side by side (feat_array.py:240-244, one AttentionModelCore per
+ * encoder: misc/RecurrentFusionModel.py:139-146) -- in ONE pair of launches / one launch: the M cells of a stage-I step are
+ * independent (misc/RecurrentFusionModel.py:101-114).  Contiguous layouts: proj / dproj (B, L_g, A), att_seq (B, L_g, D_g),
+ * z / dz (B, D_g), alpha and the raw-score scratch (B, L_g).  Same kernels and per-row arithmetic as the per-encoder calls:
+ * bit-identical results.  L_host / D_host: host arrays of ngroups ints. */
+int rfn_attn_fwd_het(int ngroups, const float* const* proj, const float* const* hproj, const float* const* w_out,
+                     const float* const* b_out, const float* const* att_seq, int B, const int* L_host, int A,
+                     const int* D_host, float* const* scores_scratch, float* const* alpha, float* const* z, void* stream);
+int rfn_attn_bwd_het(int ngroups, const float* const* proj, const float* const* hproj, const float* const* w_out,
+                     const float* const* alpha, const float* const* att_seq, const float* const* dz, int B,
+                     const int* L_host, int A, const int* D_host, float* const* dproj, int accumulate_dproj,
+                     float* const* dhproj, float* const* dw_part, void* stream);
 /* The same for `ngroups` encoders that share (L, A, D) and every stride, one launch (grid = B x ngroups). */
 int rfn_attn_bwd_grouped(int ngroups, const float* const* proj, int64_t proj_sb, int64_t proj_sl,
                          const float* const* hproj, const float* const* w_out, const float* const* alpha,

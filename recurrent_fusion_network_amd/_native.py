@@ -110,6 +110,8 @@ def _load():
         'rfn_attn_bwd': (C.c_int, [P, L, L, P, P, P, P, L, L, P, L, I, I, I, I, P, L, L, I, P, P, P]),
         'rfn_attn_fwd_grouped': (C.c_int, [I, P, L, L, P, P, P, P, L, L, I, I, I, I, P, P, P, L, P]),
         'rfn_attn_bwd_grouped': (C.c_int, [I, P, L, L, P, P, P, P, L, L, P, L, I, I, I, I, P, L, L, I, P, P, P]),
+        'rfn_attn_fwd_het': (C.c_int, [I, P, P, P, P, P, I, P, I, P, P, P, P, P]),
+        'rfn_attn_bwd_het': (C.c_int, [I, P, P, P, P, P, P, I, P, I, P, P, I, P, P, P]),
         'rfn_attn_small_fwd': (C.c_int, [I, P, L, L, P, P, P, P, L, L, I, I, I, I, P, P, L, P]),
         'rfn_attn_small_bwd': (C.c_int, [I, P, L, L, P, P, P, P, L, L, P, L, I, I, I, I, P, L, L, I, P, P, P, P]),
         'rfn_dropout_mask': (C.c_int, [U64, U64, L, F, P, P]),

@@ -80,9 +80,49 @@ struct AttnEncPtrs {
     float* dw_part[RFN_MAX_ENC];
     char* ks_img[RFN_MAX_ENC];   // attn_scores_bwd_k<.., EMIT>: k-slow bf16 plane image that receives dproj (rfn.h, rfn_x3_split_ks)
 };
+// Per-encoder extents and strides of one grouped launch.  Encoders of one launch share A (att_hid_size) only: their maps
+// may differ in L and D (the reference ships 196 x 2048, 64 x 1536, 64 x 1280 and 49 x 2208 maps together,
+// feat_array.py:240-244); the grid is sized for the largest and the blocks past an encoder's own extent leave at once.
+struct AttnDims {
+    int L[RFN_MAX_ENC], D[RFN_MAX_ENC];
+    long psb[RFN_MAX_ENC], psl[RFN_MAX_ENC];   // proj:   (b, l, :) at b*psb + l*psl
+    long xsb[RFN_MAX_ENC], xsl[RFN_MAX_ENC];   // att_seq
+    long dsb[RFN_MAX_ENC], dsl[RFN_MAX_ENC];   // dproj
+    long ldz[RFN_MAX_ENC];                     // row stride of z / dz
+    int maxL, maxD;
+};
+static AttnDims attn_dims_uniform(int ng, int L, int D, long psb, long psl, long xsb, long xsl, long dsb, long dsl, long ldz) {
+    AttnDims m;
+    memset(&m, 0, sizeof(m));
+    for (int g = 0; g < ng && g < RFN_MAX_ENC; ++g) {
+        m.L[g] = L; m.D[g] = D; m.psb[g] = psb; m.psl[g] = psl; m.xsb[g] = xsb; m.xsl[g] = xsl;
+        m.dsb[g] = dsb; m.dsl[g] = dsl; m.ldz[g] = ldz;
+    }
+    m.maxL = L; m.maxD = D;
+    return m;
+}
+// contiguous maps: proj (B, L_g, A), att_seq (B, L_g, D_g), z / dz (B, D_g), dproj like proj
+static int attn_dims_het(int ng, const int* L, const int* D, int A, AttnDims* out) {
+    AttnDims m;
+    memset(&m, 0, sizeof(m));
+    if (!L || !D || ng < 1 || ng > RFN_MAX_ENC) return RFN_ERR_SHAPE;
+    for (int g = 0; g < ng; ++g) {
+        if (L[g] <= 0 || D[g] <= 0) return RFN_ERR_SHAPE;
+        m.L[g] = L[g]; m.D[g] = D[g];
+        m.psb[g] = (long)L[g] * A; m.psl[g] = A; m.xsb[g] = (long)L[g] * D[g]; m.xsl[g] = D[g];
+        m.dsb[g] = m.psb[g]; m.dsl[g] = A; m.ldz[g] = D[g];
+        m.maxL = L[g] > m.maxL ? L[g] : m.maxL;
+        m.maxD = D[g] > m.maxD ? D[g] : m.maxD;
+    }
+    *out = m;
+    return RFN_OK;
+}
 
 template <bool VEC>
-__global__ __launch_bounds__(ATT_THREADS) void attn_scores_raw_k(const AttnEncPtrs E, long sb, long sl, int L, int A) {
+__global__ __launch_bounds__(ATT_THREADS) void attn_scores_raw_k(const AttnEncPtrs E, const AttnDims Dm, int A) {
+    const int L = Dm.L[blockIdx.z];
+    if ((int)blockIdx.x * SC_ROWS >= L) return;     // a shorter map of a heterogeneous launch
+    const long sb = Dm.psb[blockIdx.z], sl = Dm.psl[blockIdx.z];
     const float* __restrict__ proj = E.proj[blockIdx.z];
     const float* __restrict__ hproj = E.hproj[blockIdx.z];
     const float* __restrict__ w_out = E.w_out[blockIdx.z];
@@ -148,8 +188,10 @@ extern "C" int rfn_attn_scores_fwd(const float* proj, int64_t proj_sb, int64_t p
 // same reduction order as attn_softmax_k so the weights are bit-identical) and the first block publishes them
 // to alpha_out -- the separate softmax launch of the split path disappears.
 template <bool VEC, bool SOFTMAX>
-__global__ __launch_bounds__(ATT_THREADS) void attn_context_fwd_k(const AttnEncPtrs E, long sb, long sl, int L, int D,
-                                                                 long ldz) {
+__global__ __launch_bounds__(ATT_THREADS) void attn_context_fwd_k(const AttnEncPtrs E, const AttnDims Dm) {
+    const int L = Dm.L[blockIdx.z], D = Dm.D[blockIdx.z];
+    if ((int)blockIdx.x * ATT_THREADS * (VEC ? 4 : 1) >= D) return;     // a narrower map of a heterogeneous launch
+    const long sb = Dm.xsb[blockIdx.z], sl = Dm.xsl[blockIdx.z], ldz = Dm.ldz[blockIdx.z];
     const float* __restrict__ x = E.x[blockIdx.z];
     const float* __restrict__ alpha = E.alpha_in[blockIdx.z];
     float* __restrict__ z = E.z[blockIdx.z];
@@ -208,23 +250,29 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_context_fwd_k(const AttnEncP
 }
 
 template <bool SOFTMAX>
-static int launch_context(int ng, const AttnEncPtrs& E, int64_t sb, int64_t sl, int B, int L, int D, int64_t ldz,
-                          hipStream_t st) {
-    if (B <= 0 || L <= 0 || D <= 0 || ng < 1 || ng > RFN_MAX_ENC) return RFN_ERR_SHAPE;
-    if ((size_t)L * sizeof(float) > 64 * 1024) return RFN_ERR_SHAPE;
-    bool vec = (D % 4 == 0) && (sb % 4 == 0) && (sl % 4 == 0) && (ldz % 4 == 0);
+static int launch_context_d(int ng, const AttnEncPtrs& E, const AttnDims& Dm, int B, hipStream_t st) {
+    if (B <= 0 || ng < 1 || ng > RFN_MAX_ENC || Dm.maxL <= 0 || Dm.maxD <= 0) return RFN_ERR_SHAPE;
+    if ((size_t)Dm.maxL * sizeof(float) > 64 * 1024) return RFN_ERR_SHAPE;
+    bool vec = true;
     for (int g = 0; g < ng; ++g) {
         if (!E.x[g] || !E.alpha_in[g] || !E.z[g] || (SOFTMAX && !E.alpha_out[g])) return RFN_ERR_ARG;
-        vec = vec && rfn_aligned16(E.x[g]) && rfn_aligned16(E.z[g]);
+        vec = vec && (Dm.D[g] % 4 == 0) && (Dm.xsb[g] % 4 == 0) && (Dm.xsl[g] % 4 == 0) && (Dm.ldz[g] % 4 == 0) &&
+              rfn_aligned16(E.x[g]) && rfn_aligned16(E.z[g]);
     }
     if (vec)
-        hipLaunchKernelGGL((attn_context_fwd_k<true, SOFTMAX>), dim3(rfn_cdiv(D, 4 * ATT_THREADS), B, ng),
-                           dim3(ATT_THREADS), L * sizeof(float), st, E, (long)sb, (long)sl, L, D, (long)ldz);
+        hipLaunchKernelGGL((attn_context_fwd_k<true, SOFTMAX>), dim3(rfn_cdiv(Dm.maxD, 4 * ATT_THREADS), B, ng),
+                           dim3(ATT_THREADS), Dm.maxL * sizeof(float), st, E, Dm);
     else
-        hipLaunchKernelGGL((attn_context_fwd_k<false, SOFTMAX>), dim3(rfn_cdiv(D, ATT_THREADS), B, ng),
-                           dim3(ATT_THREADS), L * sizeof(float), st, E, (long)sb, (long)sl, L, D, (long)ldz);
+        hipLaunchKernelGGL((attn_context_fwd_k<false, SOFTMAX>), dim3(rfn_cdiv(Dm.maxD, ATT_THREADS), B, ng),
+                           dim3(ATT_THREADS), Dm.maxL * sizeof(float), st, E, Dm);
     RFN_CHECK_LAUNCH();
     return RFN_OK;
+}
+template <bool SOFTMAX>
+static int launch_context(int ng, const AttnEncPtrs& E, int64_t sb, int64_t sl, int B, int L, int D, int64_t ldz,
+                          hipStream_t st) {
+    if (L <= 0 || D <= 0) return RFN_ERR_SHAPE;
+    return launch_context_d<SOFTMAX>(ng, E, attn_dims_uniform(ng, L, D, 0, 0, sb, sl, 0, 0, ldz), B, st);
 }
 
 extern "C" int rfn_attn_context_fwd(const float* att_seq, int64_t sb, int64_t sl, const float* alpha, int B, int L,
@@ -237,25 +285,27 @@ extern "C" int rfn_attn_context_fwd(const float* att_seq, int64_t sb, int64_t sl
     return launch_context<false>(1, E, sb, sl, B, L, D, ldz, (hipStream_t)stream);
 }
 
-static int launch_scores_raw_g(int ng, const AttnEncPtrs& E, int64_t proj_sb, int64_t proj_sl, int B, int L, int A,
-                               hipStream_t st) {
-    if (B <= 0 || L <= 0 || A <= 0 || ng < 1 || ng > RFN_MAX_ENC) return RFN_ERR_SHAPE;
+static int launch_scores_raw_d(int ng, const AttnEncPtrs& E, const AttnDims& Dm, int B, int A, hipStream_t st) {
+    if (B <= 0 || Dm.maxL <= 0 || A <= 0 || ng < 1 || ng > RFN_MAX_ENC) return RFN_ERR_SHAPE;
     const size_t lds = (2 * ((A + 3) & ~3)) * sizeof(float);
     if (lds > 64 * 1024) return RFN_ERR_SHAPE;
-    bool vec = (A % 4 == 0) && (proj_sb % 4 == 0) && (proj_sl % 4 == 0);
+    bool vec = (A % 4 == 0);
     for (int g = 0; g < ng; ++g) {
         if (!E.proj[g] || !E.hproj[g] || !E.w_out[g] || !E.scores[g]) return RFN_ERR_ARG;
-        vec = vec && rfn_aligned16(E.proj[g]);
+        vec = vec && (Dm.psb[g] % 4 == 0) && (Dm.psl[g] % 4 == 0) && rfn_aligned16(E.proj[g]);
     }
-    dim3 grid(rfn_cdiv(L, SC_ROWS), B, ng);
+    dim3 grid(rfn_cdiv(Dm.maxL, SC_ROWS), B, ng);
     if (vec)
-        hipLaunchKernelGGL(attn_scores_raw_k<true>, grid, dim3(ATT_THREADS), lds, st, E, (long)proj_sb, (long)proj_sl, L,
-                           A);
+        hipLaunchKernelGGL(attn_scores_raw_k<true>, grid, dim3(ATT_THREADS), lds, st, E, Dm, A);
     else
-        hipLaunchKernelGGL(attn_scores_raw_k<false>, grid, dim3(ATT_THREADS), lds, st, E, (long)proj_sb, (long)proj_sl,
-                           L, A);
+        hipLaunchKernelGGL(attn_scores_raw_k<false>, grid, dim3(ATT_THREADS), lds, st, E, Dm, A);
     RFN_CHECK_LAUNCH();
     return RFN_OK;
+}
+static int launch_scores_raw_g(int ng, const AttnEncPtrs& E, int64_t proj_sb, int64_t proj_sl, int B, int L, int A,
+                               hipStream_t st) {
+    if (L <= 0) return RFN_ERR_SHAPE;
+    return launch_scores_raw_d(ng, E, attn_dims_uniform(ng, L, 1, proj_sb, proj_sl, 0, 0, 0, 0, 0), B, A, st);
 }
 static int launch_scores_raw(const float* proj, int64_t proj_sb, int64_t proj_sl, const float* hproj,
                              const float* w_out, const float* b_out, int B, int L, int A, float* scores,
@@ -407,9 +457,11 @@ extern "C" int rfn_attn_context_bwd_dseq(const float* alpha, const float* dz, in
 // ((k * 3 + plane) * ks_mp + ks_col0 + a) * 2 bytes): 8 bytes per lane and plane, whole rows coalesced -- the separate split
 // pass over dproj (a read of 4 and a write of 6 bytes per element) disappears.
 template <bool VEC, bool FUSED, bool EMIT = false>
-__global__ __launch_bounds__(SB_THREADS) void attn_scores_bwd_k(const AttnEncPtrs E, long sb, long sl, int L, int A,
-                                                               long dsb, long dsl, int accumulate, long xsb, long xsl,
-                                                               long lddz, int D, int vec_x, int ks_mp, int ks_col0) {
+__global__ __launch_bounds__(SB_THREADS) void attn_scores_bwd_k(const AttnEncPtrs E, const AttnDims Dm, int A, int accumulate,
+                                                               int vec_x, int ks_mp, int ks_col0) {
+    const int L = Dm.L[blockIdx.y], D = Dm.D[blockIdx.y];
+    const long sb = Dm.psb[blockIdx.y], sl = Dm.psl[blockIdx.y], dsb = Dm.dsb[blockIdx.y], dsl = Dm.dsl[blockIdx.y];
+    const long xsb = Dm.xsb[blockIdx.y], xsl = Dm.xsl[blockIdx.y], lddz = Dm.ldz[blockIdx.y];
     const float* proj = E.proj[blockIdx.y];   // may alias dproj
     const float* __restrict__ hproj = E.hproj[blockIdx.y];
     const float* __restrict__ w_out = E.w_out[blockIdx.y];
@@ -571,47 +623,51 @@ __global__ __launch_bounds__(SB_THREADS) void attn_scores_bwd_k(const AttnEncPtr
 }
 
 template <bool FUSED>
-static int launch_scores_bwd(int ng, const AttnEncPtrs& E, int64_t proj_sb, int64_t proj_sl, int B, int L, int A,
-                             int64_t dproj_sb, int64_t dproj_sl, int accumulate_dproj, int64_t xsb, int64_t xsl,
-                             int64_t lddz, int D, hipStream_t st, int ks_mp = 0, int ks_col0 = 0) {
+static int launch_scores_bwd_d(int ng, const AttnEncPtrs& E, const AttnDims& Dm, int B, int A, int accumulate_dproj,
+                               hipStream_t st, int ks_mp = 0, int ks_col0 = 0) {
     const bool emit = ks_mp > 0;   // dproj goes to E.ks_img as bf16 planes instead of f32
+    const int L = Dm.maxL, D = Dm.maxD;     // LDS is sized for the largest map of the launch
     if (B <= 0 || L <= 0 || A <= 0 || ng < 1 || ng > RFN_MAX_ENC) return RFN_ERR_SHAPE;
     size_t fl = (size_t)(2 + 2 * SB_WAVES) * ((A + 3) & ~3) + SB_WAVES + L;
     if (FUSED) fl = (size_t)(2 + 2 * SB_WAVES) * ((A + 3) & ~3) + SB_WAVES + 2 * ((L + 3) & ~3) + ((D + 3) & ~3);
     const size_t lds = fl * sizeof(float);
     if (lds > 150 * 1024) return RFN_ERR_SHAPE;
-    bool vec = (A % 4 == 0) && (proj_sb % 4 == 0) && (proj_sl % 4 == 0) && (dproj_sb % 4 == 0) && (dproj_sl % 4 == 0);
-    bool vx = FUSED && (D % 4 == 0) && (xsb % 4 == 0) && (xsl % 4 == 0);
+    bool vec = (A % 4 == 0);
+    bool vx = FUSED;
     for (int g = 0; g < ng; ++g) {
         if (!E.proj[g] || !E.hproj[g] || !E.w_out[g] || !E.alpha_in[g] || !E.dhproj[g] || !E.dw_part[g]) return RFN_ERR_ARG;
         if (emit ? !E.ks_img[g] : !E.dproj[g]) return RFN_ERR_ARG;
         if (FUSED ? (!E.x[g] || !E.dz[g]) : !E.dalpha[g]) return RFN_ERR_ARG;
-        vec = vec && rfn_aligned16(E.proj[g]) && (emit || rfn_aligned16(E.dproj[g]));
-        vx = vx && rfn_aligned16(E.x[g]);
+        vec = vec && (Dm.psb[g] % 4 == 0) && (Dm.psl[g] % 4 == 0) && (Dm.dsb[g] % 4 == 0) && (Dm.dsl[g] % 4 == 0) &&
+              rfn_aligned16(E.proj[g]) && (emit || rfn_aligned16(E.dproj[g]));
+        vx = vx && (Dm.D[g] % 4 == 0) && (Dm.xsb[g] % 4 == 0) && (Dm.xsl[g] % 4 == 0) && rfn_aligned16(E.x[g]);
     }
     if (emit) {
         if (!FUSED || !vec || accumulate_dproj || (ks_mp & 3) || (ks_col0 & 3)) return RFN_ERR_SHAPE;
         if constexpr (FUSED) {
             auto k = attn_scores_bwd_k<true, true, true>;
             if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(k, dim3(B, ng), dim3(SB_THREADS), lds, st, E, (long)proj_sb, (long)proj_sl, L, A, 0L, 0L, 0,
-                               (long)xsb, (long)xsl, (long)lddz, D, (int)vx, ks_mp, ks_col0);
+            hipLaunchKernelGGL(k, dim3(B, ng), dim3(SB_THREADS), lds, st, E, Dm, A, 0, (int)vx, ks_mp, ks_col0);
         }
     } else if (vec) {
         auto k = attn_scores_bwd_k<true, FUSED>;
         if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k, dim3(B, ng), dim3(SB_THREADS), lds, st, E, (long)proj_sb, (long)proj_sl, L, A,
-                           (long)dproj_sb, (long)dproj_sl, accumulate_dproj, (long)xsb, (long)xsl, (long)lddz, D,
-                           (int)vx, 0, 0);
+        hipLaunchKernelGGL(k, dim3(B, ng), dim3(SB_THREADS), lds, st, E, Dm, A, accumulate_dproj, (int)vx, 0, 0);
     } else {
         auto k = attn_scores_bwd_k<false, FUSED>;
         if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k, dim3(B, ng), dim3(SB_THREADS), lds, st, E, (long)proj_sb, (long)proj_sl, L, A,
-                           (long)dproj_sb, (long)dproj_sl, accumulate_dproj, (long)xsb, (long)xsl, (long)lddz, D,
-                           (int)vx, 0, 0);
+        hipLaunchKernelGGL(k, dim3(B, ng), dim3(SB_THREADS), lds, st, E, Dm, A, accumulate_dproj, (int)vx, 0, 0);
     }
     RFN_CHECK_LAUNCH();
     return RFN_OK;
+}
+template <bool FUSED>
+static int launch_scores_bwd(int ng, const AttnEncPtrs& E, int64_t proj_sb, int64_t proj_sl, int B, int L, int A,
+                             int64_t dproj_sb, int64_t dproj_sl, int accumulate_dproj, int64_t xsb, int64_t xsl,
+                             int64_t lddz, int D, hipStream_t st, int ks_mp = 0, int ks_col0 = 0) {
+    if (L <= 0 || (FUSED && D <= 0)) return RFN_ERR_SHAPE;
+    return launch_scores_bwd_d<FUSED>(ng, E, attn_dims_uniform(ng, L, D, proj_sb, proj_sl, xsb, xsl, dproj_sb, dproj_sl, lddz),
+                                      B, A, accumulate_dproj, st, ks_mp, ks_col0);
 }
 
 extern "C" int rfn_attn_scores_bwd(const float* proj, int64_t proj_sb, int64_t proj_sl, const float* hproj,
@@ -673,6 +729,52 @@ extern "C" int rfn_attn_bwd(const float* proj, int64_t proj_sb, int64_t proj_sl,
                             int accumulate_dproj, float* dhproj, float* dw_part, void* stream) {
     return rfn_attn_bwd_grouped(1, &proj, proj_sb, proj_sl, &hproj, &w_out, &alpha, &att_seq, sb, sl, &dz, lddz, B, L,
                                 A, D, &dproj, dproj_sb, dproj_sl, accumulate_dproj, &dhproj, &dw_part, stream);
+}
+
+// The two calls above for encoders whose maps differ in (L, D) (they share A): contiguous layouts -- proj / dproj
+// (B, L_g, A), att_seq (B, L_g, D_g), z / dz (B, D_g), alpha and the raw-score scratch (B, L_g).  Same kernels, same
+// per-row arithmetic as the per-encoder calls (bit-identical); the grid covers the largest map.
+extern "C" int rfn_attn_fwd_het(int ngroups, const float* const* proj, const float* const* hproj, const float* const* w_out,
+                                const float* const* b_out, const float* const* att_seq, int B, const int* L, int A,
+                                const int* D, float* const* scores_scratch, float* const* alpha, float* const* z,
+                                void* stream) {
+    if (ngroups < 1 || ngroups > RFN_MAX_ENC) return RFN_ERR_SHAPE;
+    if (!proj || !hproj || !w_out || !att_seq || !scores_scratch || !alpha || !z) return RFN_ERR_ARG;
+    AttnDims Dm;
+    RFN_TRY(attn_dims_het(ngroups, L, D, A, &Dm));
+    AttnEncPtrs E;
+    memset(&E, 0, sizeof(E));
+    for (int g = 0; g < ngroups; ++g) {
+        if (!scores_scratch[g] || !alpha[g] || scores_scratch[g] == alpha[g]) return RFN_ERR_ARG;
+        E.proj[g] = proj[g];
+        E.hproj[g] = hproj[g];
+        E.w_out[g] = w_out[g];
+        E.b_out[g] = b_out ? b_out[g] : nullptr;
+        E.scores[g] = scores_scratch[g];
+        E.x[g] = att_seq[g];
+        E.alpha_in[g] = scores_scratch[g];
+        E.alpha_out[g] = alpha[g];
+        E.z[g] = z[g];
+    }
+    RFN_TRY(launch_scores_raw_d(ngroups, E, Dm, B, A, (hipStream_t)stream));
+    return launch_context_d<true>(ngroups, E, Dm, B, (hipStream_t)stream);
+}
+extern "C" int rfn_attn_bwd_het(int ngroups, const float* const* proj, const float* const* hproj, const float* const* w_out,
+                                const float* const* alpha, const float* const* att_seq, const float* const* dz, int B,
+                                const int* L, int A, const int* D, float* const* dproj, int accumulate_dproj,
+                                float* const* dhproj, float* const* dw_part, void* stream) {
+    if (ngroups < 1 || ngroups > RFN_MAX_ENC) return RFN_ERR_SHAPE;
+    if (!proj || !hproj || !w_out || !alpha || !att_seq || !dz || !dproj || !dhproj || !dw_part) return RFN_ERR_ARG;
+    AttnDims Dm;
+    RFN_TRY(attn_dims_het(ngroups, L, D, A, &Dm));
+    AttnEncPtrs E;
+    memset(&E, 0, sizeof(E));
+    for (int g = 0; g < ngroups; ++g) {
+        E.proj[g] = proj[g]; E.hproj[g] = hproj[g]; E.w_out[g] = w_out[g]; E.alpha_in[g] = alpha[g];
+        E.x[g] = att_seq[g]; E.dz[g] = dz[g];
+        E.dproj[g] = dproj[g]; E.dhproj[g] = dhproj[g]; E.dw_part[g] = dw_part[g];
+    }
+    return launch_scores_bwd_d<true>(ngroups, E, Dm, B, A, accumulate_dproj, (hipStream_t)stream);
 }
 
 // =====================================================================================================

@@ -695,11 +695,34 @@ static int prefix_fwd_impl(const rfn_dims* d, int B, const float* const* prm, co
             RFN_TRY(rfn_attn_fwd_grouped(M, a_p, L0 * A, (long)A, a_hp, a_w, a_b, att, L0 * D0, D0, B, (int)L0,
                                          A, (int)D0, a_sc, a_al, a_z, D0, st));
         }
+        bool het_done = false;
+        if (!same_ld && M > 1) {   // maps of different (L, D): still one pair of launches (rfn_attn_fwd_het)
+            const float *a_p[RFN_MAX_ENC], *a_hp[RFN_MAX_ENC], *a_w[RFN_MAX_ENC], *a_b[RFN_MAX_ENC];
+            float *a_sc[RFN_MAX_ENC], *a_al[RFN_MAX_ENC], *a_z[RFN_MAX_ENC];
+            int a_L[RFN_MAX_ENC], a_D[RFN_MAX_ENC];
+            size_t sc_off = 0;
+            for (int i = 0; i < M; ++i) {
+                const long Li = d->L[i], Di = d->D[i];
+                a_p[i] = W + Lo.P1[i] + (long)t * B * Li * A;
+                a_hp[i] = hp + (long)i * B * A;
+                a_w[i] = prm[P.s1(t, i, 4)];
+                a_b[i] = prm[P.s1(t, i, 5)];
+                a_sc[i] = W + Lo.gws + sc_off;
+                sc_off += ((size_t)B * Li + 3) & ~(size_t)3;
+                a_al[i] = W + Lo.al1[i] + (long)t * B * Li;
+                a_z[i] = W + Lo.z1[i] + (long)t * B * Di;
+                a_L[i] = (int)Li;
+                a_D[i] = (int)Di;
+            }
+            if (sc_off > GEMM_WS_FLOATS) return RFN_ERR_SHAPE;
+            RFN_TRY(rfn_attn_fwd_het(M, a_p, a_hp, a_w, a_b, att, B, a_L, A, a_D, a_sc, a_al, a_z, st));
+            het_done = true;
+        }
         for (int i = 0; i < M; ++i) {
             const long Li = d->L[i], Di = d->D[i];
             float* al = W + Lo.al1[i] + (long)t * B * Li;
             float* z = W + Lo.z1[i] + (long)t * B * Di;
-            if (!same_ld) {
+            if (!same_ld && !het_done) {
                 if ((size_t)B * Li > GEMM_WS_FLOATS) return RFN_ERR_SHAPE;
                 RFN_TRY(rfn_attn_fwd(W + Lo.P1[i] + (long)t * B * Li * A, Li * A, (long)A, hp + (long)i * B * A,
                                      prm[P.s1(t, i, 4)], prm[P.s1(t, i, 5)], att[i], Li * Di, Di, B, (int)Li, A,
@@ -1035,6 +1058,18 @@ extern "C" int rfn_prefix_bwd(const rfn_dims* d, int B, const float* const* prm,
                               seg_dx(g + (long)i * B * 4 * R, 4 * R, prm[P.s1(t, i, 8)], d->D[0], 4 * R));
             RFN_TRY(gemm_groups(B, d->D[0], M, pr, 0, gx));
         }
+        bool dz_done = same_d && M > 1;
+        if (!dz_done && M > 1) {   // heterogeneous feature widths: the M products still share one launch (an output each)
+            rfn_cell_out kz[RFN_MAX_ENC];
+            for (int i = 0; i < M; ++i) {
+                kz[i] = cell_out(W + Lo.dz1[i], d->D[i], d->D[i], 0);
+                cell_dx(kz[i], g + (long)i * B * 4 * R, 4 * R, prm[P.s1(t, i, 8)], d->D[i], 4 * R);
+            }
+            if (cell_ok(B, M, kz, R)) {
+                RFN_TRY(cell_run(B, M, kz, R, 0.f, 0, st));
+                dz_done = true;
+            }
+        }
         bool same_ld = same_d && M > 1;
         for (int i = 1; i < M; ++i) same_ld = same_ld && d->L[i] == d->L[0];
         const bool grouped_bwd = same_ld && (B >= FUSED_ATTN_BWD_MIN_B ||
@@ -1063,14 +1098,36 @@ extern "C" int rfn_prefix_bwd(const rfn_dims* d, int B, const float* const* prm,
                                              B, (int)L0, A, (int)D0, a_dp, L0 * A, (long)A, 0, a_dhp, a_dw, st));
             }
         }
+        bool het_bwd = !grouped_bwd && !same_ld && M > 1 && dz_done;
+        for (int i = 0; i < M && het_bwd; ++i)     // every encoder would take the fused exact-f32 launch on its own
+            het_bwd = !x3_takes(d, B, i) &&
+                      (B >= FUSED_ATTN_BWD_MIN_B || (long)d->L[i] * d->D[i] <= FUSED_ATTN_BWD_SMALL_MAP);
+        if (het_bwd) {   // maps of different (L, D): the M attention backwards of this step in one launch
+            const float *a_p[RFN_MAX_ENC], *a_hp[RFN_MAX_ENC], *a_w[RFN_MAX_ENC], *a_al[RFN_MAX_ENC], *a_dz[RFN_MAX_ENC];
+            float *a_dp[RFN_MAX_ENC], *a_dhp[RFN_MAX_ENC], *a_dw[RFN_MAX_ENC];
+            int a_L[RFN_MAX_ENC], a_D[RFN_MAX_ENC];
+            for (int i = 0; i < M; ++i) {
+                a_dp[i] = W + Lo.P1[i] + (long)t * B * d->L[i] * A;
+                a_p[i] = a_dp[i];
+                a_hp[i] = hp + i * BA;
+                a_w[i] = prm[P.s1(t, i, 4)];
+                a_al[i] = W + Lo.al1[i] + (long)t * B * d->L[i];
+                a_dz[i] = W + Lo.dz1[i];
+                a_dhp[i] = dhp + i * BA;
+                a_dw[i] = dwp + ((long)t * M + i) * BA;
+                a_L[i] = d->L[i];
+                a_D[i] = d->D[i];
+            }
+            RFN_TRY(rfn_attn_bwd_het(M, a_p, a_hp, a_w, a_al, att, a_dz, B, a_L, A, a_D, a_dp, 0, a_dhp, a_dw, st));
+        }
         for (int i = 0; i < M; ++i) {
             const long Li = d->L[i], Di = d->D[i];
             float* dz = W + Lo.dz1[i];
-            if (!(same_d && M > 1))
+            if (!dz_done)
                 RFN_TRY(gemm1(B, (int)Di, seg_dx(g + (long)i * B * 4 * R, 4 * R, prm[P.s1(t, i, 8)], Di, 4 * R), dz, Di, 0, gx));
             float* dali = dal + (long)i * B * Li;
             float* p1 = W + Lo.P1[i] + (long)t * B * Li * A;
-            if (grouped_bwd) {
+            if (grouped_bwd || het_bwd) {
                 // done above
             } else if (B >= FUSED_ATTN_BWD_MIN_B && x3_takes(d, B, i)) {   // ... with dP1 as bf16 planes
                 const float* p1c = p1;

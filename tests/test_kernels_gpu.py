@@ -429,6 +429,56 @@ def test_stage1_attention_grouped_over_encoders_matches_single_calls(dev):
         assert maxerr(al[g], al_ref) < 2e-6 and maxerr(z[g], z_ref) < 1e-5
 
 
+@pytest.mark.parametrize('Ls,Ds,A', [((50, 17, 64, 9), (96, 160, 36, 200), 64), ((196, 64, 49), (2048, 1536, 2208), 512),
+                                     ((5, 7), (18, 30), 30)])
+def test_stage1_attention_over_heterogeneous_encoders_matches_single_calls(dev, Ls, Ds, A):
+    """rfn_attn_fwd_het / rfn_attn_bwd_het: encoders with different (L, D) maps in one launch (the reference's shipped
+    feat_array.py:240-244 mix) against one call per encoder: same bits, and fp64 parity of alpha / z."""
+    import ctypes as C
+    n = N()
+    G, B = len(Ls), 5
+    st = n.stream_ptr()
+    proj = [rnd(B, Ls[g], A, seed=10 + g).to(dev) for g in range(G)]
+    hp = [rnd(B, A, seed=20 + g).to(dev) for g in range(G)]
+    w = [rnd(A, seed=30 + g, scale=0.3).to(dev) for g in range(G)]
+    bo = [rnd(1, seed=40 + g).to(dev) for g in range(G)]
+    x = [rnd(B, Ls[g], Ds[g], seed=50 + g).to(dev) for g in range(G)]
+    dz = [rnd(B, Ds[g], seed=60 + g).to(dev) for g in range(G)]
+    raw = [torch.empty(B, Ls[g], device=dev) for g in range(G)]
+    al = [torch.empty(B, Ls[g], device=dev) for g in range(G)]
+    z = [torch.empty(B, Ds[g], device=dev) for g in range(G)]
+    La, Da = (C.c_int * G)(*Ls), (C.c_int * G)(*Ds)
+    n.check(n.lib.rfn_attn_fwd_het(G, n.ptr_array(proj), n.ptr_array(hp), n.ptr_array(w), n.ptr_array(bo), n.ptr_array(x), B,
+                                   La, A, Da, n.ptr_array(raw), n.ptr_array(al), n.ptr_array(z), st), 'rfn_attn_fwd_het')
+    dp = [torch.empty(B, Ls[g], A, device=dev) for g in range(G)]
+    dhp = [torch.empty(B, A, device=dev) for g in range(G)]
+    dwp = [torch.empty(B, A, device=dev) for g in range(G)]
+    n.check(n.lib.rfn_attn_bwd_het(G, n.ptr_array(proj), n.ptr_array(hp), n.ptr_array(w), n.ptr_array(al), n.ptr_array(x),
+                                   n.ptr_array(dz), B, La, A, Da, n.ptr_array(dp), 0, n.ptr_array(dhp), n.ptr_array(dwp), st),
+            'rfn_attn_bwd_het')
+    for g in range(G):
+        L, D = Ls[g], Ds[g]
+        raw1, al1, z1 = torch.empty(B, L, device=dev), torch.empty(B, L, device=dev), torch.empty(B, D, device=dev)
+        n.check(n.lib.rfn_attn_fwd(proj[g].data_ptr(), L * A, A, hp[g].data_ptr(), w[g].data_ptr(), bo[g].data_ptr(),
+                                   x[g].data_ptr(), L * D, D, B, L, A, D, raw1.data_ptr(), al1.data_ptr(), z1.data_ptr(),
+                                   D, st))
+        assert torch.equal(al1, al[g]) and torch.equal(z1, z[g])
+        dp1, dhp1, dwp1 = torch.empty(B, L, A, device=dev), torch.empty(B, A, device=dev), torch.empty(B, A, device=dev)
+        n.check(n.lib.rfn_attn_bwd(proj[g].data_ptr(), L * A, A, hp[g].data_ptr(), w[g].data_ptr(), al1.data_ptr(),
+                                   x[g].data_ptr(), L * D, D, dz[g].data_ptr(), D, B, L, A, D, dp1.data_ptr(), L * A, A,
+                                   0, dhp1.data_ptr(), dwp1.data_ptr(), st))
+        assert torch.equal(dp1, dp[g]) and torch.equal(dhp1, dhp[g]) and torch.equal(dwp1, dwp[g])
+        al_ref, z_ref = attn_ref(proj[g].cpu(), hp[g].cpu(), w[g].cpu(), bo[g].cpu(), x[g].cpu())
+        assert maxerr(al[g], al_ref) < 2e-6 and maxerr(z[g], z_ref) < 2e-5
+    # in place (dproj = proj) and accumulate, as the path uses it
+    inpl = [t.clone() for t in proj]
+    n.check(n.lib.rfn_attn_bwd_het(G, n.ptr_array(inpl), n.ptr_array(hp), n.ptr_array(w), n.ptr_array(al), n.ptr_array(x),
+                                   n.ptr_array(dz), B, La, A, Da, n.ptr_array(inpl), 0, n.ptr_array(dhp), n.ptr_array(dwp), st),
+            'rfn_attn_bwd_het (in place)')
+    for g in range(G):
+        assert torch.equal(inpl[g], dp[g])
+
+
 def test_attention_time_major_strides(dev):
     """Stage II / decoder read thoughts stored (step, batch, feature): stride_b = R, stride_l = B*R."""
     n = N()
