@@ -590,8 +590,38 @@ __device__ __forceinline__ void x3_tile(const X3Args& args, const int row0, cons
     }
 }
 
-// grid.x: main_tiles whole tiles (blocks that share an XCD, id % 8, take consecutive tiles, tn fastest: the 16 column
-// tiles of a row panel run side by side on one XCD and share the panel through its L2), then 4 quarter-tile blocks per
+// Tile index -> (tm, tn).  The 32 tiles an XCD keeps in flight (one per CU) should share operand panels through its L2:
+// X3_BAND_ROWS x X3_BAND_COLS = 8 x 4 consecutive indices form one block of the tile grid, so a K step of those 32 tiles
+// fetches 8 + 4 panels instead of the 2 + 16 of a row-major walk over 16 column tiles (fabric traffic of the projection
+// launch 5.77 -> see profiles/r03_x3_traffic.md).  Bands of 8 tile rows, inside a band groups of 4 tile columns, row-major
+// inside a group; ragged last band / last group handled.
+#ifndef X3_BAND_ROWS
+#define X3_BAND_ROWS 8
+#endif
+#ifndef X3_BAND_COLS
+#define X3_BAND_COLS 4
+#endif
+__device__ __forceinline__ void x3_tile_of(int wg, int tiles_m, int tiles_n, int& tm, int& tn) {
+    const int per_band = X3_BAND_ROWS * tiles_n;
+    const int band = wg / per_band;
+    int idx = wg - band * per_band;
+    const int br = min(X3_BAND_ROWS, tiles_m - band * X3_BAND_ROWS);
+    const int per_group = br * X3_BAND_COLS;
+    int grp = idx / per_group;
+    const int full = tiles_n / X3_BAND_COLS;           // whole groups of X3_BAND_COLS columns
+    int gc = X3_BAND_COLS;
+    if (grp >= full) {                                 // the ragged last group
+        grp = full;
+        gc = tiles_n - full * X3_BAND_COLS;
+    }
+    idx -= grp * per_group;
+    const int r = idx / gc;
+    tm = band * X3_BAND_ROWS + r;
+    tn = grp * X3_BAND_COLS + (idx - r * gc);
+}
+
+// grid.x: main_tiles whole tiles (blocks that share an XCD, id % 8, take consecutive tile indices, x3_tile_of above),
+// then 4 quarter-tile blocks per
 // remaining tile: the last, partly filled round of a long launch is spread over four times as many CUs.  grid.z: K slices.
 template <int SHAPE, int BM, int BN, int WGM, int WGN, int SLOTS, bool TAIL, bool KS = false>
 __global__ __launch_bounds__(64 * WGM * WGN) void x3_gemm_k(const X3Args args) {
@@ -603,12 +633,14 @@ __global__ __launch_bounds__(64 * WGM * WGN) void x3_gemm_k(const X3Args args) {
         int wg = blockIdx.x;
         const int q = args.main_tiles / 8, r = args.main_tiles % 8, xcd = wg % 8;
         wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + wg / 8;
-        const int tm = wg / args.tiles_n, tn = wg % args.tiles_n;
+        int tm, tn;
+        x3_tile_of(wg, args.tiles_m, args.tiles_n, tm, tn);
         x3_tile<SHAPE, BM, BN, WGM, WGN, SLOTS, KS>(args, tm * BM, tn * BN, kc0, per, ks);
     } else if constexpr (TAIL) {
         const int t = blockIdx.x - args.main_tiles;
         const int wg = args.main_tiles + t / 4, qd = t % 4;
-        const int tm = wg / args.tiles_n, tn = wg % args.tiles_n;
+        int tm, tn;
+        x3_tile_of(wg, args.tiles_m, args.tiles_n, tm, tn);
         x3_tile<SHAPE, BM / 2, BN / 2, WGM, WGN, SLOTS, KS>(args, tm * BM + (qd >> 1) * (BM / 2), tn * BN + (qd & 1) * (BN / 2),
                                                              kc0, per, ks);
     }
