@@ -13,6 +13,7 @@ rocprofv3 --kernel-trace --stats -d $O/exact -o t --output-format csv -- python3
 rocprofv3 --kernel-trace --stats -d $O/x3 -o t --output-format csv -- python3 $R/bench.py --no-cpu-baseline --gemm bf16x3 > $O/x3.log 2>&1
 rocprofv3 --kernel-trace --stats -d $O/c2 -o t --output-format csv -- python3 $R/bench.py --workload c2 --no-cpu-baseline --no-alt-line > $O/c2.log 2>&1
 rocprofv3 --kernel-trace --stats -d $O/dec -o t --output-format csv -- python3 $R/tools/prof_decode.py > $O/dec.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/c3het -o t --output-format csv -- python3 $R/bench.py --workload c3het --no-cpu-baseline --no-alt-line > $O/c3het.log 2>&1
 cd $R
 python tools/trace_phases.py $O/exact/t_kernel_trace.csv --top 8 > $O/phases_exact.txt
 python tools/trace_phases.py $O/x3/t_kernel_trace.csv --top 8 > $O/phases_x3.txt
@@ -26,5 +27,10 @@ for args in "--workload c2" "--workload c3het" "--recipe" "--label-smoothing" "-
 done
 python bench.py --no-cpu-baseline --workload c5 --gemm bf16x3 2>/dev/null | tail -1 >> $O/secondary.jsonl
 bash tools/run_gemm_pmc.sh r03 "" all > $O/pmc_gemm.txt 2>&1
-rm -f $O/exact/t_kernel_trace.csv $O/x3/t_kernel_trace.csv $O/c2/t_kernel_trace.csv $O/dec/t_kernel_trace.csv    # tens of MB; the summaries stay
+: > $O/shards.jsonl      # single-GPU steps of data-parallel shards (tools/dp_predict.py)
+for b in 256 128 64 32; do
+  python bench.py --no-cpu-baseline --batch $b 2>/dev/null | tail -1 >> $O/shards.jsonl
+done
+python tools/step_launches.py $O/c3het/t_kernel_trace.csv > $O/step_launches_c3het.txt 2>/dev/null
+rm -f $O/exact/t_kernel_trace.csv $O/x3/t_kernel_trace.csv $O/c2/t_kernel_trace.csv $O/dec/t_kernel_trace.csv $O/c3het/t_kernel_trace.csv    # tens of MB; the summaries stay
 ls -la $O
