@@ -32,6 +32,7 @@ def main():
     ap.add_argument('--reps', type=int, default=200)
     ap.add_argument('--floor', action='store_true')
     ap.add_argument('--slots', type=lambda x: [int(v) for v in x.split(',')], default=[2, 3, 4, 6])
+    ap.add_argument('--variants', type=lambda x: [int(v) for v in x.split(',')], default=[1, 2, 3])
     a = ap.parse_args()
     g = torch.Generator(device=dev).manual_seed(1)
     rnd = lambda *s: torch.randn(*s, device=dev, generator=g) * 0.1  # noqa: E731
@@ -43,6 +44,9 @@ def main():
         ('stage II K1: 4 hp | g = h2h(h)', 256, [(512, [512])] * 4 + [(2048, [512])], False, 1),
         ('stage II K3: g += sum z_2_h -> lstm', 256, [(2048, [512] * 4)], True, 1),
         ('decoder K3 at B=64', 64, [(2048, [512])], True, 1),
+        ('decoder K1 at B=64', 64, [(512, [512]), (2048, [512])], False, 1),
+        ('decoder bwd Kb1 at B=64', 64, [(512, [2048]), (512, [2048])], False, 0),
+        ('decoder bwd Kb2 at B=64', 64, [(512, [512])], False, 0),
         ('decoder K3 at B=640 (beam)', 640, [(2048, [512])], True, 1),
         ('decoder bwd: dz | dhrec = dg . W', 256, [(512, [2048]), (512, [2048])], False, 0),
         ('decoder bwd: dhrec += dhp . W', 256, [(512, [512])], False, 0),
@@ -81,7 +85,7 @@ def main():
                                            0, 0.0, 0, 0, N.stream_ptr()))
         line += ' old %6.1f us |' % timeit(old, a.reps)
         arr, st = N.cell_gemm_args(outs), N.stream_ptr()
-        for v in [0] + [t + 16 * sl for t in (1, 2, 3) for sl in a.slots]:
+        for v in [0] + [t + 16 * sl for t in a.variants for sl in a.slots]:
             if N.lib.rfn_cell_gemm(M, len(outs), arr, R, 0.0, 0, v, st) != 0:
                 line += ' v%d/%d   -- ' % (v & 15, v >> 4)
                 continue
