@@ -91,9 +91,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef GEMM_NT_STAGES
 #define GEMM_NT_STAGES 1   /* LDS stages of the big NT tile: measured 131 TF single-buffered (3 blocks/CU) vs 125 */
 #endif
-#ifndef GEMM_MEDIUM_TARGET_NT
-#define GEMM_MEDIUM_TARGET_NT 512
-#endif
 #ifndef GEMM_TAIL_HALF
 #define GEMM_TAIL_HALF 1   /* half-height tiles for the last, partly filled round of a big NT launch */
 #endif
