@@ -126,6 +126,47 @@ def test_gemm_split_k_is_deterministic_and_correct(dev, ak, bk):
         assert maxerr(Cg, r) < 1e-3
 
 
+@pytest.mark.parametrize('M,Nn,K,ak,bk,groups', [
+    (4352, 512, 9488, 1, 0, 1),      # logit dX at C3: 136 tiles, the old rule's 544-block launch
+    (1088, 512, 9488, 1, 0, 1),      # ... at C2: 36 tiles
+    (9472, 512, 1088, 0, 0, 1),      # logit dW at C2: 296 tiles
+    (4096, 1536, 4096, 0, 0, 1),     # a heterogeneous encoder's att_2_att_h weight gradient: 384 tiles (K shortened)
+    (4096, 2176, 3136, 0, 0, 1),     # ... 544 tiles: between one and two rounds
+    (256, 2048, 2048, 1, 0, 4),      # stage-I dH: one full round, 4 groups
+])
+def test_gemm_medium_products_split_by_the_cost_model(dev, M, Nn, K, ak, bk, groups):
+    """Products below two rounds of 128 x 128 tiles take their K split from launch_tile's cost model (tools/split_probe.py):
+    every choice must match fp64, be deterministic, not depend on the LDS-lean flag (data-parallel hosts set it: the step
+    must stay bit-equal), and a forced different split must agree to re-association error."""
+    n = N()
+    ws = torch.empty(256 << 20, dtype=torch.uint8, device=dev)
+    g = torch.Generator(device=dev).manual_seed(M + Nn + K)
+    probs, refs, keep = [], [], []
+    for _ in range(groups):
+        A = torch.randn((M, K) if ak else (K, M), device=dev, generator=g) * 0.1
+        B = torch.randn((Nn, K) if bk else (K, Nn), device=dev, generator=g) * 0.1
+        keep += [A, B]
+        Am = A if ak else A.t()
+        Bm = B.t() if bk else B
+        refs.append(Am.double() @ Bm.double())
+        probs.append([(A, K if ak else M, ak, B, K if bk else Nn, bk, K, None)])
+
+    def run(flags):
+        Cs = [torch.empty(M, Nn, device=dev) for _ in range(groups)]
+        n.gemm(M, Nn, [(C, Nn, sg) for C, sg in zip(Cs, probs)], ws=ws, flags=flags)
+        return Cs
+    base = run(0)
+    tol = 3e-6 * K ** 0.5
+    for C, r in zip(base, refs):
+        assert maxerr(C, r) < tol
+    for other in (run(0), run(n.GEMM_OPT_LDS_LEAN)):
+        for C, C0 in zip(other, base):
+            assert torch.equal(C, C0)
+    for forced in (1, 2, 5):
+        for C, r in zip(run(forced << 8), refs):
+            assert maxerr(C, r) < tol
+
+
 def test_gemm_weight_gradient_emits_bias_gradient(dev):
     """dW = dY^T X with a_colsum = colsum(dY) riding on the same launch (both tile sizes, vec and scalar)."""
     n = N()
