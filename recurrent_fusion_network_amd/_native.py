@@ -22,6 +22,7 @@ GEMM_OPT_NO_DMA = 2
 GEMM_OPT_BF16X3 = 4
 GEMM_OPT_BF16X3_ANY_SIZE = 8
 GEMM_OPT_SPLITK_IN_KERNEL = 16
+ADAM_MAXBUCKET = 16               # rfn.h RFN_ADAM_MAXBUCKET
 
 
 class RfnError(RuntimeError):
@@ -140,6 +141,7 @@ def _load():
         'rfn_rl_loss': (C.c_int, [P, L, P, L, P, L, P, L, L, I, I, I, F, P, L, I, F, P, P, I, P, L, P, L, L, P]),
         'rfn_rl_loss_ex': (C.c_int, [P, L, P, L, P, L, P, L, L, I, I, I, I, F, P, L, I, F, P, P, P, I, P, L, P, L, L, P]),
         'rfn_adam_step': (C.c_int, [P, P, P, P, L, F, F, F, F, F, F, F, I, P]),
+        'rfn_adam_step_multi': (C.c_int, [I, P, P, P, P, P, F, F, F, F, F, F, F, I, P]),
         'rfn_greedy_pick': (C.c_int, [P, L, I, I, I, P, P, L, P, L, P, P, P]),
         'rfn_multinomial_pick': (C.c_int, [P, L, I, I, F, P, P, F, P, L, P]),
         'rfn_beam_step': (C.c_int, [P, L, I, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P]),

@@ -9,6 +9,8 @@ Trainer-facing surface of ``torch.optim.Adam`` that the reference's loops touch:
 ``param_groups[0]['lr']`` (``utils.set_lr``, misc/utils.py:286-290; train.py:102-104), ``state_dict()`` /
 ``load_state_dict()`` (``optimizer_<id>.pth``, train.py:86-88,232-233).
 """
+import ctypes as C
+
 import torch
 
 from . import _native as N
@@ -140,14 +142,21 @@ class FusedClampAdam:
         g0 = self.param_groups[0]
         self.step_count += 1
         self.model._weights_epoch = getattr(self.model, '_weights_epoch', 0) + 1   # invalidates reuse_prefix entries
+        todo = []
         for name, st in self.flat.items():
             g = self.model._last_flat_grads.get(name)
             if g is None:
                 continue
             if g.numel() != st['n']:
                 raise N.RfnError('flat gradient layout changed')
-            N.check(N.lib.rfn_adam_step(st['p'].data_ptr(), g.data_ptr(), st['m'].data_ptr(), st['v'].data_ptr(),
-                                        st['n'], g0['lr'], g0['betas'][0], g0['betas'][1], g0['eps'],
-                                        g0['weight_decay'], g0['grad_clip'], grad_scale, self.step_count,
-                                        N.stream_ptr()),
-                    'rfn_adam_step')
+            todo.append((st, g))
+        # every bucket in one launch (rfn_adam_step_multi: same element arithmetic, no per-bucket ramp and tail)
+        for lo in range(0, len(todo), N.ADAM_MAXBUCKET):
+            part = todo[lo:lo + N.ADAM_MAXBUCKET]
+            sizes = (C.c_int64 * len(part))(*[st['n'] for st, _ in part])
+            N.check(N.lib.rfn_adam_step_multi(len(part), N.ptr_array([st['p'] for st, _ in part]),
+                                              N.ptr_array([g for _, g in part]), N.ptr_array([st['m'] for st, _ in part]),
+                                              N.ptr_array([st['v'] for st, _ in part]), sizes, g0['lr'], g0['betas'][0],
+                                              g0['betas'][1], g0['eps'], g0['weight_decay'], g0['grad_clip'], grad_scale,
+                                              self.step_count, N.stream_ptr()),
+                    'rfn_adam_step_multi')

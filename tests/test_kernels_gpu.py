@@ -806,6 +806,34 @@ def test_criteria_match_torch(dev, eps):
     assert maxerr(pd.grad, pr.grad) < 1e-7
 
 
+def test_adam_multi_bucket_launch_is_bit_identical_to_per_bucket_calls(dev):
+    """rfn_adam_step_multi: every flat bucket of the optimizer in one launch, same bits as one rfn_adam_step per bucket
+    (vector-aligned buckets, a ragged one, an unaligned view)."""
+    import ctypes as C
+    n = N()
+    st = n.stream_ptr()
+    sizes = [4096 * 300, 10007, 64, 4 * 12345 + 4]
+    base = [torch.randn(s_ + 4, device=dev, generator=torch.Generator(device=dev).manual_seed(k)) * 0.1 for k, s_ in enumerate(sizes)]
+    views = [b[:s_] for b, s_ in zip(base, sizes)]
+    views[3] = base[3][1:1 + sizes[3]]             # 4-byte offset: takes the scalar path
+    gs = [torch.randn(s_, device=dev, generator=torch.Generator(device=dev).manual_seed(10 + k)) * 2.0 for k, s_ in enumerate(sizes)]
+
+    def fresh():
+        return ([v.clone() for v in views], [torch.zeros(s_, device=dev) for s_ in sizes], [torch.zeros(s_, device=dev) for s_ in sizes])
+    p1, m1, v1 = fresh()
+    p2, m2, v2 = fresh()
+    for step in (1, 2, 3):
+        for k in range(len(sizes)):
+            n.check(n.lib.rfn_adam_step(p1[k].data_ptr(), gs[k].data_ptr(), m1[k].data_ptr(), v1[k].data_ptr(), sizes[k], 5e-4,
+                                        0.9, 0.999, 1e-8, 1e-5, 1.0, 0.5, step, st))
+        n.check(n.lib.rfn_adam_step_multi(len(sizes), n.ptr_array(p2), n.ptr_array(gs), n.ptr_array(m2), n.ptr_array(v2),
+                                          (C.c_int64 * len(sizes))(*sizes), 5e-4, 0.9, 0.999, 1e-8, 1e-5, 1.0, 0.5, step, st))
+    for k in range(len(sizes)):
+        assert torch.equal(p1[k], p2[k]) and torch.equal(m1[k], m2[k]) and torch.equal(v1[k], v2[k])
+    assert n.lib.rfn_adam_step_multi(17, n.ptr_array(p2 * 5), n.ptr_array(gs * 5), n.ptr_array(m2 * 5), n.ptr_array(v2 * 5),
+                                     (C.c_int64 * 20)(*(sizes * 5)), 5e-4, 0.9, 0.999, 1e-8, 0.0, 1.0, 1.0, 1, st) != 0
+
+
 def test_adam_and_greedy_pick(dev):
     n = N()
     st = n.stream_ptr()
