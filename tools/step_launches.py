@@ -19,7 +19,7 @@ def short(n):
 
 ev = [(int(r['Start_Timestamp']), int(r['End_Timestamp']), short(r['Kernel_Name']),
        int(r['Grid_Size_X']) // max(1, int(r['Workgroup_Size_X']))) for r in rows]
-adam = [i for i, e in enumerate(ev) if e[2].startswith('adam_k')]
+adam = [i for i, e in enumerate(ev) if e[2].startswith(('adam_k', 'adam_multi_k'))]
 groups, cur = [], [adam[0]]
 for x, y in zip(adam, adam[1:]):
     if y - x < 5:

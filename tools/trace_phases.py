@@ -27,7 +27,7 @@ def main():
     rows = list(csv.DictReader(open(a.csv)))
     rows.sort(key=lambda r: int(r['Start_Timestamp']))
     ev = [(int(r['Start_Timestamp']), int(r['End_Timestamp']), short(r['Kernel_Name'])) for r in rows]
-    adam = [i for i, e in enumerate(ev) if e[2].startswith('adam_k')]
+    adam = [i for i, e in enumerate(ev) if e[2].startswith(('adam_k', 'adam_multi_k'))]
     groups, cur = [], [adam[0]]
     for x, y in zip(adam, adam[1:]):
         if y - x < 5:
@@ -67,7 +67,7 @@ def main():
     while i_wg < len(step) and not re.search(r'fill_small_k', step[i_wg][2]):
         i_wg += 1
     i_wg += 1
-    i_ad = first(r'adam_k')
+    i_ad = first(r'adam_(multi_)?k')
     bounds = [('feature projections', 0, i_s1f), ('stage I forward recurrence', i_s1f, i_mid),
               ('stage II + decoder forward + criterion', i_mid, i_lb), ('logit layer backward', i_lb, i_db),
               ('decoder + stage II backward', i_db, i_s1b), ('stage I backward recurrence', i_s1b, i_wg),
