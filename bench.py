@@ -282,35 +282,64 @@ def launch_ranks(args, argv):
 
 
 def selftest_rank(args):
-    """One rank of --selftest-launch: the rendezvous, barrier and max-over-ranks timing of the real run on CPU
-    tensors; no model, no GPU.  `value` is null: this line proves the launch recipe, it is not a measurement."""
+    """One rank of --selftest-launch: the rendezvous, barrier, max-over-ranks timing and the failure discipline (RunGuard)
+    of the real run on CPU tensors; no model, no GPU.  `value` is null: this line proves the launch recipe, it is not a
+    measurement."""
     import torch
     from recurrent_fusion_network_amd import parallel as DP
     rank, world, _ = DP.init_from_env(os.environ.get('RFN_DIST_BACKEND', 'gloo'))
     if world != args.gpus:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
-    if os.environ.get('RFN_BENCH_FAIL_RANK') == str(rank):     # test hook: a rank that dies before the result line
-        raise SystemExit('rank %d: injected failure' % rank)
+    guard = RunGuard(rank, world)
+    fail = os.environ.get('RFN_BENCH_FAIL_RANK') == str(rank)     # test hooks: a rank that dies mid-run
+    where = os.environ.get('RFN_BENCH_FAIL_WHERE', 'headline')
     cpu = torch.device('cpu')
-    if world > 1:
-        torch.distributed.barrier()
-    t0 = time.perf_counter()
-    flat = torch.full((1024,), float(rank + 1))
-    works = DP.allreduce_flat([flat], world, async_op=True)
-    for wk in works:
-        wk.wait()
-    assert float(flat[0]) == world * (world + 1) / 2.0
-    elapsed = DP.max_over_ranks(time.perf_counter() - t0, world, cpu)
-    if rank == 0:
-        B = args.batch or WORKLOADS[args.workload]['B']
-        print(json.dumps({'metric': METRIC, 'value': None, 'unit': 'captions/s', 'n_gpus': world, 'steps': args.steps,
-                          'warmup': args.warmup, 'ms_per_step': round(elapsed * 1e3, 3), 'higher_is_better': True,
-                          'scaling': 'strong' if args.strong else 'weak', 'vs_baseline': None, 'dtype': 'f32',
-                          'data': 'synthetic', 'selftest': True,
-                          'rccl_ranks': torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
-                          'config': {'workload': 'launcher self-test (no GPU work)', 'captions_per_gpu': B}}), flush=True)
+
+    def exchange():
+        flat = torch.full((1024,), float(rank + 1))
+        for wk in DP.allreduce_flat([flat], world, async_op=True):
+            wk.wait()
+        assert float(flat[0]) == world * (world + 1) / 2.0
+
+    try:
+        if world > 1:
+            torch.distributed.barrier()
+        t0 = time.perf_counter()
+        if fail and where == 'headline':      # the peers are inside the all-reduce below when this rank gives up
+            raise RuntimeError('injected failure on rank %d in the headline leg (RFN_BENCH_FAIL_RANK)' % rank)
+        exchange()
+        elapsed = DP.max_over_ranks(time.perf_counter() - t0, world, cpu)
+        out = None
+        if rank == 0:
+            B = args.batch or WORKLOADS[args.workload]['B']
+            out = {'metric': METRIC, 'value': None, 'unit': 'captions/s', 'n_gpus': world, 'steps': args.steps,
+                   'warmup': args.warmup, 'ms_per_step': round(elapsed * 1e3, 3), 'higher_is_better': True,
+                   'scaling': 'strong' if args.strong else 'weak', 'vs_baseline': None, 'dtype': 'f32',
+                   'data': 'synthetic', 'selftest': True,
+                   'rccl_ranks': torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
+                   'config': {'workload': 'launcher self-test (no GPU work)', 'captions_per_gpu': B}}
+            guard.line = out
+        if world > 1 and not args.strong:     # an optional leg, with the real run's discipline
+            guard.begin_optional('strong', 60.0)
+            try:
+                if fail and where == 'strong':
+                    raise RuntimeError('injected failure in the strong leg')
+                if fail and where == 'strong-hang':
+                    guard.deadline = time.monotonic() + 1.0
+                    time.sleep(3600)
+                exchange()
+            except Exception as e:      # noqa: BLE001
+                guard.optional_failed('strong', '%s: %s' % (type(e).__name__, e))
+            guard.end_optional()
+            if rank == 0:
+                out['strong'] = {'value': None, 'scaling': 'strong'}
+        if rank == 0:
+            guard.emit(out)
+    except BaseException as e:      # noqa: BLE001
+        guard.fatal(e)
     if torch.distributed.is_initialized():
         torch.distributed.barrier()
+        guard.close()
         torch.distributed.destroy_process_group()
 
 
@@ -399,6 +428,128 @@ def run_decode(args, rank, world, dev):
     print(json.dumps(out), flush=True)
 
 
+class RunGuard:
+    """What keeps the one driver-run line of an N-rank job from hanging or getting lost.
+
+    A rank that raises must never enter a collective its peers are not in: they sit in a gradient all-reduce and everybody
+    would wait for the NCCL watchdog (10 min).  So ranks agree through a flag FILE (one node; name keyed by the launcher's pid
+    and the rendezvous port), polled by a daemon thread on every rank -- a thread, because the main thread of a healthy rank
+    may be blocked inside a collective or a device synchronisation (both release the GIL).
+
+    * a failure before the headline is measured: `fatal(exc)` -- traceback, flag, os._exit(1).  Peers see the flag and
+      exit 1 at once (torchrun tears the job down as soon as the first child is gone; the flag covers other launchers).
+    * a failure or an overrun inside an OPTIONAL leg (the strong-scaling and bf16x3 re-timings): the headline is already
+      in rank 0's hands (`self.line`), so rank 0 prints it with `{leg: {"error": ...}}` and every rank exits 0.
+    """
+    POLL_S = 0.25
+
+    def __init__(self, rank, world):
+        import tempfile
+        import threading
+        self.rank, self.world = rank, world
+        self.path = os.path.join(tempfile.gettempdir(), 'rfn_bench_%d_%s.flag' % (os.getppid(), os.environ.get('MASTER_PORT', '0')))
+        self.line = None            # rank 0: the result line as far as it is known (set once the headline leg is done)
+        self.leg = None             # the optional leg in progress
+        self.deadline = None
+        self.lock = threading.Lock()
+        self.closed = False
+        if world > 1:
+            if rank == 0:
+                try:
+                    os.unlink(self.path)     # a flag left by an earlier run under the same launcher pid and port
+                except OSError:
+                    pass
+            threading.Thread(target=self._watch, name='rfn-bench-guard', daemon=True).start()
+
+    def _flag(self, text):
+        try:
+            with open(self.path, 'a') as f:
+                f.write(text.replace('\n', ' ')[:400] + '\n')
+        except OSError:
+            pass
+
+    def _read(self):
+        try:
+            with open(self.path) as f:
+                return f.readline().strip()
+        except OSError:
+            return None
+
+    def _watch(self):
+        while not self.closed:
+            time.sleep(self.POLL_S)
+            msg = self._read()
+            if msg is None and self.deadline is not None and time.monotonic() > self.deadline:
+                msg = 'optional\t%s\trank %d: the leg overran its deadline' % (self.leg, self.rank)
+                self._flag(msg)
+            if msg is None or self.closed:
+                continue
+            if msg.startswith('optional\t'):
+                _, leg, text = (msg.split('\t', 2) + ['', ''])[:3]
+                self._finish_without(leg, text)
+                return
+            sys.stderr.write('bench.py rank %d: leaving, a peer failed: %s\n' % (self.rank, msg))
+            sys.stderr.flush()
+            os._exit(1)
+
+    def _finish_without(self, leg, text):
+        """Optional leg `leg` is abandoned job-wide: rank 0 prints the line it holds, everybody exits 0."""
+        waited = 0.0
+        while self.rank == 0 and self.line is None and waited < 300.0:
+            time.sleep(self.POLL_S)          # a peer failed while rank 0 was still pricing the headline's roofline
+            waited += self.POLL_S
+        with self.lock:
+            if self.closed:
+                return
+            self.closed = True
+            if self.rank == 0 and self.line is not None:
+                self.line.setdefault(leg or 'optional', {'error': text})
+                print(json.dumps(self.line), flush=True)
+            sys.stderr.write('bench.py rank %d: optional leg %s abandoned (%s)\n' % (self.rank, leg, text))
+            sys.stderr.flush()
+            os._exit(0 if (self.rank != 0 or self.line is not None) else 1)
+
+    def fatal(self, exc):
+        import traceback
+        traceback.print_exception(type(exc), exc, exc.__traceback__)
+        sys.stderr.write('bench.py rank %d: failed at t=%.3f before the result line; not entering any collective\n'
+                         % (self.rank, time.time()))
+        sys.stderr.flush()
+        if self.world > 1:
+            self._flag('fatal\trank %d: %s: %s' % (self.rank, type(exc).__name__, exc))
+        os._exit(1)
+
+    def begin_optional(self, leg, seconds):
+        self.leg, self.deadline = leg, time.monotonic() + seconds
+
+    def end_optional(self):
+        self.leg, self.deadline = None, None
+
+    def optional_failed(self, leg, err):
+        """This rank raised inside optional leg `leg`.  With peers around nobody may wait for it: flag and leave."""
+        text = 'rank %d: %s' % (self.rank, err)
+        self._flag('optional\t%s\t%s' % (leg, text))
+        first = (self._read() or '').split('\t', 2)         # the FIRST failure is the cause; later ones are its echoes
+        if len(first) == 3 and first[0] == 'optional':
+            leg, text = first[1], first[2]
+        self._finish_without(leg, text)
+
+    def close(self):
+        self.closed = True
+        if self.world > 1 and self.rank == 0:
+            try:
+                os.unlink(self.path)
+            except OSError:
+                pass
+
+    def emit(self, line):
+        with self.lock:
+            if self.closed:
+                return
+            self.closed = True
+            print(json.dumps(line), flush=True)
+
+
 def run_rank(args):
     import torch
     import recurrent_fusion_network_amd as R
@@ -409,19 +560,25 @@ def run_rank(args):
         raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     dev = torch.device('cuda', int(os.environ.get('RFN_DEVICE_INDEX', local)))   # test hook: ranks sharing one GPU
     torch.cuda.set_device(dev)
+    guard = RunGuard(rank, world)
     try:
         if args.workload == 'c5':
             run_decode(args, rank, world, dev)
         else:
-            run_train(args, rank, world, dev, R, DP)
-    finally:
-        if torch.distributed.is_initialized():
-            torch.distributed.barrier()
-            torch.distributed.destroy_process_group()
+            run_train(args, rank, world, dev, R, DP, guard)
+    except BaseException as e:      # noqa: BLE001  (SystemExit included: whatever it is, the peers must not wait for us)
+        # NOT a collective: the peers are inside a gradient all-reduce this rank will never join
+        guard.fatal(e)
+    # every rank got here: the line is out, the collectives below are matched
+    if torch.distributed.is_initialized():
+        torch.distributed.barrier()
+        guard.close()
+        torch.distributed.destroy_process_group()
 
 
-def run_train(args, rank, world, dev, R, DP):
+def run_train(args, rank, world, dev, R, DP, guard):
     import torch
+    import recurrent_fusion_network_amd._native as N
     w = dict(WORKLOADS[args.workload])
     B = args.batch or w['B']
     global_B = B * world
@@ -433,6 +590,7 @@ def run_train(args, rank, world, dev, R, DP):
     cfg.use_label_smoothing = int(args.label_smoothing)
     cfg.drop_prob_lm = float(args.drop_lm)
     torch.manual_seed(100 + rank)            # opts.py:178 default seed, + rank (train.py:23)
+    in_group = torch.distributed.is_initialized()
 
     model = R.RecurrentFusionModel(cfg).to(dev)
     seeded_weights_(model, 100)              # identical replicas on every rank
@@ -440,20 +598,22 @@ def run_train(args, rank, world, dev, R, DP):
     model.ss_prob = float(args.ss_prob)
     x3 = args.gemm == 'bf16x3'
     if x3:
-        import recurrent_fusion_network_amd._native as N
         model.gemm_flags |= N.GEMM_OPT_BF16X3
     if args.lds_lean:
-        import recurrent_fusion_network_amd._native as N
         model.gemm_flags |= N.GEMM_OPT_LDS_LEAN
     if args.micro_batches >= 0 and hasattr(model, 'micro_batches'):
         model.micro_batches = args.micro_batches
     crit = R.ReviewNetEnsembleCriterion(cfg)
     opt = R.FusedClampAdam(model, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5, grad_clip=1.0)
-    fc, att, labels, masks, top = synthetic_inputs(cfg, B, 100 + rank, dev)
+    inputs = synthetic_inputs(cfg, B, 100 + rank, dev)
 
     sync = DP.GradSync(model, world)     # per-bucket async all-reduce, overlapped with the rest of backward
+    start = opt.snapshot() if (not x3 and not args.no_alt_line) else None     # the bf16x3 leg restarts from here
 
     trace = [] if args.trace_steps else None
+    fail_rank = os.environ.get('RFN_BENCH_FAIL_RANK') == str(rank)            # test hooks: a rank that dies mid-run
+    fail_where = os.environ.get('RFN_BENCH_FAIL_WHERE', 'headline')
+    counts = {}
 
     def mark(row):
         if trace is not None:
@@ -461,7 +621,8 @@ def run_train(args, rank, world, dev, R, DP):
             e.record()
             row.append(e)
 
-    def step():
+    def step(inp, leg='headline'):
+        fc, att, labels, masks, top = inp
         row = []
         mark(row)
         opt.zero_grad()
@@ -475,6 +636,10 @@ def run_train(args, rank, world, dev, R, DP):
         mark(row)
         if trace is not None:
             trace.append((row, time.perf_counter()))
+        counts[leg] = counts.get(leg, 0) + 1
+        if fail_rank and leg == fail_where and counts[leg] == 2:
+            torch.cuda.synchronize()
+            raise RuntimeError('injected failure on rank %d in the %s leg (RFN_BENCH_FAIL_RANK)' % (rank, leg))
         return loss
 
     def dump_trace(label, n):
@@ -493,34 +658,68 @@ def run_train(args, rank, world, dev, R, DP):
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    def settle():                       # the same number of untimed steps on every rank: the slowest clock decides
+    def allocs():
+        st = torch.cuda.memory_stats(dev)
+        return st.get('num_device_alloc', 0) + st.get('num_device_free', 0)
+
+    def settle(inp, leg, seconds=0.0, n_steps=None):
+        """Untimed steps before the warm-up: for `seconds` (the same number of steps on every rank: the slowest clock
+        decides), or exactly `n_steps` of them."""
         n = 0
-        if args.settle > 0:
+        if n_steps is not None:
+            keep = None
+            for _ in range(n_steps):
+                keep = step(inp, leg)      # noqa: F841  held like the timed loop holds it: same allocator pattern
+                n += 1
+            return n
+        if seconds > 0:
             ts = time.perf_counter()
             keep = None
             while True:
-                keep = step()            # held like the timed loop holds it: same allocator pattern (see the warm-up loop)
+                keep = step(inp, leg)      # noqa: F841
                 n += 1
                 torch.cuda.synchronize()
                 # every rank leaves after the same step: continue while ANY rank's clock is still inside the window
-                if DP.max_over_ranks(1.0 if time.perf_counter() - ts < args.settle else 0.0, world, dev) == 0.0:
+                if DP.max_over_ranks(1.0 if time.perf_counter() - ts < seconds else 0.0, world, dev) == 0.0:
                     break
         return n
 
-    settle_n = settle()
-    for _ in range(args.warmup):
-        step()
-    fence()
-    a0 = torch.cuda.memory_stats(dev).get('num_device_alloc', 0) + torch.cuda.memory_stats(dev).get('num_device_free', 0)
-    t0, c0 = time.perf_counter(), time.thread_time()
-    for _ in range(args.steps):
-        loss = step()
-    fence()
-    dev_allocs = torch.cuda.memory_stats(dev).get('num_device_alloc', 0) + torch.cuda.memory_stats(dev).get('num_device_free', 0) - a0
-    host_cpu = (time.thread_time() - c0) / max(1e-9, time.perf_counter() - t0)   # share of the timed region the launching
-    elapsed = DP.max_over_ranks(time.perf_counter() - t0, world, dev)             # thread was on a CPU (1.0 = never descheduled)
+    def time_leg(inp, leg, seconds=0.0, n_settle=None):
+        """settle + W warm-up steps + EXACTLY K timed steps bracketed by barrier + synchronize.  Local times only: the
+        max over ranks is taken by the caller, outside any try block."""
+        n = settle(inp, leg, seconds, n_settle)
+        loss = None
+        for _ in range(args.warmup):
+            loss = step(inp, leg)
+        fence()
+        sync.record = True
+        a0, t0, c0 = allocs(), time.perf_counter(), time.thread_time()
+        for _ in range(args.steps):
+            loss = step(inp, leg)
+        fence()
+        local = time.perf_counter() - t0
+        host_cpu = (time.thread_time() - c0) / max(1e-9, local)      # share of the timed region the launching thread was
+        sync.record = False                                          # on a CPU (1.0 = never descheduled)
+        exposed, per_bucket, how = sync.exposed_ms()
+        return dict(local=local, loss=float(loss.detach()), allocs=int(allocs() - a0), host_cpu=host_cpu, settle_n=n,
+                    exposed=exposed, per_bucket=per_bucket, exposed_how=how)
+
+    def exposed_fields(r):
+        """exposed_ms: mean time per step the compute stream (or, on a host-blocking backend, the host) waited for the
+        gradient exchange, this rank; max over ranks beside it."""
+        if r['exposed'] is None:
+            return {'exposed_ms': None}
+        worst = DP.max_over_ranks(r['exposed'], world, dev)
+        return {'exposed_ms': round(worst, 3), 'exposed_ms_rank0': round(r['exposed'], 3),
+                'exposed_ms_by_bucket_rank0': {k: round(v, 3) for k, v in r['per_bucket'].items()},
+                'exposed_measured_by': r['exposed_how']}
+
+    # ---- the headline leg: nothing optional runs before this is measured and in rank 0's hands -------------------------
+    head = time_leg(inputs, 'headline', seconds=args.settle)
+    elapsed = DP.max_over_ranks(head['local'], world, dev)
+    head_x = exposed_fields(head)
     dump_trace('exact' if not x3 else 'bf16x3', args.steps)
-    final_loss = float(loss.detach())
+    final_loss = head['loss']
     digest = None
     if args.digest:
         import hashlib
@@ -530,46 +729,143 @@ def run_train(args, rank, world, dev, R, DP):
             flat = opt.flat[name]['p'].double()
             hsh.update(struct.pack('<dd', float(flat.sum()), float((flat * flat).sum())))
         digest = hsh.hexdigest()[:16]
-    # the same W + K steps once more with the two long products on the bf16 matrix cores: reported
-    # beside the headline as out['bf16x3'], never as `value`
+    ms = elapsed / args.steps * 1e3
+    out = None
+    if rank == 0:
+        M = len(w['enc'])
+        uniform = all(e == w['enc'][0] for e in w['enc'])
+        shape = ('M=%d encoders, L=%d, D=%d' % (M, w['enc'][0][0], w['enc'][0][1]) if uniform else
+                 'M=%d encoders (L,D,fc)=%s' % (M, ','.join('(%d,%d,%d)' % e for e in w['enc'])))
+        extras = ''.join([', label smoothing 0.1' if args.label_smoothing else '',
+                          ', drop_prob_lm %.2g' % args.drop_lm if args.drop_lm else '',
+                          ', ss_prob %.2g' % args.ss_prob if args.ss_prob else ''])
+        out = {
+            'metric': METRIC, 'value': round(global_B * args.steps / elapsed, 2), 'unit': 'captions/s', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 3), 'higher_is_better': True,
+            'scaling': 'strong' if args.strong else 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'settle_s': args.settle, 'settle_steps': head['settle_n'], 'host_thread_cpu_share': round(head['host_cpu'], 3),
+            'device_mallocs_frees_in_timed_region': head['allocs'],
+            'rccl_ranks': torch.distributed.get_world_size() if in_group else 1,
+            'dist_backend': torch.distributed.get_backend() if in_group else None,
+            'config': {'workload': '%s: RecurrentFusionModel XE train step (zero_grad+fwd+criterion+bwd+clamp+Adam), '
+                                   '%s, R=A=E=512, T1=T2=8, K=1000, V+1=9488, seq=16 (17 decoder steps)%s'
+                                   % (w['desc'], shape, extras),
+                       'captions_per_gpu': B, 'global_batch': global_B,
+                       'parallelism': 'dp%d (batch sharded, RCCL all-reduce of grads)' % world if world > 1 else 'single GPU',
+                       'micro_batches': int(getattr(model, 'micro_batches', 1) or 1),
+                       'final_loss': round(final_loss, 4), 'updates': head['settle_n'] + args.warmup + args.steps,
+                       'gemm_flags': int(model.gemm_flags), 'digest': digest},
+        }
+        if in_group:
+            out.update(head_x)
+        if x3:
+            out['dtype'] = 'f32 (the two long products as 3 bf16 planes x 6 MFMA products, f32 accumulate; the rest exact f32)'
+            out['config']['gemm'] = 'bf16x3'
+        # roofline of the dominant kernel, timed live with HIP events on the launch stream
+        att = inputs[1]
+        secs, flops = time_dominant_kernel(model, att, reps=5)
+        achieved = flops / secs / 1e12
+        # HBM-side bytes per launch of that kernel, from the rocprofv3 --pmc passes (null when the kernel source has
+        # changed since they were taken)
+        traffic = pmc_traffic(args.workload, B == w['B'])
+        traffic_x3 = pmc_traffic(args.workload + '_bf16x3', B == w['B'])
+        L0, D0 = w['enc'][0][0], w['enc'][0][1]
+        if x3:      # priced in bf16 MFMA FLOP (6 plane products per f32 product) against the bf16 peak
+            roof = {'bound': 'mfma', 'achieved': round(6 * achieved, 2), 'peak': BF16_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                    'frac': round(6 * achieved / BF16_MFMA_PEAK_TFLOPS, 4), 'traffic': traffic_x3,
+                    'traffic_unit': 'bytes per launch (2*FETCH_SIZE + WRITE_SIZE)',
+                    'f32_equivalent_tflops': round(achieved, 2),
+                    'algorithmic_bytes': int(6 * (B * L0 * D0 + 8 * 512 * D0) + 4 * B * L0 * 8 * 512),
+                    'kernel': 'x3_gemm_k (grouped att_2_att_h projection of encoder 0 on plane images, %.3f TFLOP of f32 '
+                              'product = %.3f TFLOP of bf16 MFMA per launch, %.3f ms per launch)'
+                              % (flops / 1e12, 6 * flops / 1e12, secs * 1e3)}
+        else:
+            roof = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                    'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': traffic,
+                    'traffic_unit': 'bytes per launch (2*FETCH_SIZE + WRITE_SIZE)',
+                    'algorithmic_bytes': int(4 * (B * L0 * D0 + 8 * 512 * D0 + B * L0 * 8 * 512)),
+                    'kernel': 'rfn_gemm_kernel NT big tile (grouped att_2_att_h projection of encoder 0, '
+                              '%.3f TFLOP per launch, %.3f ms per launch)' % (flops / 1e12, secs * 1e3)}
+        out['roofline'] = roof
+        # whole-step view against the same peak (SURVEY.md 8d algorithmic FLOP of one step)
+        step_flops = (w['step_tflop'] * 1e12 * (B / w['B'])) if w['step_tflop'] else train_step_flops(cfg, B)
+        out['roofline']['step_frac'] = round(step_flops / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)
+        out['roofline']['step_tflop'] = round(step_flops / 1e12, 4)
+        guard.line = out                   # from here on the headline cannot be lost to an optional leg
+
+    # ---- optional legs: re-timings reported beside the headline, never as `value` ---------------------------------------
+    # Each runs under try / except; with peers around, a rank that fails (or a leg that overruns) ends the job through the
+    # guard -- rank 0 prints the line it holds -- because a failing rank cannot tell its peers through a collective.
+    budget = 60.0 + 4.0 * (args.settle + (head['settle_n'] + 2 * args.warmup + 2 * args.steps) * ms * 1e-3)
+
+    def optional(leg, fn):
+        guard.begin_optional(leg, budget)
+        err, res = None, None
+        try:
+            res = fn()
+        except Exception as e:      # noqa: BLE001  (reported in the line, the headline stands)
+            err = '%s: %s' % (type(e).__name__, e)
+            sync.abandon()
+            sync.record = False
+            if world > 1:
+                guard.optional_failed(leg, err)          # does not return
+        guard.end_optional()
+        return err, res
+
+    # (1) the other reading of the metric: the SAME global batch one GPU runs (B captions), sharded over the ranks
+    strong = None
+    if in_group and not args.strong:
+        lo, hi = DP.shard_rows(B, rank, world)
+        if DP.max_over_ranks(1.0 if hi - lo < 1 else 0.0, world, dev) > 0.0:
+            strong = {'error': 'a global batch of %d rows cannot be sharded over %d ranks' % (B, world)}
+        else:
+            shard_inputs = synthetic_inputs(cfg, hi - lo, 1100 + rank, dev) if world > 1 else inputs
+            err, r = optional('strong', lambda: time_leg(shard_inputs, 'strong', seconds=min(args.settle, 1.0)))
+            if err:
+                strong = {'error': err}
+            else:
+                s_elapsed = DP.max_over_ranks(r['local'], world, dev)
+                s_ms = s_elapsed / args.steps * 1e3
+                s_flops = (w['step_tflop'] * 1e12 * ((hi - lo) / w['B'])) if w['step_tflop'] else train_step_flops(cfg, hi - lo)
+                strong = {'value': round(B * args.steps / s_elapsed, 2), 'unit': 'captions/s', 'ms_per_step': round(s_ms, 3),
+                          'global_batch': B, 'captions_per_gpu': hi - lo, 'scaling': 'strong',
+                          'device_mallocs_frees_in_timed_region': r['allocs'],
+                          'step_frac': round(s_flops / (s_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)}
+                strong.update(exposed_fields(r))
+            del shard_inputs
+        if rank == 0:
+            out['strong'] = strong
+
+    # (2) the same W + K steps with the two long products on the bf16 matrix cores, from the SAME
+    # starting weights and optimizer state and after the same number of updates as the headline leg, so that the two
+    # `final_loss` values are comparable
     alt = None
     if not x3 and not args.no_alt_line:
-        # The headline above is already measured: nothing in this opt-in leg may lose it.  Every rank runs the leg under
-        # try / finally (failures of this mode are shape-dependent and therefore the same on every rank), the flag is
-        # cleared whatever happens, and the collectives that agree on the outcome sit outside the try.
-        import recurrent_fusion_network_amd._native as N
-        alt_err, alt_local, alt_allocs, loss_alt = None, 0.0, 0, None
-        model.gemm_flags |= N.GEMM_OPT_BF16X3
-        try:
-            settle()                         # first use of this mode's workspaces and kernels
-            for _ in range(args.warmup):
-                loss_alt = step()
-            fence()
-            a1 = torch.cuda.memory_stats(dev).get('num_device_alloc', 0) + torch.cuda.memory_stats(dev).get('num_device_free', 0)
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                loss_alt = step()
-            fence()
-            alt_allocs = torch.cuda.memory_stats(dev).get('num_device_alloc', 0) + torch.cuda.memory_stats(dev).get('num_device_free', 0) - a1
-            alt_local = time.perf_counter() - t1
-            final_alt = float(loss_alt.detach())
-        except Exception as e:      # noqa: BLE001  (reported in the line, the exact-f32 headline stands)
-            alt_err = '%s: %s' % (type(e).__name__, e)
-            sync.works.clear()
-            sync.buckets.clear()
-        any_failed = DP.max_over_ranks(1.0 if alt_err else 0.0, world, dev) > 0.0
-        if any_failed:
-            alt = {'error': alt_err or 'another rank failed in bf16x3 mode'}
+        def x3_leg():
+            opt.restore(start)
+            model.gemm_flags |= N.GEMM_OPT_BF16X3
+            try:
+                return time_leg(inputs, 'bf16x3', n_settle=head['settle_n'])
+            finally:
+                model.gemm_flags &= ~N.GEMM_OPT_BF16X3
+        err, r = optional('bf16x3', x3_leg)
+        if err:
+            alt = {'error': err}
         else:
-            alt_elapsed = DP.max_over_ranks(alt_local, world, dev)
+            alt_elapsed = DP.max_over_ranks(r['local'], world, dev)
             dump_trace('bf16x3', args.steps)
             alt = {'value': round(global_B * args.steps / alt_elapsed, 2), 'unit': 'captions/s',
-                   'ms_per_step': round(alt_elapsed / args.steps * 1e3, 3), 'final_loss': round(final_alt, 4),
-                   'device_mallocs_frees_in_timed_region': int(alt_allocs),
+                   'ms_per_step': round(alt_elapsed / args.steps * 1e3, 3), 'final_loss': round(r['loss'], 4),
+                   'updates': r['settle_n'] + args.warmup + args.steps,
+                   'final_loss_note': 'same start, same number of updates as config.final_loss',
+                   'device_mallocs_frees_in_timed_region': r['allocs'],
                    'dtype': 'f32 (the two long products as 3 bf16 planes x 6 MFMA products, f32 accumulate; the rest exact f32)'}
+            if in_group:
+                alt.update(exposed_fields(r))
             if rank == 0:
+                model.gemm_flags |= N.GEMM_OPT_BF16X3
                 try:
-                    secs_a, flops_a = time_dominant_kernel(model, att, reps=5)
+                    secs_a, flops_a = time_dominant_kernel(model, inputs[1], reps=5)
                     alt['roofline'] = {'bound': 'mfma', 'achieved': round(6 * flops_a / secs_a / 1e12, 2),
                                        'peak': BF16_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                                        'frac': round(6 * flops_a / secs_a / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4),
@@ -578,71 +874,15 @@ def run_train(args, rank, world, dev, R, DP):
                     alt['roofline']['traffic'] = pmc_traffic(args.workload + '_bf16x3', B == w['B'])
                 except Exception as e:      # noqa: BLE001
                     alt['roofline'] = {'error': '%s: %s' % (type(e).__name__, e)}
-        model.gemm_flags &= ~N.GEMM_OPT_BF16X3
+                finally:
+                    model.gemm_flags &= ~N.GEMM_OPT_BF16X3
+        if rank == 0:
+            out['bf16x3'] = alt
     if rank != 0:
         return
-    ms = elapsed / args.steps * 1e3
-    M = len(w['enc'])
-    uniform = all(e == w['enc'][0] for e in w['enc'])
-    shape = ('M=%d encoders, L=%d, D=%d' % (M, w['enc'][0][0], w['enc'][0][1]) if uniform else
-             'M=%d encoders (L,D,fc)=%s' % (M, ','.join('(%d,%d,%d)' % e for e in w['enc'])))
-    extras = ''.join([', label smoothing 0.1' if args.label_smoothing else '',
-                      ', drop_prob_lm %.2g' % args.drop_lm if args.drop_lm else '',
-                      ', ss_prob %.2g' % args.ss_prob if args.ss_prob else ''])
-    out = {
-        'metric': METRIC, 'value': round(global_B * args.steps / elapsed, 2), 'unit': 'captions/s', 'n_gpus': world,
-        'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 3), 'higher_is_better': True,
-        'scaling': 'strong' if args.strong else 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-        'settle_s': args.settle, 'settle_steps': settle_n, 'host_thread_cpu_share': round(host_cpu, 3),
-        'device_mallocs_frees_in_timed_region': int(dev_allocs),
-        'rccl_ranks': torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
-        'dist_backend': torch.distributed.get_backend() if torch.distributed.is_initialized() else None,
-        'config': {'workload': '%s: RecurrentFusionModel XE train step (zero_grad+fwd+criterion+bwd+clamp+Adam), '
-                               '%s, R=A=E=512, T1=T2=8, K=1000, V+1=9488, seq=16 (17 decoder steps)%s'
-                               % (w['desc'], shape, extras),
-                   'captions_per_gpu': B, 'global_batch': global_B,
-                   'parallelism': 'dp%d (batch sharded, RCCL all-reduce of grads)' % world if world > 1 else 'single GPU',
-                   'micro_batches': int(getattr(model, 'micro_batches', 1) or 1),
-                   'final_loss': round(final_loss, 4), 'gemm_flags': int(model.gemm_flags), 'digest': digest},
-    }
-    if x3:
-        out['dtype'] = 'f32 (the two long products as 3 bf16 planes x 6 MFMA products, f32 accumulate; the rest exact f32)'
-        out['config']['gemm'] = 'bf16x3'
-
-    # roofline of the dominant kernel, timed live with HIP events on the launch stream
-    secs, flops = time_dominant_kernel(model, att, reps=5)
-    achieved = flops / secs / 1e12
-    # HBM-side bytes per launch of that kernel, from the rocprofv3 --pmc passes (null when the kernel source has changed
-    # since they were taken)
-    traffic = pmc_traffic(args.workload, B == w['B'])
-    traffic_x3 = pmc_traffic(args.workload + '_bf16x3', B == w['B'])
-    L0, D0 = w['enc'][0][0], w['enc'][0][1]
-    if x3:      # priced in bf16 MFMA FLOP (6 plane products per f32 product) against the bf16 peak
-        roof = {'bound': 'mfma', 'achieved': round(6 * achieved, 2), 'peak': BF16_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': round(6 * achieved / BF16_MFMA_PEAK_TFLOPS, 4), 'traffic': traffic_x3,
-                'traffic_unit': 'bytes per launch (2*FETCH_SIZE + WRITE_SIZE)',
-                'f32_equivalent_tflops': round(achieved, 2),
-                'algorithmic_bytes': int(6 * (B * L0 * D0 + 8 * 512 * D0) + 4 * B * L0 * 8 * 512),
-                'kernel': 'x3_gemm_k (grouped att_2_att_h projection of encoder 0 on plane images, %.3f TFLOP of f32 '
-                          'product = %.3f TFLOP of bf16 MFMA per launch, %.3f ms per launch)'
-                          % (flops / 1e12, 6 * flops / 1e12, secs * 1e3)}
-    else:
-        roof = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': traffic,
-                'traffic_unit': 'bytes per launch (2*FETCH_SIZE + WRITE_SIZE)',
-                'algorithmic_bytes': int(4 * (B * L0 * D0 + 8 * 512 * D0 + B * L0 * 8 * 512)),
-                'kernel': 'rfn_gemm_kernel NT big tile (grouped att_2_att_h projection of encoder 0, '
-                          '%.3f TFLOP per launch, %.3f ms per launch)' % (flops / 1e12, secs * 1e3)}
-    out['roofline'] = roof
-    # whole-step view against the same peak (SURVEY.md 8d algorithmic FLOP of one step)
-    step_flops = (w['step_tflop'] * 1e12 * (B / w['B'])) if w['step_tflop'] else train_step_flops(cfg, B)
-    out['roofline']['step_frac'] = round(step_flops / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)
-    out['roofline']['step_tflop'] = round(step_flops / 1e12, 4)
-    if alt is not None:
-        out['bf16x3'] = alt
     if world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(cfg, args.cpu_sample, 100)
-    print(json.dumps(out), flush=True)
+    guard.emit(out)
 
 
 def main(argv=None):

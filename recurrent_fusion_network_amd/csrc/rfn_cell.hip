@@ -7,23 +7,7 @@
 // Element-wise and tiny (B*R elements): one thread per (b, j), coalesced along j.
 #include "rfn_common.h"
 
-// Philox4x32-10 keyed by `seed`; counter = (element index, call-site offset).  One 32-bit draw per
-// element; forward and backward regenerate the same mask from (seed, offset) instead of storing it.
-__device__ __forceinline__ uint32_t mulhi32(uint32_t a, uint32_t b) { return __umulhi(a, b); }
-__device__ __forceinline__ float rfn_philox_uniform(uint64_t seed, uint64_t offset, uint64_t idx) {
-    uint32_t c0 = (uint32_t)idx, c1 = (uint32_t)(idx >> 32), c2 = (uint32_t)offset, c3 = (uint32_t)(offset >> 32);
-    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = mulhi32(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const uint32_t hi1 = mulhi32(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
-        const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
-        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-        k0 += 0x9E3779B9u;
-        k1 += 0xBB67AE85u;
-    }
-    return (float)(c0 >> 8) * (1.0f / 16777216.0f);  // [0, 1)
-}
+// dropout masks: rfn_philox_uniform (rfn_common.h)
 
 __global__ __launch_bounds__(256) void lstm_fwd_k(float* __restrict__ gates, long ldg, const float* c_prev /* may alias c_next */,
                                                   long ldcp, float* c_next, long ldcn,

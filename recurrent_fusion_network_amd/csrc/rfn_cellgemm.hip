@@ -70,21 +70,6 @@ struct CgArgs {
     CgSeg seg[CG_MAXSEG];
 };
 
-// Philox4x32-10 exactly as rfn_cell.hip draws it: forward here, backward there (or here) regenerate the same mask
-__device__ __forceinline__ float cg_philox_uniform(uint64_t seed, uint64_t offset, uint64_t idx) {
-    uint32_t c0 = (uint32_t)idx, c1 = (uint32_t)(idx >> 32), c2 = (uint32_t)offset, c3 = (uint32_t)(offset >> 32);
-    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
-        const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
-        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-        k0 += 0x9E3779B9u;
-        k1 += 0xBB67AE85u;
-    }
-    return (float)(c0 >> 8) * (1.0f / 16777216.0f);
-}
 
 template <int N>
 __device__ __forceinline__ void cg_wait_vmcnt() {
@@ -362,7 +347,7 @@ __global__ __launch_bounds__(64 * (BM / 32) * WK) void cell_gemm_k(const CgArgs 
             O.c_next[(long)grow * O.ldcn + unit] = c;
             float hv = og * tanhf(c);
             if (a.drop_p > 0.f) {
-                const float uu = cg_philox_uniform(a.seed, O.drop_offset, (uint64_t)((long)grow * R + unit));
+                const float uu = rfn_philox_uniform(a.seed, O.drop_offset, (uint64_t)((long)grow * R + unit));
                 hv = (uu >= a.drop_p) ? hv * (1.0f / (1.0f - a.drop_p)) : 0.f;
             }
             O.h_next[(long)grow * O.ldh + unit] = hv;
@@ -382,7 +367,7 @@ __global__ __launch_bounds__(64 * (BM / 32) * WK) void cell_gemm_k(const CgArgs 
             float dhv = (s + b_in[e][0]) + b_in[e][1];
             if (O.C) O.C[(long)grow * O.ldc + unit] = dhv;   // total d h of that call (kept for the caller's bookkeeping)
             if (a.drop_p > 0.f) {
-                const float uu = cg_philox_uniform(a.seed, O.drop_offset, (uint64_t)((long)grow * R + unit));
+                const float uu = rfn_philox_uniform(a.seed, O.drop_offset, (uint64_t)((long)grow * R + unit));
                 dhv = (uu >= a.drop_p) ? dhv * (1.0f / (1.0f - a.drop_p)) : 0.f;
             }
             const float ig = b_in[e][2], fg = b_in[e][3], og = b_in[e][4], gg = b_in[e][5];

@@ -45,6 +45,24 @@ __device__ __forceinline__ float rfn_tanh_fast(float x) {
     const float e = __expf(2.0f * x);
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
 }
+// Philox4x32-10 keyed by `seed`; counter = (element index, call-site offset).  One 32-bit draw per element; forward and
+// backward regenerate the same dropout mask from (seed, offset) instead of storing it.  THE one definition: the LSTM
+// kernels (rfn_cell.hip), the gate GEMM's reduce (rfn_gemm.hip) and the cell GEMM's epilogues (rfn_cellgemm.hip) must
+// draw identical bits for a forward mask and its backward twin to agree; rfn_dropout_mask (rfn.h) publishes them.
+__device__ __forceinline__ float rfn_philox_uniform(uint64_t seed, uint64_t offset, uint64_t idx) {
+    uint32_t c0 = (uint32_t)idx, c1 = (uint32_t)(idx >> 32), c2 = (uint32_t)offset, c3 = (uint32_t)(offset >> 32);
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return (float)(c0 >> 8) * (1.0f / 16777216.0f);  // [0, 1)
+}
 // ---- f32 -> three bf16 planes (x = p0 + p1 + p2; csrc/rfn_gemm_x3.hip) ---------------------------------------------
 __device__ __forceinline__ unsigned x3_bf16_rne(float x) {
     const unsigned u = __float_as_uint(x);

@@ -1017,20 +1017,6 @@ __global__ __launch_bounds__(256) void rfn_gemm_reduce_k(const GemmArgs args) {
 // order, the biases, applies the gate math and writes the activations back into C, c_next and the (dropout-masked)
 // h_next.  Group g = cell g of a stage-I step: its state pointers advance by the gs_* strides, its dropout stream is
 // offset + g.  (misc/RecurrentFusionModel.py:53-73)
-__device__ __forceinline__ float gemm_philox_uniform(uint64_t seed, uint64_t offset, uint64_t idx) {
-    uint32_t c0 = (uint32_t)idx, c1 = (uint32_t)(idx >> 32), c2 = (uint32_t)offset, c3 = (uint32_t)(offset >> 32);
-    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
-        const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
-        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-        k0 += 0x9E3779B9u;
-        k1 += 0xBB67AE85u;
-    }
-    return (float)(c0 >> 8) * (1.0f / 16777216.0f);
-}
 __global__ __launch_bounds__(256) void rfn_gemm_reduce_lstm_k(const GemmArgs args) {
     const int R = args.N / 4, M = args.M;
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
@@ -1071,7 +1057,7 @@ __global__ __launch_bounds__(256) void rfn_gemm_reduce_lstm_k(const GemmArgs arg
     L.c_next[grp * L.gs_cnext + (long)row * L.ldcn + j] = c;
     float hv = og * tanhf(c);
     if (L.drop_p > 0.f) {
-        const float u = gemm_philox_uniform(L.seed, L.offset + (uint64_t)grp, (uint64_t)idx);
+        const float u = rfn_philox_uniform(L.seed, L.offset + (uint64_t)grp, (uint64_t)idx);
         hv = (u >= L.drop_p) ? hv * (1.0f / (1.0f - L.drop_p)) : 0.f;
     }
     L.h_next[grp * L.gs_h + (long)row * L.ldh + j] = hv;

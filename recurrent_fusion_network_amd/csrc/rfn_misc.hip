@@ -489,6 +489,11 @@ __global__ __launch_bounds__(256) void log_softmax_topk_k(const float* __restric
                 if (pos[p] >= cols || wi[p][pos[p]] == 0x7fffffff) continue;
                 if (bp < 0 || lsm_before(wv[p][pos[p]], wi[p][pos[p]], wv[bp][pos[bp]], wi[bp][pos[bp]])) bp = p;
             }
+            if (bp < 0) {                        // a row with fewer than `cols` comparable entries (NaN logits): no
+                topv[(long)r * W + c] = -INFINITY;   // candidate is left -- never index the lists with -1; the slot
+                topi[(long)r * W + c] = 0;           // reads as "token 0 at -inf", which the beam step can never pick
+                continue;                            // over a real candidate
+            }
             topv[(long)r * W + c] = wv[bp][pos[bp]];
             topi[(long)r * W + c] = wi[bp][pos[bp]];
             ++pos[bp];

@@ -902,21 +902,31 @@ extern "C" int rfn_prefix_bwd(const rfn_dims* d, int B, const float* const* prm,
     // Fused form of a step (3 launches): Kb1 = dh_rec and every dz_i = dgates . [W_hh | W_z_i] in one launch; the M
     // attention backwards; Kb2 = dh_rec += sum_i dhp_i . W_h_i whose epilogue completes d h of step t-1 (+ its external
     // share dh2e[t-1]) and runs that step's LSTM backward.
-    bool fused2 = !d->review_maxout;
-    {
-        rfn_cell_out t1[RFN_MAX_ENC + 1], t2;
-        float* g0 = W + Lo.g2;
-        t1[0] = cell_out(dhrec, R, R, 0);
-        cell_dx(t1[0], g0, G2, prm[P.s2_hh_w(0)], R, G2);
+    // The operands of EVERY step are validated before the fused form is chosen (each step has its own weights and slabs;
+    // a step the cell GEMM cannot take must not be discovered mid-sweep, when the gates are already gate gradients).
+    auto s2_kb1 = [&](int t, rfn_cell_out* kb1) {
+        float* g = W + Lo.g2 + (long)t * B * G2;
+        kb1[0] = cell_out(dhrec, R, R, 0);
+        cell_dx(kb1[0], g, G2, prm[P.s2_hh_w(t)], R, G2);
         for (int i = 0; i < M; ++i) {
-            t1[1 + i] = cell_out(dz2 + i * BR, R, R, 0);
-            cell_dx(t1[1 + i], g0, G2, prm[P.s2(0, i, 0)], R, G2);
+            kb1[1 + i] = cell_out(dz2 + i * BR, R, R, 0);
+            cell_dx(kb1[1 + i], g, G2, prm[P.s2(t, i, 0)], R, G2);
         }
-        t2 = cell_out(dhrec, R, R, 1);
-        for (int i = 0; i < M; ++i) cell_dx(t2, W + Lo.dhp2 + i * BA, A, prm[P.s2(0, i, 4)], R, A);
-        rfn_cell_out t3 = t2;
-        cell_lstm_bwd(t3, g0, G2, c2, R, c2 + BR, R, dh2e, R, dc2, R, dc2, R, OFF_STAGE2);
-        fused2 = fused2 && cell_ok(B, M + 1, t1, R) && cell_ok(B, 1, &t2, R) && cell_ok(B, 1, &t3, R);
+    };
+    auto s2_kb2 = [&](int t, rfn_cell_out& kb2) {
+        float* dhp = W + Lo.dhp2 + (long)t * M * BA;
+        kb2 = cell_out(dhrec, R, R, 1);
+        for (int i = 0; i < M; ++i) cell_dx(kb2, dhp + i * BA, A, prm[P.s2(t, i, 4)], R, A);
+        if (t > 0)
+            cell_lstm_bwd(kb2, W + Lo.g2 + (long)(t - 1) * B * G2, G2, c2 + (t - 1) * BR, R, c2 + t * BR, R, dh2e + (t - 1) * BR, R,
+                          dc2, R, dc2, R, OFF_STAGE2 + (uint64_t)(t - 1));
+    };
+    bool fused2 = !d->review_maxout;
+    for (int t = 0; t < T2 && fused2; ++t) {
+        rfn_cell_out t1[RFN_MAX_ENC + 1], t2;
+        s2_kb1(t, t1);
+        s2_kb2(t, t2);
+        fused2 = cell_ok(B, M + 1, t1, R) && cell_ok(B, 1, &t2, R);
     }
     if (fused2) {   // LSTM backward of the last step: only the external gradients (thoughts, reason head, decoder state)
         float* dht = dh2e + (T2 - 1) * BR;
@@ -945,12 +955,7 @@ extern "C" int rfn_prefix_bwd(const rfn_dims* d, int B, const float* const* prm,
             RFN_TRY(gemm_groups(B, R, M + 1, pr, 0, gx));
         } else {
             rfn_cell_out kb1[RFN_MAX_ENC + 1];
-            kb1[0] = cell_out(dhrec, R, R, 0);
-            cell_dx(kb1[0], g, G2, prm[P.s2_hh_w(t)], R, G2);
-            for (int i = 0; i < M; ++i) {
-                kb1[1 + i] = cell_out(dz2 + i * BR, R, R, 0);
-                cell_dx(kb1[1 + i], g, G2, prm[P.s2(t, i, 0)], R, G2);
-            }
+            s2_kb1(t, kb1);
             RFN_TRY(cell_run(B, M + 1, kb1, R, 0.f, 0, st));
         }
         {   // whole attention backward of the M encoders in one fused launch (dP overwrites P in place)
@@ -976,11 +981,8 @@ extern "C" int rfn_prefix_bwd(const rfn_dims* d, int B, const float* const* prm,
         if (!fused2) {
             RFN_TRY(gemm_segs(B, R, M, segs, dhrec, R, 1, gx));
         } else {
-            rfn_cell_out kb2 = cell_out(dhrec, R, R, 1);
-            for (int i = 0; i < M; ++i) cell_dx(kb2, dhp + i * BA, A, prm[P.s2(t, i, 4)], R, A);
-            if (t > 0)
-                cell_lstm_bwd(kb2, W + Lo.g2 + (long)(t - 1) * B * G2, G2, c2 + (t - 1) * BR, R, c2 + t * BR, R, dh2e + (t - 1) * BR, R,
-                              dc2, R, dc2, R, OFF_STAGE2 + (uint64_t)(t - 1));
+            rfn_cell_out kb2;
+            s2_kb2(t, kb2);
             RFN_TRY(cell_run(B, 1, &kb2, R, d->drop_reason, seed, st));
         }
     }
@@ -1465,18 +1467,27 @@ extern "C" int rfn_decoder_bwd(const rfn_dims* d, int B, int S, const float* con
     // Fused form of a backward step (3 launches): Kb1 = [dh_rec | dz] = dgates . [W_hh | W_z] in one launch (they share the
     // gate gradients); the attention backward; Kb2 = dh_rec += dhp . W_h whose epilogue completes d h of step s-1
     // (+ the logit layer's share dhe[s-1]) and runs that step's LSTM backward -- the next thing the sweep needs.
+    // every step's operands are validated before the fused form is chosen (see the stage-II sweep in rfn_prefix_bwd)
+    auto dec_kb1 = [&](int s, rfn_cell_out* kb1) {
+        float* g = gd + (long)s * B * GD;
+        kb1[0] = cell_out(dhrec, R, R, 0);
+        cell_dx(kb1[0], g, GD, prm[P.dec(2)], R, GD);
+        kb1[1] = cell_out(dz, R, R, 0);
+        cell_dx(kb1[1], g, GD, prm[P.dec(4)], R, GD);
+    };
+    auto dec_kb2 = [&](int s, rfn_cell_out& kb2) {
+        kb2 = cell_out(dhrec, R, R, 1);
+        cell_dx(kb2, W + Lo.dhpd + s * BA, A, prm[P.dec(8)], R, A);
+        if (s > 0)
+            cell_lstm_bwd(kb2, gd + (long)(s - 1) * B * GD, GD, cd + (s - 1) * BR, R, cd + s * BR, R, dhe + (s - 1) * BR, R,
+                          dc, R, dc, R, OFF_DECODER + (uint64_t)(s - 1));
+    };
     bool fused = !d->decoder_maxout;
-    {
+    for (int s = 0; s < S && fused; ++s) {
         rfn_cell_out t1[2], t2;
-        t1[0] = cell_out(dhrec, R, R, 0);
-        cell_dx(t1[0], gd, GD, prm[P.dec(2)], R, GD);
-        t1[1] = cell_out(dz, R, R, 0);
-        cell_dx(t1[1], gd, GD, prm[P.dec(4)], R, GD);
-        t2 = cell_out(dhrec, R, R, 1);
-        cell_dx(t2, W + Lo.dhpd, A, prm[P.dec(8)], R, A);
-        rfn_cell_out t3 = t2;
-        cell_lstm_bwd(t3, gd, GD, cd, R, cd + BR, R, dhe, R, dc, R, dc, R, OFF_DECODER);
-        fused = fused && cell_ok(B, 2, t1, R) && cell_ok(B, 1, &t2, R) && cell_ok(B, 1, &t3, R);
+        dec_kb1(s, t1);
+        dec_kb2(s, t2);
+        fused = cell_ok(B, 2, t1, R) && cell_ok(B, 1, &t2, R);
     }
     if (fused)   // LSTM backward of the last step: nothing recurrent flows into it
         RFN_TRY(rfn_lstm_bwd(gd + (long)(S - 1) * B * GD, GD, cd + (S - 1) * BR, R, cd + S * BR, R, dhe + (S - 1) * BR, R, nullptr,
@@ -1488,18 +1499,11 @@ extern "C" int rfn_decoder_bwd(const rfn_dims* d, int B, int S, const float* con
         float* dhp = W + Lo.dhpd + s * BA;
         if (fused) {
             rfn_cell_out kb1[2], kb2;
-            kb1[0] = cell_out(dhrec, R, R, 0);
-            cell_dx(kb1[0], g, GD, prm[P.dec(2)], R, GD);
-            kb1[1] = cell_out(dz, R, R, 0);
-            cell_dx(kb1[1], g, GD, prm[P.dec(4)], R, GD);
+            dec_kb1(s, kb1);
             RFN_TRY(cell_run(B, 2, kb1, R, 0.f, 0, st));
             RFN_TRY(attn1_bwd(W + Lo.Pd, A, BA, W + Lo.hpd + s * BA, prm[P.dec(10)], al, comb, R, BR, dz, R, B, T2, A, R,
                               dPd, A, BA, 1, dhp, W + Lo.dwp + s * BA, d_comb, st));
-            kb2 = cell_out(dhrec, R, R, 1);
-            cell_dx(kb2, dhp, A, prm[P.dec(8)], R, A);
-            if (s > 0)
-                cell_lstm_bwd(kb2, gd + (long)(s - 1) * B * GD, GD, cd + (s - 1) * BR, R, cd + s * BR, R, dhe + (s - 1) * BR, R,
-                              dc, R, dc, R, OFF_DECODER + (uint64_t)(s - 1));
+            dec_kb2(s, kb2);
             RFN_TRY(cell_run(B, 1, &kb2, R, d->drop_lm, seed, st));
             continue;
         }

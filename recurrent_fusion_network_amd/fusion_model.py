@@ -140,7 +140,10 @@ class _PrefixFn(torch.autograd.Function):
         ws_bytes = ws.numel()
         att_ptrs = N.ptr_array(ctx.att)
         if ctx.consumed and ctx.snapshot is not None:
-            ws.copy_(ctx.snapshot)      # model.retain_activations: the activations of the ORIGINAL forward (see below)
+            # model.retain_activations: the activations of the ORIGINAL forward (see below).  Through .data: `ws` is a
+            # saved tensor, and a versioned in-place write would make autograd refuse the NEXT backward over this graph
+            # (ppo_k = 10 passes in the reference's loop, train_rl.py:190-201)
+            ws.data.copy_(ctx.snapshot)
         elif ctx.consumed:
             # backward overwrites activations in place (projections -> their gradients, gates -> gate gradients), so a
             # second backward over the same graph (loss.backward(retain_graph=True) in the PPO loop, train_rl.py:190-201)
@@ -230,7 +233,7 @@ class _DecoderFn(torch.autograd.Function):
         d_h0 = torch.empty_like(h0)
         d_c0 = torch.empty_like(c0)
         if ctx.consumed and ctx.snapshot is not None:
-            ws.copy_(ctx.snapshot)
+            ws.data.copy_(ctx.snapshot)          # .data: no version bump on a saved tensor (see _PrefixFn.backward)
         elif ctx.consumed:
             # second backward over the same graph: recompute phase 2 first (see _PrefixFn.backward), log-probs included,
             # so the pass differentiated is self-consistent at the current weights
@@ -738,8 +741,10 @@ class _BeamResults:
 
 
 class _LazyList(list):
-    """A list of known length whose entries are produced (all at once) by `fill()` the first time any of them is read:
-    indexing, slicing, iteration, comparison and printing see the filled list."""
+    """A list of known length whose entries are produced (all at once) by `fill()` the first time the list is looked at.
+    EVERY method of `list` other than `len()` fills first -- reads (indexing, iteration, comparison, `+`, `copy`, `index`,
+    `reversed`, printing, pickling ...) and mutators alike -- so no caller can ever see a placeholder; it pickles as a
+    plain list."""
 
     def __init__(self, n, fill):
         super().__init__([None] * n)
@@ -750,25 +755,28 @@ class _LazyList(list):
             fill, self._fill = self._fill, None
             list.__setitem__(self, slice(None), fill())
 
-    def __getitem__(self, k):
+    def __reduce_ex__(self, protocol):
         self._ensure()
-        return list.__getitem__(self, k)
+        return (list, (list(list.__iter__(self)),))
 
-    def __iter__(self):
-        self._ensure()
-        return list.__iter__(self)
 
-    def __repr__(self):
-        self._ensure()
-        return list.__repr__(self)
+def _lazy_method(name):
+    plain = getattr(list, name)
 
-    def __eq__(self, other):
+    def method(self, *args, **kwargs):
         self._ensure()
-        return list.__eq__(self, other)
+        return plain(self, *args, **kwargs)
+    method.__name__ = name
+    return method
 
-    def __contains__(self, x):
-        self._ensure()
-        return list.__contains__(self, x)
+
+for _name in ('__getitem__', '__iter__', '__repr__', '__eq__', '__ne__', '__lt__', '__le__', '__gt__', '__ge__',
+              '__contains__', '__add__', '__mul__', '__rmul__', '__iadd__', '__imul__', '__reversed__', '__setitem__',
+              '__delitem__', 'copy', 'index', 'count', 'append', 'extend', 'insert', 'pop', 'remove', 'reverse', 'sort',
+              'clear'):
+    setattr(_LazyList, _name, _lazy_method(_name))
+_LazyList.__radd__ = lambda self, other: other + list(self)        # list has no __radd__: `[x] + lazy` lands here for non-lists
+_LazyList.__hash__ = None
 
 
 class _Stepper:

@@ -107,34 +107,51 @@ class FusedClampAdam:
             ps, offs, _ = self.model.bucket_layout(name)
             for p, o in zip(ps, offs):
                 where[id(p)] = (name, o)
-        steps = set()
-        for st in self.flat.values():
-            st['m'].zero_()
-            st['v'].zero_()
+        # validate everything first: a rejected checkpoint must leave the moments and the step count as they were
+        g0 = groups[0]
+        if g0.get('amsgrad', False):
+            raise N.RfnError('amsgrad state is not supported by the fused update')
+        steps, todo = set(), []
         for pos, key in enumerate(order):
             ent = sd['state'].get(key)
             if ent is None:         # a parameter Adam never stepped: moments stay zero
                 continue
             p = params[pos]
-            if tuple(ent['exp_avg'].shape) != tuple(p.shape):
-                raise N.RfnError('optimizer state %s has shape %s, parameter %d has %s'
-                                 % (key, tuple(ent['exp_avg'].shape), pos, tuple(p.shape)))
+            for field in ('exp_avg', 'exp_avg_sq'):
+                if tuple(ent[field].shape) != tuple(p.shape):
+                    raise N.RfnError('optimizer state %s.%s has shape %s, parameter %d has %s'
+                                     % (key, field, tuple(ent[field].shape), pos, tuple(p.shape)))
+            steps.add(int(ent['step']))
+            todo.append((p, ent))
+        if len(steps) > 1:
+            raise N.RfnError('torch.optim.Adam state has per-parameter step counts %s; the fused update keeps one' % sorted(steps))
+        for st in self.flat.values():
+            st['m'].zero_()
+            st['v'].zero_()
+        for p, ent in todo:
             name, o = where[id(p)]
             n = p.numel()
             self.flat[name]['m'][o:o + n].copy_(ent['exp_avg'].reshape(-1))
             self.flat[name]['v'][o:o + n].copy_(ent['exp_avg_sq'].reshape(-1))
-            steps.add(int(ent['step']))
-        if len(steps) > 1:
-            raise N.RfnError('torch.optim.Adam state has per-parameter step counts %s; the fused update keeps one' % sorted(steps))
         self.step_count = steps.pop() if steps else 0
-        g0 = groups[0]
-        if g0.get('amsgrad', False):
-            raise N.RfnError('amsgrad state is not supported by the fused update')
         for k in ('lr', 'eps', 'weight_decay'):
             if k in g0:
                 self.param_groups[0][k] = g0[k]
         if 'betas' in g0:
             self.param_groups[0]['betas'] = tuple(g0['betas'])
+
+    def snapshot(self):
+        """Parameters, moments and step count as they are now (device copies): `restore` puts a run back at this point,
+        so two legs of a benchmark can take the same number of updates from the same start."""
+        return {'step_count': self.step_count,
+                'buckets': {name: tuple(st[k].detach().clone() for k in ('p', 'm', 'v')) for name, st in self.flat.items()}}
+
+    def restore(self, snap):
+        for name, st in self.flat.items():
+            for k, src in zip(('p', 'm', 'v'), snap['buckets'][name]):
+                st[k].copy_(src)
+        self.step_count = int(snap['step_count'])
+        self.model._weights_epoch = getattr(self.model, '_weights_epoch', 0) + 1
 
     # ---- the update ------------------------------------------------------------------------------------
     def step(self, grad_scale=1.0):

@@ -9,6 +9,7 @@ then two per encoder).  The reference divides the loss by the LOCAL batch size, 
 to the 1-rank step on the concatenated batch.
 """
 import os
+import time
 
 import torch
 import torch.distributed as dist
@@ -66,6 +67,12 @@ class GradSync:
         self.world = world
         self.works = []
         self.buckets = []
+        # exposed-wait bookkeeping (bench.py `exposed_ms`): off unless `record` is set.  On the nccl backend a wait() only
+        # makes the compute stream wait for the collective's stream, so the time that stream really stalls is the distance
+        # between two HIP events recorded around the wait -- read after the timed region, no synchronisation added.  Other
+        # backends block the host inside wait(): the host clock around it is the exposed time.
+        self.record = False
+        self._pending = []               # per finish(): (bucket names, [event_0 .. event_n]) or (bucket names, [seconds])
         model.grad_ready_hook = self.on_bucket
         if world > 1 and hasattr(model, 'gemm_flags'):
             # A one-round weight-gradient GEMM holds its LDS on every CU for its whole 6 ms: keep the big tiles lean
@@ -79,11 +86,51 @@ class GradSync:
             self.works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True))
 
     def finish(self):
-        for w in self.works:
-            w.wait()
+        if self.record and self.works:
+            on_stream = dist.get_backend() == 'nccl'
+            marks = []
+            for w in self.works:
+                if on_stream:
+                    e = torch.cuda.Event(enable_timing=True)
+                    e.record()
+                    marks.append(e)
+                    w.wait()
+                else:
+                    t0 = time.perf_counter()
+                    w.wait()
+                    marks.append(time.perf_counter() - t0)
+            if on_stream:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                marks.append(e)
+            self._pending.append((list(self.buckets), marks, on_stream))
+        else:
+            for w in self.works:
+                w.wait()
         self.works.clear()
         self.buckets.clear()
         return 1.0 / self.world
+
+    def abandon(self):
+        """Forget queued collectives and measurements (a leg that raised half way through a step)."""
+        self.works.clear()
+        self.buckets.clear()
+        self._pending.clear()
+
+    def exposed_ms(self):
+        """-> (mean ms per step the compute stream waited for gradient exchange, {bucket: mean ms}, how it was measured)
+        over the steps finished since the last call.  Call after the device has been synchronised."""
+        steps, total, per, how = len(self._pending), 0.0, {}, None
+        for names, marks, on_stream in self._pending:
+            how = 'hip events around each wait on the compute stream' if on_stream else 'host clock around each blocking wait'
+            for k, name in enumerate(names):
+                ms = marks[k].elapsed_time(marks[k + 1]) if on_stream else marks[k] * 1e3
+                per[name] = per.get(name, 0.0) + ms
+                total += ms
+        self._pending.clear()
+        if not steps:
+            return None, {}, None
+        return total / steps, {k: v / steps for k, v in per.items()}, how
 
 
 def allreduce_model_grads(model, world):

@@ -3,8 +3,10 @@ itself (fresh child processes, decided before torch or the GPU is touched), rela
 failing rank as a non-zero exit code."""
 import json
 import os
+import re
 import subprocess
 import sys
+import time
 
 import pytest
 
@@ -38,15 +40,48 @@ def test_two_ranks_self_launch_one_line_over_gloo():
     assert out['metric'].startswith('captions/sec') and out['scaling'] == 'weak' and out['value'] is None
 
 
+def _failed_at(stderr):
+    """Wall-clock time at which the injected failure happened (RunGuard.fatal prints it)."""
+    m = re.search(r'failed at t=([0-9.]+)', stderr)
+    assert m, stderr[-2000:]
+    return float(m.group(1))
+
+
 def test_strong_flag_and_failing_rank_propagates():
     r = subprocess.run([sys.executable, BENCH, '--gpus', '2', '--steps', '1', '--selftest-launch', '--strong'],
                        env=_env(RFN_DIST_BACKEND='gloo'), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and _json_lines(r.stdout)[0]['scaling'] == 'strong'
-    # ranks that disagree with --gpus die: the parent must not print a line and must exit non-zero
+    # a rank that dies before the headline exists: no line, non-zero exit, and QUICKLY -- the failing rank must not enter a
+    # collective (its peers are inside an all-reduce it will never join) and the peers must not wait for a watchdog
     r = subprocess.run([sys.executable, BENCH, '--gpus', '2', '--steps', '1', '--selftest-launch'],
                        env=_env(RFN_DIST_BACKEND='gloo', RFN_BENCH_FAIL_RANK='1'), capture_output=True, text=True,
                        timeout=300)
+    done = time.time()
     assert r.returncode != 0 and not _json_lines(r.stdout)
+    assert done - _failed_at(r.stderr) < 60.0
+
+
+def test_eight_ranks_self_launch_over_gloo():
+    """The N = 8 launch the driver will make, on CPU: 8 fresh ranks, one line, weak + strong legs."""
+    r = subprocess.run([sys.executable, BENCH, '--gpus', '8', '--steps', '1', '--selftest-launch'],
+                       env=_env(RFN_DIST_BACKEND='gloo', OMP_NUM_THREADS='1'), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1, r.stdout
+    assert lines[0]['n_gpus'] == 8 and lines[0]['rccl_ranks'] == 8 and lines[0]['strong'] == {'value': None, 'scaling': 'strong'}
+
+
+@pytest.mark.parametrize('where', ['strong', 'strong-hang'])
+def test_a_failing_optional_leg_cannot_lose_the_headline(where):
+    """Once the headline is measured, a rank that raises (or hangs past the deadline) inside an optional leg ends the job
+    through the flag file: rank 0 prints the line it holds with the leg's error, exit code 0."""
+    r = subprocess.run([sys.executable, BENCH, '--gpus', '4', '--steps', '1', '--selftest-launch'],
+                       env=_env(RFN_DIST_BACKEND='gloo', RFN_BENCH_FAIL_RANK='2', RFN_BENCH_FAIL_WHERE=where, OMP_NUM_THREADS='1'),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1, r.stdout
+    assert lines[0]['n_gpus'] == 4 and 'rank 2' in lines[0]['strong']['error']
 
 
 @pytest.mark.gpu
@@ -97,3 +132,59 @@ def test_one_rank_rccl_group_with_lean_tiles_is_bit_equal_to_the_plain_step():
     assert a['rccl_ranks'] == 1 and a['dist_backend'] is None and a['config']['gemm_flags'] == 0
     assert b['rccl_ranks'] == 1 and b['dist_backend'] == 'nccl' and b['config']['gemm_flags'] & 1
     assert a['config']['digest'] and a['config']['digest'] == b['config']['digest'], (a['config'], b['config'])
+
+
+@pytest.mark.gpu
+def test_failing_rank_inside_the_train_step_exits_fast():
+    """rank 1 raises inside run_train after its first step while rank 0 is inside the bucket all-reduce of
+    the next one.  The parent must return non-zero within 60 s of the failure (no finally-barrier, no watchdog wait)."""
+    r = subprocess.run([sys.executable, BENCH, '--gpus', '2', '--workload', 'c2', '--batch', '4', '--steps', '2',
+                        '--warmup', '1', '--settle', '0.5', '--no-cpu-baseline', '--no-alt-line'],
+                       env=_env(RFN_DIST_BACKEND='gloo', RFN_DEVICE_INDEX='0', HSA_ENABLE_IPC_MODE_LEGACY='0',
+                                RFN_BENCH_FAIL_RANK='1'), capture_output=True, text=True, timeout=900)
+    done = time.time()
+    assert r.returncode != 0 and not _json_lines(r.stdout), r.stdout
+    assert 'injected failure on rank 1 in the headline leg' in r.stderr
+    assert done - _failed_at(r.stderr) < 60.0
+
+
+@pytest.mark.gpu
+def test_failing_rank_inside_the_strong_leg_keeps_the_headline():
+    r = subprocess.run([sys.executable, BENCH, '--gpus', '2', '--workload', 'c2', '--batch', '8', '--steps', '2',
+                        '--warmup', '1', '--settle', '0.5', '--no-cpu-baseline', '--no-alt-line'],
+                       env=_env(RFN_DIST_BACKEND='gloo', RFN_DEVICE_INDEX='0', HSA_ENABLE_IPC_MODE_LEGACY='0',
+                                RFN_BENCH_FAIL_RANK='1', RFN_BENCH_FAIL_WHERE='strong'),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = _json_lines(r.stdout)[0]
+    assert out['value'] > 0 and 'roofline' in out and 'injected failure' in out['strong']['error']
+
+
+@pytest.mark.gpu
+def test_two_rank_line_carries_weak_and_strong_legs_with_exposed_wait():
+    """one run answers both readings of the metric -- the weak headline (B captions per rank) and the
+    SAME global batch sharded (`strong`) -- each with the time its step waited for the gradient exchange."""
+    r = subprocess.run([sys.executable, BENCH, '--gpus', '2', '--workload', 'c2', '--batch', '8', '--steps', '2',
+                        '--warmup', '1', '--settle', '0.5', '--no-cpu-baseline'],
+                       env=_env(RFN_DIST_BACKEND='gloo', RFN_DEVICE_INDEX='0', HSA_ENABLE_IPC_MODE_LEGACY='0'),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = _json_lines(r.stdout)[0]
+    assert out['scaling'] == 'weak' and out['config']['global_batch'] == 16 and out['exposed_ms'] >= 0.0
+    st = out['strong']
+    assert st['scaling'] == 'strong' and st['global_batch'] == 8 and st['captions_per_gpu'] == 4
+    assert st['value'] > 0 and st['exposed_ms'] >= 0.0 and set(st['exposed_ms_by_bucket_rank0']) >= {'decoder', 'core', 'enc0a', 'enc1b'}
+    x3 = out['bf16x3']
+    assert x3['updates'] == out['config']['updates'] and abs(x3['final_loss'] - out['config']['final_loss']) < 0.05 * abs(out['config']['final_loss'])
+
+
+@pytest.mark.gpu
+def test_one_rank_rccl_line_carries_strong_and_exposed_ms():
+    env = _env(RFN_FORCE_DIST='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(29500 + os.getpid() % 1000),
+               HSA_ENABLE_IPC_MODE_LEGACY='0')
+    r = subprocess.run([sys.executable, BENCH, '--workload', 'c2', '--batch', '16', '--steps', '3', '--warmup', '1',
+                        '--settle', '0.5', '--no-cpu-baseline', '--no-alt-line'], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = _json_lines(r.stdout)[0]
+    assert out['dist_backend'] == 'nccl' and out['exposed_measured_by'].startswith('hip events')
+    assert out['exposed_ms'] >= 0.0 and out['strong']['exposed_ms'] >= 0.0 and out['strong']['captions_per_gpu'] == 16

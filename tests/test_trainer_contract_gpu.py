@@ -176,37 +176,41 @@ def test_retained_graph_after_a_weight_update_matches_the_reference_semantics(de
     lr = 0.05
 
     # oracle: an in-place update through .data leaves the saved tensors' version alone, as PyTorch 0.3.1 optimizers did
+    passes = 4                                             # ppo_k further passes, a weight update before each
     Pg = {k: v.detach().clone().requires_grad_(True) for k, v in P.items()}
     lp, heads = O.forward(cfg, Pg, fc, att, labels)
     loss = O.xe_criterion(cfg, lp, labels[:, 1:], masks[:, 1:], heads, top, 1.0)
-    loss.backward(retain_graph=True)
-    for v in Pg.values():
-        v.data.add_(v.grad, alpha=-lr)
-        v.grad = None
-    loss.backward(retain_graph=True)
-    want = {k: v.grad for k, v in Pg.items()}
+    want = []
+    for _ in range(passes):
+        loss.backward(retain_graph=True)
+        want.append({k: v.grad for k, v in Pg.items()})
+        for v in Pg.values():
+            v.data.add_(v.grad, alpha=-lr)
+            v.grad = None
 
-    def second_pass(retain):
+    def run_passes(retain):
         model = build(cfg, P, dev, train=True)
         model.retain_activations = retain
         crit = R.ReviewNetEnsembleCriterion(cfg)
         l_ = _loss(model, crit, *to_dev(batch, dev))
-        l_.backward(retain_graph=True)
-        first = {k: p.grad.clone() for k, p in model.named_parameters()}
-        with torch.no_grad():
-            for p in model.parameters():
-                p.data.add_(p.grad, alpha=-lr)
-                p.grad = None
-        model._last_flat_grads.clear()
-        l_.backward(retain_graph=True)
-        return first, {k: p.grad.clone() for k, p in model.named_parameters()}
+        got = []
+        for _ in range(passes):
+            l_.backward(retain_graph=True)
+            got.append({k: p.grad.clone() for k, p in model.named_parameters()})
+            with torch.no_grad():
+                for p in model.parameters():
+                    p.data.add_(p.grad, alpha=-lr)
+                    p.grad = None
+            model._last_flat_grads.clear()
+        return got
 
-    first, got = second_pass(True)
-    for k, w in want.items():
-        assert maxerr(got[k], w) <= 1e-5 + 1e-3 * float(w.abs().max()), k
-    # logit.weight's gradient is dlogits^T h: activations and saved log-probs only -> unchanged by the update, bit for bit
-    assert torch.equal(got['logit.weight'], first['logit.weight'])
-    _, recomputed = second_pass(False)
-    assert not torch.equal(recomputed['logit.weight'], first['logit.weight'])
-    worst = max(float((recomputed[k].cpu() - w).abs().max()) / (1e-5 + 1e-3 * float(w.abs().max())) for k, w in want.items())
+    got = run_passes(True)
+    for n in range(passes):
+        for k, w in want[n].items():
+            assert maxerr(got[n][k], w) <= 1e-5 + 1e-3 * float(w.abs().max()), (n, k)
+        # logit.weight's gradient is dlogits^T h: activations and saved log-probs only -> unchanged by the updates, bit for bit
+        assert torch.equal(got[n]['logit.weight'], got[0]['logit.weight'])
+    recomputed = run_passes(False)
+    assert not torch.equal(recomputed[1]['logit.weight'], recomputed[0]['logit.weight'])
+    worst = max(float((recomputed[1][k].cpu() - w).abs().max()) / (1e-5 + 1e-3 * float(w.abs().max())) for k, w in want[1].items())
     assert worst > 1.0          # the recompute path is a different (self-consistent) gradient: the flag matters
