@@ -132,7 +132,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_scores_raw_k(const AttnEncPt
     const int Ap = (A + 3) & ~3;
     float* hp_s = sm;
     float* w_s = sm + Ap;
-    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int a = tid; a < A; a += ATT_THREADS) {
         hp_s[a] = hproj[(long)b * A + a];
         w_s[a] = w_out[a];
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_scores_raw_k(const AttnEncPt
 // alpha = softmax_l(scores) in place, one block per batch row (L values: trivial)
 __global__ __launch_bounds__(ATT_THREADS) void attn_softmax_k(float* __restrict__ alpha, int L) {
     __shared__ float red[ATT_WAVES];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     float* a = alpha + (long)b * L;
     float m = -INFINITY;
     for (int l = tid; l < L; l += ATT_THREADS) m = fmaxf(m, a[l]);
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_context_fwd_k(const AttnEncP
     for (int l = tid; l < L; l += ATT_THREADS) al_s[l] = alpha[(long)b * L + l];
     if constexpr (SOFTMAX) {
         __shared__ float red[ATT_WAVES];
-        const int lane = tid & 63, wave = tid >> 6;
+        const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         float m = -INFINITY;   // each thread re-reads exactly the entries it wrote: no barrier needed yet
         for (int l = tid; l < L; l += ATT_THREADS) m = fmaxf(m, al_s[l]);
         m = rfn_wave_max(m);
@@ -362,7 +362,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_dalpha_k(const float* __rest
                                                             const float* __restrict__ dz, long lddz, int L, int D,
                                                             float* __restrict__ dalpha) {
     extern __shared__ __attribute__((aligned(16))) float dz_s[];
-    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int d = tid; d < D; d += ATT_THREADS) dz_s[d] = dz[b * lddz + d];
     __syncthreads();
     for (int grp = 0; grp < ROWS / (RG * ATT_WAVES); ++grp) {
@@ -481,7 +481,10 @@ __global__ __launch_bounds__(SB_THREADS) void attn_scores_bwd_k(const AttnEncPtr
     float* red_w = sm + (2 + SB_WAVES) * Ap;       // [SB_WAVES][Ap]
     float* dot_s = sm + (2 + 2 * SB_WAVES) * Ap;   // [SB_WAVES]
     float* ds_s = dot_s + SB_WAVES;                // [L]
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // wave index as a scalar: the rows a wave walks (l = wave + ...) are then wave-uniform, so every row address below is a
+    // scalar base + this lane's column offset instead of a 64-bit per-lane pointer (fewer VGPRs: the plane-emitting
+    // instantiation spilled three of its 128)
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int a = tid; a < A; a += SB_THREADS) {
         hp_s[a] = hproj[(long)b * A + a];
         w_s[a] = w_out[a];
@@ -807,7 +810,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_small_fwd_k(const AttnSmallA
     float* hp_s = sm;
     float* w_s = sm + Ap;
     float* s_s = sm + 2 * Ap;   // [L] scores, then alpha
-    const int b = blockIdx.x, g = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x, g = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const float* proj = a.proj[g] + b * a.psb;
     for (int i = tid; i < A; i += ATT_THREADS) {
         hp_s[i] = a.hproj[g][(long)b * A + i];
@@ -852,7 +855,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_small_bwd_k(const AttnSmallA
     const int Lp = (L + 3) & ~3;
     float* al_s = dz_s + Dp;          // [Lp]
     float* ds_s = al_s + Lp;          // [Lp]
-    const int b = blockIdx.x, g = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x, g = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const float* dz = a.z[g] + b * a.ldz;
     for (int i = tid; i < A; i += ATT_THREADS) {
         hp_s[i] = a.hproj[g][(long)b * A + i];

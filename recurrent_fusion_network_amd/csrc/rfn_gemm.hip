@@ -94,6 +94,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef GEMM_TAIL_HALF
 #define GEMM_TAIL_HALF 1   /* half-height tiles for the last, partly filled round of a big NT launch */
 #endif
+#ifndef GEMM_TAIL_MIN_ROUNDS
+#define GEMM_TAIL_MIN_ROUNDS 2 /* full rounds in front of a tail round (4 until round 4: a B = 32 shard's projection is 3.06 rounds) */
+#endif
 #ifndef GEMM_DMA
 #define GEMM_DMA 1         /* big interior tiles are staged by LDS-DMA (global_load_lds_dwordx4) into a ring of slots */
 #endif
@@ -1124,7 +1127,7 @@ static int launch_cfg(const GemmArgs& a_in, hipStream_t st) {
         RFN_TRY(prepare_kernel(kt, ks_t, lds, THREADS, &occ));
         const int slots_per_xcd = (device_cus() / 8) * occ;
         const int q = nblk / 8, tail = slots_per_xcd > 0 ? q % slots_per_xcd : 0;
-        const bool has_tail = a.splitk == 1 && nblk % 8 == 0 && slots_per_xcd > 0 && q / slots_per_xcd >= 4 &&
+        const bool has_tail = a.splitk == 1 && nblk % 8 == 0 && slots_per_xcd > 0 && q / slots_per_xcd >= GEMM_TAIL_MIN_ROUNDS &&
                               tail > 0 && 2 * tail <= slots_per_xcd;
         GemmArgs t = a;
         t.tail_idx_main = has_tail ? q - tail : 0;

@@ -337,6 +337,21 @@ static bool x3_takes(const rfn_dims* d, int B, int i) {
     return 2.0 * B * d->L[i] * d->D[i] * d->A * d->T1 >= 2e10;
 }
 static int x3_row_pad(int rows) { return (rows + 255) / 256 * 256; }   // row pitch of a k-slow image
+// Stage-I attention backward, which form runs (decided here, once, because the weight-gradient pass has to know whether the
+// attention launches already wrote dP1 as bf16 planes).  The fused kernel (d alpha kept in LDS, one block per batch row and
+// encoder) needs enough blocks to stream at the chip's rate: the GROUPED launch of all M encoders counts M * B of them, a
+// per-encoder launch B.  Below that the split d-alpha kernel's (L/64, B) grid fills the chip better -- unless the map is so
+// small that launches, not bytes, are the cost.
+static bool attn_bwd_grouped(const rfn_dims* d, int B) {
+    if (d->M < 2) return false;
+    for (int i = 1; i < d->M; ++i)
+        if (d->D[i] != d->D[0] || d->L[i] != d->L[0]) return false;
+    return (long)B * d->M >= FUSED_ATTN_BWD_MIN_B || (!x3_takes(d, B, 0) && (long)d->L[0] * d->D[0] <= FUSED_ATTN_BWD_SMALL_MAP);
+}
+static bool x3_dp_emitted(const rfn_dims* d, int B, int i) {   // dP1 of encoder i reaches its k-slow plane image from the attention launches
+    if (!x3_takes(d, B, i)) return false;
+    return attn_bwd_grouped(d, B) || B >= FUSED_ATTN_BWD_MIN_B;
+}
 static size_t x3_scratch_floats(const rfn_dims* d, int B, int train) {
     size_t most = 0;
     for (int i = 0; i < d->M; ++i) {
@@ -1074,8 +1089,7 @@ extern "C" int rfn_prefix_bwd(const rfn_dims* d, int B, const float* const* prm,
         }
         bool same_ld = same_d && M > 1;
         for (int i = 1; i < M; ++i) same_ld = same_ld && d->L[i] == d->L[0];
-        const bool grouped_bwd = same_ld && (B >= FUSED_ATTN_BWD_MIN_B ||
-                                             (!x3_takes(d, B, 0) && (long)d->L[0] * d->D[0] <= FUSED_ATTN_BWD_SMALL_MAP));
+        const bool grouped_bwd = attn_bwd_grouped(d, B);
         if (grouped_bwd) {   // all encoders' attention backward of this step: one launch
             const long L0 = d->L[0], D0 = d->D[0];
             const float *a_p[RFN_MAX_ENC], *a_hp[RFN_MAX_ENC], *a_w[RFN_MAX_ENC], *a_al[RFN_MAX_ENC], *a_dz[RFN_MAX_ENC];
@@ -1229,7 +1243,7 @@ extern "C" int rfn_prefix_bwd_wgrad(const rfn_dims* d, int B, const float* const
                 srcs[t] = W + Lo.P1[i] + (long)t * BL * A;
                 outs[t] = grd[P.s1(t, i, 0)];
             }
-            if (B < FUSED_ATTN_BWD_MIN_B) {
+            if (!x3_dp_emitted(d, B, i)) {
                 RFN_TRY(rfn_x3_split_ks(srcs, T1, A, BL, A, ksP, st));
             } else if (BL % 32) {   // the attention kernels wrote the B*L real rows; the GEMM also reads the pad rows
                 const long row_bytes = 3L * x3_row_pad(TA) * 2;

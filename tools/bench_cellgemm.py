@@ -31,6 +31,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--reps', type=int, default=200)
     ap.add_argument('--floor', action='store_true')
+    ap.add_argument('--small', action='store_true')
     ap.add_argument('--slots', type=lambda x: [int(v) for v in x.split(',')], default=[2, 3, 4, 6])
     ap.add_argument('--variants', type=lambda x: [int(v) for v in x.split(',')], default=[1, 2, 3])
     a = ap.parse_args()
@@ -52,6 +53,20 @@ def main():
         ('decoder bwd: dhrec += dhp . W', 256, [(512, [512])], False, 0),
         ('stage II bwd: dhrec, 4 dz', 256, [(512, [2048])] * 5, False, 0),
     ]
+    if a.small:      # the small-shard regime (B = 32 / 64 per GPU; BASELINE config 2): grids far below 256 CUs
+        cases = []
+        for Ms in (32, 64):
+            cases += [
+                ('B=%d decoder K1: hp | g += h2h(h)' % Ms, Ms, [(512, [512]), (2048, [512])], False, 1),
+                ('B=%d decoder K3 -> lstm' % Ms, Ms, [(2048, [512])], True, 1),
+                ('B=%d stage II K1: 4 hp | g' % Ms, Ms, [(512, [512])] * 4 + [(2048, [512])], False, 1),
+                ('B=%d stage II K3 -> lstm' % Ms, Ms, [(2048, [512] * 4)], True, 1),
+                ('B=%d decoder bwd Kb1' % Ms, Ms, [(512, [2048]), (512, [2048])], False, 0),
+                ('B=%d decoder bwd Kb2' % Ms, Ms, [(512, [512])], False, 0),
+                ('B=%d stage II bwd: dhrec, 4 dz' % Ms, Ms, [(512, [2048])] * 5, False, 0),
+                ('B=%d stage I gates 4 enc K=4096 -> lstm' % Ms, Ms, [(2048, [2048, 2048])], True, 1),
+                ('B=%d stage I dz 4 enc N=2048 K=2048' % Ms, Ms, [(2048, [2048])] * 4, False, 0),
+            ]
     if a.floor:      # fixed cost vs K slope: one output N = 2048 at M = 256, both epilogues
         cases = [('K=%d %s' % (k, 'lstm' if l else 'store'), 256, [(2048, [k])], l, 1) for l in (False, True)
                  for k in (64, 256, 512, 1024, 2048)]
