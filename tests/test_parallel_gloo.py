@@ -1,4 +1,4 @@
-"""CPU, world_size 2 over gloo: the data-parallel recipe of recurrent_fusion_network_amd/parallel.py
+"""CPU, world_size 2 and 4 over gloo: the data-parallel recipe of recurrent_fusion_network_amd/parallel.py
 (shard rows -> local gradients -> SUM all-reduce of flat buffers -> scale 1/world BEFORE the element-wise
 clamp -> Adam) reproduces the single-process step on the concatenated batch.
 The per-rank compute is the CPU oracle here (the HIP path needs a GPU); the distributed plumbing under test
@@ -6,6 +6,7 @@ is the product's."""
 import os
 import sys
 
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -40,11 +41,15 @@ def _worker(rank, world, port, q):
     sync = DP.GradSync(holder, world)
     n3 = flat.numel() // 3
     chunks = [flat[:n3], flat[n3:2 * n3], flat[2 * n3:]]          # views: reduced in place
+    sync.record = True              # bench.py's exposed_ms: how long the step waited for the exchange, bucket by bucket
     for i, c in enumerate(chunks):
         holder.grad_ready_hook('bucket%d' % i, c)
     assert sync.buckets == ['bucket0', 'bucket1', 'bucket2']
     scale = sync.finish()
     assert scale == 1.0 / world and not sync.works
+    total, per, how = sync.exposed_ms()
+    assert total >= 0.0 and sorted(per) == ['bucket0', 'bucket1', 'bucket2'] and abs(sum(per.values()) - total) < 1e-9
+    assert how.startswith('host clock') and sync.exposed_ms() == (None, {}, None)       # drained by the read
     t = DP.max_over_ranks(float(rank + 1), world, torch.device('cpu'))
     assert t == float(world)
     # clamp AFTER averaging, then Adam -- as rfn_adam_step does with grad_scale
@@ -62,15 +67,16 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_step_equals_single_process_step():
+@pytest.mark.parametrize('world', [2, 4])
+def test_n_rank_step_equals_single_process_step(world):
     sys.path.insert(0, ROOT)
     from oracle import rfn_oracle as O
     from recurrent_fusion_network_amd import parallel as DP
     assert [DP.shard_rows(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 8), (8, 10)]
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    port = 29500 + os.getpid() % 2000
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29500 + os.getpid() % 2000 + world
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     stepped = q.get(timeout=300)
