@@ -7,7 +7,7 @@ f32, the HIP path with the stage-I projections on bf16 planes.  Per mode: rows w
 ids, the step of first divergence, the fp64 top1-top2 margin at that step, and quantiles of max_v |log-prob - fp64 log-prob|
 over all (row, step) pairs whose prefixes still agree.  One JSON object on stdout.
 
-    python tools/x3_flip_rate.py [--rows 4096] [--chunk 512] > profiles/r04_x3_flip_rate.json
+    python tools/x3_flip_rate.py [--workload c2|c3] [--rows 4096] [--chunk 512] > profiles/r04_x3_flip_rate.json
 """
 import argparse
 import json
@@ -35,9 +35,10 @@ def main():
     ap.add_argument('--rows', type=int, default=4096)
     ap.add_argument('--chunk', type=int, default=512)
     ap.add_argument('--seed', type=int, default=31)
+    ap.add_argument('--workload', default='c2', choices=['c2', 'c3'], help='model size: C2 (M=2, L=49, D=512) or C3 (M=4, L=196, D=2048)')
     a = ap.parse_args()
     dev = torch.device('cuda:0')
-    cfg = HB.make_cfg(HB.WORKLOADS['c2'])
+    cfg = HB.make_cfg(HB.WORKLOADS[a.workload])
     P = O.seeded_params(cfg, a.seed)
     P64 = {k: v.double() for k, v in P.items()}
     model = R.RecurrentFusionModel(cfg)
@@ -86,7 +87,8 @@ def main():
             st['dlogp'].append(d[ok])
         stats['x3_vs_exact']['rows_differ'] += int((got['exact_f32'] != got['bf16x3']).any(1).sum())
         sys.stderr.write('rows %d..%d done (fp64 on the host: %.1f s so far)\n' % (c0, c0 + nb, t_cpu))
-    out = {'model': 'C2-sized RecurrentFusionModel (M=2, L=49, D=512, R=A=E=512, T1=T2=8, V+1=9488), seeded uniform(+-0.1) weights',
+    w = HB.WORKLOADS[a.workload]
+    out = {'model': '%s-sized RecurrentFusionModel (M=%d, L=%d, D=%d, R=A=E=512, T1=T2=8, V+1=9488), seeded uniform(+-0.1) weights' % (w['desc'], w['M'], w['L'], w['D']),
            'rows': a.rows, 'seq_length': S, 'reference': 'oracle/rfn_oracle.py in float64 on %d host threads, %.1f s' % (torch.get_num_threads(), t_cpu),
            'fp64_margin_top1_top2': quantiles(torch.cat(margins_all)),
            'fp64_margin_smallest': float(torch.cat(margins_all).min())}
