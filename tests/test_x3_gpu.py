@@ -259,3 +259,49 @@ def test_gemm_random_shapes_both_image_kinds(dev):
         mag = a.double().abs().t() @ b.double().abs()
         err = float(((out_f.double() - ref).abs() / (mag + 1e-30)).max())
         assert err <= 8 * U, (case, M, N_, K, splitk, err / U)
+
+
+def test_greedy_decode_stays_with_the_exact_path_and_as_close_to_fp64(dev):
+    """The flip-rate record in miniature (tools/x3_flip_rate.py, profiles/r04_x3_flip_rate*.json): on 256 random rows of a
+    C2-shaped model, greedy decoding with the plane GEMM picks exactly the tokens the exact-f32 path picks; where either differs
+    from an fp64 decode of the same model, the fp64 top1-top2 margin at that step is inside the f32 noise of the path; and the
+    two modes sit at the same distance from the fp64 log-probs."""
+    import recurrent_fusion_network_amd as R
+    import recurrent_fusion_network_amd._native as N
+    from oracle import rfn_oracle as O
+    info = [dict(att_num=49, att_feat_size=512, fc_feat_size=512)] * 2
+    cfg = O.make_cfg(info, vocab_size=9487, rnn_size=512, input_encoding_size=512, att_hid_size=512, num_review_steps_0=8,
+                     num_review_steps=8, top_words_count=1000, seq_length=16)
+    P = O.seeded_params(cfg, 77)
+    rows = 256
+    fc, att, _, _, _ = O.synthetic_batch(cfg, rows, seed=78)
+    with torch.no_grad():
+        seq64, _, lp64, _ = O.sample_greedy(cfg, {k: v.double() for k, v in P.items()}, [f.double() for f in fc],
+                                            [x.double() for x in att])
+    S, T = cfg.seq_length, lp64.size(1)
+    ids64 = torch.zeros(rows, S, dtype=torch.long)
+    ids64[:, :seq64.size(1)] = seq64
+    top2 = lp64.topk(2, dim=2).values
+    margin = top2[:, :, 0] - top2[:, :, 1]
+    model = R.RecurrentFusionModel(cfg)
+    model.load_state_dict(P)
+    model = model.to(dev).eval()
+    got, dist = {}, {}
+    for name, flags in (('exact', 0), ('x3', N.GEMM_OPT_BF16X3 | N.GEMM_OPT_BF16X3_ANY_SIZE)):
+        model.gemm_flags = flags
+        with torch.no_grad():
+            seq, _, lp, _ = model.sample([f.to(dev) for f in fc], [x.to(dev) for x in att], {'sample_max': 1})
+        ids = torch.zeros(rows, S, dtype=torch.long)
+        ids[:, :seq.size(1)] = seq.cpu()
+        got[name] = ids
+        differ = ids != ids64
+        first = torch.where(differ.any(1), differ.float().argmax(1), torch.full((rows,), S))
+        for r in torch.nonzero(differ.any(1)).flatten().tolist():      # a flip against fp64 needs a margin inside the noise
+            assert float(margin[r, int(first[r])]) < 1e-5, (name, r, int(first[r]), float(margin[r, int(first[r])]))
+        Tm = min(T, lp.size(1))
+        ok = torch.arange(Tm)[None, :] <= first[:, None]
+        d = (lp.cpu().double()[:, :Tm] - lp64[:, :Tm]).abs().amax(2)[ok]
+        dist[name] = (float(d.median()), float(d.max()))
+        assert dist[name][1] < 2e-5, (name, dist[name])
+    assert torch.equal(got['exact'], got['x3'])
+    assert dist['x3'][0] < 1.25 * dist['exact'][0] and dist['x3'][1] < 1.5 * dist['exact'][1], dist
