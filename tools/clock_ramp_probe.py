@@ -32,3 +32,16 @@ P.mul_(1e-6)
 print('  with 1e-6-scaled dP: nothing before %.1f us | part-A pair before %.1f' % (t(lambda:None), t(parta)))
 P.zero_(); P[:, ::7, ::5]=1e-4
 print('  with sparse dP: nothing before %.1f us' % t(lambda:None))
+# controlled A/B: dense and sparse operands alternate, every launch behind the same K = B weight-gradient pair
+Pd = torch.randn(T, BL, A, device=dev)
+Ps = torch.zeros(T, BL, A, device=dev); Ps[:, ::7, ::5] = 1e-4
+Xs = torch.zeros(BL, D, device=dev); Xs[::3, ::4] = 1.0
+def tn_of(Pm, Xm): return [(dW[t_], D, [(Pm[t_], A, 0, Xm, D, 0, BL, None)]) for t_ in range(T)]
+cases = [('dense dP, dense X', tn_of(Pd, X)), ('sparse dP, dense X', tn_of(Ps, X)), ('sparse dP, sparse X', tn_of(Ps, Xs))]
+acc = {n: [] for n, _ in cases}
+for rnd in range(6):
+    for n, pr in cases:
+        parta(); e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); nv.gemm(A, D, pr, ws=ws); e1.record(); torch.cuda.synchronize()
+        if rnd: acc[n].append(e0.elapsed_time(e1) * 1e3)
+print('  alternating, each behind the part-A pair: ' + ' | '.join('%s %.1f us (min %.1f)' % (n, sum(v) / len(v), min(v)) for n, v in acc.items()))
