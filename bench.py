@@ -425,7 +425,19 @@ def run_decode(args, rank, world, dev):
                        'beam5_frac': round(fwd_flops / t_beam / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)}
     if world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(cfg, min(args.cpu_sample, 16), 100, mode='greedy')
+    flush_c_stdio()
     print(json.dumps(out), flush=True)
+
+
+def flush_c_stdio():
+    """RCCL prints its version banner through C stdio when the communicator is created; with stdout redirected that buffer
+    is only flushed at exit, i.e. AFTER the result line Python printed.  A driver that reads the last line of stdout must find
+    the JSON line there, so the C buffers are flushed before anything this script prints."""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:      # noqa: BLE001
+        pass
 
 
 class RunGuard:
@@ -504,6 +516,7 @@ class RunGuard:
             self.closed = True
             if self.rank == 0 and self.line is not None:
                 self.line.setdefault(leg or 'optional', {'error': text})
+                flush_c_stdio()
                 print(json.dumps(self.line), flush=True)
             sys.stderr.write('bench.py rank %d: optional leg %s abandoned (%s)\n' % (self.rank, leg, text))
             sys.stderr.flush()
@@ -547,6 +560,7 @@ class RunGuard:
             if self.closed:
                 return
             self.closed = True
+            flush_c_stdio()
             print(json.dumps(line), flush=True)
 
 
@@ -561,6 +575,9 @@ def run_rank(args):
     dev = torch.device('cuda', int(os.environ.get('RFN_DEVICE_INDEX', local)))   # test hook: ranks sharing one GPU
     torch.cuda.set_device(dev)
     guard = RunGuard(rank, world)
+    if torch.distributed.is_initialized():
+        torch.distributed.barrier()          # creates the communicator now: its banner goes out before any result
+        flush_c_stdio()
     try:
         if args.workload == 'c5':
             run_decode(args, rank, world, dev)
@@ -574,6 +591,8 @@ def run_rank(args):
         torch.distributed.barrier()
         guard.close()
         torch.distributed.destroy_process_group()
+    sys.stdout.flush()
+    os._exit(0)        # nothing may follow the result line on stdout (library atexit chatter, late C stdio buffers)
 
 
 def run_train(args, rank, world, dev, R, DP, guard):
