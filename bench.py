@@ -625,6 +625,8 @@ def run_train(args, rank, world, dev, R, DP, guard):
     crit = R.ReviewNetEnsembleCriterion(cfg)
     opt = R.FusedClampAdam(model, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5, grad_clip=1.0)
     inputs = synthetic_inputs(cfg, B, 100 + rank, dev)
+    if args.strong:
+        inputs = tuple(inputs) + (DP.shard_loss_scale(B, global_B, world),)
 
     sync = DP.GradSync(model, world)     # per-bucket async all-reduce, overlapped with the rest of backward
     start = opt.snapshot() if (not x3 and not args.no_alt_line) else None     # the bf16x3 leg restarts from here
@@ -641,12 +643,15 @@ def run_train(args, rank, world, dev, R, DP, guard):
             row.append(e)
 
     def step(inp, leg='headline'):
-        fc, att, labels, masks, top = inp
+        fc, att, labels, masks, top = inp[:5]
+        loss_scale = inp[5] if len(inp) > 5 else 1.0      # uneven shards weigh their local mean (parallel.shard_loss_scale)
         row = []
         mark(row)
         opt.zero_grad()
         log_prob, top_pred = model(fc, att, labels)
         loss = crit(log_prob, labels[:, 1:], masks[:, 1:], top_pred, top, 1.0)
+        if loss_scale != 1.0:
+            loss = loss * loss_scale
         mark(row)
         loss.backward()
         mark(row)
@@ -839,6 +844,7 @@ def run_train(args, rank, world, dev, R, DP, guard):
             strong = {'error': 'a global batch of %d rows cannot be sharded over %d ranks' % (B, world)}
         else:
             shard_inputs = synthetic_inputs(cfg, hi - lo, 1100 + rank, dev) if world > 1 else inputs
+            shard_inputs = tuple(shard_inputs) + (DP.shard_loss_scale(hi - lo, B, world),)
             err, r = optional('strong', lambda: time_leg(shard_inputs, 'strong', seconds=min(args.settle, 1.0)))
             if err:
                 strong = {'error': err}

@@ -44,6 +44,16 @@ def shard_rows(n_rows, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def shard_loss_scale(n_local, n_global, world):
+    """Factor a rank multiplies its LOCAL loss with before backward when the shards are not all the same size.
+
+    The criteria divide by the local batch size (misc/utils.py:184), so a rank's gradient is the mean over ITS rows; the
+    exchange sums the ranks and the optimizer scales by 1/world.  For the result to equal the single-process gradient of the
+    concatenated batch -- the mean over ALL rows -- rank r's loss has to weigh n_r / n_global instead of 1 / world:
+    multiply it by n_r * world / n_global (exactly 1.0 for equal shards)."""
+    return float(n_local) * float(world) / float(n_global)
+
+
 def allreduce_flat(buffers, world, async_op=False):
     """Sum all-reduce of the flat gradient buffers, in the given order.  Returns work handles when async."""
     if world <= 1:

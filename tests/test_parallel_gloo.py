@@ -1,4 +1,4 @@
-"""CPU, world_size 2 and 4 over gloo: the data-parallel recipe of recurrent_fusion_network_amd/parallel.py
+"""CPU, world_size 2, 3 (uneven shards) and 4 over gloo: the data-parallel recipe of recurrent_fusion_network_amd/parallel.py
 (shard rows -> local gradients -> SUM all-reduce of flat buffers -> scale 1/world BEFORE the element-wise
 clamp -> Adam) reproduces the single-process step on the concatenated batch.
 The per-rank compute is the CPU oracle here (the HIP path needs a GPU); the distributed plumbing under test
@@ -33,7 +33,10 @@ def _worker(rank, world, port, q):
     loss, grads = O.train_step_loss_and_grads(cfg, P, [sl(f) for f in fc], [sl(a) for a in att], sl(labels), sl(masks),
                                               sl(top), 1.0)
     keys = sorted(grads)
-    flat = torch.cat([grads[k].reshape(-1) * 40.0 for k in keys])     # x40: make the clamp bite
+    # shards of different sizes (world 3: 3 + 3 + 2 rows) weigh their local mean by rows / all rows (1.0 for equal shards)
+    w_loss = DP.shard_loss_scale(hi - lo, 8, world)
+    assert world == 3 or w_loss == 1.0
+    flat = torch.cat([grads[k].reshape(-1) * (40.0 * w_loss) for k in keys])     # x40: make the clamp bite
     # the overlapped path of bench.py: buckets are handed to GradSync as backward finishes them
     class _M:                       # the two attributes GradSync touches
         grad_ready_hook = None
@@ -67,7 +70,7 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('world', [2, 4])
+@pytest.mark.parametrize('world', [2, 3, 4])
 def test_n_rank_step_equals_single_process_step(world):
     sys.path.insert(0, ROOT)
     from oracle import rfn_oracle as O
@@ -93,7 +96,7 @@ def test_n_rank_step_equals_single_process_step(world):
     full = {k: g * 40.0 for k, g in grads.items()}
     clipped_some = False
     for k in grads:
-        # equal shards: mean of the shard gradients == gradient of the concatenated batch
+        # (row-weighted) mean of the shard gradients == gradient of the concatenated batch
         assert float((torch.from_numpy(avg[k]) - full[k]).abs().max()) < 1e-5 + 1e-4 * float(full[k].abs().max()), k
         clipped_some |= bool((full[k].abs() > 1.0).any())
     assert clipped_some
