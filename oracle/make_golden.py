@@ -522,6 +522,7 @@ def generate_dropout(name, RefModel, ref_utils, outdir):
 
 
 SHOWTELL = dict(fc=2048, R=512, V=9487, B=4, S=16, seed=11, max_words=9)   # BASELINE config 1
+SHOWTELL_END_BIAS = 0.5     # added to logit.bias[0] for the second beam-search fixture
 
 
 def showtell_cfg():
@@ -571,6 +572,26 @@ def generate_showtell(outdir):
         cfg.use_label_smoothing = 1
         loss_ls = ref_utils.LanguageModelCriterion(cfg)(lp, labels[:, 1:], masks[:, 1:])
         seq, seq_lp, lp_all = model.sample(fc, None, {'sample_max': 1})
+    # beam search (misc/ShowTellModel.py:95-185) needs PyTorch-0.3.1 indexing like the fusion model's; twice: on the seeded
+    # weights (no beam ends early) and with the END logit raised by SHOWTELL_END_BIAS, where beams that emitted END keep
+    # competing and the done lists grow past the beam size
+    beams = {}
+    for tag, bias in (('beam3', 0.0), ('beam3e', SHOWTELL_END_BIAS)):
+        Wb = dict(W)
+        Wb['logit.bias'] = W['logit.bias'].clone()
+        Wb['logit.bias'][0] += bias
+        model.load_state_dict(Wb)
+        with torch.no_grad(), LegacyIndexing():
+            bseq, blp = model.sample(fc, None, {'beam_size': 3})
+        counts = [len(d) for d in model.done_beams]
+        pad = max(counts)
+        beams[tag + '_seq'] = bseq.numpy().copy()
+        beams[tag + '_seq_logprobs'] = blp.numpy().copy()
+        beams[tag + '_done_counts'] = np.array(counts)
+        beams[tag + '_done_p'] = np.array([[float(b['p']) for b in d] + [0.0] * (pad - len(d)) for d in model.done_beams])
+        beams[tag + '_done_seq'] = np.stack([torch.stack([b['seq'] for b in d] + [torch.zeros_like(d[0]['seq'])] * (pad - len(d))).numpy()
+                                             for d in model.done_beams])
+    model.load_state_dict(W)
     t5 = lp.topk(5, dim=2)
     out = dict(weights_digest=digest([W[k] for k in sorted(W)]), inputs_digest=digest([fc]), labels=labels.numpy(),
                log_prob_shape=np.array(lp.shape), log_prob_top5_val=t5.values.numpy(), log_prob_top5_idx=t5.indices.numpy(),
@@ -578,6 +599,7 @@ def generate_showtell(outdir):
                xe_loss=np.float64(loss.item()), xe_loss_ls=np.float64(loss_ls.item()),
                greedy_seq=seq.numpy(), greedy_seq_logprobs=seq_lp.numpy(), greedy_logprobs_all_shape=np.array(lp_all.shape),
                state_dict_keys=np.array(sorted(W)))
+    out.update(beams)
     path = os.path.join(outdir, 'showtell.npz')
     np.savez_compressed(path, **out)
     print('showtell xe %.6f greedy T=%d -> %s (%.1f KB)' % (loss.item(), seq.size(1), path, os.path.getsize(path) / 1024))

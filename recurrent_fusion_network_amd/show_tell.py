@@ -6,7 +6,9 @@ stock PyTorch modules so that `models.setup(opt)` serves `caption_model = 'show_
 plumbing (forward -> LanguageModelCriterion, greedy sample) can be exercised without a GPU.  Same constructor fields,
 same `state_dict` keys (`img_embed`, `core` = nn.LSTM(bias=False), `embed`, `logit`) and the same step conventions:
 step 0 feeds the image embedding, step 1 the BOS token 0, outputs start at step 1, the loop stops at the first
-all-zero label column (>= 2).  Beam search is not restated (the fusion model's device-resident beam is the product's).
+all-zero label column (>= 2).  `sample_beam` restates the reference's per-image search (:95-185) with its own rules, which
+differ from the fusion model's: a beam that has emitted END keeps competing (no skip), every beam alive at the last step is
+recorded as done.
 """
 import torch
 import torch.nn as nn
@@ -71,7 +73,7 @@ class ShowTellModel(nn.Module):
     def sample(self, fc_feats, att_feats, opt={}):
         """-> (seq (B, <=S), seqLogprobs, logprobs_all (B, <=S+1, V+1)); greedy or temperature multinomial (:186-240)."""
         if opt.get('beam_size', 1) > 1:
-            raise NotImplementedError('show_tell: beam search is not provided (see the module docstring)')
+            return self.sample_beam(fc_feats, att_feats, opt)
         sample_max, temperature = opt.get('sample_max', 1), opt.get('temperature', 1.0)
         n = fc_feats.size(0)
         state = self._zero_state(fc_feats, n)
@@ -97,6 +99,65 @@ class ShowTellModel(nn.Module):
             e = fc_feats.new_zeros(n, 0)
             return e.long(), e, torch.stack(all_lp, 1)
         return torch.stack(seq, 1), torch.stack(seq_lp, 1), torch.stack(all_lp, 1).contiguous()
+
+
+    def sample_beam(self, fc_feats, att_feats, opt={}):
+        """misc/ShowTellModel.py:95-185 -> (seq (B, S) int64, seqLogprobs (B, S)); side effect `self.done_beams[k]` = the
+        finished beams of image k, best first, as dicts {'seq', 'logps', 'p'}.
+
+        One image at a time on `beam_size` rows, as the reference does.  Step 0 feeds the image embedding, step 1 BOS; from
+        step 2 on the candidates are (sorted-vocabulary column c, beam q) in that nesting order -- only beam 0 at step 2 --
+        scored by the beam's running sum + the column's log-prob in float32, ordered by a STABLE sort on -p; the best
+        `beam_size` fork their prefix and LSTM state; a beam whose new token is END (0), and every beam at the last step,
+        is appended to the done list.  Unlike the fusion model's search (:475 there) a beam that already ended is not
+        skipped: it feeds token 0 and keeps competing -- kept, because it changes which beams survive."""
+        beam_size = opt.get('beam_size', 10)
+        n, S = fc_feats.size(0), self.seq_length
+        assert beam_size <= self.vocab_size + 1, 'lets assume this for now'
+        seq = torch.zeros(S, n, dtype=torch.long)
+        seq_lp = torch.zeros(S, n)
+        self.done_beams = [[] for _ in range(n)]
+        with torch.no_grad():
+            for k in range(n):
+                state = self._zero_state(fc_feats, beam_size)
+                beam_seq = torch.zeros(S, beam_size, dtype=torch.long)
+                beam_lp = torch.zeros(S, beam_size)
+                beam_sum = torch.zeros(beam_size)
+                logp = None
+                for t in range(S + 2):
+                    if t == 0:
+                        xt = self.img_embed(fc_feats[k:k + 1]).expand(beam_size, self.input_encoding_size)
+                    elif t == 1:
+                        xt = self.embed(torch.zeros(beam_size, dtype=torch.long, device=fc_feats.device))
+                    else:
+                        ys, ix = torch.sort(logp.float().cpu(), 1, True)
+                        rows = 1 if t == 2 else beam_size
+                        cols = min(beam_size, ys.size(1))
+                        total = beam_sum[:rows, None] + ys[:rows, :cols]                  # float32, as the reference sums
+                        cands = [(c, q) for c in range(cols) for q in range(rows)]        # column-major candidate order
+                        cands.sort(key=lambda cq: -float(total[cq[1], cq[0]]))            # stable
+                        prev_seq, prev_lp = beam_seq[:t - 2].clone(), beam_lp[:t - 2].clone()
+                        new_state = [x.clone() for x in state]
+                        for vix in range(beam_size):
+                            c, q = cands[vix]
+                            if t > 2:
+                                beam_seq[:t - 2, vix] = prev_seq[:, q]
+                                beam_lp[:t - 2, vix] = prev_lp[:, q]
+                            for dst, src in zip(new_state, state):
+                                dst[:, vix] = src[:, q]
+                            beam_seq[t - 2, vix] = ix[q, c]
+                            beam_lp[t - 2, vix] = ys[q, c]
+                            beam_sum[vix] = total[q, c]
+                            if int(ix[q, c]) == 0 or t == S + 1:
+                                self.done_beams[k].append({'seq': beam_seq[:, vix].clone(), 'logps': beam_lp[:, vix].clone(),
+                                                           'p': float(beam_sum[vix])})
+                        state = tuple(new_state)
+                        xt = self.embed(beam_seq[t - 2].to(fc_feats.device))
+                    logp, state = self._advance(xt, state)
+                self.done_beams[k].sort(key=lambda b: -b['p'])                            # stable, best first (:181)
+                seq[:, k] = self.done_beams[k][0]['seq']
+                seq_lp[:, k] = self.done_beams[k][0]['logps']
+        return seq.t(), seq_lp.t()
 
 
 class LanguageModelCriterion(nn.Module):

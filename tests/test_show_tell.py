@@ -50,3 +50,27 @@ def test_show_tell_greedy_decode_ids_exact():
     loss = R.LanguageModelCriterion(cfg)(model(fc, None, labels), labels[:, 1:], masks[:, 1:])
     loss.backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
+
+
+def test_show_tell_beam_search_matches_the_reference():
+    """misc/ShowTellModel.py:95-185 through sample(beam_size=3): the reference's own rules (only beam 0 at the first merge,
+    column-major candidates, stable sort, a beam that emitted END keeps competing) -- on the seeded weights, where no beam
+    ends early, and with the END logit raised, where the done lists grow to 34-46 entries per image."""
+    from oracle import make_golden as G
+    R, cfg, model, fc, labels, masks, gold = _case()
+    W = {k: v.clone() for k, v in model.state_dict().items()}
+    for tag, bias in (('beam3', 0.0), ('beam3e', G.SHOWTELL_END_BIAS)):
+        Wb = dict(W)
+        Wb['logit.bias'] = W['logit.bias'].clone()
+        Wb['logit.bias'][0] += bias
+        model.load_state_dict(Wb)
+        seq, seq_lp = model.sample(fc, None, {'beam_size': 3})
+        assert torch.equal(seq, torch.from_numpy(gold[tag + '_seq'])), tag
+        assert float((seq_lp - torch.from_numpy(gold[tag + '_seq_logprobs'])).abs().max()) < 1e-5
+        counts = [len(d) for d in model.done_beams]
+        assert counts == list(gold[tag + '_done_counts']), tag
+        for k, d in enumerate(model.done_beams):
+            assert np.allclose([b['p'] for b in d], gold[tag + '_done_p'][k][:len(d)], atol=1e-5)
+            assert all(np.array_equal(b['seq'].numpy(), gold[tag + '_done_seq'][k][j]) for j, b in enumerate(d))
+            assert all(d[j]['p'] >= d[j + 1]['p'] for j in range(len(d) - 1))       # best first
+    assert max(gold['beam3e_done_counts']) > 3          # the END rule was exercised
