@@ -342,7 +342,12 @@ def sample_beam(cfg, P, fc_feats, att_feats, beam_size: int):
     """Per-image beam search (misc/RecurrentFusionModel.py:352-543).  Pure-Python bookkeeping,
     so only for small cases.  Candidate order: outer loop over sorted column c, inner over beam q
     (:470-478); stable sort by -p (:482); beams whose previous token was 0 are skipped (:475);
-    only row 0 is active at t == 1 (:468-469)."""
+    only row 0 is active at t == 1 (:468-469).
+    `P` may be a LIST of parameter dicts: the ensemble of eval_utils.eval_ensemble (eval_utils.py:387-720) -- every member
+    keeps its own state, the members' logits of a step are summed and divided by their number before the log-softmax
+    (eval_utils.py:268-317), everything else is the same search.  A single dict is a one-member list (x / 1 and a sum of
+    one term leave every bit alone)."""
+    members = list(P) if isinstance(P, (list, tuple)) else [P]
     B = fc_feats[0].size(0)
     S = cfg.seq_length
     seq = torch.zeros(S, B, dtype=torch.long)
@@ -351,8 +356,11 @@ def sample_beam(cfg, P, fc_feats, att_feats, beam_size: int):
     for k in range(B):
         fc_k = [f[k:k + 1].expand(beam_size, f.size(1)).contiguous() for f in fc_feats]   # :379-386
         att_k = [a[k:k + 1].expand(beam_size, a.size(1), a.size(2)).contiguous() for a in att_feats]
-        hs, cs = init_state(cfg, P, fc_k)
-        comb, reason_pred, (h, c) = thought_vectors(cfg, P, att_k, hs, cs)
+        st = []
+        for Pm in members:
+            hs, cs = init_state(cfg, Pm, fc_k)
+            comb, reason_pred, (h, c) = thought_vectors(cfg, Pm, att_k, hs, cs)
+            st.append([comb, h, c])
         reason_batch.append(reason_pred)
         beam_seq = torch.zeros(S, beam_size, dtype=torch.long)
         beam_lp = torch.zeros(S, beam_size)
@@ -361,7 +369,7 @@ def sample_beam(cfg, P, fc_feats, att_feats, beam_size: int):
         logprobs = None
         for t in range(S + 1):                                                    # :451
             if t == 0:
-                xt = P['embed.weight'][torch.zeros(beam_size, dtype=torch.long)]
+                tok = torch.zeros(beam_size, dtype=torch.long)
             else:
                 ys, ix = torch.sort(logprobs.float(), 1, True)                    # :463
                 cands = []
@@ -377,7 +385,7 @@ def sample_beam(cfg, P, fc_feats, att_feats, beam_size: int):
                 if len(cands) == 0:                                               # :480
                     break
                 cands = sorted(cands, key=lambda x: -x['p'])                      # :482 (stable)
-                nh, nc = h.clone(), c.clone()
+                new_st = [[m_[1].clone(), m_[2].clone()] for m_ in st]
                 if t > 1:
                     prev_seq = beam_seq[:t - 1].clone()
                     prev_lp = beam_lp[:t - 1].clone()
@@ -386,18 +394,23 @@ def sample_beam(cfg, P, fc_feats, att_feats, beam_size: int):
                     if t > 1:
                         beam_seq[:t - 1, vix] = prev_seq[:, v['q']]
                         beam_lp[:t - 1, vix] = prev_lp[:, v['q']]
-                    nh[vix] = h[v['q']]                                           # :499-501
-                    nc[vix] = c[v['q']]
+                    for m_, n_ in zip(st, new_st):                                # :499-501
+                        n_[0][vix] = m_[1][v['q']]
+                        n_[1][vix] = m_[2][v['q']]
                     beam_seq[t - 1, vix] = v['c']
                     beam_lp[t - 1, vix] = v['r']
                     beam_sum[vix] = v['p']
                     if v['c'] == 0 or t == S:                                     # :508
                         done.append(dict(seq=beam_seq[:, vix].clone(), logps=beam_lp[:, vix].clone(),
                                          p=float(beam_sum[vix])))
-                h, c = nh, nc
-                xt = P['embed.weight'][beam_seq[t - 1]]
-            logits, h, c = one_time_step(cfg, P, xt, comb, h, c)
-            logprobs = torch.log_softmax(logits, dim=1)
+                for m_, n_ in zip(st, new_st):
+                    m_[1], m_[2] = n_
+                tok = beam_seq[t - 1]
+            total = None
+            for Pm, m_ in zip(members, st):
+                logits, m_[1], m_[2] = one_time_step(cfg, Pm, Pm['embed.weight'][tok], m_[0], m_[1], m_[2])
+                total = logits if total is None else total + logits
+            logprobs = torch.log_softmax(total / float(len(members)), dim=1)
         done = sorted(done, key=lambda x: -x['p'])                                # :529
         seq[:, k] = done[0]['seq']
         seq_lp[:, k] = done[0]['logps']

@@ -7,12 +7,17 @@ get_thought_vectors with arities the model does not have) a
 `.cuda()` copies.  Here the members' steps run through rfn_decoder_step, the logit sum / division / log-softmax /
 greedy pick are HIP kernels, members living on other ranks contribute through ONE sum all-reduce of the (B, V+1)
 logits per step, and nothing is read back until the loop ends.
+
+`sample_beam` is the same averaging under the fusion model's beam search (eval_utils.eval_ensemble, eval_utils.py:387-720,
+whose bookkeeping is misc/RecurrentFusionModel.py:451-531): all images' beams share one decoder batch of B * beam rows per
+member, the candidate / stable-sort / fork / done-beam rules run on the device (rfn_beam_step_topk) on the W best entries of
+the averaged log-softmax (rfn_log_softmax_topk), every member's state follows the same fork order.
 """
 import torch
 import torch.distributed as dist
 
 from . import _native as N
-from .fusion_model import _Stepper
+from .fusion_model import _Stepper, _sorted_done_beams
 
 
 class EnsembleDecoder:
@@ -73,3 +78,58 @@ class EnsembleDecoder:
                 t_stop = t
                 break
         return seq[:, :t_stop - 1], seq_lp[:, :t_stop - 1], logp_all[:, :t_stop].contiguous()
+
+    @torch.no_grad()
+    def sample_beam(self, fc_feats, att_feats, opt={}):
+        """Beam search on the members' averaged distribution -> (seq (B, S), seqLogprobs (B, S), top_seq, top_prob) with
+        the conventions of RecurrentFusionModel.sample_beam (best done beam per image; per-image lists of all done beams,
+        best first); `self.done_beams` as there.  A one-member ensemble IS that model's sample_beam, bit for bit."""
+        W = opt.get('beam_size', 10)
+        m0 = self.models[0]
+        B, S, V1 = fc_feats[0].size(0), m0.seq_length, m0.vocab_size + 1
+        if W > 16 or S > 32 or W > V1:
+            raise N.RfnError('beam search supports beam_size <= 16 (and <= V+1) and seq_length <= 32')
+        steppers = []
+        for m in self.models:
+            comb, h, c, _ = m._prefix(fc_feats, att_feats, False, 0)
+            steppers.append(_Stepper(m, comb.repeat_interleave(W, dim=1).contiguous(),       # row k * W + q = image k
+                                     h.repeat_interleave(W, dim=0).contiguous(), c.repeat_interleave(W, dim=0).contiguous()))
+        dev = steppers[0].h.device
+        st = N.stream_ptr()
+        rows, max_done = B * W, W * S
+        bs = torch.zeros(S, B, W, dtype=torch.long, device=dev)
+        bl = torch.zeros(S, B, W, device=dev)
+        bsum = torch.zeros(B, W, device=dev)
+        order = torch.zeros(rows, dtype=torch.int32, device=dev)
+        ids = torch.zeros(rows, dtype=torch.long, device=dev)
+        done_seq = torch.zeros(B, max_done, S, dtype=torch.long, device=dev)
+        done_lp = torch.zeros(B, max_done, S, device=dev)
+        done_p = torch.zeros(B, max_done, device=dev)
+        done_n = torch.zeros(B, dtype=torch.int32, device=dev)
+        active = torch.ones(B, dtype=torch.int32, device=dev)
+        topv = torch.empty(rows, W, device=dev)
+        topi = torch.empty(rows, W, dtype=torch.int32, device=dev)
+        logit_sum = torch.empty(rows, V1, device=dev)
+        logit_m = torch.empty(rows, V1, device=dev)
+        for t in range(S + 1):
+            if t >= 1:
+                N.check(N.lib.rfn_beam_step_topk(topv.data_ptr(), topi.data_ptr(), V1, W, S, t, B, max_done, bs.data_ptr(),
+                                                 bl.data_ptr(), bsum.data_ptr(), order.data_ptr(), ids.data_ptr(),
+                                                 done_seq.data_ptr(), done_lp.data_ptr(), done_p.data_ptr(), done_n.data_ptr(),
+                                                 active.data_ptr(), st), 'rfn_beam_step_topk')
+                if t == S:
+                    break                      # the reference runs one more decoder step whose output is never used
+                for sp in steppers:
+                    sp.reorder(order)
+            for j, sp in enumerate(steppers):
+                sp.step(ids, out=logit_sum if j == 0 else logit_m, want='logits')
+                if j:
+                    N.check(N.lib.rfn_axpby_2d(1.0, logit_m.data_ptr(), V1, 1.0, logit_sum.data_ptr(), V1, rows, V1, st))
+            if self.group is not None:
+                dist.all_reduce(logit_sum, op=dist.ReduceOp.SUM, group=self.group)
+            N.check(N.lib.rfn_div_2d(logit_sum.data_ptr(), V1, rows, V1, float(self.n_total), st))
+            N.check(N.lib.rfn_log_softmax_topk(logit_sum.data_ptr(), V1, rows, V1, W, topv.data_ptr(), topi.data_ptr(), st),
+                    'rfn_log_softmax_topk')
+        seq, seq_lp, top_seq, top_prob, self.done_beams = _sorted_done_beams(done_seq, done_lp, done_p, done_n, S, max_done)
+        return seq, seq_lp, top_seq, top_prob
+

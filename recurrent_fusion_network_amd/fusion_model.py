@@ -691,25 +691,29 @@ class RecurrentFusionModel(nn.Module):
                                         order.data_ptr(), ids.data_ptr(), done_seq.data_ptr(), done_lp.data_ptr(),
                                         done_p.data_ptr(), done_n.data_ptr(), active.data_ptr(), max_done,
                                         stepper.ws.data_ptr(), stepper.ws_bytes, stepper.seed, N.stream_ptr()), 'rfn_beam_loop')
-            # done beams sorted by -p, stably, as the reference's sorted(..., key=-p) (:529) -- on the device, for all
-            # images at once: the call returns with everything queued and nothing read back, so the host's next batch
-            # (and its stage-I/II GEMMs) starts while this one is still decoding
-            key = torch.where(torch.arange(max_done, device=dev)[None, :] < done_n[:, None], -done_p,
-                              torch.full_like(done_p, float('inf')))
-            rank = torch.sort(key, dim=1, stable=True).indices
-            pick = rank[:, :, None].expand(-1, -1, S)
-            s_all, l_all, p_all = done_seq.gather(1, pick), done_lp.gather(1, pick), done_p.gather(1, rank)
-            seq, seq_lp = s_all[:, 0].contiguous(), l_all[:, 0].contiguous()       # (B, S): best done beam per image
+            seq, seq_lp, top_seq, top_prob, done_beams = _sorted_done_beams(done_seq, done_lp, done_p, done_n, S, max_done)
             heads = reason.unsqueeze(2).expand(-1, -1, W, -1)                       # (M+1, B, W, K) broadcast view
-        # The per-image Python structures (top_seq, top_prob, reason_pred_batch, self.done_beams: thousands of small
-        # objects) need the done counts on the host: they are lists that fill themselves on first access, so a loop that
-        # only consumes the returned captions never waits for them.
-        src = _BeamResults(s_all, l_all, p_all, done_n)
-        top_seq = _LazyList(B, lambda: src.top_seq())
-        top_prob = _LazyList(B, lambda: src.top_prob())
-        self.done_beams = _LazyList(B, lambda: src.done_beams())
+        self.done_beams = done_beams
         reason_batch = _LazyList(B, lambda: [list(t.unbind(0)) for t in heads.unbind(1)])
         return seq, seq_lp, top_seq, top_prob, reason_batch
+
+
+def _sorted_done_beams(done_seq, done_lp, done_p, done_n, S, max_done):
+    """Done beams sorted by -p, stably, as the reference's sorted(..., key=-p) (:529) -- on the device, for all images at
+    once: the caller returns with everything queued and nothing read back, so the host's next batch (and its stage-I/II
+    GEMMs) starts while this one is still decoding.  -> (seq (B, S) best done beam per image, its log-probs, and the
+    per-image Python structures top_seq / top_prob / done_beams: thousands of small objects that need the done counts on
+    the host, so they are lists that fill themselves on first access -- a loop that only consumes the returned captions
+    never waits for them)."""
+    dev, B = done_p.device, done_p.size(0)
+    key = torch.where(torch.arange(max_done, device=dev)[None, :] < done_n[:, None], -done_p,
+                      torch.full_like(done_p, float('inf')))
+    rank = torch.sort(key, dim=1, stable=True).indices
+    pick = rank[:, :, None].expand(-1, -1, S)
+    s_all, l_all, p_all = done_seq.gather(1, pick), done_lp.gather(1, pick), done_p.gather(1, rank)
+    src = _BeamResults(s_all, l_all, p_all, done_n)
+    return (s_all[:, 0].contiguous(), l_all[:, 0].contiguous(), _LazyList(B, lambda: src.top_seq()),
+            _LazyList(B, lambda: src.top_prob()), _LazyList(B, lambda: src.done_beams()))
 
 
 class _BeamResults:
@@ -827,6 +831,12 @@ class _Stepper:
         self.t += 1
         return out
 
-    def reorder(self, index):
-        self.h = self.h.index_select(0, index).contiguous()
-        self.c = self.c.index_select(0, index).contiguous()
+    def reorder(self, order):
+        """Row r continues from row order[r] (int32, device): rfn_gather_rows on h and c."""
+        if order.dtype != torch.int32 or not order.is_contiguous():
+            order = order.to(torch.int32).contiguous()
+        h2, c2 = torch.empty_like(self.h), torch.empty_like(self.c)
+        st = N.stream_ptr()
+        N.check(N.lib.rfn_gather_rows(self.h.data_ptr(), h2.data_ptr(), order.data_ptr(), self.B, self.d.R, st), 'rfn_gather_rows')
+        N.check(N.lib.rfn_gather_rows(self.c.data_ptr(), c2.data_ptr(), order.data_ptr(), self.B, self.d.R, st), 'rfn_gather_rows')
+        self.h, self.c = h2, c2

@@ -564,6 +564,37 @@ def test_ensemble_decode_matches_oracle(dev):
         assert torch.equal(s1, models[0].sample(fc, att, {'sample_max': 1})[0])
 
 
+def test_ensemble_beam_search_matches_oracle(dev):
+    """eval_utils.eval_ensemble (eval_utils.py:387-720): the fusion model's beam search on the mean of the members'
+    logits.  Three members against the oracle's member-list search; one member against the model's own sample_beam
+    (which reference-generated goldens pin), bit for bit."""
+    from oracle import rfn_oracle as O
+    from recurrent_fusion_network_amd.ensemble import EnsembleDecoder
+    cfg, spec, P, batch, gold = load_case('mid')
+    Ps = [P, O.seeded_params(cfg, 41), O.seeded_params(cfg, 42)]
+    models = [build(cfg, p, dev) for p in Ps]
+    fc, att, labels, masks, top = to_dev(batch, dev)
+    ens = EnsembleDecoder(models)
+    seq, seq_lp, top_seq, top_prob = ens.sample_beam(fc, att, {'beam_size': 3})
+    o_seq, o_lp, o_top_seq, o_top_prob, _, o_done = O.sample_beam(cfg, Ps, batch[0], batch[1], 3)
+    assert torch.equal(seq.cpu(), o_seq)
+    assert maxerr(seq_lp, o_lp) < LOGP_TOL
+    for k in range(len(o_top_seq)):
+        assert torch.equal(top_seq[k], o_top_seq[k]), k
+        assert max(abs(a - b) for a, b in zip(top_prob[k], o_top_prob[k])) < 1e-3
+        assert len(ens.done_beams[k]) == len(o_done[k])
+    # the members disagree with each other: the ensemble's captions are not simply member 0's
+    with torch.no_grad():
+        own = [m.sample(fc, att, {'beam_size': 3})[0] for m in models]
+    assert any(not torch.equal(o, seq) for o in own)
+    # one member: the model's own search
+    s1, l1, t1, p1 = EnsembleDecoder(models[:1]).sample_beam(fc, att, {'beam_size': 3})
+    with torch.no_grad():
+        m_seq, m_lp, m_top_seq, m_top_prob, _ = models[0].sample(fc, att, {'beam_size': 3})
+    assert torch.equal(s1, m_seq) and torch.equal(l1, m_lp)
+    assert all(torch.equal(a, b) for a, b in zip(t1, m_top_seq)) and list(p1) == list(m_top_prob)
+
+
 def test_cpu_inputs_fail_loudly():
     import recurrent_fusion_network_amd as R
     cfg, spec, P, batch, gold = load_case('tiny0')
