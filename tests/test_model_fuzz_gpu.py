@@ -71,3 +71,41 @@ def test_random_configuration_matches_oracle(dev, seed, gemm):
     assert seq_lp.shape == o_seq[1].shape
     if seq_lp.numel():                     # every row may emit END at once: an empty (B, 0) sample, as the reference
         assert float((seq_lp.cpu() - o_seq[1]).abs().max()) < 1e-3
+
+
+@pytest.mark.parametrize('gemm', ['exact', 'bf16x3'])
+@pytest.mark.parametrize('M,B', [(4, 24), (4, 23), (3, 33), (2, 50), (4, 31)])
+def test_mid_size_batches_of_uniform_encoders(dev, M, B, gemm):
+    """The batch sizes of data-parallel shards: uniform encoders with maps too big for the small-map rule (L * D > 32768),
+    M * B on both sides of the threshold at which the stage-I attention backward of all encoders runs as ONE fused launch
+    (csrc/rfn_path.hip attn_bwd_grouped: 96 blocks; with bf16x3 that launch also writes dP1 as bf16 planes).  Every
+    gradient against the oracle, greedy ids bit-exact."""
+    import recurrent_fusion_network_amd as R
+    from oracle import rfn_oracle as O
+    L, D = 70, 512
+    info = [dict(att_num=L, att_feat_size=D, fc_feat_size=40) for _ in range(M)]
+    cfg = O.make_cfg(info, vocab_size=90, rnn_size=32, input_encoding_size=24, att_hid_size=256, num_review_steps_0=2,
+                     num_review_steps=2, top_words_count=12, seq_length=5)
+    P = O.seeded_params(cfg, 900 + B, scale=0.08)
+    fc, att, labels, masks, top = O.synthetic_batch(cfg, B, seed=901 + B)
+    model = R.RecurrentFusionModel(cfg)
+    model.load_state_dict(P)
+    model = model.to(dev).eval()
+    if gemm == 'bf16x3':
+        import recurrent_fusion_network_amd._native as N
+        model.gemm_flags |= N.GEMM_OPT_BF16X3 | N.GEMM_OPT_BF16X3_ANY_SIZE
+    d = lambda ts: [t.to(dev) for t in ts]  # noqa: E731
+    lp, reason = model(d(fc), d(att), labels.to(dev))
+    loss = R.ReviewNetEnsembleCriterion(cfg)(lp, labels.to(dev)[:, 1:], masks.to(dev)[:, 1:], reason, top.to(dev), 1.0)
+    loss.backward()
+    o_lp, _ = O.forward(cfg, P, fc, att, labels)
+    o_loss, o_grads = O.train_step_loss_and_grads(cfg, P, fc, att, labels, masks, top, 1.0)
+    assert float((lp.detach().cpu() - o_lp).abs().max()) < 1e-3
+    assert abs(float(loss.detach()) - float(o_loss)) < 1e-4 * max(1.0, abs(float(o_loss)))
+    named = dict(model.named_parameters())
+    for k, g in o_grads.items():
+        err = float((named[k].grad.cpu() - g).abs().max())
+        assert err <= 1e-6 + 1e-3 * float(g.abs().max()), (k, err, float(g.abs().max()))
+    with torch.no_grad():
+        seq = model.sample(d(fc), d(att), {'sample_max': 1})[0]
+    assert torch.equal(seq.cpu(), O.sample_greedy(cfg, P, fc, att)[0])
