@@ -1194,8 +1194,9 @@ extern "C" int rfn_prefix_bwd(const rfn_dims* d, int B, const float* const* prm,
         RFN_TRY(rfn_fill_small_f32(outs, T1 * M, 1, 0.f, st));
     }
     // weight gradients of stage I (per encoder; see rfn_prefix_bwd_wgrad) unless the caller defers them
-    if (!defer_wgrad)
-        for (int i = 0; i < M; ++i) RFN_TRY(rfn_prefix_bwd_wgrad(d, B, att, grd, ws, ws_bytes, i, 3, st));
+    if (!defer_wgrad)   // the short part-A products of every encoder first, then the long att_2_att_h products back to back
+        for (int part = 1; part <= 2; ++part)
+            for (int i = 0; i < M; ++i) RFN_TRY(rfn_prefix_bwd_wgrad(d, B, att, grd, ws, ws_bytes, i, part, st));
     return RFN_OK;
 }
 

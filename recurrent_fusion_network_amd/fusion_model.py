@@ -167,13 +167,18 @@ class _PrefixFn(torch.autograd.Function):
                                      N.ptr(d_h), N.ptr(d_c), N.ptr(d_reason), gtable, ws.data_ptr(), ws_bytes,
                                      ctx.seed, 1, N.stream_ptr()), 'rfn_prefix_bwd')
         model._bucket_done('core', flats['core'])
-        # ... then one encoder at a time, so a data-parallel host overlaps bucket i's all-reduce with the
-        # GEMMs of encoder i+1 (the largest of backward)
-        for i in range(M):
-            for part, tag in ((1, 'a'), (2, 'b')):
-                N.check(N.lib.rfn_prefix_bwd_wgrad(C.byref(d), B, att_ptrs, gtable, ws.data_ptr(), ws_bytes, i,
-                                                   part, N.stream_ptr()), 'rfn_prefix_bwd_wgrad')
-                model._bucket_done('enc%d%s' % (i, tag), flats['enc%d%s' % (i, tag)])
+        # ... then the per-encoder stage-I weight gradients, the BIG buckets first: part a of every encoder (H2h, z2h,
+        # h_2_att_h: 277 MB each at C3, short K = B GEMMs) is produced and handed over before the first long att_2_att_h
+        # product (part b: 34 MB, the largest GEMMs of backward) starts, so a data-parallel host has 71 % of the gradient
+        # bytes in flight under ALL of those GEMMs instead of encoder i's bucket under encoder i's GEMM only -- at a
+        # 32-caption shard the b-products are 3.3 ms against 5+ ms of exchange
+        todo = [(i, part, tag) for part, tag in ((1, 'a'), (2, 'b')) for i in range(M)]
+        if getattr(model, '_wgrad_interleaved', False):      # tools A/B only: encoder by encoder (a0 b0 a1 b1 ...)
+            todo = [(i, part, tag) for i in range(M) for part, tag in ((1, 'a'), (2, 'b'))]
+        for i, part, tag in todo:
+            N.check(N.lib.rfn_prefix_bwd_wgrad(C.byref(d), B, att_ptrs, gtable, ws.data_ptr(), ws_bytes, i,
+                                               part, N.stream_ptr()), 'rfn_prefix_bwd_wgrad')
+            model._bucket_done('enc%d%s' % (i, tag), flats['enc%d%s' % (i, tag)])
         return (None, None, None, None, None) + (None,) * (2 * M) + (None,) * len(ctx.params)
 
 
@@ -310,7 +315,7 @@ class RecurrentFusionModel(nn.Module):
         self._decoder_slots = [i for i, n in enumerate(self._slot_names) if is_dec(n)]
         # gradient buckets, in the order their gradients become final during backward: the decoder, the
         # fusion "core" (everything of phase 1 except the per-encoder stage-I weights) and two buckets per
-        # encoder (rfn_prefix_bwd_wgrad parts 1 and 2).  Each bucket is one flat buffer = one all-reduce = one Adam launch.
+        # encoder (rfn_prefix_bwd_wgrad parts 1 and 2; all a-buckets are produced before the first b-bucket).  Each bucket is one flat buffer = one all-reduce = one Adam launch.
         enc_re = re.compile(r'^review_steps_individual\.\d+\.lstm\.(\d+)\.(att_model\.att_2_att_h|att_model\.h_2_att_h|H2h|z2h)\.')
         self._bucket_slots = {'decoder': list(self._decoder_slots), 'core': []}
         for i in range(M):
@@ -322,7 +327,7 @@ class RecurrentFusionModel(nn.Module):
                 self._bucket_slots['core'].append(idx)
             else:
                 self._bucket_slots['enc%s%s' % (m.group(1), 'b' if 'att_2_att_h' in m.group(2) else 'a')].append(idx)
-        self._prefix_buckets = ['core'] + [b for i in range(M) for b in ('enc%da' % i, 'enc%db' % i)]
+        self._prefix_buckets = ['core'] + ['enc%da' % i for i in range(M)] + ['enc%db' % i for i in range(M)]   # production order
         self.grad_ready_hook = None      # callable(bucket_name, flat_grad_tensor), see parallel.GradSync
         # Opt-in: real batches hold each image's features `seq_per_img` times in a row (dataloader.py:251-252).
         # With this set to that count, stages I/II run once per image and their outputs are fanned out to the

@@ -77,8 +77,9 @@ def test_two_gpu_ranks_equal_the_single_process_step(dev):
         assert p.exitcode == 0
     O, cfg, P, batch = _setup()
     order1, full, ref = _step(cfg, P, batch, 1, dev)
-    # buckets are announced in the order backward finishes them: decoder, fusion core, then per encoder a / b
-    assert order == order1 == ['decoder', 'core', 'enc0a', 'enc0b', 'enc1a', 'enc1b']
+    # buckets are announced in the order backward finishes them: decoder, fusion core, every encoder's big a-bucket, then the
+    # b-buckets of the long att_2_att_h products
+    assert order == order1 == ['decoder', 'core', 'enc0a', 'enc1a', 'enc0b', 'enc1b']
     clipped = False
     for k, g in full.items():
         a = torch.from_numpy(avg[k])

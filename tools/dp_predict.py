@@ -6,8 +6,8 @@ when backward ends.  The exchange is one ring all-reduce per bucket, issued in t
 (decoder, core, then enc_i a / enc_i b per encoder); bucket b of S_b bytes takes 2 (N-1)/N S_b / BW on the RCCL stream,
 buckets queue behind each other, and a bucket cannot start before backward has produced it.  Ready times are taken as
 fractions of the measured step (from the phase trace of the C3 step, profiles/r03_phases.txt: backward starts at 46 % of
-the step, decoder bucket at 53 %, core at 60 %, encoder i's big bucket (a) at 60 % + i * 9.1 % + 0.5 %, its small bucket
-(b) at 60 % + (i + 1) * 9.1 %, clamp+Adam is the last 3.5 %) -- the fractions hold within a few points down to B = 32
+the step, decoder bucket at 53 %, core at 60 %, the encoders' big buckets (a) at 60.5 ... 62 %, encoder i's small bucket
+(b) at 62 % + (i + 1) * 8.6 %, clamp+Adam is the last 3.5 %) -- the fractions hold within a few points down to B = 32
 because every phase scales with the batch except Adam.  BW: 153 GB/s = one xGMI link (a single ring, the pessimistic
 end), 7 x 153 GB/s = all links of the fully connected node (the optimistic end).
 
@@ -26,9 +26,10 @@ for ln in open(path):
 
 MB = 1e6
 BUCKETS = [('decoder', 54 * MB, 0.53), ('core', 262 * MB, 0.60)]
+for i in range(4):       # round 4: every encoder's big a-bucket is produced before the first long att_2_att_h product
+    BUCKETS.append(('enc%da' % i, 277 * MB, 0.60 + (i + 1) * 0.005))
 for i in range(4):
-    BUCKETS.append(('enc%da' % i, 277 * MB, 0.60 + i * 0.09125 + 0.005))
-    BUCKETS.append(('enc%db' % i, 34 * MB, 0.60 + (i + 1) * 0.09125))
+    BUCKETS.append(('enc%db' % i, 34 * MB, 0.62 + (i + 1) * 0.08625))
 ADAM = 0.035          # share of the step after the last bucket is produced
 TOTAL = sum(b[1] for b in BUCKETS)
 
@@ -48,8 +49,9 @@ def step_ms(compute_ms, n, bw):
 
 print('gradient exchange per step: %.2f GB in %d buckets; ring all-reduce moves 2 (N-1)/N of that per GPU' % (TOTAL / 1e9, len(BUCKETS)))
 print()
-print('| N | scaling | captions / rank | shard step, exact / bf16x3 (measured, ms) | step at 153 GB/s (exact / x3) | step at 1071 GB/s (exact / x3) | captions/s at 1071 GB/s (exact) |')
-print('|---|---|---|---|---|---|---|')
+MID = 350e9      # a mid estimate: the bus bandwidth RCCL typically sustains for large all-reduces on an 8-GPU xGMI node
+print('| N | scaling | captions / rank | shard step, exact / bf16x3 (measured, ms) | step at 153 GB/s (exact / x3) | step at 350 GB/s (exact / x3) | step at 1071 GB/s (exact / x3) | captions/s at 350 / 1071 GB/s (exact) |')
+print('|---|---|---|---|---|---|---|---|')
 for n in (1, 2, 4, 8):
     for kind in ('weak', 'strong'):
         b = 256 if kind == 'weak' else 256 // n
@@ -57,7 +59,8 @@ for n in (1, 2, 4, 8):
             continue
         ex, x3 = meas[b]
         lo = [step_ms(t, n, 153e9) for t in (ex, x3)]
+        mid = [step_ms(t, n, MID) for t in (ex, x3)]
         hi = [step_ms(t, n, 7 * 153e9) for t in (ex, x3)]
-        print('| %d | %s | %d | %.1f / %.1f | %.1f / %.1f (exposed %.1f / %.1f) | %.1f / %.1f (exposed %.1f / %.1f) | %.0f |' % (
-            n, kind, b, ex, x3, lo[0][0], lo[1][0], lo[0][1], lo[1][1], hi[0][0], hi[1][0], hi[0][1], hi[1][1],
-            n * b / hi[0][0] * 1e3))
+        fmt = lambda r: '%.1f / %.1f (exposed %.1f / %.1f)' % (r[0][0], r[1][0], r[0][1], r[1][1])  # noqa: E731
+        print('| %d | %s | %d | %.1f / %.1f | %s | %s | %s | %.0f / %.0f |' % (
+            n, kind, b, ex, x3, fmt(lo), fmt(mid), fmt(hi), n * b / mid[0][0] * 1e3, n * b / hi[0][0] * 1e3))
