@@ -483,7 +483,7 @@ class RunGuard:
     def _read(self):
         try:
             with open(self.path) as f:
-                return f.readline().strip()
+                return f.readline().strip() or None       # created but not yet written: nothing to act on
         except OSError:
             return None
 
