@@ -952,6 +952,30 @@ def test_beam_step_kernel_matches_python_bookkeeping(dev, W, V1, S, ties):
             assert abs(float(dp[k, j]) - rp) < 1e-5
 
 
+def test_log_softmax_topk_of_rows_with_nan_logits_stays_in_bounds(dev):
+    """a row whose logits are NaN offers no comparable candidate to the final merge; the kernel must write
+    (-inf, token 0) placeholders instead of indexing its candidate lists with -1.  Healthy rows beside it are untouched."""
+    n = N()
+    V1, W, rows = 1000, 5, 6
+    g = torch.Generator().manual_seed(5)
+    logits = torch.randn(rows, V1, generator=g)
+    logits[1] = float('nan')                      # a whole row of NaN
+    logits[4, 3:] = float('nan')                  # fewer comparable entries than W (three finite ones... made NaN by the sum)
+    lg = logits.to(dev)
+    topv = torch.full((rows, W), 7.0, device=dev)
+    topi = torch.full((rows, W), 123456, dtype=torch.int32, device=dev)
+    n.check(n.lib.rfn_log_softmax_topk(lg.data_ptr(), V1, rows, V1, W, topv.data_ptr(), topi.data_ptr(), n.stream_ptr()))
+    torch.cuda.synchronize()
+    ti, tv = topi.cpu(), topv.cpu()
+    assert int(ti.min()) >= 0 and int(ti.max()) < V1                      # every written token id is a valid row index
+    for r in (1, 4):
+        assert bool(((tv[r] == float('-inf')) | torch.isnan(tv[r])).all()), tv[r]
+    lp = torch.log_softmax(logits.double(), 1)
+    for r in (0, 2, 3, 5):
+        order = torch.sort(lp[r], descending=True, stable=True).indices[:W]
+        assert torch.equal(ti[r].long(), order)
+
+
 @pytest.mark.parametrize('W,V1,rows,ties', [(5, 9488, 37, False), (3, 301, 12, True), (16, 9488, 6, False), (8, 50, 9, True),
                                              (5, 10, 4, False)])
 def test_log_softmax_topk_and_the_beam_step_it_feeds(dev, W, V1, rows, ties):
