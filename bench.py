@@ -238,6 +238,9 @@ def parse_args(argv=None):
     ap.add_argument('--digest', action='store_true',
                     help="add config.digest: a hash of the loss bits and of every parameter bucket's float64 sum / sum of "
                          'squares after the timed steps -- two runs that agree bit for bit print the same digest')
+    ap.add_argument('--graph', action='store_true',
+                    help='replay the train step from a captured HIP graph (graphed.GraphedTrainStep; single GPU, dropout 0): for '
+                         'configurations whose 350 launches a slow host cannot issue as fast as the device retires them')
     ap.add_argument('--selftest-launch', action='store_true',
                     help='launcher / rendezvous check without a GPU: ranks meet, reduce a timing, rank 0 prints the line')
     args = ap.parse_args(argv)
@@ -628,7 +631,11 @@ def run_train(args, rank, world, dev, R, DP, guard):
     if args.strong:
         inputs = tuple(inputs) + (DP.shard_loss_scale(B, global_B, world),)
 
+    if args.graph and (in_group or (not x3 and not args.no_alt_line)):
+        raise SystemExit('--graph: single GPU, one GEMM mode per run (add --no-alt-line)')
     sync = DP.GradSync(model, world)     # per-bucket async all-reduce, overlapped with the rest of backward
+    if args.graph:
+        model.grad_ready_hook = None     # no exchange to overlap on one GPU
     start = opt.snapshot() if (not x3 and not args.no_alt_line) else None     # the bf16x3 leg restarts from here
 
     trace = [] if args.trace_steps else None
@@ -642,7 +649,15 @@ def run_train(args, rank, world, dev, R, DP, guard):
             e.record()
             row.append(e)
 
+    graphed = {}
+
     def step(inp, leg='headline'):
+        if args.graph:                      # one captured graph per input set (its buffers are the graph's static inputs)
+            if id(inp) not in graphed:
+                from recurrent_fusion_network_amd.graphed import GraphedTrainStep
+                graphed[id(inp)] = GraphedTrainStep(model, crit, opt, *inp[:5])
+            counts[leg] = counts.get(leg, 0) + 1
+            return graphed[id(inp)]()
         fc, att, labels, masks, top = inp[:5]
         loss_scale = inp[5] if len(inp) > 5 else 1.0      # uneven shards weigh their local mean (parallel.shard_loss_scale)
         row = []
@@ -778,6 +793,7 @@ def run_train(args, rank, world, dev, R, DP, guard):
                        'parallelism': 'dp%d (batch sharded, RCCL all-reduce of grads)' % world if world > 1 else 'single GPU',
                        'micro_batches': int(getattr(model, 'micro_batches', 1) or 1),
                        'final_loss': round(final_loss, 4), 'updates': head['settle_n'] + args.warmup + args.steps,
+                       'hip_graph': bool(args.graph),
                        'gemm_flags': int(model.gemm_flags), 'digest': digest},
         }
         if in_group:

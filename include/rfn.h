@@ -516,6 +516,14 @@ int rfn_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float
 int rfn_adam_step_multi(int nbuckets, float* const* p, const float* const* g, float* const* m, float* const* v,
                         const int64_t* n_host, float lr, float beta1, float beta2, float eps, float weight_decay,
                         float grad_clip, float grad_scale, int step, void* stream);
+/* The same launch with its two step-dependent scalars read from DEVICE memory: coef_dev[0] = lr / (1 - beta1^step),
+ * coef_dev[1] = 1 / sqrt(1 - beta2^step), computed by the host exactly as rfn_adam_step_multi computes them (in double, then
+ * rounded to float) and written there before the launch.  Everything else of the call is step-independent, so a HIP graph
+ * that captured it can be replayed for every step (kernel arguments are frozen by a capture; train.py:162-163 steps the
+ * optimizer once per iteration).  Bit-identical to rfn_adam_step_multi for the same coefficients. */
+int rfn_adam_step_multi_coef(int nbuckets, float* const* p, const float* const* g, float* const* m, float* const* v,
+                             const int64_t* n_host, const float* coef_dev, float beta1, float beta2, float eps,
+                             float weight_decay, float grad_clip, float grad_scale, void* stream);
 
 /* greedy pick of sample() (misc/RecurrentFusionModel.py:619-649) for one step t >= 1:
  * it = argmax_v logp[b,:] (first maximum), lp_out[b] = that value,

@@ -11,7 +11,8 @@ from .models import setup  # noqa: F401
 from .feeder import FeatureFeeder, read_image_features  # noqa: F401
 from .eval_shim import eval_step, unique_image_rows  # noqa: F401
 from .show_tell import ShowTellModel, LanguageModelCriterion  # noqa: F401
+from .graphed import GraphedTrainStep  # noqa: F401
 
 __all__ = ['RecurrentFusionModel', 'ReviewNetEnsembleCriterion', 'ReviewNetRewardCriterion', 'clip_gradient',
            'FusedClampAdam', 'setup', 'FeatureFeeder', 'read_image_features', 'eval_step', 'unique_image_rows', 'ShowTellModel',
-           'LanguageModelCriterion']
+           'LanguageModelCriterion', 'GraphedTrainStep']

@@ -142,6 +142,7 @@ def _load():
         'rfn_rl_loss_ex': (C.c_int, [P, L, P, L, P, L, P, L, L, I, I, I, I, F, P, L, I, F, P, P, P, I, P, L, P, L, L, P]),
         'rfn_adam_step': (C.c_int, [P, P, P, P, L, F, F, F, F, F, F, F, I, P]),
         'rfn_adam_step_multi': (C.c_int, [I, P, P, P, P, P, F, F, F, F, F, F, F, I, P]),
+        'rfn_adam_step_multi_coef': (C.c_int, [I, P, P, P, P, P, P, F, F, F, F, F, F, P]),
         'rfn_greedy_pick': (C.c_int, [P, L, I, I, I, P, P, L, P, L, P, P, P]),
         'rfn_multinomial_pick': (C.c_int, [P, L, I, I, F, P, P, F, P, L, P]),
         'rfn_beam_step': (C.c_int, [P, L, I, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P]),

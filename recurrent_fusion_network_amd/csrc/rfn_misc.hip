@@ -1095,8 +1095,16 @@ struct AdamBuckets {
     int vec[RFN_ADAM_MAXBUCKET];
     int nb;
 };
+// coef != NULL: the two step-dependent scalars (lr / (1 - beta1^t), 1 / sqrt(1 - beta2^t)) are read from device memory
+// instead of the kernel arguments -- the form a captured HIP graph replays, where kernel arguments are frozen
+// (rfn_adam_step_multi_coef).  Same values, same arithmetic.
 __global__ __launch_bounds__(256) void adam_multi_k(const AdamBuckets B, float lr_over_bc1, float beta1, float beta2, float eps,
-                                                    float inv_sqrt_bc2, float wd, float clip, float gscale) {
+                                                    float inv_sqrt_bc2, float wd, float clip, float gscale,
+                                                    const float* __restrict__ coef) {
+    if (coef) {
+        lr_over_bc1 = coef[0];
+        inv_sqrt_bc2 = coef[1];
+    }
     const long stride = (long)gridDim.x * 256, i0 = (long)blockIdx.x * 256 + threadIdx.x;
     for (int k = 0; k < B.nb; ++k) {
         if (B.vec[k]) {
@@ -1135,10 +1143,10 @@ __global__ __launch_bounds__(256) void adam_multi_k(const AdamBuckets B, float l
         }
     }
 }
-extern "C" int rfn_adam_step_multi(int nbuckets, float* const* p, const float* const* g, float* const* m, float* const* v,
-                                   const int64_t* n, float lr, float beta1, float beta2, float eps, float weight_decay,
-                                   float grad_clip, float grad_scale, int step, void* stream) {
-    if (nbuckets < 1 || nbuckets > RFN_ADAM_MAXBUCKET || step < 1) return RFN_ERR_SHAPE;
+static int adam_multi_launch(int nbuckets, float* const* p, const float* const* g, float* const* m, float* const* v,
+                             const int64_t* n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                             float grad_clip, float grad_scale, int step, const float* coef, void* stream) {
+    if (nbuckets < 1 || nbuckets > RFN_ADAM_MAXBUCKET || (!coef && step < 1)) return RFN_ERR_SHAPE;
     if (!p || !g || !m || !v || !n) return RFN_ERR_ARG;
     AdamBuckets B;
     memset(&B, 0, sizeof(B));
@@ -1152,12 +1160,30 @@ extern "C" int rfn_adam_step_multi(int nbuckets, float* const* p, const float* c
         most = work > most ? work : most;
     }
     B.nb = nbuckets;
-    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    float c0 = 0.f, c1 = 0.f;
+    if (!coef) {
+        const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+        c0 = (float)(lr / bc1);
+        c1 = (float)(1.0 / sqrt(bc2));
+    }
     const int blocks = (int)(most / 256 + 1 < 4096 ? most / 256 + 1 : 4096);
-    hipLaunchKernelGGL(adam_multi_k, dim3(blocks), dim3(256), 0, (hipStream_t)stream, B, (float)(lr / bc1), beta1, beta2, eps,
-                       (float)(1.0 / sqrt(bc2)), weight_decay, grad_clip, grad_scale);
+    hipLaunchKernelGGL(adam_multi_k, dim3(blocks), dim3(256), 0, (hipStream_t)stream, B, c0, beta1, beta2, eps, c1, weight_decay,
+                       grad_clip, grad_scale, coef);
     RFN_CHECK_LAUNCH();
     return RFN_OK;
+}
+extern "C" int rfn_adam_step_multi(int nbuckets, float* const* p, const float* const* g, float* const* m, float* const* v,
+                                   const int64_t* n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                   float grad_clip, float grad_scale, int step, void* stream) {
+    return adam_multi_launch(nbuckets, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, grad_clip, grad_scale, step, nullptr,
+                             stream);
+}
+extern "C" int rfn_adam_step_multi_coef(int nbuckets, float* const* p, const float* const* g, float* const* m, float* const* v,
+                                        const int64_t* n, const float* coef_dev, float beta1, float beta2, float eps,
+                                        float weight_decay, float grad_clip, float grad_scale, void* stream) {
+    if (!coef_dev) return RFN_ERR_ARG;
+    return adam_multi_launch(nbuckets, p, g, m, v, n, 0.f, beta1, beta2, eps, weight_decay, grad_clip, grad_scale, 0, coef_dev,
+                             stream);
 }
 
 // ---- multinomial pick of sample() / scheduled sampling (misc/RecurrentFusionModel.py:623-631, 260-270) --------

@@ -154,8 +154,20 @@ class FusedClampAdam:
         self.model._weights_epoch = getattr(self.model, '_weights_epoch', 0) + 1
 
     # ---- the update ------------------------------------------------------------------------------------
-    def step(self, grad_scale=1.0):
-        """grad_scale multiplies the gradient before the clamp (1/world_size after a sum all-reduce)."""
+    def coefficients(self, step):
+        """(lr / (1 - beta1^step), 1 / sqrt(1 - beta2^step)) as float32, computed exactly as rfn_adam_step_multi computes them
+        (float arguments widened to double, the quotient rounded to float): what rfn_adam_step_multi_coef reads from device
+        memory when the update is replayed from a captured graph (graphed.GraphedTrainStep)."""
+        import numpy as np
+        g0 = self.param_groups[0]
+        lr, b1, b2 = (np.float64(np.float32(x)) for x in (g0['lr'], g0['betas'][0], g0['betas'][1]))
+        bc1, bc2 = 1.0 - np.power(b1, np.float64(step)), 1.0 - np.power(b2, np.float64(step))
+        return float(np.float32(lr / bc1)), float(np.float32(1.0 / np.sqrt(bc2)))
+
+    def step(self, grad_scale=1.0, coef_dev=None):
+        """grad_scale multiplies the gradient before the clamp (1/world_size after a sum all-reduce).
+        coef_dev: a 2-float device tensor holding `coefficients(step_count + 1)` -- the launch then takes its step-dependent
+        scalars from there instead of its kernel arguments (the graph-replayable form)."""
         g0 = self.param_groups[0]
         self.step_count += 1
         self.model._weights_epoch = getattr(self.model, '_weights_epoch', 0) + 1   # invalidates reuse_prefix entries
@@ -171,9 +183,13 @@ class FusedClampAdam:
         for lo in range(0, len(todo), N.ADAM_MAXBUCKET):
             part = todo[lo:lo + N.ADAM_MAXBUCKET]
             sizes = (C.c_int64 * len(part))(*[st['n'] for st, _ in part])
-            N.check(N.lib.rfn_adam_step_multi(len(part), N.ptr_array([st['p'] for st, _ in part]),
-                                              N.ptr_array([g for _, g in part]), N.ptr_array([st['m'] for st, _ in part]),
-                                              N.ptr_array([st['v'] for st, _ in part]), sizes, g0['lr'], g0['betas'][0],
-                                              g0['betas'][1], g0['eps'], g0['weight_decay'], g0['grad_clip'], grad_scale,
-                                              self.step_count, N.stream_ptr()),
-                    'rfn_adam_step_multi')
+            ptrs = (N.ptr_array([st['p'] for st, _ in part]), N.ptr_array([g for _, g in part]),
+                    N.ptr_array([st['m'] for st, _ in part]), N.ptr_array([st['v'] for st, _ in part]))
+            if coef_dev is not None:
+                N.check(N.lib.rfn_adam_step_multi_coef(len(part), *ptrs, sizes, coef_dev.data_ptr(), g0['betas'][0],
+                                                       g0['betas'][1], g0['eps'], g0['weight_decay'], g0['grad_clip'],
+                                                       grad_scale, N.stream_ptr()), 'rfn_adam_step_multi_coef')
+            else:
+                N.check(N.lib.rfn_adam_step_multi(len(part), *ptrs, sizes, g0['lr'], g0['betas'][0], g0['betas'][1], g0['eps'],
+                                                  g0['weight_decay'], g0['grad_clip'], grad_scale, self.step_count,
+                                                  N.stream_ptr()), 'rfn_adam_step_multi')

@@ -214,3 +214,53 @@ def test_retained_graph_after_a_weight_update_matches_the_reference_semantics(de
     assert not torch.equal(recomputed[1]['logit.weight'], recomputed[0]['logit.weight'])
     worst = max(float((recomputed[1][k].cpu() - w).abs().max()) / (1e-5 + 1e-3 * float(w.abs().max())) for k, w in want[1].items())
     assert worst > 1.0          # the recompute path is a different (self-consistent) gradient: the flag matters
+
+
+def test_graphed_train_step_is_bit_identical_to_the_eager_step(dev):
+    """graphed.GraphedTrainStep: zero_grad + forward + criterion + backward + clamp + Adam captured once in a HIP graph and
+    replayed on three different batches = the same three eager steps, bit for bit (loss, every parameter, both Adam moments,
+    `.grad`), including Adam's step-dependent bias correction, which the replay reads from device memory
+    (rfn_adam_step_multi_coef).  Constructing the wrapper must not train; dropout > 0 is refused."""
+    import recurrent_fusion_network_amd as R
+    from recurrent_fusion_network_amd.graphed import GraphedTrainStep
+    cfg, spec, P, batch, gold = load_case('mid')
+    fc, att, labels, masks, top = to_dev(batch, dev)
+    B = labels.size(0)
+    perms = [torch.arange(B, device=dev), torch.arange(B, device=dev).flip(0), torch.roll(torch.arange(B, device=dev), 2)]
+    batches = [([f[p] for f in fc], [a[p] for a in att], labels[p], masks[p], top[p]) for p in perms]
+    kw = dict(lr=5e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5, grad_clip=0.01)      # a clamp that bites, a big lr
+    crit = R.ReviewNetEnsembleCriterion(cfg)
+
+    eager = build(cfg, P, dev, train=True)
+    o1 = R.FusedClampAdam(eager, **kw)
+    want = []
+    for b in batches:
+        o1.zero_grad()
+        lp, reason = eager(b[0], b[1], b[2])
+        loss = crit(lp, b[2][:, 1:], b[3][:, 1:], reason, b[4], 1.0)
+        loss.backward()
+        o1.step()
+        want.append(loss.detach().clone())
+
+    model = build(cfg, P, dev, train=True)
+    o2 = R.FusedClampAdam(model, **kw)
+    before = {k: p.detach().clone() for k, p in model.named_parameters()}
+    g = GraphedTrainStep(model, crit, o2, *batches[0])
+    assert o2.step_count == 0 and all(torch.equal(p, before[k]) for k, p in model.named_parameters())   # capture did not train
+    for b, w in zip(batches, want):
+        loss = g(*b)
+        assert torch.equal(loss.detach(), w)
+    assert o2.step_count == 3
+    for (k, p), (_, q) in zip(model.named_parameters(), eager.named_parameters()):
+        assert torch.equal(p, q), k
+        assert torch.equal(p.grad, q.grad), k
+    for name in o1.flat:            # the moments of every parameter (the 16-B padding between parameters holds no state)
+        params, offs, _ = model.bucket_layout(name)
+        for p_, o in zip(params, offs):
+            for k in ('m', 'v'):
+                assert torch.equal(o1.flat[name][k][o:o + p_.numel()], o2.flat[name][k][o:o + p_.numel()]), (name, k)
+    # what a capture would freeze is refused
+    cfg.drop_prob_lm = 0.3
+    drop = build(cfg, P, dev, train=True)
+    with pytest.raises(R._native.RfnError):
+        GraphedTrainStep(drop, crit, R.FusedClampAdam(drop, **kw), *batches[0])
