@@ -764,9 +764,10 @@ def run_train(args, rank, world, dev, R, DP, guard):
         import hashlib
         import struct
         hsh = hashlib.sha256(struct.pack('<f', final_loss))
-        for name in model.bucket_names():
-            flat = opt.flat[name]['p'].double()
-            hsh.update(struct.pack('<dd', float(flat.sum()), float((flat * flat).sum())))
+        # over the PARAMETERS, in name order (the flat buckets also hold the 16-B padding between them, which is no state)
+        ps = [p_.detach().double() for _, p_ in sorted(model.named_parameters())]
+        sums = torch.stack([q.sum() for q in ps] + [(q * q).sum() for q in ps]).cpu().tolist()
+        hsh.update(struct.pack('<%dd' % len(sums), *sums))
         digest = hsh.hexdigest()[:16]
     ms = elapsed / args.steps * 1e3
     out = None
