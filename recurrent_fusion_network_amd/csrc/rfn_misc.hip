@@ -1016,12 +1016,16 @@ extern "C" int rfn_multilabel_margin(const float* pred, int B, int K, const int6
 __device__ __forceinline__ void adam_elem(float& pv, float gv, float& mv, float& vv, float lr_over_bc1, float beta1,
                                           float beta2, float eps, float inv_sqrt_bc2, float wd, float clip,
                                           float gscale) {
+    // The operation tree is pinned: no implicit contraction, fused multiply-adds only where written.  The per-bucket kernel,
+    // the multi-bucket kernel and its graph-replayable form (scalars from memory instead of kernel arguments) must produce the
+    // same bits, and left to itself the compiler fuses differently depending on where the scalars live.
+#pragma clang fp contract(off)
     gv *= gscale;
     gv = fminf(fmaxf(gv, -clip), clip);
-    gv += wd * pv;
-    mv = beta1 * mv + (1.0f - beta1) * gv;
-    vv = beta2 * vv + (1.0f - beta2) * gv * gv;
-    pv = pv - lr_over_bc1 * mv / (sqrtf(vv) * inv_sqrt_bc2 + eps);
+    gv = __builtin_fmaf(wd, pv, gv);
+    mv = __builtin_fmaf(beta1, mv, (1.0f - beta1) * gv);
+    vv = __builtin_fmaf(beta2, vv, ((1.0f - beta2) * gv) * gv);
+    pv = pv - (lr_over_bc1 * mv) / __builtin_fmaf(sqrtf(vv), inv_sqrt_bc2, eps);
 }
 // VEC: 16 B per lane on all seven streams (flat buckets are 16-B aligned and a multiple of 4 long)
 template <bool VEC>
