@@ -594,8 +594,15 @@ def run_rank(args):
         torch.distributed.barrier()
         guard.close()
         torch.distributed.destroy_process_group()
+    # nothing may follow the result line on stdout (library chatter at exit, late C stdio buffers): whatever is still written
+    # to file descriptor 1 goes to the null device.  The process ends normally -- a profiler attached to it (rocprofv3 writes
+    # its tables from exit handlers) must get to run them.
     sys.stdout.flush()
-    os._exit(0)        # nothing may follow the result line on stdout (library atexit chatter, late C stdio buffers)
+    flush_c_stdio()
+    try:
+        os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
+    except OSError:
+        pass
 
 
 def run_train(args, rank, world, dev, R, DP, guard):
