@@ -241,6 +241,9 @@ def parse_args(argv=None):
     ap.add_argument('--graph', action='store_true',
                     help='replay the train step from a captured HIP graph (graphed.GraphedTrainStep; single GPU, dropout 0): for '
                          'configurations whose 350 launches a slow host cannot issue as fast as the device retires them')
+    ap.add_argument('--no-persist', action='store_true',
+                    help='A/B: RFN_PATH_OPT_NO_PERSIST -- the stage-II / decoder recurrences as three launches per step and '
+                         'direction (rounds 3-4) instead of one persistent launch per chain')
     ap.add_argument('--selftest-launch', action='store_true',
                     help='launcher / rendezvous check without a GPU: ranks meet, reduce a timing, rank 0 prints the line')
     args = ap.parse_args(argv)
@@ -266,6 +269,8 @@ def launch_ranks(args, argv):
     env = dict(os.environ)
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')     # dmabuf IPC: RCCL needs it on this driver
     env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    import uuid
+    env['RFN_BENCH_RUN_ID'] = uuid.uuid4().hex       # names this launch's RunGuard flag file: no earlier run can share it
     proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
     line = None
     for out in proc.stdout:
@@ -274,6 +279,10 @@ def launch_ranks(args, argv):
         else:
             sys.stderr.write(out)
     rc = proc.wait()
+    try:
+        os.unlink(run_guard_path(env))               # a failed run leaves its flag behind: the parent removes it
+    except OSError:
+        pass
     if rc != 0:
         sys.stderr.write('bench.py: a rank failed (torch.distributed.run exit code %d)\n' % rc)
         return rc
@@ -443,12 +452,37 @@ def flush_c_stdio():
         pass
 
 
+def _proc_start_ticks(pid):
+    """Start time of process `pid` in clock ticks since boot (field 22 of /proc/<pid>/stat): tells two launchers that
+    happened to get the same pid apart."""
+    try:
+        with open('/proc/%d/stat' % pid) as f:
+            return f.read().rsplit(')', 1)[1].split()[19]
+    except (OSError, IndexError):
+        return '0'
+
+
+def run_guard_path(env=None):
+    """The flag file of THIS launch.  bench.py's own launcher hands every rank a fresh RFN_BENCH_RUN_ID; under an external
+    launcher (torch.distributed.run's static rendezvous gives every job the run id 'none') the ranks' common parent -- its
+    pid AND its start time -- plus the rendezvous port name the launch, so a flag left behind by an earlier failed run can
+    never be read as this run's, and nobody has to delete anything at start-up (rank 0 used to unlink a leftover
+    in its constructor, racing the peers' watcher threads both ways)."""
+    import tempfile
+    env = os.environ if env is None else env
+    run_id = env.get('RFN_BENCH_RUN_ID')
+    if not run_id:
+        ppid = os.getppid()
+        run_id = '%d_%s_%s' % (ppid, _proc_start_ticks(ppid), env.get('MASTER_PORT', '0'))
+    return os.path.join(tempfile.gettempdir(), 'rfn_bench_%s.flag' % run_id)
+
+
 class RunGuard:
     """What keeps the one driver-run line of an N-rank job from hanging or getting lost.
 
     A rank that raises must never enter a collective its peers are not in: they sit in a gradient all-reduce and everybody
-    would wait for the NCCL watchdog (10 min).  So ranks agree through a flag FILE (one node; name keyed by the launcher's pid
-    and the rendezvous port), polled by a daemon thread on every rank -- a thread, because the main thread of a healthy rank
+    would wait for the NCCL watchdog (10 min).  So ranks agree through a flag FILE (one node; named by a per-launch nonce,
+    `run_guard_path`), polled by a daemon thread on every rank -- a thread, because the main thread of a healthy rank
     may be blocked inside a collective or a device synchronisation (both release the GIL).
 
     * a failure before the headline is measured: `fatal(exc)` -- traceback, flag, os._exit(1).  Peers see the flag and
@@ -459,21 +493,15 @@ class RunGuard:
     POLL_S = 0.25
 
     def __init__(self, rank, world):
-        import tempfile
         import threading
         self.rank, self.world = rank, world
-        self.path = os.path.join(tempfile.gettempdir(), 'rfn_bench_%d_%s.flag' % (os.getppid(), os.environ.get('MASTER_PORT', '0')))
+        self.path = run_guard_path()
         self.line = None            # rank 0: the result line as far as it is known (set once the headline leg is done)
         self.leg = None             # the optional leg in progress
         self.deadline = None
         self.lock = threading.Lock()
         self.closed = False
         if world > 1:
-            if rank == 0:
-                try:
-                    os.unlink(self.path)     # a flag left by an earlier run under the same launcher pid and port
-                except OSError:
-                    pass
             threading.Thread(target=self._watch, name='rfn-bench-guard', daemon=True).start()
 
     def _flag(self, text):
@@ -630,6 +658,8 @@ def run_train(args, rank, world, dev, R, DP, guard):
         model.gemm_flags |= N.GEMM_OPT_BF16X3
     if args.lds_lean:
         model.gemm_flags |= N.GEMM_OPT_LDS_LEAN
+    if args.no_persist:
+        model.path_flags |= N.PATH_OPT_NO_PERSIST
     if args.micro_batches >= 0 and hasattr(model, 'micro_batches'):
         model.micro_batches = args.micro_batches
     crit = R.ReviewNetEnsembleCriterion(cfg)
@@ -657,6 +687,7 @@ def run_train(args, rank, world, dev, R, DP, guard):
             row.append(e)
 
     graphed = {}
+    in_step = {}                # per timed step and encoder: ms of the projection / weight-gradient launch (headline leg)
 
     def step(inp, leg='headline'):
         if args.graph:                      # one captured graph per input set (its buffers are the graph's static inputs)
@@ -737,13 +768,30 @@ def run_train(args, rank, world, dev, R, DP, guard):
         loss = None
         for _ in range(args.warmup):
             loss = step(inp, leg)
+        # the dominant launches INSIDE the timed steps: HIP events recorded by the path itself around every encoder's
+        # hoisted projection and weight-gradient launch (rfn_dims.probe_events), one event set per timed step, read
+        # after the region's own fence -- nothing is synchronised for them
+        probes = None
+        if leg == 'headline' and not args.graph:
+            n_ev = 4 * len(w['enc'])
+            probes = [[torch.cuda.Event(enable_timing=True) for _ in range(n_ev)] for _ in range(args.steps)]
+            for evs in probes:
+                for e in evs:
+                    e.record()         # creates the HIP event behind it
         fence()
         sync.record = True
         a0, t0, c0 = allocs(), time.perf_counter(), time.thread_time()
-        for _ in range(args.steps):
+        for k in range(args.steps):
+            if probes is not None:
+                model.set_probe_events(probes[k])
             loss = step(inp, leg)
         fence()
         local = time.perf_counter() - t0
+        model.set_probe_events(None)
+        if probes is not None:
+            M_ = len(w['enc'])
+            in_step['fwd_ms'] = [[evs[2 * i].elapsed_time(evs[2 * i + 1]) for i in range(M_)] for evs in probes]
+            in_step['wgrad_ms'] = [[evs[2 * M_ + 2 * i].elapsed_time(evs[2 * M_ + 2 * i + 1]) for i in range(M_)] for evs in probes]
         host_cpu = (time.thread_time() - c0) / max(1e-9, local)      # share of the timed region the launching thread was
         sync.record = False                                          # on a CPU (1.0 = never descheduled)
         exposed, per_bucket, how = sync.exposed_ms()
@@ -811,8 +859,24 @@ def run_train(args, rank, world, dev, R, DP, guard):
             out['config']['gemm'] = 'bf16x3'
         # roofline of the dominant kernel, timed live with HIP events on the launch stream
         att = inputs[1]
-        secs, flops = time_dominant_kernel(model, att, reps=5)
-        achieved = flops / secs / 1e12
+        secs_alone, flops = time_dominant_kernel(model, att, reps=5)
+        standalone = flops / secs_alone / 1e12
+        # `achieved` = the projection launches INSIDE the timed steps (all encoders, all K steps): sum of their algorithmic
+        # FLOP / sum of their durations.  The stand-alone figure (5 back-to-back launches of encoder 0's projection, the
+        # best case) stays beside it as frac_standalone.
+        A_, T1_ = model.att_hid_size, model.num_review_steps_0
+        enc_flops = [2.0 * B * e[0] * e[1] * A_ * T1_ for e in w['enc']]
+        secs, achieved, in_step_note = secs_alone, standalone, 'stand-alone launches (no in-step events: --graph)'
+        wgrad_tf = None
+        if in_step.get('fwd_ms') and min(min(r) for r in in_step['fwd_ms']) > 1e-3:
+            tot_ms = sum(sum(r) for r in in_step['fwd_ms'])
+            n_l = sum(len(r) for r in in_step['fwd_ms'])
+            achieved = sum(enc_flops) * len(in_step['fwd_ms']) / (tot_ms * 1e-3) / 1e12
+            secs = tot_ms * 1e-3 / n_l
+            flops = sum(enc_flops) / len(enc_flops)
+            in_step_note = 'mean of the %d projection launches inside the %d timed steps' % (n_l, len(in_step['fwd_ms']))
+            wg_ms = sum(sum(r) for r in in_step['wgrad_ms'])
+            wgrad_tf = sum(enc_flops) * len(in_step['wgrad_ms']) / (wg_ms * 1e-3) / 1e12
         # HBM-side bytes per launch of that kernel, from the rocprofv3 --pmc passes (null when the kernel source has
         # changed since they were taken)
         traffic = pmc_traffic(args.workload, B == w['B'])
@@ -832,8 +896,16 @@ def run_train(args, rank, world, dev, R, DP, guard):
                     'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': traffic,
                     'traffic_unit': 'bytes per launch (2*FETCH_SIZE + WRITE_SIZE)',
                     'algorithmic_bytes': int(4 * (B * L0 * D0 + 8 * 512 * D0 + B * L0 * 8 * 512)),
-                    'kernel': 'rfn_gemm_kernel NT big tile (grouped att_2_att_h projection of encoder 0, '
-                              '%.3f TFLOP per launch, %.3f ms per launch)' % (flops / 1e12, secs * 1e3)}
+                    'kernel': 'rfn_gemm_kernel NT big tile (grouped att_2_att_h projection of one encoder, '
+                              '%.3f TFLOP per launch, %.3f ms per launch: %s)' % (flops / 1e12, secs * 1e3, in_step_note),
+                    'frac_standalone': round(standalone / FP32_MFMA_PEAK_TFLOPS, 4),
+                    'standalone_ms': round(secs_alone * 1e3, 3)}
+            if wgrad_tf is not None:
+                roof['wgrad_frac'] = round(wgrad_tf / FP32_MFMA_PEAK_TFLOPS, 4)     # the TN twin (dW = dP^T X), in step
+                roof['in_step_ms'] = {'projection': [round(sum(r[i] for r in in_step['fwd_ms']) / len(in_step['fwd_ms']), 3)
+                                                     for i in range(len(w['enc']))],
+                                      'weight_gradient': [round(sum(r[i] for r in in_step['wgrad_ms']) / len(in_step['wgrad_ms']), 3)
+                                                          for i in range(len(w['enc']))]}
         out['roofline'] = roof
         # whole-step view against the same peak (SURVEY.md 8d algorithmic FLOP of one step)
         step_flops = (w['step_tflop'] * 1e12 * (B / w['B'])) if w['step_tflop'] else train_step_flops(cfg, B)

@@ -36,7 +36,7 @@ extern "C" {
 #define RFN_ERR_ARG (-5)         /* null / misaligned pointer */
 
 #define RFN_MAX_ENC 8
-#define RFN_ABI_VERSION 5
+#define RFN_ABI_VERSION 6
 
 /* Model dimensions: the fields RecurrentFusionModel.__init__ reads from `opt`
  * (misc/RecurrentFusionModel.py:118-151).  Limits (RFN_ERR_SHAPE otherwise): M <= RFN_MAX_ENC,
@@ -59,7 +59,17 @@ typedef struct rfn_dims {
     float drop_reason;         /* opt.drop_prob_reason (stage II)                         */
     float drop_lm;             /* opt.drop_prob_lm     (decoder)                          */
     uint32_t gemm_flags;       /* RFN_GEMM_OPT_* bits applied to every GEMM of the path (0 = defaults)  */
+    uint32_t path_flags;       /* RFN_PATH_OPT_* bits (0 = defaults)                                    */
+    /* Measurement hook (NULL = off; bench.py's in-step roofline): an array of 4*M hipEvent_t created by the caller
+     * with timing enabled.  rfn_prefix_fwd records events [2i] / [2i+1] on the launch stream right before / after
+     * encoder i's hoisted att_2_att_h projection launch (the path's dominant kernel), rfn_prefix_bwd_wgrad records
+     * [2M+2i] / [2M+2i+1] around encoder i's att_2_att_h weight-gradient launch.  Recording is asynchronous; the
+     * caller reads the pairs after its own synchronisation.  Nothing else in the library looks at it. */
+    void* const* probe_events;
 } rfn_dims;
+/* rfn_dims.path_flags */
+#define RFN_PATH_OPT_NO_PERSIST 1u   /* A/B hook: run the stage-II / decoder recurrences as three launches per step and
+                                      * direction (rounds 3-4) instead of one persistent launch per chain             */
 
 int rfn_abi_version(void);
 const char* rfn_error_string(int code);

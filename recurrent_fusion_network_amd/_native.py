@@ -16,7 +16,8 @@ LIB_PATH = os.path.join(_HERE, 'librfn_hip.so')
 RFN_MAX_ENC = 8
 RFN_GEMM_MAXSEG = 8
 RFN_GEMM_MAXGROUP = 8
-ABI_VERSION = 5
+ABI_VERSION = 6
+PATH_OPT_NO_PERSIST = 1       # rfn.h RFN_PATH_OPT_NO_PERSIST
 GEMM_OPT_LDS_LEAN = 1
 GEMM_OPT_NO_DMA = 2
 GEMM_OPT_BF16X3 = 4
@@ -35,7 +36,7 @@ class Dims(C.Structure):
                 ('L', C.c_int32 * RFN_MAX_ENC), ('D', C.c_int32 * RFN_MAX_ENC), ('F', C.c_int32 * RFN_MAX_ENC),
                 ('review_maxout', C.c_int32), ('decoder_maxout', C.c_int32),
                 ('drop_fusion', C.c_float), ('drop_reason', C.c_float), ('drop_lm', C.c_float),
-                ('gemm_flags', C.c_uint32)]
+                ('gemm_flags', C.c_uint32), ('path_flags', C.c_uint32), ('probe_events', C.c_void_p)]
 
 
 class GemmSeg(C.Structure):
@@ -208,7 +209,7 @@ def ptr_array(tensors):
 
 
 def make_dims(M, R, A, E, T1, T2, K, V1, L, D, Fc, review_maxout=0, decoder_maxout=0, drop_fusion=0.0,
-              drop_reason=0.0, drop_lm=0.0, gemm_flags=0) -> Dims:
+              drop_reason=0.0, drop_lm=0.0, gemm_flags=0, path_flags=0) -> Dims:
     if M > RFN_MAX_ENC:
         raise RfnError('at most %d encoders are supported' % RFN_MAX_ENC)
     d = Dims()
@@ -218,6 +219,8 @@ def make_dims(M, R, A, E, T1, T2, K, V1, L, D, Fc, review_maxout=0, decoder_maxo
     d.review_maxout, d.decoder_maxout = int(review_maxout), int(decoder_maxout)
     d.drop_fusion, d.drop_reason, d.drop_lm = drop_fusion, drop_reason, drop_lm
     d.gemm_flags = int(gemm_flags)
+    d.path_flags = int(path_flags)
+    d.probe_events = None
     return d
 
 

@@ -136,6 +136,12 @@ int gemm_dw(int N, int K, float* dW, long ldw, float* db, const float* dY, long 
 // reduction elements) on the bounds-checked kernel.  Same sums, same order per output element except the dX split,
 // which adds the remainder's partial product last.
 static inline int aligned_part(int n) { return (n / 128) * 128; }
+
+// rfn_dims.probe_events (rfn.h): the caller's timing events around the dominant launches, recorded on the launch stream
+static inline int probe_mark(const rfn_dims* d, int idx, void* st) {
+    if (!d->probe_events || !d->probe_events[idx]) return RFN_OK;
+    return hipEventRecord((hipEvent_t)d->probe_events[idx], (hipStream_t)st) == hipSuccess ? RFN_OK : RFN_ERR_LAUNCH;
+}
 int gemm_logits(int rows, int V1, const float* h, int R, const float* Wl, const float* bl, float* C, const GemmCtx& gx) {
     // both operands are [row][k]: the LDS-DMA kernel takes the ragged vocabulary in one launch (edge tiles clamp their
     // source rows); only a hidden size that is not a whole K step keeps the main + remainder split
@@ -657,13 +663,17 @@ static int prefix_fwd_impl(const rfn_dims* d, int B, const float* const* prm, co
                 bias[t] = prm[P.s1(t, i, 1)];
             }
             RFN_TRY(rfn_x3_split(srcs, T1, Di, A, Di, 1, imgW, st));
+            RFN_TRY(probe_mark(d, 2 * i, st));
             RFN_TRY(rfn_x3_gemm(BL, T1 * A, Di, imgX, imgW, BL, A, outs, bias, A, 0, 1, nullptr, st));
+            RFN_TRY(probe_mark(d, 2 * i + 1, st));
             continue;
         }
         for (int t = 0; t < T1; ++t)
             pr[t] = prob1(W + Lo.P1[i] + (long)t * B * d->L[i] * A, A,
                           seg_lin(att[i], d->D[i], prm[P.s1(t, i, 0)], d->D[i], d->D[i], prm[P.s1(t, i, 1)]));
+        RFN_TRY(probe_mark(d, 2 * i, st));
         RFN_TRY(gemm_groups(B * d->L[i], A, T1, pr, 0, gx));
+        RFN_TRY(probe_mark(d, 2 * i + 1, st));
     }
 
     // ---- stage I: T1 steps x M cells (:213-217, :101-114, :47-74) ---------------------------
@@ -1252,12 +1262,16 @@ extern "C" int rfn_prefix_bwd_wgrad(const rfn_dims* d, int B, const float* const
                     hipSuccess)
                     return RFN_ERR_LAUNCH;
             }
-            return rfn_x3_gemm_ks(TA, (int)Di, BL, ksP, ksX, A, (int)Di, outs, nullptr, Di, 0, sk, part, st);
+            RFN_TRY(probe_mark(d, 2 * M + 2 * i, st));
+            RFN_TRY(rfn_x3_gemm_ks(TA, (int)Di, BL, ksP, ksX, A, (int)Di, outs, nullptr, Di, 0, sk, part, st));
+            return probe_mark(d, 2 * M + 2 * i + 1, st);
         }
         for (int t = 0; t < T1; ++t)
             pr[t] = prob_dw(grd[P.s1(t, i, 0)], Di, nullptr, W + Lo.P1[i] + (long)t * B * Li * A, A, att[i], Di,
                             (int)(B * Li));
-        return gemm_groups_split_cols(A, (int)Di, T1, pr, 0, gx);
+        RFN_TRY(probe_mark(d, 2 * M + 2 * i, st));
+        RFN_TRY(gemm_groups_split_cols(A, (int)Di, T1, pr, 0, gx));
+        return probe_mark(d, 2 * M + 2 * i + 1, st);
     };
     if ((parts & 2) && !(parts & 1)) return part_b();
     // part A: H2h, z2h, h_2_att_h (large bucket, short GEMMs: K = B rows per step).  Their bias gradients are column

@@ -12,6 +12,7 @@ parameter names (``review_steps_individual.{t}.lstm.{i}.att_model.att_2_att_h.we
 """
 from __future__ import annotations
 
+import collections.abc
 import ctypes as C
 import re
 import weakref
@@ -303,6 +304,8 @@ class RecurrentFusionModel(nn.Module):
         # RFN_GEMM_OPT_* bits handed to every GEMM of the path (rfn.h); a data-parallel host sets
         # N.GEMM_OPT_LDS_LEAN so RCCL's kernels can co-reside with the long weight-gradient GEMMs (parallel.GradSync does)
         self.gemm_flags = 0
+        self.path_flags = 0              # RFN_PATH_OPT_* bits (rfn.h); 0 = defaults
+        self._probe = None
         self._dims = {}
         self._param_cache = {}
         self._slot_names = N.param_names(self._dims_for(False))
@@ -348,6 +351,9 @@ class RecurrentFusionModel(nn.Module):
         self._weights_epoch = 0          # bumped by FusedClampAdam.step (it writes parameters behind autograd's back)
         self._last_flat_grads = {}
         self._steps_cache = None
+        # set by graphed.GraphedTrainStep while it captures / warms up: run exactly this many decoder steps instead of
+        # stopping at the first all-zero label column (the loader's masks are zero on the extra steps)
+        self.fixed_decoder_steps = None
         self.done_beams = []
 
     def init_weights(self):
@@ -358,8 +364,27 @@ class RecurrentFusionModel(nn.Module):
             _uniform(self.reason_linear_individual[i].weight, self.fc2h[i].weight)
 
     # ---- plumbing -------------------------------------------------------------------------------
+    def set_probe_events(self, events):
+        """Measurement hook (rfn.h rfn_dims.probe_events): 4*M `torch.cuda.Event(enable_timing=True)` objects that the path
+        records around its dominant launches -- [2i], [2i+1] encoder i's hoisted projection (forward), [2M+2i], [2M+2i+1] its
+        att_2_att_h weight gradient (backward) -- or None to switch the hook off.  The events must have been recorded once
+        (that is when PyTorch creates the HIP event behind them); the caller keeps them alive while the hook is set."""
+        if events is None:
+            self._probe = None
+            return
+        if len(events) != 4 * self.num_feat_array:
+            raise N.RfnError('set_probe_events: expected %d events' % (4 * self.num_feat_array))
+        arr = (C.c_void_p * len(events))(*[int(e.cuda_event) for e in events])
+        self._probe = (arr, list(events))
+
     def _dims_for(self, train: bool) -> N.Dims:
-        key = (bool(train), int(self.gemm_flags))
+        d = self._dims_cached(train)
+        probe = getattr(self, '_probe', None)
+        d.probe_events = C.cast(probe[0], C.c_void_p) if probe is not None else None
+        return d
+
+    def _dims_cached(self, train: bool) -> N.Dims:
+        key = (bool(train), int(self.gemm_flags), int(self.path_flags))
         if key not in self._dims:
             self._dims[key] = N.make_dims(
                 self.num_feat_array, self.rnn_size, self.att_hid_size, self.input_encoding_size,
@@ -368,7 +393,7 @@ class RecurrentFusionModel(nn.Module):
                 review_maxout=self.review_maxout, decoder_maxout=self.decoder_maxout,
                 drop_fusion=self.drop_prob_fusion if train else 0.0,
                 drop_reason=self.drop_prob_reason if train else 0.0,
-                drop_lm=self.drop_prob_lm if train else 0.0, gemm_flags=self.gemm_flags)
+                drop_lm=self.drop_prob_lm if train else 0.0, gemm_flags=self.gemm_flags, path_flags=self.path_flags)
         return self._dims[key]
 
     def _params_of(self, slots):
@@ -520,6 +545,10 @@ class RecurrentFusionModel(nn.Module):
         """Number of decoder steps: the reference breaks at the first all-zero column i >= 1 (:274).  The
         answer for a given (tensor, version) is cached, so a caller that reuses one label tensor pays the
         device read-back once instead of the reference's 17 syncs per forward."""
+        if self.fixed_decoder_steps is not None:      # a captured step runs a fixed count (graphed.GraphedTrainStep)
+            if not 1 <= self.fixed_decoder_steps <= seq.size(1):
+                raise N.RfnError('fixed_decoder_steps = %d does not fit labels of %d columns' % (self.fixed_decoder_steps, seq.size(1)))
+            return int(self.fixed_decoder_steps)
         key = (seq.data_ptr(), seq._version, tuple(seq.shape))
         hit = self._steps_cache
         if hit is not None and hit[0] == key and hit[1] is seq:
@@ -749,43 +778,93 @@ class _BeamResults:
                 for k, n in enumerate(counts)]
 
 
-class _LazyList(list):
-    """A list of known length whose entries are produced (all at once) by `fill()` the first time the list is looked at.
-    EVERY method of `list` other than `len()` fills first -- reads (indexing, iteration, comparison, `+`, `copy`, `index`,
-    `reversed`, printing, pickling ...) and mutators alike -- so no caller can ever see a placeholder; it pickles as a
-    plain list."""
+class _LazyList(collections.abc.MutableSequence):
+    """A sequence of known length whose entries are produced (all at once) by `fill()` the first time anything but its
+    length is asked for.  Deliberately NOT a subclass of `list`: C fast paths that take a list subclass (`PySequence_Fast`,
+    `PyList_GET_ITEM`: json's C encoder, `str.join`, some torch / numpy converters) read the list's item array directly and
+    would see unfilled placeholders without any Python-level hook running.  As a plain `MutableSequence` every consumer goes
+    through `__getitem__` / `__iter__` / `__len__` (which fill first), and a consumer that insists on a real list fails
+    loudly (`json.dumps(x)` raises TypeError; `json.dumps(list(x))` / `x.materialize()` is the spelling).  Indexing,
+    slicing, iteration, comparison with lists, `+`, `in`, `reversed`, `sorted`, printing, copying, pickling (as a plain
+    list) and in-place edits behave like the list the reference returns (misc/RecurrentFusionModel.py:529-543)."""
+
+    __slots__ = ('_n', '_fill', '_items')
+    __hash__ = None
 
     def __init__(self, n, fill):
-        super().__init__([None] * n)
-        self._fill = fill
+        self._n, self._fill, self._items = int(n), fill, None
 
-    def _ensure(self):
-        if self._fill is not None:
+    def materialize(self):
+        """The plain `list` behind this object (filled now if it was not)."""
+        if self._items is None:
             fill, self._fill = self._fill, None
-            list.__setitem__(self, slice(None), fill())
+            items = list(fill())
+            if len(items) != self._n:
+                raise N.RfnError('lazy list promised %d entries, its producer made %d' % (self._n, len(items)))
+            self._items = items
+        return self._items
+
+    def __len__(self):
+        return self._n if self._items is None else len(self._items)
+
+    def __getitem__(self, i):
+        return self.materialize()[i]
+
+    def __setitem__(self, i, v):
+        self.materialize()[i] = v
+
+    def __delitem__(self, i):
+        del self.materialize()[i]
+
+    def insert(self, i, v):
+        self.materialize().insert(i, v)
+
+    def __iter__(self):
+        return iter(self.materialize())
+
+    def __repr__(self):
+        return repr(self.materialize())
+
+    def _other(self, other):
+        return other.materialize() if isinstance(other, _LazyList) else other
+
+    def __eq__(self, other):
+        return self.materialize() == self._other(other)
+
+    def __ne__(self, other):
+        return self.materialize() != self._other(other)
+
+    def __lt__(self, other):
+        return self.materialize() < self._other(other)
+
+    def __le__(self, other):
+        return self.materialize() <= self._other(other)
+
+    def __gt__(self, other):
+        return self.materialize() > self._other(other)
+
+    def __ge__(self, other):
+        return self.materialize() >= self._other(other)
+
+    def __add__(self, other):
+        return self.materialize() + list(self._other(other))
+
+    def __radd__(self, other):
+        return list(other) + self.materialize()
+
+    def __mul__(self, k):
+        return self.materialize() * k
+
+    __rmul__ = __mul__
+
+    def copy(self):
+        return list(self.materialize())
+
+    def sort(self, **kw):
+        self.materialize().sort(**kw)
 
     def __reduce_ex__(self, protocol):
-        self._ensure()
-        return (list, (list(list.__iter__(self)),))
-
-
-def _lazy_method(name):
-    plain = getattr(list, name)
-
-    def method(self, *args, **kwargs):
-        self._ensure()
-        return plain(self, *args, **kwargs)
-    method.__name__ = name
-    return method
-
-
-for _name in ('__getitem__', '__iter__', '__repr__', '__eq__', '__ne__', '__lt__', '__le__', '__gt__', '__ge__',
-              '__contains__', '__add__', '__mul__', '__rmul__', '__iadd__', '__imul__', '__reversed__', '__setitem__',
-              '__delitem__', 'copy', 'index', 'count', 'append', 'extend', 'insert', 'pop', 'remove', 'reverse', 'sort',
-              'clear'):
-    setattr(_LazyList, _name, _lazy_method(_name))
-_LazyList.__radd__ = lambda self, other: other + list(self)        # list has no __radd__: `[x] + lazy` lands here for non-lists
-_LazyList.__hash__ = None
+        return (list, (list(self.materialize()),))
 
 
 class _Stepper:

@@ -24,3 +24,25 @@ def test_lazy_list_never_shows_a_placeholder():
     one = mk()
     n = len(calls)
     assert one[0] == 5 and one[1] == 6 and list(one) == [5, 6] and len(calls) == n + 1      # filled exactly once
+
+
+def test_lazy_list_has_no_c_level_back_door():
+    """a `list` SUBCLASS is read by C fast paths (json's C encoder, str.join, PySequence_Fast) through its item
+    array, behind every Python-level hook: an unfilled lazy list showed them its placeholders.  The type is a plain
+    MutableSequence now: consumers either go through __iter__ / __getitem__ (and see the filled entries) or refuse it."""
+    import json
+
+    import pytest
+    assert not isinstance(_LazyList(1, lambda: [0]), list)
+    lazy = _LazyList(2, lambda: [0.5, 0.25])
+    with pytest.raises(TypeError):
+        json.dumps(lazy)                                      # loud, never '[null, null]'
+    assert json.dumps(list(_LazyList(2, lambda: [0.5, 0.25]))) == '[0.5, 0.25]'
+    assert json.dumps(_LazyList(2, lambda: [0.5, 0.25]).materialize()) == '[0.5, 0.25]'
+    assert json.dumps(_LazyList(2, lambda: [0.5, 0.25]), default=list) == '[0.5, 0.25]'
+    assert ','.join(_LazyList(2, lambda: ['a', 'b'])) == 'a,b'        # PySequence_Fast on a non-list iterates
+    assert tuple(_LazyList(2, lambda: [1, 2])) == (1, 2) and [*_LazyList(2, lambda: [1, 2])] == [1, 2]
+    import numpy as np
+    assert np.asarray(_LazyList(2, lambda: [1.0, 2.0])).tolist() == [1.0, 2.0]
+    with pytest.raises(Exception):
+        _LazyList(3, lambda: [1]).materialize()               # a producer that breaks its promise is an error, not a short list

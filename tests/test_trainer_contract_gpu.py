@@ -264,3 +264,79 @@ def test_graphed_train_step_is_bit_identical_to_the_eager_step(dev):
     drop = build(cfg, P, dev, train=True)
     with pytest.raises(R._native.RfnError):
         GraphedTrainStep(drop, crit, R.FusedClampAdam(drop, **kw), *batches[0])
+
+
+def test_graphed_train_step_serves_batches_of_any_caption_length_and_refuses_what_it_cannot_replay(dev):
+    """the capture used to freeze the example batch's decoder-step count and replay it on whatever labels were
+    copied in.  Now the step is captured with all seq_length + 1 decoder steps: a batch whose longest caption is shorter
+    replays to the eager result (the masks add exact zeros on the extra steps), a batch whose captions are LONGER than the
+    example's replays correctly too, and shape / hyper-parameter / mode changes are refused instead of silently ignored."""
+    import recurrent_fusion_network_amd as R
+    from recurrent_fusion_network_amd.graphed import GraphedTrainStep
+    cfg, spec, P, batch, gold = load_case('mid')
+    fc, att, labels, masks, top = to_dev(batch, dev)
+    ncol = labels.size(1)
+
+    def cut(keep):      # captions of at most `keep` words: END at column keep + 1, zeros and zero masks behind it
+        lab, msk = labels.clone(), masks.clone()
+        lab[:, keep + 1:] = 0
+        msk[:, keep + 2:] = 0
+        return (fc, att, lab, msk, top)
+
+    short, longer = cut(3), cut(ncol - 3)
+    kw = dict(lr=5e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5, grad_clip=0.01)
+    crit = R.ReviewNetEnsembleCriterion(cfg)
+
+    def eager_steps(bs):
+        m = build(cfg, P, dev, train=True)
+        o = R.FusedClampAdam(m, **kw)
+        losses = []
+        for b in bs:
+            o.zero_grad()
+            lp, reason = m(b[0], b[1], b[2])
+            assert lp.size(1) == m._decoder_steps(b[2])
+            loss = crit(lp, b[2][:, 1:], b[3][:, 1:], reason, b[4], 1.0)
+            loss.backward()
+            o.step()
+            losses.append(float(loss))
+        return m, losses
+
+    eager, want = eager_steps([short, longer, short])
+    assert eager._decoder_steps(short[2]) == 4 and eager._decoder_steps(longer[2]) == ncol - 2
+    model = build(cfg, P, dev, train=True)
+    opt = R.FusedClampAdam(model, **kw)
+    g = GraphedTrainStep(model, crit, opt, *short)          # captured on the SHORT batch
+    assert g.steps == ncol - 1 and model.fixed_decoder_steps is None
+    got = [float(g(*b)) for b in (short, longer, short)]
+    for a, b in zip(got, want):
+        assert abs(a - b) <= 1e-5 * max(1.0, abs(b)), (got, want)
+    for (k, p), (_, q) in zip(model.named_parameters(), eager.named_parameters()):
+        assert float((p - q).abs().max()) <= 1e-6 + 1e-4 * float(q.abs().max()), k
+
+    # a capture at the example's own count refuses a batch that needs another count (it used to drop the extra tokens)
+    m2 = build(cfg, P, dev, train=True)
+    g2 = GraphedTrainStep(m2, crit, R.FusedClampAdam(m2, **kw), *short, full_length=False)
+    assert g2.steps == 4
+    g2(*short)
+    with pytest.raises(R._native.RfnError, match='decoder steps'):
+        g2(*longer)
+    # shapes are checked before the copy into the static buffers (copy_ would broadcast a one-row batch)
+    with pytest.raises(R._native.RfnError, match='captured step holds'):
+        g(fc, att, short[2][:1], short[3], top)
+    with pytest.raises(R._native.RfnError, match='captured step holds'):
+        g([f[:1] for f in fc], att, short[2], short[3], top)
+    # what the captured launches hold as arguments must not change silently
+    opt.param_groups[0]['weight_decay'] = 0.0
+    with pytest.raises(R._native.RfnError, match='weight_decay'):
+        g(*short)
+    opt.param_groups[0]['weight_decay'] = kw['weight_decay']
+    model.ss_prob = 0.25
+    with pytest.raises(R._native.RfnError):
+        g(*short)
+    model.ss_prob = 0.0
+    model.eval()
+    with pytest.raises(R._native.RfnError, match='training'):
+        g(*short)
+    model.train()
+    opt.set_lr(1e-3)            # the one thing a replay re-reads
+    g(*short)
