@@ -1,0 +1,392 @@
+// Device body of the row-panel GEMM of the recurrences (rfn_cellgemm.hip has the story) as a function, so that two kernels
+// can run it: cell_gemm_k (one launch per product, rfn_cellgemm.hip) and the persistent recurrence kernels (rfn_chain.hip),
+// which walk the products of ALL steps of a chain inside one launch with a grid barrier between dependent phases.
+//
+// XB ("cross-block") = the second use.  Inside one launch the caches do not keep blocks coherent: a CU's vector L1 is never
+// refreshed by another CU's stores and the per-XCD L2s are not coherent with each other.  So in XB mode EVERY global access
+// to a buffer that some block of the launch writes takes the sc1 form -- loads bypass L1 and are served coherently
+// (global_load / buffer_load / global_load_lds ... sc1), stores write through (sc1) -- parameters (weights, biases) stay
+// plain; each storing wave drains its stores (s_waitcnt vmcnt(0)) before the block's arrive at the grid barrier
+// (rfn_chain.hip).  The arithmetic is untouched: a product computed in either mode is the same bits.
+// In XB mode the descriptor sits in LDS (built per step by the persistent kernel), so what steers control flow or forms a
+// DMA base is made wave-uniform again with readfirstlane.
+#pragma once
+#include "rfn_common.h"
+#include "rfn_xb.h"
+
+typedef float cg_f32x16 __attribute__((ext_vector_type(16)));
+typedef float cg_f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void cg_lds_void;
+typedef const __attribute__((address_space(1))) void cg_gbl_void;
+
+#define CG_MAXSEG 24
+#define CG_MAX_SLOTS 6            /* ring slots are a launch parameter: as many as LDS allows for the blocks a CU hosts */
+#define CG_BN 32                   /* tile width: 8 units x 4 gates in the gate epilogue */
+enum { CG_EPI_STORE = 0, CG_EPI_LSTM = 1, CG_EPI_LSTM_BWD = 2 };
+
+struct CgSeg {
+    const float* A;
+    const float* B;
+    const float* bias;
+    long lda, ldb;
+    int K, pad;
+};
+struct CgOut {
+    float* C;
+    long ldc;
+    // gate epilogues (forward: c_prev, c_next, h_next; backward: gates, c_prev, c_next, dh_ext, dc_next, dc_prev)
+    const float* c_prev;
+    float* c_next;
+    float* h_next;
+    float* gates;
+    const float* dh_ext;
+    const float* dc_next;
+    float* dc_prev;
+    long ldcp, ldcn, ldh, ldg, lddh, lddcn, lddcp;
+    unsigned long long drop_offset;
+    int N, accumulate, seg0, nseg, tile0, tiles_n;
+};
+struct CgArgs {
+    int M, nout, R, tiles_m;
+    float drop_p;
+    int slots;
+    unsigned long long seed;
+    CgOut out[RFN_CELL_MAXOUT];
+    CgSeg seg[CG_MAXSEG];
+};
+
+
+template <int N>
+__device__ __forceinline__ void cg_wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+
+// BM x 32 output tile, K steps of BK, WK waves per 32x32 sub-tile (each takes every WK-th k-group of 8).
+// BKF: B is an nn.Linear weight [n][k] (forward products); !BKF: B is [k][n] (dX = dY . W: the reduction index is W's row).
+// bid: the tile this call computes (cell_gemm_k: blockIdx.x; the persistent kernels deal tiles to blocks themselves).
+// The caller provides the ring (`smem`, a.slots slots) and, between two calls of one block, a __syncthreads().
+template <int BM, int BK, int WK, bool BKF, int EPI, bool XB>
+__device__ __forceinline__ void cg_tile(const CgArgs& a, const int bid, float* smem) {
+    constexpr int BN = CG_BN;
+    constexpr int WM = BM / 32, W = WM * WK, T = 64 * W;
+    constexpr int A_FL = BM * BK, B_FL = BN * BK, SLOT_FL = A_FL + B_FL;
+    constexpr int PA = A_FL / 256, PB = B_FL / 256, P = PA + PB;   // 1-KiB pieces per K step
+    static_assert(P % W == 0, "pieces must divide evenly over the waves");
+    constexpr int NIW = P / W;
+    constexpr int CPR = BK / 4;      // 16-B chunks per [row][k] row
+    constexpr int RPP = 64 / CPR;    // rows per piece
+    constexpr int KG = BK / 8;       // k-groups per K step
+    static_assert(KG % WK == 0 && (BK == 32 || BK == 64), "unsupported K step");
+    static_assert(WK * BM * BN <= 2 * SLOT_FL, "the partial tiles reuse the ring (at least two slots)");
+    static_assert(NIW * (CG_MAX_SLOTS - 1) <= 63, "vmcnt is a 6-bit counter");
+    static_assert((EPI == CG_EPI_LSTM) ? BKF : true, "the gate epilogue belongs to forward products");
+    static_assert((EPI == CG_EPI_LSTM_BWD) ? !BKF : true, "the gate-gradient epilogue belongs to dX products");
+    constexpr int U = BN / 4;                       // units per tile of the gate epilogue
+    constexpr int NV = BM * BN / 4 / T;             // float4 of the tile per thread       (store epilogue)
+    constexpr int NP = BM * U / T;                  // (row, unit) pairs per thread         (gate epilogue)
+    constexpr int NE = BM * BN / T;                 // (row, unit) elements per thread      (gate-gradient epilogue)
+    static_assert(NV >= 1 && NP >= 1 && BM * BN % (4 * T) == 0 && BM * U % T == 0, "epilogue tiling");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wk = wave / WM, wm = wave - wk * WM;
+    const int l31 = lane & 31, h = lane >> 5;
+
+    int r = 0;
+    const int nout = XB ? xb_uni(a.nout) : a.nout;
+    for (int i = 1; i < nout; ++i)
+        if (bid >= a.out[i].tile0) r = i;
+    if constexpr (XB) r = xb_uni(r);
+    const CgOut& O = a.out[r];
+    const int lt = bid - (XB ? xb_uni(O.tile0) : O.tile0);
+    const int tiles_n = XB ? xb_uni(O.tiles_n) : O.tiles_n;
+    const int tm = lt / tiles_n, tn = lt - tm * tiles_n;
+    const int row0 = tm * BM, col0 = tn * BN;
+    const int M = XB ? xb_uni(a.M) : a.M, R = XB ? xb_uni(a.R) : a.R;
+    const int nseg = XB ? xb_uni(O.nseg) : O.nseg, seg0 = XB ? xb_uni(O.seg0) : O.seg0;
+
+    auto swz = [](int row) -> int { return BK == 32 ? ((row >> 1) & 7) : (row & 15); };
+
+    cg_f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+
+    int total_iters = 0;
+    for (int s = 0; s < nseg; ++s) total_iters += a.seg[seg0 + s].K / BK;
+    if constexpr (XB) total_iters = xb_uni(total_iters);
+
+    // per-lane byte offsets of this wave's pieces inside the current segment's operands; piece p = wave + W * j
+    uint32_t off[NIW];
+    const char* baseA = nullptr;
+    const char* baseB = nullptr;
+    long stepB = 0;
+    int seg = 0, k0 = 0, segK = 0;
+    auto setup = [&]() {
+        if (seg >= nseg) return;
+        const CgSeg& sg = a.seg[seg0 + seg];
+        segK = XB ? xb_uni(sg.K) : sg.K;
+        baseA = (const char*)sg.A;
+        baseB = (const char*)sg.B;
+        stepB = BKF ? (long)BK * 4 : (long)BK * sg.ldb * 4;
+        if constexpr (XB) {
+            baseA = xb_uni_ptr(baseA);
+            baseB = xb_uni_ptr(baseB);
+            stepB = BKF ? (long)BK * 4 : (long)BK * 4 * xb_uni((int)sg.ldb);
+        }
+#pragma unroll
+        for (int j = 0; j < NIW; ++j) {
+            const int p = wave + W * j;
+            if (p < PA) {
+                const int rt = p * RPP + lane / CPR;
+                int gr = row0 + rt;
+                gr = gr < M ? gr : M - 1;     // rows past the batch: a valid row is fetched, its results are dropped
+                off[j] = (uint32_t)(((long)gr * sg.lda + 4 * ((lane % CPR) ^ swz(rt))) * 4);
+            } else {
+                const int pb = p - PA;
+                if constexpr (BKF) {
+                    const int rt = pb * RPP + lane / CPR;   // tile column = row of the [n][k] weight
+                    long n;
+                    if constexpr (EPI == CG_EPI_LSTM) n = (long)(rt / U) * R + tn * U + rt % U;   // gate-major columns
+                    else n = col0 + rt;
+                    off[j] = (uint32_t)((n * sg.ldb + 4 * ((lane % CPR) ^ swz(rt))) * 4);
+                } else {
+                    constexpr int CQ = BN / 4, KPP = 64 / CQ;
+                    const int kr = pb * KPP + lane / CQ;
+                    off[j] = (uint32_t)(((long)kr * sg.ldb + col0 + 4 * (lane % CQ)) * 4);
+                }
+            }
+        }
+    };
+    setup();
+    auto issue = [&](int slot) {
+        float* st = smem + slot * SLOT_FL;
+#pragma unroll
+        for (int j = 0; j < NIW; ++j) {
+            const int p = wave + W * j;
+            // XB: the activations (A) may be another block's output of this very launch: sc1; the weights (B) are parameters
+            if (XB && p < PA)
+                __builtin_amdgcn_global_load_lds((cg_gbl_void*)(baseA + off[j]), (cg_lds_void*)(st + p * 256), 16, 0, 16);
+            else
+                __builtin_amdgcn_global_load_lds((cg_gbl_void*)(((p < PA) ? baseA : baseB) + off[j]), (cg_lds_void*)(st + p * 256), 16, 0, 0);
+        }
+        baseA += BK * 4;
+        baseB += stepB;
+        k0 += BK;
+        if (k0 >= segK) {
+            k0 = 0;
+            ++seg;
+            setup();
+        }
+    };
+
+    // ---- everything the epilogue reads from global memory is requested first (oldest in the vector-memory queue: the
+    // counted waits of the K loop then never wait for more than the K step they need) and lands under the loop -----------
+    cg_f32x4 e_prev[NV], e_bias[NV];                       // store epilogue
+    float g_prev[NP][4], g_bias[NP][4], g_cprev[NP];       // gate epilogue
+    float b_in[(EPI == CG_EPI_LSTM_BWD) ? NE : 1][9];      // gate-gradient epilogue: prev dh, dh_ext, i f o g, c_prev, c_next, dc_next
+    if constexpr (EPI == CG_EPI_STORE) {
+        constexpr int C4 = BN / 4;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int idx = tid + v * T;
+            const int row = idx / C4, c4 = idx - row * C4;
+            int grow = row0 + row;
+            grow = grow < M ? grow : M - 1;
+            const int col = col0 + 4 * c4;
+            cg_f32x4 b = {0.f, 0.f, 0.f, 0.f};
+            for (int s = 0; s < nseg; ++s) {
+                const float* bp = a.seg[seg0 + s].bias;
+                if (bp) b += *reinterpret_cast<const cg_f32x4*>(bp + col);
+            }
+            e_bias[v] = b;
+            e_prev[v] = cg_f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (XB) {
+                if (O.accumulate) e_prev[v] = xb_buf_ld4_sc1(xb_rsrc(xb_uni_ptr(O.C)), (uint32_t)(((long)grow * O.ldc + col) * 4));
+            } else {
+                if (O.accumulate) e_prev[v] = *reinterpret_cast<const cg_f32x4*>(O.C + (long)grow * O.ldc + col);
+            }
+        }
+    } else if constexpr (EPI == CG_EPI_LSTM) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int idx = tid + p * T;
+            const int row = idx / U, u = idx - row * U;
+            int grow = row0 + row;
+            grow = grow < M ? grow : M - 1;
+            const int unit = tn * U + u;
+            const float* G = O.C + (long)grow * O.ldc;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float b = 0.f;
+                for (int s = 0; s < nseg; ++s) {
+                    const float* bp = a.seg[seg0 + s].bias;
+                    if (bp) b += bp[g * R + unit];
+                }
+                g_bias[p][g] = b;
+                g_prev[p][g] = O.accumulate ? xb_ld1<XB>(G + g * R + unit) : 0.f;
+            }
+            g_cprev[p] = xb_ld1<XB>(O.c_prev + (long)grow * O.ldcp + unit);
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const int idx = tid + e * T;
+            const int row = idx / BN, cc = idx - row * BN;
+            int grow = row0 + row;
+            grow = grow < M ? grow : M - 1;
+            const int unit = col0 + cc;
+            const float* G = O.gates + (long)grow * O.ldg;
+            b_in[e][0] = O.accumulate ? xb_ld1<XB>(O.C + (long)grow * O.ldc + unit) : 0.f;
+            b_in[e][1] = O.dh_ext ? xb_ld1<XB>(O.dh_ext + (long)grow * O.lddh + unit) : 0.f;
+            b_in[e][2] = xb_ld1<XB>(G + unit);
+            b_in[e][3] = xb_ld1<XB>(G + R + unit);
+            b_in[e][4] = xb_ld1<XB>(G + 2 * R + unit);
+            b_in[e][5] = xb_ld1<XB>(G + 3 * R + unit);
+            b_in[e][6] = xb_ld1<XB>(O.c_prev + (long)grow * O.ldcp + unit);
+            b_in[e][7] = xb_ld1<XB>(O.c_next + (long)grow * O.ldcn + unit);
+            b_in[e][8] = O.dc_next ? xb_ld1<XB>(O.dc_next + (long)grow * O.lddcn + unit) : 0.f;
+        }
+    }
+
+    // Ring of SL slots, SL - 1 K steps in flight: a step is a few hundred matrix-pipe cycles but a microsecond of L2 / fabric
+    // latency under load, so the ring is as deep as the LDS of the blocks sharing a CU allows (host: cg_dispatch).
+    const int SL = XB ? xb_uni(a.slots) : a.slots;
+    int issued = 0;
+    for (int s = 0; s < SL - 1 && s < total_iters; ++s) {
+        issue(s);
+        ++issued;
+    }
+
+    const int swa = swz(l31), swb = swz(l31);   // tile rows are l31 + multiples of 32
+    int cur = 0, fill = SL - 1;
+    for (int it = 0; it < total_iters; ++it) {
+        // this wave's pieces of step `it` have landed; the `younger` steps issued after it stay in flight
+        switch (issued - it - 1) {
+            case 0: cg_wait_vmcnt<0>(); break;
+            case 1: cg_wait_vmcnt<NIW>(); break;
+            case 2: cg_wait_vmcnt<2 * NIW>(); break;
+            case 3: cg_wait_vmcnt<3 * NIW>(); break;
+            case 4: cg_wait_vmcnt<4 * NIW>(); break;
+            default: cg_wait_vmcnt<5 * NIW>(); break;
+        }
+        __builtin_amdgcn_s_barrier();                     // ... everyone's have, and slot (it - 1) % SL is free
+        if (issued < total_iters) {
+            issue(fill);
+            ++issued;
+        }
+        const float* a_l = smem + cur * SLOT_FL;
+        const float* b_l = a_l + A_FL;
+#pragma unroll
+        for (int t = 0; t < KG / WK; ++t) {
+            const int q = wk + WK * t;
+            const cg_f32x4 af = *reinterpret_cast<const cg_f32x4*>(a_l + (wm * 32 + l31) * BK + 4 * ((2 * q + h) ^ swa));
+            cg_f32x4 bf;
+            if constexpr (BKF) {
+                bf = *reinterpret_cast<const cg_f32x4*>(b_l + l31 * BK + 4 * ((2 * q + h) ^ swb));
+            } else {
+                const float* pb = b_l + (8 * q + 4 * h) * BN + l31;
+                bf[0] = pb[0];
+                bf[1] = pb[BN];
+                bf[2] = pb[2 * BN];
+                bf[3] = pb[3 * BN];
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c], bf[c], acc, 0, 0, 0);
+        }
+        cur = (cur + 1 == SL) ? 0 : cur + 1;
+        fill = (fill + 1 == SL) ? 0 : fill + 1;
+    }
+
+    // ---- the WK partial tiles meet in LDS (the ring is free: every DMA has been waited for) ----------------------------
+    __syncthreads();
+    float* slab = smem;   // [WK][BM][BN]
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int row = wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        slab[(wk * BM + row) * BN + l31] = acc[i];
+    }
+    __syncthreads();
+
+    if constexpr (EPI == CG_EPI_STORE) {
+        constexpr int C4 = BN / 4;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int idx = tid + v * T;
+            const int row = idx / C4, c4 = idx - row * C4, grow = row0 + row;
+            if (grow >= M) continue;
+            cg_f32x4 x = *reinterpret_cast<const cg_f32x4*>(slab + row * BN + 4 * c4);
+#pragma unroll
+            for (int w = 1; w < WK; ++w) x += *reinterpret_cast<const cg_f32x4*>(slab + (w * BM + row) * BN + 4 * c4);
+            x += e_bias[v];
+            if (O.accumulate) x += e_prev[v];
+            if constexpr (XB) xb_buf_st4_sc1(xb_rsrc(xb_uni_ptr(O.C)), (uint32_t)(((long)grow * O.ldc + col0 + 4 * c4) * 4), x);
+            else *reinterpret_cast<cg_f32x4*>(O.C + (long)grow * O.ldc + col0 + 4 * c4) = x;
+        }
+    } else if constexpr (EPI == CG_EPI_LSTM) {
+        // LSTM gate epilogue (rfn_cell.hip lstm_fwd_k, same formulas): tile column g * U + u = gate g of unit tn * U + u
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int idx = tid + p * T;
+            const int row = idx / U, u = idx - row * U, grow = row0 + row;
+            if (grow >= M) continue;
+            const int unit = tn * U + u;
+            float* G = O.C + (long)grow * O.ldc;
+            float pre[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float s = slab[row * BN + g * U + u];
+#pragma unroll
+                for (int w = 1; w < WK; ++w) s += slab[(w * BM + row) * BN + g * U + u];
+                pre[g] = (s + g_bias[p][g]) + g_prev[p][g];
+            }
+            const float ig = rfn_sigmoid(pre[0]), fg = rfn_sigmoid(pre[1]), og = rfn_sigmoid(pre[2]);
+            const float gg = tanhf(pre[3]);
+            xb_st1<XB>(G + unit, ig);
+            xb_st1<XB>(G + R + unit, fg);
+            xb_st1<XB>(G + 2 * R + unit, og);
+            xb_st1<XB>(G + 3 * R + unit, gg);
+            const float c = fg * g_cprev[p] + ig * gg;
+            xb_st1<XB>(O.c_next + (long)grow * O.ldcn + unit, c);
+            float hv = og * tanhf(c);
+            if (a.drop_p > 0.f) {
+                const float uu = rfn_philox_uniform(a.seed, O.drop_offset, (uint64_t)((long)grow * R + unit));
+                hv = (uu >= a.drop_p) ? hv * (1.0f / (1.0f - a.drop_p)) : 0.f;
+            }
+            xb_st1<XB>(O.h_next + (long)grow * O.ldh + unit, hv);
+        }
+    } else {
+        // The product is the recurrent part of d h of the cell call that produced `gates` (the next one the backward
+        // sweep processes): finish that gradient and run its LSTM backward here (rfn_cell.hip lstm_bwd_k, same formulas).
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const int idx = tid + e * T;
+            const int row = idx / BN, cc = idx - row * BN, grow = row0 + row;
+            if (grow >= M) continue;
+            const int unit = col0 + cc;
+            float s = slab[row * BN + cc];
+#pragma unroll
+            for (int w = 1; w < WK; ++w) s += slab[(w * BM + row) * BN + cc];
+            float dhv = (s + b_in[e][0]) + b_in[e][1];
+            if (O.C) xb_st1<XB>(O.C + (long)grow * O.ldc + unit, dhv);   // total d h of that call (kept for the caller's bookkeeping)
+            if (a.drop_p > 0.f) {
+                const float uu = rfn_philox_uniform(a.seed, O.drop_offset, (uint64_t)((long)grow * R + unit));
+                dhv = (uu >= a.drop_p) ? dhv * (1.0f / (1.0f - a.drop_p)) : 0.f;
+            }
+            const float ig = b_in[e][2], fg = b_in[e][3], og = b_in[e][4], gg = b_in[e][5];
+            const float tc = tanhf(b_in[e][7]);
+            float dc = dhv * og * (1.0f - tc * tc);
+            if (O.dc_next) dc += b_in[e][8];
+            const float d_o = dhv * tc;
+            const float d_i = dc * gg;
+            const float d_f = dc * b_in[e][6];
+            const float d_g = dc * ig;
+            float* G = O.gates + (long)grow * O.ldg;
+            xb_st1<XB>(G + unit, d_i * ig * (1.0f - ig));
+            xb_st1<XB>(G + R + unit, d_f * fg * (1.0f - fg));
+            xb_st1<XB>(G + 2 * R + unit, d_o * og * (1.0f - og));
+            xb_st1<XB>(G + 3 * R + unit, d_g * (1.0f - gg * gg));
+            xb_st1<XB>(O.dc_prev + (long)grow * O.lddcp + unit, dc * fg);
+        }
+    }
+}
+

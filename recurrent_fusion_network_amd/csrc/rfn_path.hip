@@ -21,7 +21,9 @@
 #include <string.h>
 #include <initializer_list>
 
-#include "rfn_common.h"
+#include <vector>
+
+#include "rfn_internal.h"
 
 namespace {
 
@@ -252,6 +254,11 @@ bool cell_ok(int B, int n, const rfn_cell_out* outs, int R) {
 int cell_run(int B, int n, const rfn_cell_out* outs, int R, float drop_p, uint64_t seed, void* st) {
     return rfn_cell_gemm(B, n, outs, R, drop_p, seed, 0, st);
 }
+// the same launch prepared instead of launched: one phase of a recurrence-chain step (rfn_chain.hip)
+int cell_prepare(int B, int n, const rfn_cell_out* outs, int R, float drop_p, uint64_t seed, CgPrepared* pz) {
+    return rfn_cg_prepare(B, n, outs, R, drop_p, seed, 0, pz);
+}
+inline bool chain_persist(const rfn_dims* d) { return !(d->path_flags & RFN_PATH_OPT_NO_PERSIST); }
 
 // Up to MEM_BATCH copies / zero fills of f32 buffers in ONE launch (src == NULL: zero).  The path's bookkeeping moves (initial
 // states into the workspace, gradient slabs zeroed before they are accumulated into) come in twos and threes; each was a
@@ -327,6 +334,7 @@ struct PrefixLayout {
     size_t Hs, Cs, hp1, g1, rmat, rarg, h2, c2, hp2, al2, z2, g2;
     size_t dHs, dC, dal, dwp, dhp1, dh2e, dhrec, dc2, dz2, dhp2;
     size_t gws;
+    size_t bar;     // grid-barrier counters of the persistent recurrence kernels (RFN_CHAIN_BAR_WORDS uint32, rfn_chain.hip)
     size_t tk;      // split-K tile counters (GEMM_TICKETS int32), zeroed at the head of every entry point that splits
     size_t x3;      // plane images + split-K partials of the bf16-plane GEMMs (RFN_GEMM_OPT_BF16X3), 0 floats otherwise
     size_t x3p[RFN_MAX_ENC];   // train: encoder i's dP1 as a k-slow plane image (all T1 steps), kept from the backward
@@ -399,6 +407,7 @@ PrefixLayout prefix_layout(const rfn_dims* d, int B, int train) {
     L.g2 = b.take(T2 * Bz * G2);
     L.gws = b.take(GEMM_WS_FLOATS);
     L.tk = b.take(GEMM_TICKETS);
+    L.bar = b.take(RFN_CHAIN_BAR_WORDS);
     L.x3 = b.take(x3_scratch_floats(d, B, train));
     if (train)
         for (int i = 0; i < d->M; ++i)
@@ -423,7 +432,7 @@ PrefixLayout prefix_layout(const rfn_dims* d, int B, int train) {
 struct DecoderLayout {
     size_t Pd, xs, gd, hd, cd, hpd, ald, zd, logits;
     size_t dhe, dhrec, dc, dz, dal, dwp, dhpd, dPd, dxs;
-    size_t gws, tk;
+    size_t gws, tk, bar;
     size_t total;
 };
 DecoderLayout decoder_layout(const rfn_dims* d, int B, int S, int train) {
@@ -443,6 +452,7 @@ DecoderLayout decoder_layout(const rfn_dims* d, int B, int S, int train) {
     L.logits = b.take(Sz * Bz * V1);  // logits in forward, dlogits in backward
     L.gws = b.take(GEMM_WS_FLOATS);
     L.tk = b.take(GEMM_TICKETS);
+    L.bar = b.take(RFN_CHAIN_BAR_WORDS);
     if (train) {
         L.dhe = b.take(Sz * Bz * R);
         L.dhrec = b.take(Bz * R);
@@ -1332,13 +1342,16 @@ extern "C" size_t rfn_decoder_ws_bytes(const rfn_dims* d, int B, int S, int trai
 // the step-wise and the free-running pass, so the three are bit-identical by construction.
 // Fused form (3 launches): K1 = h_2_att_h(h) and g += h2h(h) in one launch (they share h); the attention; K3 =
 // g += z2h(z) with the LSTM update as its epilogue.  h_next / c_next may alias h / c (free-running step).
-static int decoder_cell_core(const rfn_dims* d, int B, const float* const* prm, const float* comb, const float* cproj,
-                             const float* h, const float* c, float* h_next, float* c_next, float* hp, float* al, float* z,
-                             float* g, const GemmCtx& gx, uint64_t seed, int step, void* st) {
+// The fused form of that step (3 launches), prepared: K1 = h_2_att_h(h) and g += h2h(h) in one launch (they share h); the
+// attention; K3 = g += z2h(z) with the LSTM update as its epilogue.  false: the cell GEMM cannot take the step (maxout, widths).
+static bool decoder_cell_prepare(const rfn_dims* d, int B, const float* const* prm, const float* comb, const float* cproj,
+                                 const float* h, const float* c, float* h_next, float* c_next, float* hp, float* al, float* z,
+                                 float* g, uint64_t seed, int step, ChainStep* cs) {
     const PIdx P(d);
     const int R = d->R, A = d->A, T2 = d->T2;
     const int GD = gate_width(d->decoder_maxout, R);
     const long BR = (long)B * R, BA = (long)B * A;
+    if (d->decoder_maxout) return false;
     rfn_cell_out k1[2], k3;
     k1[0] = cell_out(hp, A, A, 0);
     cell_lin(k1[0], h, R, prm[P.dec(8)], R, R, prm[P.dec(9)]);
@@ -1347,10 +1360,24 @@ static int decoder_cell_core(const rfn_dims* d, int B, const float* const* prm, 
     k3 = cell_out(g, GD, GD, 1);
     cell_lin(k3, z, R, prm[P.dec(4)], R, R, prm[P.dec(5)]);
     cell_lstm(k3, c, R, c_next, R, h_next, R, OFF_DECODER + (uint64_t)step);
-    if (!d->decoder_maxout && cell_ok(B, 2, k1, R) && cell_ok(B, 1, &k3, R)) {
-        RFN_TRY(cell_run(B, 2, k1, R, 0.f, 0, st));
-        RFN_TRY(attn1_fwd(cproj, A, BA, hp, prm[P.dec(10)], prm[P.dec(11)], comb, R, BR, B, T2, A, R, al, z, R, st));
-        return cell_run(B, 1, &k3, R, d->drop_lm, seed, st);
+    if (!cell_ok(B, 2, k1, R) || !cell_ok(B, 1, &k3, R)) return false;
+    const float *w = prm[P.dec(10)], *bo = prm[P.dec(11)];
+    return cell_prepare(B, 2, k1, R, 0.f, 0, &cs->g0) == RFN_OK &&
+           rfn_attn_small_prepare_fwd(1, &cproj, A, BA, &hp, &w, &bo, &comb, R, BR, B, T2, A, R, &al, &z, R, &cs->at) == RFN_OK &&
+           cell_prepare(B, 1, &k3, R, d->drop_lm, seed, &cs->g2) == RFN_OK;
+}
+
+static int decoder_cell_core(const rfn_dims* d, int B, const float* const* prm, const float* comb, const float* cproj,
+                             const float* h, const float* c, float* h_next, float* c_next, float* hp, float* al, float* z,
+                             float* g, const GemmCtx& gx, uint64_t seed, int step, void* st) {
+    const PIdx P(d);
+    const int R = d->R, A = d->A, T2 = d->T2;
+    const int GD = gate_width(d->decoder_maxout, R);
+    const long BR = (long)B * R, BA = (long)B * A;
+    {
+        ChainStep cs;
+        if (decoder_cell_prepare(d, B, prm, comb, cproj, h, c, h_next, c_next, hp, al, z, g, seed, step, &cs))
+            return rfn_chain_run(&cs, 1, 0, nullptr, st);   // one step: its three launches
     }
     RFN_TRY(gemm1(B, A, seg_lin(h, R, prm[P.dec(8)], R, R, prm[P.dec(9)]), hp, A, 0, gx));
     RFN_TRY(attn1_fwd(cproj, A, BA, hp, prm[P.dec(10)], prm[P.dec(11)], comb, R, BR, B, T2, A, R, al, z, R, st));
@@ -1379,6 +1406,18 @@ static int decoder_fwd_cell(const rfn_dims* d, int B, int s, const float* const*
     float* g = W + Lo.gd + (long)s * B * GD;
     return decoder_cell_core(d, B, prm, comb, W + Lo.Pd, hc, cd + s * BR, hd + (s + 1) * BR, cd + (s + 1) * BR, hp, al, z, g,
                              gx, seed, s, st);
+}
+
+static bool decoder_fwd_cell_prepare(const rfn_dims* d, int B, int s, const float* const* prm, const float* comb, float* W,
+                                     const DecoderLayout& Lo, uint64_t seed, ChainStep* cs) {
+    const int R = d->R, A = d->A, T2 = d->T2;
+    const int GD = gate_width(d->decoder_maxout, R);
+    const long BR = (long)B * R, BA = (long)B * A;
+    float* hd = W + Lo.hd;
+    float* cd = W + Lo.cd;
+    return decoder_cell_prepare(d, B, prm, comb, W + Lo.Pd, hd + s * BR, cd + s * BR, hd + (s + 1) * BR, cd + (s + 1) * BR,
+                                W + Lo.hpd + s * BA, W + Lo.ald + (long)s * B * T2, W + Lo.zd + s * BR,
+                                W + Lo.gd + (long)s * B * GD, seed, s, cs);
 }
 
 // Loop-invariant part of phase 2: projection of the fused thoughts (applied once instead of every step) and the
@@ -1414,7 +1453,16 @@ extern "C" int rfn_decoder_fwd(const rfn_dims* d, int B, int S, const float* con
     // all token embeddings and their i2h projections in one go (teacher forcing: ids are known)
     RFN_TRY(rfn_embed_fwd(prm[P.embed()], E, V1, ids, B, ld_ids, 1, S * B, W + Lo.xs, E, st));
     RFN_TRY(gemm1(S * B, GD, seg_lin(W + Lo.xs, E, prm[P.dec(0)], E, E, prm[P.dec(1)]), W + Lo.gd, GD, 0, gx_whole));
-    for (int s = 0; s < S; ++s) RFN_TRY(decoder_fwd_cell(d, B, s, prm, comb, W, Lo, gx, seed, st));
+    {   // the S cell steps: one persistent launch (rfn_chain.hip) when every step takes the fused form, else step by step
+        std::vector<ChainStep> steps((size_t)S);
+        bool fused = true;
+        for (int s = 0; s < S && fused; ++s) fused = decoder_fwd_cell_prepare(d, B, s, prm, comb, W, Lo, seed, &steps[s]);
+        if (fused) {
+            RFN_TRY(rfn_chain_run(steps.data(), S, chain_persist(d), (uint32_t*)(W + Lo.bar), st));
+        } else {
+            for (int s = 0; s < S; ++s) RFN_TRY(decoder_fwd_cell(d, B, s, prm, comb, W, Lo, gx, seed, st));
+        }
+    }
     // logits of all steps, then log-softmax written in the reference's (B, S, V+1) layout
     RFN_TRY(gemm_logits(S * B, V1, W + Lo.hd + (long)B * R, R, prm[P.logit_w()], prm[P.logit_b()], W + Lo.logits, gx_whole));
     RFN_TRY(rfn_log_softmax_fwd(W + Lo.logits, V1, S * B, V1, B, (long)S * V1, V1, log_prob, st));

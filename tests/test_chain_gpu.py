@@ -1,0 +1,87 @@
+"""The persistent recurrence kernels (csrc/rfn_chain.hip: all steps of a stage-II / decoder recurrence in ONE launch, grid
+barrier between dependent phases) against the three-launches-per-step chain they replace (RFN_PATH_OPT_NO_PERSIST): the same
+device bodies on the same tiles in the same k order, so everything must agree BIT FOR BIT -- log-probs, reason heads, loss,
+every gradient, greedy ids -- on the reference-pinned golden tiers and at the benchmark shapes, run after run (a stale
+cache line in a hand-off between blocks would show up as a sporadic difference)."""
+import pytest
+import torch
+
+from conftest import load_case
+from test_model_gpu import build, to_dev
+
+pytestmark = pytest.mark.gpu
+
+
+def _step(model, crit, batch):
+    fc, att, labels, masks, top = batch
+    model.zero_grad()
+    log_prob, reason = model(fc, att, labels)
+    loss = crit(log_prob, labels[:, 1:], masks[:, 1:], reason, top, 1.0)
+    loss.backward()
+    out = {'log_prob': log_prob.detach().clone(), 'loss': loss.detach().clone()}
+    for j, r in enumerate(reason):
+        out['reason%d' % j] = r.detach().clone()
+    for k, p in model.named_parameters():
+        out['grad:' + k] = p.grad.detach().clone()
+    return out
+
+
+def _assert_same(a, b, what):
+    assert a.keys() == b.keys()
+    for k in a:
+        assert torch.equal(a[k], b[k]), '%s: %s differs (max abs %g)' % (what, k, float((a[k] - b[k]).abs().max()))
+
+
+@pytest.mark.parametrize('name', ['mid', 'c2', 'c3', 'tiny0', 'odd'])
+@pytest.mark.parametrize('train', [False, True])
+def test_persistent_chains_match_the_per_step_launches_bit_for_bit(dev, name, train):
+    """Golden tiers: `mid` / `c2` / `c3` take the persistent kernels (hidden sizes are whole K steps of 64), `tiny0` / `odd`
+    do not qualify and must quietly run the per-step launches under both settings."""
+    import recurrent_fusion_network_amd as R
+    N = R._native
+    cfg, spec, P, batch, gold = load_case(name)
+    if train:
+        cfg.drop_prob_lm, cfg.drop_prob_reason = 0.3, 0.2       # the Philox masks ride in the chain's epilogues too
+    batch = to_dev(batch, dev)
+    crit = R.ReviewNetEnsembleCriterion(cfg)
+    ref = build(cfg, P, dev, train=train)
+    ref.path_flags = N.PATH_OPT_NO_PERSIST
+    new = build(cfg, P, dev, train=train)
+    assert new.path_flags == 0
+    for rnd in range(2):
+        torch.manual_seed(5 + rnd)
+        want = _step(ref, crit, batch)
+        torch.manual_seed(5 + rnd)
+        got = _step(new, crit, batch)
+        _assert_same(got, want, '%s round %d' % (name, rnd))
+    if not train:
+        with torch.no_grad():
+            a = ref.sample(batch[0], batch[1], {'sample_max': 1})
+            b = new.sample(batch[0], batch[1], {'sample_max': 1})
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+
+
+@pytest.mark.parametrize('B', [5, 32, 64, 200])
+def test_persistent_chains_at_the_c2_shape_run_after_run(dev, B):
+    """BASELINE config 2's shape (M = 2, L = 49, D = 512, R = A = E = 512, T1 = T2 = 8, 17 decoder steps) at several batch
+    sizes -- ragged 32-row tiles, fewer tiles than blocks, more tiles than blocks, one- and multi-XCD barriers -- 12 runs
+    each against ONE run of the per-step launches: every run must reproduce it exactly."""
+    import recurrent_fusion_network_amd as R
+    from oracle import rfn_oracle as O
+    N = R._native
+    info = [dict(att_num=49, att_feat_size=512, fc_feat_size=512)] * 2
+    cfg = O.make_cfg(info, vocab_size=9487)
+    g = torch.Generator(device='cpu').manual_seed(77)
+    model = R.RecurrentFusionModel(cfg).to(dev)
+    with torch.no_grad():
+        for _, p in sorted(model.named_parameters()):
+            p.copy_((torch.rand(p.shape, generator=g) * 0.2 - 0.1).to(dev))
+    fc, att, labels, masks, top = O.synthetic_batch(cfg, B, seed=3)
+    batch = to_dev((fc, att, labels, masks, top), dev)
+    crit = R.ReviewNetEnsembleCriterion(cfg)
+    model.train()
+    model.path_flags = N.PATH_OPT_NO_PERSIST
+    want = _step(model, crit, batch)
+    model.path_flags = 0
+    for rnd in range(12):
+        _assert_same(_step(model, crit, batch), want, 'B=%d run %d' % (B, rnd))
