@@ -241,9 +241,14 @@ def parse_args(argv=None):
     ap.add_argument('--graph', action='store_true',
                     help='replay the train step from a captured HIP graph (graphed.GraphedTrainStep; single GPU, dropout 0): for '
                          'configurations whose 350 launches a slow host cannot issue as fast as the device retires them')
-    ap.add_argument('--no-persist', action='store_true',
-                    help='A/B: RFN_PATH_OPT_NO_PERSIST -- the stage-II / decoder recurrences as three launches per step and '
-                         'direction (rounds 3-4) instead of one persistent launch per chain')
+    ap.add_argument('--persist', type=int, default=0,
+                    help='A/B: RFN_PATH_OPT_PERSIST_* bits (1 decoder fwd, 2 stage II fwd, 4 decoder bwd, 8 stage II bwd; 15 = all): '
+                         'those recurrences inside ONE persistent launch each (csrc/rfn_chain.hip) instead of three launches per '
+                         'step; bit-identical, not faster on MI355X (profiles/r05_chain.md)')
+    ap.add_argument('--shard-optimizer', action='store_true',
+                    help='data parallel only: every rank updates 1/N of each flat bucket (FusedClampAdam(shard=...): '
+                         'reduce-scatter of the gradients, Adam on the shard, all-gather of the parameters under the next '
+                         'forward) instead of all-reduce + the full update on every rank; bit-identical parameters')
     ap.add_argument('--selftest-launch', action='store_true',
                     help='launcher / rendezvous check without a GPU: ranks meet, reduce a timing, rank 0 prints the line')
     args = ap.parse_args(argv)
@@ -658,19 +663,19 @@ def run_train(args, rank, world, dev, R, DP, guard):
         model.gemm_flags |= N.GEMM_OPT_BF16X3
     if args.lds_lean:
         model.gemm_flags |= N.GEMM_OPT_LDS_LEAN
-    if args.no_persist:
-        model.path_flags |= N.PATH_OPT_NO_PERSIST
+    model.path_flags |= int(args.persist) & N.PATH_OPT_PERSIST_ALL
     if args.micro_batches >= 0 and hasattr(model, 'micro_batches'):
         model.micro_batches = args.micro_batches
     crit = R.ReviewNetEnsembleCriterion(cfg)
-    opt = R.FusedClampAdam(model, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5, grad_clip=1.0)
+    shard = (rank, world) if (args.shard_optimizer and world > 1) else None
+    opt = R.FusedClampAdam(model, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5, grad_clip=1.0, shard=shard)
     inputs = synthetic_inputs(cfg, B, 100 + rank, dev)
     if args.strong:
         inputs = tuple(inputs) + (DP.shard_loss_scale(B, global_B, world),)
 
     if args.graph and (in_group or (not x3 and not args.no_alt_line)):
         raise SystemExit('--graph: single GPU, one GEMM mode per run (add --no-alt-line)')
-    sync = DP.GradSync(model, world)     # per-bucket async all-reduce, overlapped with the rest of backward
+    sync = DP.GradSync(model, world, shard_optimizer=opt if shard else None)     # per-bucket async exchange, overlapped with the rest of backward
     if args.graph:
         model.grad_ready_hook = None     # no exchange to overlap on one GPU
     start = opt.snapshot() if (not x3 and not args.no_alt_line) else None     # the bf16x3 leg restarts from here
@@ -849,7 +854,7 @@ def run_train(args, rank, world, dev, R, DP, guard):
                        'parallelism': 'dp%d (batch sharded, RCCL all-reduce of grads)' % world if world > 1 else 'single GPU',
                        'micro_batches': int(getattr(model, 'micro_batches', 1) or 1),
                        'final_loss': round(final_loss, 4), 'updates': head['settle_n'] + args.warmup + args.steps,
-                       'hip_graph': bool(args.graph),
+                       'hip_graph': bool(args.graph), 'shard_optimizer': bool(shard),
                        'gemm_flags': int(model.gemm_flags), 'digest': digest},
         }
         if in_group:

@@ -67,9 +67,14 @@ typedef struct rfn_dims {
      * caller reads the pairs after its own synchronisation.  Nothing else in the library looks at it. */
     void* const* probe_events;
 } rfn_dims;
-/* rfn_dims.path_flags */
-#define RFN_PATH_OPT_NO_PERSIST 1u   /* A/B hook: run the stage-II / decoder recurrences as three launches per step and
-                                      * direction (rounds 3-4) instead of one persistent launch per chain             */
+/* rfn_dims.path_flags: run the named recurrence -- all of its steps -- inside ONE persistent launch (csrc/rfn_chain.hip: the
+ * per-step launches' device bodies, a grid barrier between dependent phases; bit-identical results) instead of three launches
+ * per step.  Opt-in: measured on MI355X the in-launch hand-off costs what the launch boundary costs (profiles/r05_chain.md). */
+#define RFN_PATH_OPT_PERSIST_DEC_FWD 1u   /* teacher-forced decoder steps (rfn_decoder_fwd)                   */
+#define RFN_PATH_OPT_PERSIST_S2_FWD 2u    /* stage-II steps (rfn_prefix_fwd)                                  */
+#define RFN_PATH_OPT_PERSIST_DEC_BWD 4u   /* decoder backward sweep, steps S-1 ... 1 (rfn_decoder_bwd)        */
+#define RFN_PATH_OPT_PERSIST_S2_BWD 8u    /* stage-II backward sweep, steps T2-1 ... 1 (rfn_prefix_bwd)       */
+#define RFN_PATH_OPT_PERSIST_ALL 15u
 
 int rfn_abi_version(void);
 const char* rfn_error_string(int code);

@@ -17,7 +17,8 @@ RFN_MAX_ENC = 8
 RFN_GEMM_MAXSEG = 8
 RFN_GEMM_MAXGROUP = 8
 ABI_VERSION = 6
-PATH_OPT_NO_PERSIST = 1       # rfn.h RFN_PATH_OPT_NO_PERSIST
+PATH_OPT_PERSIST_DEC_FWD, PATH_OPT_PERSIST_S2_FWD, PATH_OPT_PERSIST_DEC_BWD, PATH_OPT_PERSIST_S2_BWD = 1, 2, 4, 8   # rfn.h
+PATH_OPT_PERSIST_ALL = 15
 GEMM_OPT_LDS_LEAN = 1
 GEMM_OPT_NO_DMA = 2
 GEMM_OPT_BF16X3 = 4

@@ -111,11 +111,107 @@ __device__ __forceinline__ void attn_small_fwd_body(const AttnSmallArgs& a, cons
     }
 }
 
+// The same row for the persistent recurrence kernels, software-pipelined across the grid barrier in front of it (rfn_chain.hip):
+// everything that is older than the launch -- the projection rows, the attended vectors, w_out -- is loaded into registers
+// BEFORE `hook()` (the wait half of the barrier); behind it only hproj, the one operand the previous phase produced, is
+// fetched.  Same arithmetic in the same order as attn_small_fwd_body (row_tanh_dot<true>, the softmax, the l-ordered context
+// sums), so the results are the same bits.  Shapes it is written for: A <= 512, L <= 8, D <= 512, 16-B aligned rows (the
+// caller checks with attn_small_fwd_xp_ok and uses the plain body otherwise).
+__device__ __forceinline__ bool attn_small_fwd_xp_ok(const AttnSmallArgs& a, int g) {
+    return a.A % 4 == 0 && a.A <= 512 && a.L <= 8 && a.D <= 2 * ATT_THREADS && ((a.psb | a.psl) % 4 == 0) &&
+           ((((uintptr_t)a.proj[g]) & 15) == 0);
+}
+template <typename Hook>
+__device__ __forceinline__ void attn_small_fwd_body_xp(const AttnSmallArgs& a, const int b, const int g, float* sm, Hook hook) {
+    const int A = xb_uni(a.A), L = xb_uni(a.L), D = xb_uni(a.D), Ap = (A + 3) & ~3;
+    float* hp_s = sm;
+    float* w_s = sm + Ap;
+    float* s_s = sm + 2 * Ap;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float* proj = a.proj[g] + b * a.psb;
+    const float* x = a.x[g] + b * a.xsb;
+    // ---- ahead of the barrier ----------------------------------------------------------------------------------------
+    float wv[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) wv[q] = (tid + q * ATT_THREADS < A) ? a.w_out[g][tid + q * ATT_THREADS] : 0.f;
+    f32x4 pv[2][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int l = wave + ATT_WAVES * j, c = lane * 4 + 256 * q;
+            pv[j][q] = (l < L && c < A) ? *reinterpret_cast<const f32x4*>(proj + l * a.psl + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    float xv[8][2];
+#pragma unroll
+    for (int l = 0; l < 8; ++l)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) xv[l][q] = (l < L && tid + q * ATT_THREADS < D) ? x[l * a.xsl + tid + q * ATT_THREADS] : 0.f;
+    const float bo = a.b_out[g] ? a.b_out[g][0] : 0.f;
+    hook();
+    // ---- behind it: hproj is the previous phase's output -----------------------------------------------------------------
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int i = tid + q * ATT_THREADS;
+        if (i < A) {
+            hp_s[i] = xb_ld1<true>(a.hproj[g] + (long)b * A + i);
+            w_s[i] = wv[q];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int l = wave + ATT_WAVES * j;
+        if (l < L) {
+            float part = 0.f;   // row_tanh_dot<true>: the same elements in the same order
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int c = lane * 4 + 256 * q;
+                if (c < A) {
+                    const f32x4 hh = *reinterpret_cast<const f32x4*>(hp_s + c);
+                    const f32x4 ww = *reinterpret_cast<const f32x4*>(w_s + c);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) part += rfn_tanh_fast(pv[j][q][e] + hh[e]) * ww[e];
+                }
+            }
+            const float sc = rfn_wave_sum(part) + bo;
+            if (lane == 0) s_s[l] = sc;
+        }
+    }
+    __syncthreads();
+    float m = -INFINITY, sum = 0.f;
+    for (int l = 0; l < L; ++l) m = fmaxf(m, s_s[l]);
+    for (int l = 0; l < L; ++l) sum += expf(s_s[l] - m);
+    const float inv = 1.0f / sum;
+    __syncthreads();
+    for (int l = tid; l < L; l += ATT_THREADS) {
+        const float al = expf(s_s[l] - m) * inv;
+        s_s[l] = al;
+        a.alpha[g][(long)b * L + l] = al;
+    }
+    __syncthreads();
+    float* z = a.z[g] + b * a.ldz;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int d = tid + q * ATT_THREADS;
+        if (d < D) {
+            float acc = 0.f;
+#pragma unroll
+            for (int l = 0; l < 8; ++l)
+                if (l < L) acc += s_s[l] * xv[l][q];
+            xb_st1<true>(z + d, acc);
+        }
+    }
+}
+
 // One (batch row b, encoder g) of the fused small-L attention backward.  XB: dz comes from the product before it in the
 // launch, dhproj feeds the product after it, dproj / dx are accumulated across the steps of the launch (by whichever block
 // gets the row): all sc1; alpha, hproj, proj, x are the forward pass's (an earlier launch), dw_part is read by a later one.
 template <bool VEC, bool XB>
 __device__ __forceinline__ void attn_small_bwd_body(const AttnSmallArgs& a, const int b, const int g, float* sm) {
+    // Contraction is off here: `acc ? old + dpre : dpre` and its neighbours fused into fmas or not depending on how the compiler
+    // shaped the code around them, which differs between the launch form and the persistent form; the forms must agree bit for bit.
+#pragma clang fp contract(off)
     const int A = XB ? xb_uni(a.A) : a.A, L = XB ? xb_uni(a.L) : a.L, D = XB ? xb_uni(a.D) : a.D, Ap = (A + 3) & ~3, Dp = (D + 3) & ~3;
     float* hp_s = sm;                 // [Ap]
     float* w_s = sm + Ap;             // [Ap]

@@ -34,7 +34,7 @@
 template <int BM, int BK, int WK, bool BKF, int EPI>
 __global__ __launch_bounds__(64 * (BM / 32) * WK) void cell_gemm_k(const CgArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    cg_tile<BM, BK, WK, BKF, EPI, false>(a, blockIdx.x, smem);
+    cg_tile<BM, BK, WK, BKF, EPI, false>(a, blockIdx.x, smem, [] {});
 }
 
 // ---- host side -----------------------------------------------------------------------------------------------------------

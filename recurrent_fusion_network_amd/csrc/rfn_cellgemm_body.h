@@ -56,9 +56,37 @@ struct CgArgs {
 };
 
 
+// RFN_CHAIN_TIMING builds (tools/chain_timing.py): lane 0 of a block stamps the 100 MHz clock inside the XB tile
+#ifdef RFN_CHAIN_TIMING
+#define CG_STAMP(i) do { if (XB && g_cg_stamp_local && threadIdx.x == 0) g_cg_stamp_local[i] = wall_clock64(); } while (0)
+#else
+#define CG_STAMP(i)
+#endif
+
 template <int N>
 __device__ __forceinline__ void cg_wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// at most `n` (wave-uniform, run-time) vector-memory operations of this wave still in flight; stricter when n > 30
+__device__ __forceinline__ void cg_wait_vmcnt_dyn(int n) {
+    switch (n >> 1) {   // counts are even here: two pieces per wave, operand and K step
+        case 0: cg_wait_vmcnt<0>(); break;
+        case 1: cg_wait_vmcnt<2>(); break;
+        case 2: cg_wait_vmcnt<4>(); break;
+        case 3: cg_wait_vmcnt<6>(); break;
+        case 4: cg_wait_vmcnt<8>(); break;
+        case 5: cg_wait_vmcnt<10>(); break;
+        case 6: cg_wait_vmcnt<12>(); break;
+        case 7: cg_wait_vmcnt<14>(); break;
+        case 8: cg_wait_vmcnt<16>(); break;
+        case 9: cg_wait_vmcnt<18>(); break;
+        case 10: cg_wait_vmcnt<20>(); break;
+        case 11: cg_wait_vmcnt<22>(); break;
+        case 12: cg_wait_vmcnt<24>(); break;
+        case 13: cg_wait_vmcnt<26>(); break;
+        case 14: cg_wait_vmcnt<28>(); break;
+        default: cg_wait_vmcnt<30>(); break;
+    }
 }
 
 
@@ -66,8 +94,14 @@ __device__ __forceinline__ void cg_wait_vmcnt() {
 // BKF: B is an nn.Linear weight [n][k] (forward products); !BKF: B is [k][n] (dX = dY . W: the reduction index is W's row).
 // bid: the tile this call computes (cell_gemm_k: blockIdx.x; the persistent kernels deal tiles to blocks themselves).
 // The caller provides the ring (`smem`, a.slots slots) and, between two calls of one block, a __syncthreads().
-template <int BM, int BK, int WK, bool BKF, int EPI, bool XB>
-__device__ __forceinline__ void cg_tile(const CgArgs& a, const int bid, float* smem) {
+//
+// XB adds a software pipeline across the grid barrier that precedes the tile (rfn_chain.hip): the weights (B) of the first ring
+// slots do not depend on any other block, so their DMAs are issued BEFORE `hook()` -- the wait half of the barrier -- and
+// everything another block produced (the A operand, the epilogue's previous values) is requested right after it, all K steps
+// the ring holds at once: after the barrier a tile costs one round trip for its activations instead of one for the weights
+// plus one per pair of K steps.  Piece-to-slot layout, k order and epilogue are those of the launch form.
+template <int BM, int BK, int WK, bool BKF, int EPI, bool XB, typename Hook>
+__device__ __forceinline__ void cg_tile(const CgArgs& a, const int bid, float* smem, Hook hook) {
     constexpr int BN = CG_BN;
     constexpr int WM = BM / 32, W = WM * WK, T = 64 * W;
     constexpr int A_FL = BM * BK, B_FL = BN * BK, SLOT_FL = A_FL + B_FL;
@@ -157,7 +191,7 @@ __device__ __forceinline__ void cg_tile(const CgArgs& a, const int bid, float* s
             }
         }
     };
-    setup();
+    if constexpr (!XB) setup();
     auto issue = [&](int slot) {
         float* st = smem + slot * SLOT_FL;
 #pragma unroll
@@ -178,6 +212,93 @@ __device__ __forceinline__ void cg_tile(const CgArgs& a, const int bid, float* s
             setup();
         }
     };
+
+    // ---- XB: separate cursors for the two operands (the weights run ahead of the barrier) ------------------------------------
+    constexpr int NA = PA / W, NB = PB / W;
+    static_assert(!XB || (PA % W == 0 && PB % W == 0), "XB: whole pieces per wave and operand");
+    uint32_t offA[XB ? NA : 1], offB[XB ? NB : 1];
+    const char* curA = nullptr;
+    const char* curB = nullptr;
+    long curStepB = 0;
+    int segA = 0, segB = 0, kA = 0, kB = 0, segKA = 0, segKB = 0;
+    auto setupA = [&]() {
+        if (segA >= nseg) return;
+        const CgSeg& sg = a.seg[seg0 + segA];
+        segKA = xb_uni(sg.K);
+        curA = xb_uni_ptr((const char*)sg.A);
+        const long lda = sg.lda;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const int rt = (wave + W * j) * RPP + lane / CPR;
+            int gr = row0 + rt;
+            gr = gr < M ? gr : M - 1;
+            offA[j] = (uint32_t)(((long)gr * lda + 4 * ((lane % CPR) ^ swz(rt))) * 4);
+        }
+    };
+    auto setupB = [&]() {
+        if (segB >= nseg) return;
+        const CgSeg& sg = a.seg[seg0 + segB];
+        segKB = xb_uni(sg.K);
+        curB = xb_uni_ptr((const char*)sg.B);
+        const long ldb = sg.ldb;
+        curStepB = BKF ? (long)BK * 4 : (long)BK * 4 * xb_uni((int)ldb);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int pb = wave + W * j;
+            if constexpr (BKF) {
+                const int rt = pb * RPP + lane / CPR;
+                long n;
+                if constexpr (EPI == CG_EPI_LSTM) n = (long)(rt / U) * R + tn * U + rt % U;
+                else n = col0 + rt;
+                offB[j] = (uint32_t)((n * ldb + 4 * ((lane % CPR) ^ swz(rt))) * 4);
+            } else {
+                constexpr int CQ = BN / 4, KPP = 64 / CQ;
+                const int kr = pb * KPP + lane / CQ;
+                offB[j] = (uint32_t)(((long)kr * ldb + col0 + 4 * (lane % CQ)) * 4);
+            }
+        }
+    };
+    auto issueA = [&](int slot) {   // the activations may be another block's output of this very launch: sc1
+        float* st = smem + slot * SLOT_FL;
+#pragma unroll
+        for (int j = 0; j < NA; ++j)
+            __builtin_amdgcn_global_load_lds((cg_gbl_void*)(curA + offA[j]), (cg_lds_void*)(st + (wave + W * j) * 256), 16, 0, 16);
+        curA += BK * 4;
+        kA += BK;
+        if (kA >= segKA) {
+            kA = 0;
+            ++segA;
+            setupA();
+        }
+    };
+    auto issueB = [&](int slot) {   // the weights are parameters: default policy
+        float* st = smem + slot * SLOT_FL;
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+            __builtin_amdgcn_global_load_lds((cg_gbl_void*)(curB + offB[j]), (cg_lds_void*)(st + (PA + wave + W * j) * 256), 16, 0, 0);
+        curB += curStepB;
+        kB += BK;
+        if (kB >= segKB) {
+            kB = 0;
+            ++segB;
+            setupB();
+        }
+    };
+    const int SLx = XB ? xb_uni(a.slots) : 0;
+    // K steps whose operands are requested up front: all of them when the ring holds the whole K range (every slot is then
+    // used once and the K loop needs neither counted waits nor barriers), else what the ring has in flight
+    const bool ALLIN = XB && total_iters <= SLx;
+    const int PRE = XB ? (ALLIN ? total_iters : SLx - 1) : 0;
+    if constexpr (XB) {
+        setupA();
+        setupB();
+        for (int s = 0; s < PRE; ++s) issueB(s);
+        hook();   // the grid barrier's wait: from here on the other blocks' stores of the previous phase are visible
+    }
+#ifdef RFN_CHAIN_TIMING
+    uint64_t* g_cg_stamp_local = XB ? reinterpret_cast<uint64_t*>(smem + CG_MAX_SLOTS * 0 + 8 * SLOT_FL) : nullptr;   // behind the 8-slot ring
+#endif
+    CG_STAMP(0);
 
     // ---- everything the epilogue reads from global memory is requested first (oldest in the vector-memory queue: the
     // counted waits of the K loop then never wait for more than the K step they need) and lands under the loop -----------
@@ -250,31 +371,21 @@ __device__ __forceinline__ void cg_tile(const CgArgs& a, const int bid, float* s
 
     // Ring of SL slots, SL - 1 K steps in flight: a step is a few hundred matrix-pipe cycles but a microsecond of L2 / fabric
     // latency under load, so the ring is as deep as the LDS of the blocks sharing a CU allows (host: cg_dispatch).
-    const int SL = XB ? xb_uni(a.slots) : a.slots;
+    const int SL = XB ? SLx : a.slots;
     int issued = 0;
-    for (int s = 0; s < SL - 1 && s < total_iters; ++s) {
-        issue(s);
-        ++issued;
-    }
-
-    const int swa = swz(l31), swb = swz(l31);   // tile rows are l31 + multiples of 32
-    int cur = 0, fill = SL - 1;
-    for (int it = 0; it < total_iters; ++it) {
-        // this wave's pieces of step `it` have landed; the `younger` steps issued after it stay in flight
-        switch (issued - it - 1) {
-            case 0: cg_wait_vmcnt<0>(); break;
-            case 1: cg_wait_vmcnt<NIW>(); break;
-            case 2: cg_wait_vmcnt<2 * NIW>(); break;
-            case 3: cg_wait_vmcnt<3 * NIW>(); break;
-            case 4: cg_wait_vmcnt<4 * NIW>(); break;
-            default: cg_wait_vmcnt<5 * NIW>(); break;
-        }
-        __builtin_amdgcn_s_barrier();                     // ... everyone's have, and slot (it - 1) % SL is free
-        if (issued < total_iters) {
-            issue(fill);
+    if constexpr (XB) {
+        for (int s = 0; s < PRE; ++s) issueA(s);
+        issued = PRE;
+    } else {
+        for (int s = 0; s < SL - 1 && s < total_iters; ++s) {
+            issue(s);
             ++issued;
         }
-        const float* a_l = smem + cur * SLOT_FL;
+    }
+
+    CG_STAMP(1);
+    const int swa = swz(l31), swb = swz(l31);   // tile rows are l31 + multiples of 32
+    auto k_step = [&](const float* a_l) {   // the MFMAs of one K step on the slot at a_l
         const float* b_l = a_l + A_FL;
 #pragma unroll
         for (int t = 0; t < KG / WK; ++t) {
@@ -293,11 +404,47 @@ __device__ __forceinline__ void cg_tile(const CgArgs& a, const int bid, float* s
 #pragma unroll
             for (int c = 0; c < 4; ++c) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c], bf[c], acc, 0, 0, 0);
         }
+    };
+    int cur = 0, fill = SL - 1;
+    if (ALLIN) {   // XB, whole K range resident: one wait, one barrier, then a loop the compiler can pipeline (same k order)
+        cg_wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        for (int it = 0; it < total_iters; ++it) k_step(smem + it * SLOT_FL);
+    } else
+    for (int it = 0; it < total_iters; ++it) {
+        // this wave's pieces of step `it` have landed; the `younger` steps issued after it stay in flight
+        if constexpr (XB) {
+            // issue order: B of the PRE up-front steps | A of those steps | then whole steps (A, B) from inside the loop
+            const int inloop = issued - PRE;                                   // whole steps issued from inside the loop
+            const int younger = it < PRE ? (PRE - 1 - it) * NA + inloop * (NA + NB) : (issued - 1 - it) * (NA + NB);
+            cg_wait_vmcnt_dyn(younger);
+        } else {
+            switch (issued - it - 1) {
+                case 0: cg_wait_vmcnt<0>(); break;
+                case 1: cg_wait_vmcnt<NIW>(); break;
+                case 2: cg_wait_vmcnt<2 * NIW>(); break;
+                case 3: cg_wait_vmcnt<3 * NIW>(); break;
+                case 4: cg_wait_vmcnt<4 * NIW>(); break;
+                default: cg_wait_vmcnt<5 * NIW>(); break;
+            }
+        }
+        __builtin_amdgcn_s_barrier();                     // ... everyone's have, and slot (it - 1) % SL is free
+        if (issued < total_iters) {
+            if constexpr (XB) {
+                issueA(fill);
+                issueB(fill);
+            } else {
+                issue(fill);
+            }
+            ++issued;
+        }
+        k_step(smem + cur * SLOT_FL);
         cur = (cur + 1 == SL) ? 0 : cur + 1;
         fill = (fill + 1 == SL) ? 0 : fill + 1;
     }
 
     // ---- the WK partial tiles meet in LDS (the ring is free: every DMA has been waited for) ----------------------------
+    CG_STAMP(2);
     __syncthreads();
     float* slab = smem;   // [WK][BM][BN]
 #pragma unroll
@@ -357,6 +504,10 @@ __device__ __forceinline__ void cg_tile(const CgArgs& a, const int bid, float* s
     } else {
         // The product is the recurrent part of d h of the cell call that produced `gates` (the next one the backward
         // sweep processes): finish that gradient and run its LSTM backward here (rfn_cell.hip lstm_bwd_k, same formulas).
+        // Contraction is off in this block: whether `dc = dhv * og * (1 - tc^2)` and the conditional `dc += dc_next` fuse into
+        // an fma depended on how the compiler shaped the branch around them, which differs between the launch form (uniform
+        // kernel arguments) and the persistent form (descriptor in LDS) -- one rounding, but the two forms must agree bit for bit.
+#pragma clang fp contract(off)
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
             const int idx = tid + e * T;
@@ -388,5 +539,6 @@ __device__ __forceinline__ void cg_tile(const CgArgs& a, const int bid, float* s
             xb_st1<XB>(O.dc_prev + (long)grow * O.lddcp + unit, dc * fg);
         }
     }
+    CG_STAMP(3);
 }
 

@@ -36,7 +36,12 @@
 #define CH_NOV 40                  /* words of a step's descriptors that may carry per-step overrides */
 #define CH_MAXSTEPS_OV 12          /* ... for chains of at most this many steps */
 #define CH_FLAT_MAX_BLOCKS 96      /* one counter up to here, per-XCD counters above (profiles/r05_grid_barrier.md) */
-#define CH_LDS_BYTES (96 * 1024)   /* > half of a CU's 160 KB: one block per CU */
+#define CH_SLOTS 8                  /* ring slots of a tile: with K = 512 every K step of a tile is in flight at once */
+#ifdef RFN_CHAIN_TIMING
+#define CH_LDS_BYTES (CH_SLOTS * (32 + CG_BN) * 64 * 4 + 64)   /* + the in-tile stamps */
+#else
+#define CH_LDS_BYTES (CH_SLOTS * (32 + CG_BN) * 64 * 4)   /* 128 KB, > half of a CU's 160 KB: one block per CU */
+#endif
 
 struct ChainDesc {                 // the launch arguments of one step's three phases
     CgArgs g0;
@@ -47,9 +52,37 @@ struct ChainDesc {                 // the launch arguments of one step's three p
 static_assert(sizeof(ChainDesc) % 8 == 0, "descriptors are rebuilt 8 bytes at a time");
 #define CH_NW (sizeof(ChainDesc) / 8)
 
+// Diagnostic build only (make EXTRA=-DRFN_CHAIN_TIMING; tools/chain_timing.py): every block stamps the 100 MHz clock at the
+// phase boundaries of every step into a buffer the tool registers through rfn_debug_chain_timing().  The product build has
+// neither the stamps nor the symbol.
+#ifdef RFN_CHAIN_TIMING
+#define CH_STAMPS 16
+static uint64_t* g_chain_timing = nullptr;
+static size_t g_chain_timing_words = 0;
+static int g_chain_pick = 0, g_chain_seen = 0, g_chain_last_G = 0, g_chain_last_steps = 0;
+extern "C" void rfn_debug_chain_last(int* G, int* nsteps) {   // geometry of the launch that was stamped
+    *G = g_chain_last_G;
+    *nsteps = g_chain_last_steps;
+}
+// stamps go to `buf` for the pick-th persistent launch after this call (0 = the next one)
+extern "C" void rfn_debug_chain_timing(void* buf, size_t bytes, int pick) {
+    g_chain_timing = (uint64_t*)buf;
+    g_chain_timing_words = bytes / 8;
+    g_chain_pick = pick;
+    g_chain_seen = 0;
+}
+#define CH_STAMP(i)                                                                                          \
+    do {                                                                                                     \
+        if (ca.timing && tid == 0) ca.timing[((size_t)blockIdx.x * nsteps + s) * CH_STAMPS + (i)] = wall_clock64(); \
+    } while (0)
+#else
+#define CH_STAMP(i)
+#endif
+
 struct ChainArgs {
     int nsteps, nov, xcd, pad;
     uint32_t* bar;                 // zeroed by the host: [0] flat / census counter, then the per-XCD family (chain_barrier)
+    uint64_t* timing;              // RFN_CHAIN_TIMING builds: [block][step][CH_STAMPS] clock stamps, else NULL
     int64_t base[CH_NW];
     int32_t delta[CH_NW];
     uint16_t ov_word[CH_NOV];
@@ -66,27 +99,38 @@ __device__ __forceinline__ void ch_spin(const uint32_t* p, uint32_t target) {
         if (++spins > CH_SPIN_LIMIT) __builtin_trap();   // a block of the grid is not running: fail loudly, never hang
     }
 }
-// Grid barrier number `gen` (1, 2, ...).  Every thread calls it; on return every store any block issued before its call is
-// visible to sc1 loads of every block.
-//   flat: one counter.   xcd: blocks of one XCD share a counter, the last arriver of an XCD arrives on the top counter,
-//   waits for all XCDs there and publishes the XCD's generation word, which the others of that XCD poll (XCD-local line).
-__device__ __forceinline__ void chain_barrier(uint32_t* bar, uint32_t gen, uint32_t nblocks, int xcd, uint32_t xcc, uint32_t n_xcd,
-                                              uint32_t mine) {
+// Grid barrier number `gen` (1, 2, ...) in two halves, so that a block can put loads that do not depend on the other blocks
+// between them.  arrive: every wave drains its stores, the block meets, ONE lane adds to the counter.  wait: that lane polls
+// until every block has arrived, the block meets again; from then on every store any block issued before ITS arrive is visible
+// to sc1 loads.   flat: one counter.   xcd: blocks of one XCD share a counter; its last arriver adds to the top counter, waits
+// there for all XCDs and publishes the XCD's generation word, which the others of that XCD poll (an XCD-local line).
+struct ChainBar {
+    uint32_t* bar;
+    uint32_t nblocks, xcc, n_xcd, mine;
+    int xcd;
+    uint32_t ticket;   // lane 0 of the block: what its add returned
+};
+__device__ __forceinline__ void chain_arrive(ChainBar& cb, uint32_t gen) {
+    typedef __attribute__((address_space(1))) uint32_t gu32;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wave: its stores have left
     __syncthreads();
     if (threadIdx.x == 0) {
-        typedef __attribute__((address_space(1))) uint32_t gu32;
-        if (!xcd) {
-            __hip_atomic_fetch_add((gu32*)(uintptr_t)bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            ch_spin(bar, gen * nblocks);
+        uint32_t* c = cb.xcd ? cb.bar + CH_LINE * (2 + cb.xcc) : cb.bar;
+        cb.ticket = __hip_atomic_fetch_add((gu32*)(uintptr_t)c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    (void)gen;
+}
+__device__ __forceinline__ void chain_wait(ChainBar& cb, uint32_t gen) {
+    typedef __attribute__((address_space(1))) uint32_t gu32;
+    if (threadIdx.x == 0) {
+        if (!cb.xcd) {
+            ch_spin(cb.bar, gen * cb.nblocks);
         } else {
-            uint32_t* top = bar + CH_LINE * 1;
-            uint32_t* xc = bar + CH_LINE * (2 + xcc);
-            uint32_t* xg = bar + CH_LINE * (10 + xcc);
-            const uint32_t t = __hip_atomic_fetch_add((gu32*)(uintptr_t)xc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (t + 1 == gen * mine) {
+            uint32_t* top = cb.bar + CH_LINE * 1;
+            uint32_t* xg = cb.bar + CH_LINE * (10 + cb.xcc);
+            if (cb.ticket + 1 == gen * cb.mine) {
                 __hip_atomic_fetch_add((gu32*)(uintptr_t)top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ch_spin(top, gen * n_xcd);
+                ch_spin(top, gen * cb.n_xcd);
                 __hip_atomic_store((gu32*)(uintptr_t)xg, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             } else {
                 ch_spin(xg, gen);
@@ -99,17 +143,20 @@ __device__ __forceinline__ void chain_barrier(uint32_t* bar, uint32_t gen, uint3
 template <bool FWD>
 __global__ __launch_bounds__(CH_THREADS) void chain_k(const ChainArgs ca) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    __shared__ __attribute__((aligned(16))) ChainDesc D;
+    __shared__ __attribute__((aligned(16))) ChainDesc Dbuf[2];   // this step's descriptors and the next one's (built under a barrier)
     __shared__ uint32_t s_census[2];
     const int tid = threadIdx.x, G = gridDim.x;
-    const int nsteps = ca.nsteps, xcd = ca.xcd;
-    uint32_t xcc = 0, n_xcd = 1, mine = G;
-    if (xcd) {   // who shares an XCD with this block (placement is the dispatcher's business: count, do not assume)
+    const int nsteps = ca.nsteps;
+    ChainBar cb;
+    cb.bar = ca.bar;
+    cb.nblocks = G; cb.xcc = 0; cb.n_xcd = 1; cb.mine = G; cb.xcd = 0; cb.ticket = 0;
+    if (ca.xcd) {   // who shares an XCD with this block (placement is the dispatcher's business: count, do not assume)
         typedef __attribute__((address_space(1))) uint32_t gu32;
-        xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | ((4 - 1) << 11)) & 7u;   // HW_REG_XCC_ID
+        const uint32_t xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | ((4 - 1) << 11)) & 7u;   // HW_REG_XCC_ID
         uint32_t* census = ca.bar + CH_LINE * 18;
         if (tid == 0) __hip_atomic_fetch_add((gu32*)(uintptr_t)(census + xcc), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        chain_barrier(ca.bar, 1, G, 0, 0, 0, 0);
+        chain_arrive(cb, 1);
+        chain_wait(cb, 1);          // flat, on bar[0]
         if (tid == 0) {
             uint32_t nx = 0;
             for (int x = 0; x < 8; ++x) nx += ch_ld(census + x) != 0;
@@ -117,38 +164,83 @@ __global__ __launch_bounds__(CH_THREADS) void chain_k(const ChainArgs ca) {
             s_census[1] = ch_ld(census + xcc);
         }
         __syncthreads();
-        n_xcd = s_census[0];
-        mine = s_census[1];
+        cb.xcc = xcc;
+        cb.n_xcd = s_census[0];
+        cb.mine = s_census[1];
+        cb.xcd = 1;
     }
-    uint32_t gen = 0;
-    int64_t* dw = reinterpret_cast<int64_t*>(&D);
-    for (int s = 0; s < nsteps; ++s) {
-        __syncthreads();   // the previous step's last readers of D are done
+    auto build = [&](int s) {   // descriptors of step s: base + s * delta, then the per-step overrides
+        int64_t* dw = reinterpret_cast<int64_t*>(&Dbuf[s & 1]);
         for (int i = tid; i < (int)CH_NW; i += CH_THREADS) dw[i] = ca.base[i] + (int64_t)s * ca.delta[i];
         __syncthreads();
         if (tid < ca.nov) dw[ca.ov_word[tid]] = ca.ov_val[s][tid];
         __syncthreads();
+    };
+    uint32_t gen = 0;
+    build(0);
+    for (int s = 0; s < nsteps; ++s) {
+        const ChainDesc& D = Dbuf[s & 1];
+        CH_STAMP(0);
         const int n0 = xb_uni(D.n0), nb = xb_uni(D.nb), n1 = nb * xb_uni(D.ng), n2 = xb_uni(D.n2);
+        // Every phase: the block's FIRST task carries the wait of the barrier that ended the previous phase inside it, behind
+        // the loads that do not depend on the other blocks; a block without a task in the phase just waits.
+        bool waited = (s == 0);                        // nothing precedes phase 0 of step 0
+        auto wait_prev = [&]() {
+            if (!waited) chain_wait(cb, gen);
+            waited = true;
+        };
+        CH_STAMP(1);
         // ---- phase 0: the products of the recurrent state ---------------------------------------------------------------
         for (int vb = blockIdx.x; vb < n0; vb += G) {
-            __syncthreads();   // the ring of the previous tile / phase is free
-            cg_tile<32, 64, 4, FWD, CG_EPI_STORE, true>(D.g0, vb, smem);
+            if (vb != (int)blockIdx.x) __syncthreads();   // the ring of this block's previous tile is free (arrive did it for the first)
+            cg_tile<32, 64, 4, FWD, CG_EPI_STORE, true>(D.g0, vb, smem, wait_prev);
         }
-        chain_barrier(ca.bar, ++gen, G, xcd, xcc, n_xcd, mine);
+        wait_prev();
+#ifdef RFN_CHAIN_TIMING
+        if (ca.timing && tid == 0)
+            for (int i = 0; i < 4; ++i) ca.timing[((size_t)blockIdx.x * nsteps + s) * CH_STAMPS + 8 + i] = reinterpret_cast<uint64_t*>(smem + 8 * (32 + CG_BN) * 64)[i];
+#endif
+        CH_STAMP(2);
+        chain_arrive(cb, ++gen);
+        waited = false;
+        CH_STAMP(3);
         // ---- phase 1: the small attention of every (row, encoder) ----------------------------------------------------------
         for (int vb = blockIdx.x; vb < n1; vb += G) {
-            __syncthreads();
+            if (vb != (int)blockIdx.x) __syncthreads();
             const int g = vb / nb, b = vb - g * nb;
-            if constexpr (FWD) attn_small_fwd_body<true>(D.at, b, g, smem);
-            else attn_small_bwd_body<true, true>(D.at, b, g, smem);
+            if constexpr (FWD) {
+                if (attn_small_fwd_xp_ok(D.at, g)) {
+                    attn_small_fwd_body_xp(D.at, b, g, smem, wait_prev);
+                } else {
+                    wait_prev();
+                    attn_small_fwd_body<true>(D.at, b, g, smem);
+                }
+            } else {
+                wait_prev();
+                attn_small_bwd_body<true, true>(D.at, b, g, smem);
+            }
         }
-        chain_barrier(ca.bar, ++gen, G, xcd, xcc, n_xcd, mine);
+        wait_prev();
+        CH_STAMP(4);
+        chain_arrive(cb, ++gen);
+        waited = false;
+        CH_STAMP(5);
         // ---- phase 2: the products of the contexts + the LSTM update (forward) / of d hproj + the LSTM backward below ----------
         for (int vb = blockIdx.x; vb < n2; vb += G) {
-            __syncthreads();
-            cg_tile<32, 64, 4, FWD, FWD ? CG_EPI_LSTM : CG_EPI_LSTM_BWD, true>(D.g2, vb, smem);
+            if (vb != (int)blockIdx.x) __syncthreads();
+            cg_tile<32, 64, 4, FWD, FWD ? CG_EPI_LSTM : CG_EPI_LSTM_BWD, true>(D.g2, vb, smem, wait_prev);
         }
-        if (s + 1 < nsteps) chain_barrier(ca.bar, ++gen, G, xcd, xcc, n_xcd, mine);
+        wait_prev();
+#ifdef RFN_CHAIN_TIMING
+        if (ca.timing && tid == 0)
+            for (int i = 0; i < 4; ++i) ca.timing[((size_t)blockIdx.x * nsteps + s) * CH_STAMPS + 12 + i] = reinterpret_cast<uint64_t*>(smem + 8 * (32 + CG_BN) * 64)[i];
+#endif
+        CH_STAMP(6);
+        if (s + 1 < nsteps) {
+            chain_arrive(cb, ++gen);
+            build(s + 1);              // under the barrier: nothing in it depends on the other blocks
+        }
+        CH_STAMP(7);
     }
 }
 
@@ -188,7 +280,7 @@ static bool chain_plan(const ChainStep* steps, int nsteps, ChainArgs& ca, bool& 
         if (st.g2.epi != (fwd ? CG_EPI_LSTM : CG_EPI_LSTM_BWD)) return false;
         if ((st.at.backward != 0) == fwd || (!fwd && !st.at.vec)) return false;
         if (st.at.lds > 3 * (32 + CG_BN) * 64 * sizeof(float)) return false;    // the attention scratch shares the GEMM ring
-        if (st.g0.a.slots > 3 || st.g2.a.slots > 3) return false;
+        if (st.g0.a.slots > CH_SLOTS || st.g2.a.slots > CH_SLOTS) return false;
         // 16-B sc1 accesses go through buffer descriptors with 32-bit byte offsets
         const AttnSmallArgs& a = st.at.a;
         if (!fwd && ((double)a.L * a.xsl * 4 >= 2.0e9 || (double)a.L * a.dpsl * 4 >= 2.0e9)) return false;
@@ -198,6 +290,7 @@ static bool chain_plan(const ChainStep* steps, int nsteps, ChainArgs& ca, bool& 
         D[s].g0 = st.g0.a;
         D[s].at = st.at.a;
         D[s].g2 = st.g2.a;
+        D[s].g0.slots = D[s].g2.slots = CH_SLOTS;      // one block per CU: the ring takes what the launch form leaves to co-residents
         D[s].n0 = st.g0.blocks;
         D[s].nb = st.at.B;
         D[s].ng = st.at.ngroups;
@@ -260,6 +353,13 @@ int rfn_chain_run(const ChainStep* steps, int nsteps, int persist, uint32_t* bar
     const int G = std::min(most, dev_state.cus[di]);
     ca.xcd = G > CH_FLAT_MAX_BLOCKS ? 1 : 0;
     ca.bar = bar;
+#ifdef RFN_CHAIN_TIMING
+    ca.timing = (g_chain_timing && g_chain_seen++ == g_chain_pick && (size_t)G * nsteps * CH_STAMPS <= g_chain_timing_words) ? g_chain_timing : nullptr;
+    if (ca.timing) {
+        g_chain_last_G = G;
+        g_chain_last_steps = nsteps;
+    }
+#endif
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(chain_zero_k, dim3(1), dim3(CH_THREADS), 0, st, bar);
     if (fwd) hipLaunchKernelGGL(chain_k<true>, dim3(G), dim3(CH_THREADS), CH_LDS_BYTES, st, ca);

@@ -258,7 +258,7 @@ int cell_run(int B, int n, const rfn_cell_out* outs, int R, float drop_p, uint64
 int cell_prepare(int B, int n, const rfn_cell_out* outs, int R, float drop_p, uint64_t seed, CgPrepared* pz) {
     return rfn_cg_prepare(B, n, outs, R, drop_p, seed, 0, pz);
 }
-inline bool chain_persist(const rfn_dims* d) { return !(d->path_flags & RFN_PATH_OPT_NO_PERSIST); }
+inline int chain_persist(const rfn_dims* d, uint32_t which) { return (d->path_flags & which) ? 1 : 0; }
 
 // Up to MEM_BATCH copies / zero fills of f32 buffers in ONE launch (src == NULL: zero).  The path's bookkeeping moves (initial
 // states into the workspace, gradient slabs zeroed before they are accumulated into) come in twos and threes; each was a
@@ -810,7 +810,55 @@ static int prefix_fwd_impl(const rfn_dims* d, int B, const float* const* prm, co
 
     // ---- stage II: T2 steps (:241-244, LSTMSoftMultiAttentionFeatArrayNoInputCore.py:41-73) ---
     rfn_gemm_seg segs[RFN_MAX_ENC + 1];
-    for (int t = 0; t < T2; ++t) {
+    // Fused form of a step (3 launches): K1 = every h_2_att_h_i(h) and h2h(h) in one launch (they share h); the M attentions;
+    // K3 = sum_i z_2_h_i(z_i) accumulated onto the gates with the LSTM update as its epilogue.  When every step takes it the
+    // T2 steps run inside one persistent launch (rfn_chain.hip).
+    auto s2_step = [&](int t, ChainStep* cs) -> bool {
+        float* hc = h2 + t * BR;
+        float* hn = h2 + (t + 1) * BR;
+        float* hp = W + Lo.hp2 + (long)t * M * B * A;
+        float* al = W + Lo.al2 + (long)t * M * B * T1;
+        float* z = W + Lo.z2 + (long)t * M * BR;
+        float* g = W + Lo.g2 + (long)t * B * G2;
+        if (d->review_maxout) return false;
+        rfn_cell_out k1[RFN_MAX_ENC + 1], k3;
+        for (int i = 0; i < M; ++i) {
+            k1[i] = cell_out(hp + (long)i * B * A, A, A, 0);
+            cell_lin(k1[i], hc, R, prm[P.s2(t, i, 4)], R, R, prm[P.s2(t, i, 5)]);
+        }
+        k1[M] = cell_out(g, G2, G2, 0);
+        cell_lin(k1[M], hc, R, prm[P.s2_hh_w(t)], R, R, prm[P.s2_hh_b(t)]);
+        k3 = cell_out(g, G2, G2, 1);
+        for (int i = 0; i < M; ++i) cell_lin(k3, z + i * BR, R, prm[P.s2(t, i, 0)], R, R, prm[P.s2(t, i, 1)]);
+        cell_lstm(k3, c2 + t * BR, R, c2 + (t + 1) * BR, R, hn, R, OFF_STAGE2 + (uint64_t)t);
+        if (!cell_ok(B, M + 1, k1, R) || !cell_ok(B, 1, &k3, R)) return false;
+        const float *a_p[RFN_MAX_ENC], *a_hp[RFN_MAX_ENC], *a_w[RFN_MAX_ENC], *a_b[RFN_MAX_ENC], *a_x[RFN_MAX_ENC];
+        float *a_al[RFN_MAX_ENC], *a_z[RFN_MAX_ENC];
+        for (int i = 0; i < M; ++i) {
+            a_p[i] = W + Lo.P2[i] + (long)t * A;
+            a_hp[i] = hp + (long)i * B * A;
+            a_w[i] = prm[P.s2(t, i, 6)];
+            a_b[i] = prm[P.s2(t, i, 7)];
+            a_x[i] = Hs + BMR + i * R;
+            a_al[i] = al + (long)i * B * T1;
+            a_z[i] = z + i * BR;
+        }
+        return cell_prepare(B, M + 1, k1, R, 0.f, 0, &cs->g0) == RFN_OK &&
+               rfn_attn_small_prepare_fwd(M, a_p, (long)T2 * A, (long)B * T2 * A, a_hp, a_w, a_b, a_x, MR, BMR, B, T1, A, R, a_al, a_z,
+                                          R, &cs->at) == RFN_OK &&
+               cell_prepare(B, 1, &k3, R, d->drop_reason, seed, &cs->g2) == RFN_OK;
+    };
+    bool s2_chained = false;
+    {
+        std::vector<ChainStep> steps((size_t)T2);
+        bool ok = true;
+        for (int t = 0; t < T2 && ok; ++t) ok = s2_step(t, &steps[t]);
+        if (ok) {
+            RFN_TRY(rfn_chain_run(steps.data(), T2, chain_persist(d, RFN_PATH_OPT_PERSIST_S2_FWD), (uint32_t*)(W + Lo.bar), st));
+            s2_chained = true;
+        }
+    }
+    for (int t = 0; t < T2 && !s2_chained; ++t) {
         float* hc = h2 + t * BR;
         float* hn = h2 + (t + 1) * BR;
         float* cc = c2 + t * BR;
@@ -969,7 +1017,45 @@ extern "C" int rfn_prefix_bwd(const rfn_dims* d, int B, const float* const* prm,
         RFN_TRY(rfn_lstm_bwd(W + Lo.g2 + (long)(T2 - 1) * B * G2, G2, c2 + (T2 - 1) * BR, R, c2 + T2 * BR, R, dht, R, d_c, R, dc2, R,
                              B, R, 0, d->drop_reason, seed, OFF_STAGE2 + (uint64_t)(T2 - 1), st));
     }
-    for (int t = T2 - 1; t >= 0; --t) {
+    int t_hi = T2 - 1;
+    if (fused2 && T2 >= 3) {
+        // steps T2-1 ... 1 in one persistent launch (rfn_chain.hip); step 0, whose Kb2 is a plain accumulate, follows as launches
+        std::vector<ChainStep> steps((size_t)(T2 - 1));
+        bool ok = true;
+        for (int t = T2 - 1; t >= 1 && ok; --t) {
+            ChainStep& cs = steps[(size_t)(T2 - 1 - t)];
+            rfn_cell_out kb1[RFN_MAX_ENC + 1], kb2;
+            s2_kb1(t, kb1);
+            s2_kb2(t, kb2);
+            float* hp = W + Lo.hp2 + (long)t * M * BA;
+            float* dhp = W + Lo.dhp2 + (long)t * M * BA;
+            float* al = W + Lo.al2 + (long)t * M * B * T1;
+            const float *a_p[RFN_MAX_ENC], *a_hp[RFN_MAX_ENC], *a_w[RFN_MAX_ENC], *a_al[RFN_MAX_ENC], *a_x[RFN_MAX_ENC],
+                *a_dz[RFN_MAX_ENC];
+            float *a_dp[RFN_MAX_ENC], *a_dhp[RFN_MAX_ENC], *a_dw[RFN_MAX_ENC], *a_dx[RFN_MAX_ENC];
+            for (int i = 0; i < M; ++i) {
+                a_dp[i] = W + Lo.P2[i] + (long)t * A;
+                a_p[i] = a_dp[i];
+                a_hp[i] = hp + i * BA;
+                a_w[i] = prm[P.s2(t, i, 6)];
+                a_al[i] = al + (long)i * B * T1;
+                a_x[i] = Hs + BMR + i * R;
+                a_dz[i] = dz2 + i * BR;
+                a_dhp[i] = dhp + i * BA;
+                a_dw[i] = dwp + ((long)t * M + i) * BA;
+                a_dx[i] = dHs + BMR + i * R;
+            }
+            ok = cell_prepare(B, M + 1, kb1, R, 0.f, 0, &cs.g0) == RFN_OK &&
+                 rfn_attn_small_prepare_bwd(M, a_p, (long)T2 * A, (long)B * T2 * A, a_hp, a_w, a_al, a_x, MR, BMR, a_dz, R, B, T1, A, R,
+                                            a_dp, (long)T2 * A, (long)B * T2 * A, 0, a_dhp, a_dw, a_dx, &cs.at) == RFN_OK &&
+                 cell_prepare(B, 1, &kb2, R, d->drop_reason, seed, &cs.g2) == RFN_OK;
+        }
+        if (ok) {
+            RFN_TRY(rfn_chain_run(steps.data(), T2 - 1, chain_persist(d, RFN_PATH_OPT_PERSIST_S2_BWD), (uint32_t*)(W + Lo.bar), st));
+            t_hi = 0;
+        }
+    }
+    for (int t = t_hi; t >= 0; --t) {
         float* hp = W + Lo.hp2 + (long)t * M * BA;
         float* dhp = W + Lo.dhp2 + (long)t * M * BA;
         float* al = W + Lo.al2 + (long)t * M * B * T1;
@@ -1458,7 +1544,7 @@ extern "C" int rfn_decoder_fwd(const rfn_dims* d, int B, int S, const float* con
         bool fused = true;
         for (int s = 0; s < S && fused; ++s) fused = decoder_fwd_cell_prepare(d, B, s, prm, comb, W, Lo, seed, &steps[s]);
         if (fused) {
-            RFN_TRY(rfn_chain_run(steps.data(), S, chain_persist(d), (uint32_t*)(W + Lo.bar), st));
+            RFN_TRY(rfn_chain_run(steps.data(), S, chain_persist(d, RFN_PATH_OPT_PERSIST_DEC_FWD), (uint32_t*)(W + Lo.bar), st));
         } else {
             for (int s = 0; s < S; ++s) RFN_TRY(decoder_fwd_cell(d, B, s, prm, comb, W, Lo, gx, seed, st));
         }
@@ -1569,7 +1655,31 @@ extern "C" int rfn_decoder_bwd(const rfn_dims* d, int B, int S, const float* con
     if (fused)   // LSTM backward of the last step: nothing recurrent flows into it
         RFN_TRY(rfn_lstm_bwd(gd + (long)(S - 1) * B * GD, GD, cd + (S - 1) * BR, R, cd + S * BR, R, dhe + (S - 1) * BR, R, nullptr,
                              R, dc, R, B, R, 0, d->drop_lm, seed, OFF_DECODER + (uint64_t)(S - 1), st));
-    for (int s = S - 1; s >= 0; --s) {
+    int s_hi = S - 1;
+    if (fused && S >= 3) {
+        // steps S-1 ... 1 share one form (Kb2 carries the LSTM backward of the step below): one persistent launch
+        // (rfn_chain.hip); step 0, whose Kb2 is a plain accumulate, follows as its three launches
+        std::vector<ChainStep> steps((size_t)(S - 1));
+        bool ok = true;
+        for (int s = S - 1; s >= 1 && ok; --s) {
+            ChainStep& cs = steps[(size_t)(S - 1 - s)];
+            rfn_cell_out kb1[2], kb2;
+            dec_kb1(s, kb1);
+            dec_kb2(s, kb2);
+            const float *proj = W + Lo.Pd, *hp = W + Lo.hpd + s * BA, *w = prm[P.dec(10)], *al = W + Lo.ald + (long)s * B * T2;
+            const float* dzc = dz;
+            float *dpr = dPd, *dhp = W + Lo.dhpd + s * BA, *dwp = W + Lo.dwp + s * BA, *dxc = d_comb;
+            ok = cell_prepare(B, 2, kb1, R, 0.f, 0, &cs.g0) == RFN_OK &&
+                 rfn_attn_small_prepare_bwd(1, &proj, A, BA, &hp, &w, &al, &comb, R, BR, &dzc, R, B, T2, A, R, &dpr, A, BA, 1, &dhp,
+                                            &dwp, &dxc, &cs.at) == RFN_OK &&
+                 cell_prepare(B, 1, &kb2, R, d->drop_lm, seed, &cs.g2) == RFN_OK;
+        }
+        if (ok) {
+            RFN_TRY(rfn_chain_run(steps.data(), S - 1, chain_persist(d, RFN_PATH_OPT_PERSIST_DEC_BWD), (uint32_t*)(W + Lo.bar), st));
+            s_hi = 0;
+        }
+    }
+    for (int s = s_hi; s >= 0; --s) {
         float* g = gd + (long)s * B * GD;
         float* dht = dhe + s * BR;
         float* al = W + Lo.ald + (long)s * B * T2;

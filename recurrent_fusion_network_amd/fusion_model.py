@@ -332,6 +332,12 @@ class RecurrentFusionModel(nn.Module):
                 self._bucket_slots['enc%s%s' % (m.group(1), 'b' if 'att_2_att_h' in m.group(2) else 'a')].append(idx)
         self._prefix_buckets = ['core'] + ['enc%da' % i for i in range(M)] + ['enc%db' % i for i in range(M)]   # production order
         self.grad_ready_hook = None      # callable(bucket_name, flat_grad_tensor), see parallel.GradSync
+        # callable('prefix' | 'decoder'): called right before the parameters of that phase are handed to a kernel.  A
+        # sharded optimizer (FusedClampAdam(shard=...)) waits there for the all-gather of the parameters it updated.
+        self.param_wait_hook = None
+        # flat buckets (gradients, and the optimizer's parameter / moment buffers) are padded to a multiple of this many
+        # elements: 4 * world_size under a sharded optimizer, so every rank's shard is the same 16-B aligned length
+        self.flat_pad = 1
         # Opt-in: real batches hold each image's features `seq_per_img` times in a row (dataloader.py:251-252).
         # With this set to that count, stages I/II run once per image and their outputs are fanned out to the
         # caption rows (exactly the same numbers: rows are independent); only legal while drop_prob_fusion and
@@ -399,6 +405,8 @@ class RecurrentFusionModel(nn.Module):
     def _params_of(self, slots):
         # Parameter objects are stable under .cuda()/.to() (their .data is swapped in place), so the
         # by-name lookup is done once per slot list
+        if self.param_wait_hook is not None:
+            self.param_wait_hook('decoder' if slots is self._decoder_slots else 'prefix')
         key = id(slots)
         if key not in self._param_cache:
             named = dict(self.named_parameters())
@@ -423,7 +431,8 @@ class RecurrentFusionModel(nn.Module):
         for p in params:
             offs.append(total)
             total += (p.numel() + 3) & ~3
-        return params, offs, total
+        pad = max(1, int(self.flat_pad))
+        return params, offs, -(-total // pad) * pad
 
     def _grad_buffers(self, buckets, dev):
         """One flat gradient buffer per bucket; returns ({name: flat}, {slot: view}, pointer table)."""
@@ -432,6 +441,8 @@ class RecurrentFusionModel(nn.Module):
         for name in buckets:
             params, offs, total = self.bucket_layout(name)
             flat = torch.empty(total, device=dev, dtype=torch.float32)
+            if self.flat_pad > 1:       # the shard padding behind the last parameter is exchanged and updated like data
+                flat[offs[-1] + params[-1].numel():].zero_()
             flats[name] = flat
             for slot, p, o in zip(self._bucket_slots[name], params, offs):
                 v = flat[o:o + p.numel()].view_as(p)

@@ -8,6 +8,15 @@ the headline config) instead of ~625 per-tensor updates, and a data-parallel run
 Trainer-facing surface of ``torch.optim.Adam`` that the reference's loops touch: ``zero_grad()``, ``step()``,
 ``param_groups[0]['lr']`` (``utils.set_lr``, misc/utils.py:286-290; train.py:102-104), ``state_dict()`` /
 ``load_state_dict()`` (``optimizer_<id>.pth``, train.py:86-88,232-233).
+
+Opt-in under data parallelism: ``FusedClampAdam(model, ..., shard=(rank, world))`` shards the UPDATE -- the one part of the
+step that does not shrink with the batch shard (10.9 GB of HBM traffic per step at the headline model whatever B is).  Every
+flat bucket is cut into `world` equal 16-B aligned shards; a rank keeps Adam moments for its shard only, receives the summed
+gradient of its shard (parallel.GradSync(shard_optimizer=True): reduce-scatter instead of all-reduce, half the wire bytes),
+updates its shard of the parameters with the same element arithmetic, and the shards are all-gathered into every rank's full
+parameter buffer -- asynchronously, in the order the next forward uses them, the model waiting (``param_wait_hook``) right
+before the phase that reads them.  Same wire bytes as the all-reduce in total; element for element the same update, so the
+parameters are bit-identical to the unsharded step (tests/test_parallel_gloo.py, tests/test_parallel_gpu.py).
 """
 import ctypes as C
 
@@ -17,8 +26,16 @@ from . import _native as N
 
 
 class FusedClampAdam:
-    def __init__(self, model, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_clip=1.0):
+    def __init__(self, model, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_clip=1.0, shard=None,
+                 process_group=None):
         self.model = model
+        self.shard_rank, self.shard_world = (int(shard[0]), int(shard[1])) if shard else (0, 1)
+        self.group = process_group
+        if not 0 <= self.shard_rank < self.shard_world:
+            raise N.RfnError('shard = (rank, world) with 0 <= rank < world, got %r' % (shard,))
+        if self.shard_world > 1:
+            from . import parallel as DP
+            model.flat_pad = DP.shard_pad(self.shard_world)       # before any flat buffer of this model is laid out
         # one group, torch.optim layout: utils.set_lr writes group['lr'], which step() reads
         self.param_groups = [dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay, grad_clip=grad_clip,
                                   params=list(model.parameters()))]
@@ -32,7 +49,16 @@ class FusedClampAdam:
             for o, p in zip(offs, params):
                 buf[o:o + p.numel()].copy_(p.data.reshape(-1))
                 p.data = buf[o:o + p.numel()].view_as(p)
-            self.flat[name] = dict(p=buf, m=torch.zeros_like(buf), v=torch.zeros_like(buf), n=total)
+            lo, hi = 0, total                             # the whole bucket when the update is not sharded
+            if self.shard_world > 1:
+                from . import parallel as DP
+                lo, hi = DP.shard_bounds(total, self.shard_rank, self.shard_world)
+            self.flat[name] = dict(p=buf, m=torch.zeros(hi - lo, device=buf.device), v=torch.zeros(hi - lo, device=buf.device),
+                                   n=total, lo=lo, hi=hi)
+        self._gathers = {'prefix': [], 'decoder': []}
+        self.reduced_shards = {}        # bucket -> this rank's summed gradient shard (parallel.GradSync(shard_optimizer=True))
+        if self.shard_world > 1:
+            model.param_wait_hook = self.wait_params
 
     # ---- torch.optim-style accessors ---------------------------------------------------------------
     @property
@@ -67,11 +93,21 @@ class FusedClampAdam:
             p.grad = None
         self.model._last_flat_grads.clear()
 
+    def _full_moment(self, st, key):
+        """The whole bucket's moment (a collective when the update is sharded: every rank must call it)."""
+        if self.shard_world == 1:
+            return st[key].detach().clone()
+        import torch.distributed as dist
+        parts = [torch.empty_like(st[key]) for _ in range(self.shard_world)]
+        dist.all_gather(parts, st[key].contiguous(), group=self.group)
+        return torch.cat(parts)
+
     def state_dict(self):
-        """Adam moments per bucket (flat, same layout as the parameters), the step count and the hyper-parameters."""
+        """Adam moments per bucket (flat, same layout as the parameters), the step count and the hyper-parameters.  With a
+        sharded update this gathers every rank's moment shards: call it on every rank."""
         hyper = {k: v for k, v in self.param_groups[0].items() if k != 'params'}
         return {'step_count': self.step_count, 'hyper': hyper,
-                'buckets': {name: {'m': st['m'].detach().clone(), 'v': st['v'].detach().clone(), 'n': st['n']}
+                'buckets': {name: {'m': self._full_moment(st, 'm'), 'v': self._full_moment(st, 'v'), 'n': st['n']}
                             for name, st in self.flat.items()}}
 
     def load_state_dict(self, sd):
@@ -90,8 +126,8 @@ class FusedClampAdam:
             src = sd['buckets'][name]
             if int(src['n']) != st['n']:
                 raise N.RfnError('optimizer bucket %s holds %d values, expected %d' % (name, int(src['n']), st['n']))
-            st['m'].copy_(src['m'])
-            st['v'].copy_(src['v'])
+            st['m'].copy_(src['m'][st['lo']:st['hi']])
+            st['v'].copy_(src['v'][st['lo']:st['hi']])
         self.step_count = int(sd['step_count'])
         for k, v in sd.get('hyper', {}).items():
             self.param_groups[0][k] = tuple(v) if k == 'betas' else v
@@ -125,14 +161,16 @@ class FusedClampAdam:
             todo.append((p, ent))
         if len(steps) > 1:
             raise N.RfnError('torch.optim.Adam state has per-parameter step counts %s; the fused update keeps one' % sorted(steps))
-        for st in self.flat.values():
-            st['m'].zero_()
-            st['v'].zero_()
+        full = {name: (torch.zeros(st['n'], device=st['p'].device), torch.zeros(st['n'], device=st['p'].device))
+                for name, st in self.flat.items()}
         for p, ent in todo:
             name, o = where[id(p)]
             n = p.numel()
-            self.flat[name]['m'][o:o + n].copy_(ent['exp_avg'].reshape(-1))
-            self.flat[name]['v'][o:o + n].copy_(ent['exp_avg_sq'].reshape(-1))
+            full[name][0][o:o + n].copy_(ent['exp_avg'].reshape(-1))
+            full[name][1][o:o + n].copy_(ent['exp_avg_sq'].reshape(-1))
+        for name, st in self.flat.items():
+            st['m'].copy_(full[name][0][st['lo']:st['hi']])
+            st['v'].copy_(full[name][1][st['lo']:st['hi']])
         self.step_count = steps.pop() if steps else 0
         for k in ('lr', 'eps', 'weight_decay'):
             if k in g0:
@@ -143,10 +181,12 @@ class FusedClampAdam:
     def snapshot(self):
         """Parameters, moments and step count as they are now (device copies): `restore` puts a run back at this point,
         so two legs of a benchmark can take the same number of updates from the same start."""
+        self.wait_params()
         return {'step_count': self.step_count,
                 'buckets': {name: tuple(st[k].detach().clone() for k in ('p', 'm', 'v')) for name, st in self.flat.items()}}
 
     def restore(self, snap):
+        self.wait_params()
         for name, st in self.flat.items():
             for k, src in zip(('p', 'm', 'v'), snap['buckets'][name]):
                 st[k].copy_(src)
@@ -171,14 +211,23 @@ class FusedClampAdam:
         g0 = self.param_groups[0]
         self.step_count += 1
         self.model._weights_epoch = getattr(self.model, '_weights_epoch', 0) + 1   # invalidates reuse_prefix entries
-        todo = []
+        todo, names = [], []
         for name, st in self.flat.items():
             g = self.model._last_flat_grads.get(name)
             if g is None:
                 continue
             if g.numel() != st['n']:
                 raise N.RfnError('flat gradient layout changed')
-            todo.append((st, g))
+            if self.shard_world > 1:
+                # this rank's shard: the reduce-scattered gradient when GradSync delivered one, else the slice of the
+                # (all-reduced or single-process) full buffer -- the same numbers either way
+                gs = self.reduced_shards.pop(name, None)
+                if gs is None:
+                    gs = g[st['lo']:st['hi']]
+                todo.append((dict(p=st['p'][st['lo']:st['hi']], m=st['m'], v=st['v'], n=st['hi'] - st['lo']), gs))
+            else:
+                todo.append((st, g))
+            names.append(name)
         # every bucket in one launch (rfn_adam_step_multi: same element arithmetic, no per-bucket ramp and tail)
         for lo in range(0, len(todo), N.ADAM_MAXBUCKET):
             part = todo[lo:lo + N.ADAM_MAXBUCKET]
@@ -193,3 +242,25 @@ class FusedClampAdam:
                 N.check(N.lib.rfn_adam_step_multi(len(part), *ptrs, sizes, g0['lr'], g0['betas'][0], g0['betas'][1], g0['eps'],
                                                   g0['weight_decay'], g0['grad_clip'], grad_scale, self.step_count,
                                                   N.stream_ptr()), 'rfn_adam_step_multi')
+        if self.shard_world > 1:
+            self._gather_params(names)
+
+    # ---- sharded update: parameters back to every rank ---------------------------------------------------------------
+    def _gather_params(self, names):
+        """All-gather the updated shards into every rank's full parameter buffers, asynchronously, in the order the next
+        forward reads them: the stage-I / stage-II buckets first (rfn_prefix_fwd), the decoder bucket last -- it is not read
+        before the whole prefix has run."""
+        from . import parallel as DP
+        order = [n for n in names if n != 'decoder'] + [n for n in names if n == 'decoder']
+        for name in order:
+            w = DP.gather_shards(self.flat[name]['p'], self.shard_rank, self.shard_world, self.group, async_op=True)
+            self._gathers['decoder' if name == 'decoder' else 'prefix'].append(w)
+
+    def wait_params(self, which=None):
+        """The model's `param_wait_hook`: the compute stream (nccl) or the host (other backends) waits for the gathers of the
+        buckets the phase `which` ('prefix', 'decoder'; None: all) is about to read."""
+        for key in (('prefix', 'decoder') if which is None else (which,)):
+            works = self._gathers[key]
+            for w in works:
+                w.wait()
+            works.clear()

@@ -54,6 +54,30 @@ def shard_loss_scale(n_local, n_global, world):
     return float(n_local) * float(world) / float(n_global)
 
 
+def shard_pad(world):
+    """Flat buckets of a sharded update are padded to a multiple of this many elements: `world` equal shards, each a whole
+    number of 16-B vectors (the fused update moves float4s)."""
+    return 4 * max(1, int(world))
+
+
+def shard_bounds(total_padded, rank, world):
+    """[lo, hi) of rank's shard of a flat bucket of `total_padded` elements (a multiple of shard_pad(world))."""
+    if total_padded % shard_pad(world):
+        raise ValueError('a bucket of %d elements cannot be cut into %d aligned shards' % (total_padded, world))
+    sl = total_padded // max(1, world)
+    return rank * sl, (rank + 1) * sl
+
+
+def gather_shards(full, rank, world, group=None, async_op=False):
+    """In-place all-gather of a flat buffer whose shard `rank` is up to date on this rank: afterwards every rank holds
+    every shard.  nccl: one all_gather_into_tensor; other backends: the list form onto views of `full`."""
+    lo, hi = shard_bounds(full.numel(), rank, world)
+    if dist.get_backend(group) == 'nccl':
+        return dist.all_gather_into_tensor(full, full[lo:hi], group=group, async_op=async_op)
+    sl = hi - lo
+    return dist.all_gather([full[r * sl:(r + 1) * sl] for r in range(world)], full[lo:hi].clone(), group=group, async_op=async_op)
+
+
 def allreduce_flat(buffers, world, async_op=False):
     """Sum all-reduce of the flat gradient buffers, in the given order.  Returns work handles when async."""
     if world <= 1:
@@ -73,8 +97,15 @@ class GradSync:
     them.  Each collective starts behind the compute stream at its call point (process-group semantics), so
     bucket i's transfer runs under the weight-gradient GEMMs of the encoders after it."""
 
-    def __init__(self, model, world):
+    def __init__(self, model, world, shard_optimizer=None):
+        """shard_optimizer: a FusedClampAdam built with shard=(rank, world).  Each bucket is then REDUCE-SCATTERED (half the
+        bytes of the all-reduce; the other half is the optimizer's all-gather of the updated parameters): rank r receives
+        the sum of shard r into `shard_optimizer.reduced_shards[name]`, which is what its update reads.  `.grad` then holds
+        the LOCAL gradient.  Backends without reduce-scatter (gloo) all-reduce instead -- same numbers."""
         self.world = world
+        self.sharded = shard_optimizer
+        if shard_optimizer is not None and shard_optimizer.shard_world != max(1, world):
+            raise ValueError('the optimizer shards over %d ranks, the exchange runs over %d' % (shard_optimizer.shard_world, world))
         self.works = []
         self.buckets = []
         # exposed-wait bookkeeping (bench.py `exposed_ms`): off unless `record` is set.  On the nccl backend a wait() only
@@ -93,7 +124,14 @@ class GradSync:
     def on_bucket(self, name, flat):
         self.buckets.append(name)
         if self.world > 1 or (dist.is_available() and dist.is_initialized()):
-            self.works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True))
+            opt = self.sharded
+            if opt is not None and opt.shard_world > 1 and dist.get_backend(opt.group) == 'nccl':
+                st = opt.flat[name]
+                out = torch.empty(st['hi'] - st['lo'], device=flat.device, dtype=flat.dtype)
+                self.works.append(dist.reduce_scatter_tensor(out, flat, op=dist.ReduceOp.SUM, group=opt.group, async_op=True))
+                opt.reduced_shards[name] = out
+            else:
+                self.works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True))
 
     def finish(self):
         if self.record and self.works:

@@ -1,5 +1,5 @@
 """The persistent recurrence kernels (csrc/rfn_chain.hip: all steps of a stage-II / decoder recurrence in ONE launch, grid
-barrier between dependent phases) against the three-launches-per-step chain they replace (RFN_PATH_OPT_NO_PERSIST): the same
+barrier between dependent phases; opt-in, RFN_PATH_OPT_PERSIST_*) against the three-launches-per-step chain they replace: the same
 device bodies on the same tiles in the same k order, so everything must agree BIT FOR BIT -- log-probs, reason heads, loss,
 every gradient, greedy ids -- on the reference-pinned golden tiers and at the benchmark shapes, run after run (a stale
 cache line in a hand-off between blocks would show up as a sporadic difference)."""
@@ -34,7 +34,8 @@ def _assert_same(a, b, what):
 
 @pytest.mark.parametrize('name', ['mid', 'c2', 'c3', 'tiny0', 'odd'])
 @pytest.mark.parametrize('train', [False, True])
-def test_persistent_chains_match_the_per_step_launches_bit_for_bit(dev, name, train):
+@pytest.mark.parametrize('which', [1, 2, 4, 8, 15])
+def test_persistent_chains_match_the_per_step_launches_bit_for_bit(dev, name, train, which):
     """Golden tiers: `mid` / `c2` / `c3` take the persistent kernels (hidden sizes are whole K steps of 64), `tiny0` / `odd`
     do not qualify and must quietly run the per-step launches under both settings."""
     import recurrent_fusion_network_amd as R
@@ -45,9 +46,9 @@ def test_persistent_chains_match_the_per_step_launches_bit_for_bit(dev, name, tr
     batch = to_dev(batch, dev)
     crit = R.ReviewNetEnsembleCriterion(cfg)
     ref = build(cfg, P, dev, train=train)
-    ref.path_flags = N.PATH_OPT_NO_PERSIST
+    assert ref.path_flags == 0
     new = build(cfg, P, dev, train=train)
-    assert new.path_flags == 0
+    new.path_flags = which
     for rnd in range(2):
         torch.manual_seed(5 + rnd)
         want = _step(ref, crit, batch)
@@ -80,8 +81,8 @@ def test_persistent_chains_at_the_c2_shape_run_after_run(dev, B):
     batch = to_dev((fc, att, labels, masks, top), dev)
     crit = R.ReviewNetEnsembleCriterion(cfg)
     model.train()
-    model.path_flags = N.PATH_OPT_NO_PERSIST
-    want = _step(model, crit, batch)
     model.path_flags = 0
+    want = _step(model, crit, batch)
+    model.path_flags = N.PATH_OPT_PERSIST_ALL
     for rnd in range(12):
         _assert_same(_step(model, crit, batch), want, 'B=%d run %d' % (B, rnd))

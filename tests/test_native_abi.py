@@ -37,7 +37,7 @@ def test_struct_layouts_match_the_header():
     assert C.sizeof(N.GemmProblem) == 32 + 8 * 56
     # ... + gemm_flags (ABI 4) + path_flags, 4 bytes of alignment, probe_events pointer (ABI 6)
     assert C.sizeof(N.Dims) == 8 * 4 + 3 * 8 * 4 + 2 * 4 + 3 * 4 + 4 + 4 + 4 + 8
-    assert N.Dims.probe_events.offset == 160 and N.PATH_OPT_NO_PERSIST == 1
+    assert N.Dims.probe_events.offset == 160 and N.PATH_OPT_PERSIST_ALL == 15
     assert N.GEMM_OPT_LDS_LEAN == 1 and N.GEMM_OPT_NO_DMA == 2             # rfn.h RFN_GEMM_OPT_*
 
 
