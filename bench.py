@@ -243,8 +243,13 @@ def parse_args(argv=None):
                          'configurations whose 350 launches a slow host cannot issue as fast as the device retires them')
     ap.add_argument('--persist', type=int, default=0,
                     help='A/B: RFN_PATH_OPT_PERSIST_* bits (1 decoder fwd, 2 stage II fwd, 4 decoder bwd, 8 stage II bwd; 15 = all): '
-                         'those recurrences inside ONE persistent launch each (csrc/rfn_chain.hip) instead of three launches per '
-                         'step; bit-identical, not faster on MI355X (profiles/r05_chain.md)')
+                         'those recurrences inside ONE persistent launch each (csrc/rfn_chain.hip) instead of three launches per step; '
+                         '16 = RFN_PATH_OPT_DEEP_CELLS: few-tile per-step products on the deep-ring kernel instead of the 3-slot one; '
+                         'bit-identical either way (profiles/r05_chain.md)')
+    ap.add_argument('--fused-loss', action='store_true',
+                    help='forward + criterion through RecurrentFusionModel.forward_loss (the language term straight from the '
+                         'logits, d logits written in place: no (B, T, V+1) log_prob / d log_prob round trip) instead of '
+                         'model(...) + crit(...); same loss and gradients to rounding')
     ap.add_argument('--shard-optimizer', action='store_true',
                     help='data parallel only: every rank updates 1/N of each flat bucket (FusedClampAdam(shard=...): '
                          'reduce-scatter of the gradients, Adam on the shard, all-gather of the parameters under the next '
@@ -663,7 +668,7 @@ def run_train(args, rank, world, dev, R, DP, guard):
         model.gemm_flags |= N.GEMM_OPT_BF16X3
     if args.lds_lean:
         model.gemm_flags |= N.GEMM_OPT_LDS_LEAN
-    model.path_flags |= int(args.persist) & N.PATH_OPT_PERSIST_ALL
+    model.path_flags |= int(args.persist) & (N.PATH_OPT_PERSIST_ALL | N.PATH_OPT_DEEP_CELLS)
     if args.micro_batches >= 0 and hasattr(model, 'micro_batches'):
         model.micro_batches = args.micro_batches
     crit = R.ReviewNetEnsembleCriterion(cfg)
@@ -706,8 +711,11 @@ def run_train(args, rank, world, dev, R, DP, guard):
         row = []
         mark(row)
         opt.zero_grad()
-        log_prob, top_pred = model(fc, att, labels)
-        loss = crit(log_prob, labels[:, 1:], masks[:, 1:], top_pred, top, 1.0)
+        if args.fused_loss:
+            loss, top_pred = model.forward_loss(fc, att, labels, masks, top, crit, 1.0)
+        else:
+            log_prob, top_pred = model(fc, att, labels)
+            loss = crit(log_prob, labels[:, 1:], masks[:, 1:], top_pred, top, 1.0)
         if loss_scale != 1.0:
             loss = loss * loss_scale
         mark(row)
@@ -854,7 +862,7 @@ def run_train(args, rank, world, dev, R, DP, guard):
                        'parallelism': 'dp%d (batch sharded, RCCL all-reduce of grads)' % world if world > 1 else 'single GPU',
                        'micro_batches': int(getattr(model, 'micro_batches', 1) or 1),
                        'final_loss': round(final_loss, 4), 'updates': head['settle_n'] + args.warmup + args.steps,
-                       'hip_graph': bool(args.graph), 'shard_optimizer': bool(shard),
+                       'hip_graph': bool(args.graph), 'shard_optimizer': bool(shard), 'fused_loss': bool(args.fused_loss),
                        'gemm_flags': int(model.gemm_flags), 'digest': digest},
         }
         if in_group:

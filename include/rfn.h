@@ -75,6 +75,8 @@ typedef struct rfn_dims {
 #define RFN_PATH_OPT_PERSIST_DEC_BWD 4u   /* decoder backward sweep, steps S-1 ... 1 (rfn_decoder_bwd)        */
 #define RFN_PATH_OPT_PERSIST_S2_BWD 8u    /* stage-II backward sweep, steps T2-1 ... 1 (rfn_prefix_bwd)       */
 #define RFN_PATH_OPT_PERSIST_ALL 15u
+#define RFN_PATH_OPT_DEEP_CELLS 16u       /* A/B hook: per-step products with no more tiles than CUs on the deep-ring kernel
+                                           * (rfn_cell_gemm, RFN_CELL_VARIANT_DEEP) instead of the 3-slot one; not faster      */
 
 int rfn_abi_version(void);
 const char* rfn_error_string(int code);
@@ -346,7 +348,11 @@ int rfn_attn_small_bwd(int ngroups, const float* const* proj, int64_t proj_sb, i
  * Requirements (rfn_cell_gemm_supported; otherwise RFN_ERR_UNSUPPORTED and the caller uses rfn_gemm_f32 + rfn_lstm_*):
  * every K and N a multiple of 32, 16-B aligned operands with leading dimensions that are multiples of 4, R a multiple
  * of 8 for the gate epilogue; any M.  `variant` 0 lets the library pick the tile from the column and K counts alone --
- * never from M, so a row's arithmetic does not depend on the batch it sits in (1..3 force one: tests, tools). */
+ * never from M, so a row's arithmetic does not depend on the batch it sits in (1..3 force one: tests, tools; bits 4-7 force
+ * the ring depth: tools).  RFN_CELL_VARIANT_DEEP in `variant` (A/B hook): a launch of the 32-row variant whose tiles do not
+ * outnumber the device's CUs runs on the deep-ring kernel (8 ring slots, the whole K range of K <= 512 in flight, a K loop
+ * without barriers) -- bit-identical results, measured slower inside the step (profiles/r05_chain.md). */
+#define RFN_CELL_VARIANT_DEEP 256
 #define RFN_CELL_MAXOUT 10
 #define RFN_CELL_MAXSEG 8
 #define RFN_CELL_EPI_STORE 0
@@ -486,6 +492,17 @@ int rfn_xe_loss(const float* logp, int B, int T, int V1, const int64_t* target, 
 int rfn_xe_loss_ex(const float* logp, int B, int T, int V1, const int64_t* target, int64_t ld_target,
                    const float* mask, int64_t ld_mask, float eps, float gscale, const float* gscale_dev,
                    float* scratch, float* loss_out, int accumulate_loss, float* dlogp, void* stream);
+/* The same language term straight from the LOGITS (log-softmax / NLL / label smoothing and their backward
+ * without the (B, T, V+1) log_prob and d log_prob tensors; F.log_softmax of misc/RecurrentFusionModel.py:276 + misc/utils.py:
+ * 163-184).  `logits`: time-major rows r = t * B + b with row stride ldl (the layout of the decoder workspace,
+ * rfn_decoder_logits).  _fwd: lse[r] (T*B floats) = the row's logsumexp, loss_out[0] (+)= -sum mask * q . (x - lse) / B;
+ * scratch: B*T floats.  _bwd overwrites the logits with d loss / d logits * gscale * gscale_dev[0] (gscale_dev may be NULL). */
+int rfn_xe_logits_fwd(const float* logits, int64_t ldl, int B, int T, int V1, const int64_t* target, int64_t ld_target,
+                      const float* mask, int64_t ld_mask, float eps, float* lse, float* scratch, float* loss_out,
+                      int accumulate_loss, void* stream);
+int rfn_xe_logits_bwd(float* logits, int64_t ldl, int B, int T, int V1, const int64_t* target, int64_t ld_target,
+                      const float* mask, int64_t ld_mask, float eps, const float* lse, float gscale,
+                      const float* gscale_dev, void* stream);
 /* ReviewNetRewardCriterion policy + entropy terms (misc/utils.py:50-72):
  * loss_out[0] (+)= [ -sum pol(b,t)*mask(b,t) + entropy_reg * sum mask0(b,t) * sum_v lp*exp(lp) ] / B with
  * mask0 = seq > 0, mask = [1, mask0[:, :-1]], pol = input*reward or the reference's PPO-clip surrogate.
@@ -631,8 +648,12 @@ int rfn_prefix_bwd_wgrad(const rfn_dims* d, int B, const float* const* att_feats
 /* Phase 2 = the teacher-forced decoder loop of forward() (misc/RecurrentFusionModel.py:257-281):
  * for s < S: xt = embed(ids[b,s]); decoder cell (misc/LSTMSoftAttentionCore.py:60-102);
  * log_prob[b,s,:] = log_softmax(logit(h)).  `ids` is (B, ld_ids) int64, column s feeds step s.
- * The caller derives S from the reference's break rule (:274). */
+ * The caller derives S from the reference's break rule (:274).
+ * log_prob may be NULL: the pass then stops at the logits, which stay in the workspace as time-major rows r = s * B + b of
+ * V1 floats (rfn_decoder_logits returns their address) -- the operand of rfn_xe_logits_fwd / _bwd, the loss-only form of
+ * the step (RecurrentFusionModel.forward_loss). */
 size_t rfn_decoder_ws_bytes(const rfn_dims* d, int B, int S, int train);
+float* rfn_decoder_logits(const rfn_dims* d, int B, int S, int train, void* ws);
 int rfn_decoder_fwd(const rfn_dims* d, int B, int S, const float* const* params, const float* comb,
                     const float* h0, const float* c0, const int64_t* ids, int64_t ld_ids,
                     float* log_prob /* (B,S,V1) */, void* ws, size_t ws_bytes, int train,
@@ -648,7 +669,8 @@ int rfn_decoder_fwd_step(const rfn_dims* d, int B, int S, int s, const float* co
                          const int64_t* ids_s, int64_t ld_ids, float* log_prob /* (B,S,V1) base */, void* ws,
                          size_t ws_bytes, int train, uint64_t seed, void* stream);
 /* d_log_prob (B,S,V1) in; d_comb (T2,B,R), d_h0, d_c0 (B,R) out (overwritten); the phase-2 slots of
- * grads[] (embed, logit, decoder.*) are overwritten. */
+ * grads[] (embed, logit, decoder.*) are overwritten.  log_prob == d_log_prob == NULL: the workspace's logits rows
+ * already hold d loss / d logits (rfn_xe_logits_bwd wrote them there). */
 int rfn_decoder_bwd(const rfn_dims* d, int B, int S, const float* const* params, const float* comb,
                     const float* h0, const float* c0, const int64_t* ids, int64_t ld_ids,
                     const float* log_prob, const float* d_log_prob, float* d_comb, float* d_h0,

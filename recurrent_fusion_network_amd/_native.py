@@ -19,6 +19,8 @@ RFN_GEMM_MAXGROUP = 8
 ABI_VERSION = 6
 PATH_OPT_PERSIST_DEC_FWD, PATH_OPT_PERSIST_S2_FWD, PATH_OPT_PERSIST_DEC_BWD, PATH_OPT_PERSIST_S2_BWD = 1, 2, 4, 8   # rfn.h
 PATH_OPT_PERSIST_ALL = 15
+PATH_OPT_DEEP_CELLS = 16          # rfn.h RFN_PATH_OPT_DEEP_CELLS (A/B hook)
+CELL_VARIANT_DEEP = 256
 GEMM_OPT_LDS_LEAN = 1
 GEMM_OPT_NO_DMA = 2
 GEMM_OPT_BF16X3 = 4
@@ -136,6 +138,9 @@ def _load():
         'rfn_div_2d': (C.c_int, [P, L, I, I, F, P]),
         'rfn_mean_over_groups': (C.c_int, [I, P, L, L, I, P, L, I, I, P]),
         'rfn_bcast_to_groups': (C.c_int, [I, F, P, L, P, P, L, L, I, I, I, P]),
+        'rfn_xe_logits_fwd': (C.c_int, [P, L, I, I, I, P, L, P, L, F, P, P, P, I, P]),
+        'rfn_xe_logits_bwd': (C.c_int, [P, L, I, I, I, P, L, P, L, F, P, F, P, P]),
+        'rfn_decoder_logits': (P, [DP, I, I, I, P]),
         'rfn_xe_loss': (C.c_int, [P, I, I, I, P, L, P, L, F, F, P, P, I, P, P]),
         'rfn_multilabel_margin': (C.c_int, [P, I, I, P, F, F, P, P, I, P, P]),
         'rfn_xe_loss_ex': (C.c_int, [P, I, I, I, P, L, P, L, F, F, P, P, P, I, P, P]),

@@ -34,7 +34,18 @@
 template <int BM, int BK, int WK, bool BKF, int EPI>
 __global__ __launch_bounds__(64 * (BM / 32) * WK) void cell_gemm_k(const CgArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    cg_tile<BM, BK, WK, BKF, EPI, false>(a, blockIdx.x, smem, [] {});
+    cg_tile<BM, BK, WK, BKF, EPI, false, false>(a, blockIdx.x, smem, [] {});
+}
+// The deep-ring form of the 32-row variant (rfn_cellgemm_body.h, DEEP; opt-in, RFN_CELL_VARIANT_DEEP): for launches whose tiles
+// do not outnumber the CUs -- every per-step product of the recurrences at B <= 64, the backward ones up to B = 256.
+// Bit-identical to cell_gemm_k<32, 64, 4, ...>; measured SLOWER in the step (C2 4.99-5.02 against 4.87-4.93 ms, C3 64.7 against
+// 64.3-64.6, profiles/r05_chain.md): the K loop itself is shorter (3.5 -> 2.4 us), but a 128 KB block no longer shares its CU
+// with the next launch's early blocks and the 28 requests per wave it puts in flight at once queue behind each other.
+#define CG_DEEP_SLOTS 8
+template <bool BKF, int EPI>
+__global__ __launch_bounds__(256) void cell_gemm_deep_k(const CgArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    cg_tile<32, 64, 4, BKF, EPI, false, true>(a, blockIdx.x, smem, [] {});
 }
 
 // ---- host side -----------------------------------------------------------------------------------------------------------
@@ -65,6 +76,7 @@ static int cg_launch(const CgArgs& a, int blocks, hipStream_t st) {
 static int cg_plan(CgPrepared& pz, int variant) {
     CgArgs& a = pz.a;
     const int force_slots = (variant >> 4) & 15;   // tools: bits 4-7 of `variant` force the ring depth
+    const bool deep = (variant & RFN_CELL_VARIANT_DEEP) != 0;
     variant &= 15;
     bool k64 = true;
     int max_iters = 0;
@@ -101,11 +113,50 @@ static int cg_plan(CgPrepared& pz, int variant) {
     a.slots = slots;
     pz.variant = variant;
     pz.blocks = t0;
+    pz.deep = deep && force_slots == 0;     // opt-in (A/B hook); tools that sweep the ring depth measure the shallow form
+    return RFN_OK;
+}
+
+struct CgDeepDev {
+    bool set[16] = {};
+    int cus[16] = {};
+};
+template <bool BKF, int EPI>
+static int cg_launch_deep(const CgPrepared& pz, hipStream_t st, bool* taken) {
+    static CgDeepDev ds;
+    *taken = false;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return RFN_ERR_LAUNCH;
+    const int di = dev & 15;
+    constexpr size_t lds = (size_t)CG_DEEP_SLOTS * (32 + CG_BN) * 64 * sizeof(float);
+    auto k = cell_gemm_deep_k<BKF, EPI>;
+    if (!ds.set[di]) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return RFN_ERR_LAUNCH;
+        if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return RFN_ERR_LAUNCH;
+        ds.cus[di] = cus;
+        ds.set[di] = true;
+    }
+    if (pz.blocks > ds.cus[di]) return RFN_OK;     // more tiles than CUs: co-resident shallow blocks hide latency better
+    CgArgs a = pz.a;
+    a.slots = CG_DEEP_SLOTS;
+    hipLaunchKernelGGL(k, dim3(pz.blocks), dim3(256), lds, st, a);
+    RFN_CHECK_LAUNCH();
+    *taken = true;
     return RFN_OK;
 }
 
 int rfn_cg_launch(const CgPrepared& pz, void* stream) {
     hipStream_t st = (hipStream_t)stream;
+    if (pz.variant == 3 && pz.deep) {
+        bool taken = false;
+        int rc;
+        if (pz.epi == CG_EPI_LSTM) rc = cg_launch_deep<true, CG_EPI_LSTM>(pz, st, &taken);
+        else if (pz.epi == CG_EPI_LSTM_BWD) rc = cg_launch_deep<false, CG_EPI_LSTM_BWD>(pz, st, &taken);
+        else if (pz.bkf) rc = cg_launch_deep<true, CG_EPI_STORE>(pz, st, &taken);
+        else rc = cg_launch_deep<false, CG_EPI_STORE>(pz, st, &taken);
+        if (rc != RFN_OK || taken) return rc;
+    }
 #define CG_CASE(BKF_, EPI_)                                                                 \
     switch (pz.variant) {                                                                   \
         case 1: return cg_launch<64, 32, 2, BKF_, EPI_>(pz.a, pz.blocks, st);                \

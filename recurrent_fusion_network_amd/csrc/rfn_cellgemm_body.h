@@ -100,8 +100,14 @@ __device__ __forceinline__ void cg_wait_vmcnt_dyn(int n) {
 // everything another block produced (the A operand, the epilogue's previous values) is requested right after it, all K steps
 // the ring holds at once: after the barrier a tile costs one round trip for its activations instead of one for the weights
 // plus one per pair of K steps.  Piece-to-slot layout, k order and epilogue are those of the launch form.
-template <int BM, int BK, int WK, bool BKF, int EPI, bool XB, typename Hook>
+//
+// DEEP (implied by XB; also used by the launch form when its tiles do not outnumber the CUs, i.e. when a block has a CU's LDS
+// to itself anyway): the ring is as deep as the launch's LDS allows (a.slots, up to 8), the two operands have cursors of their
+// own, and when the ring holds the whole K range every K step is requested up front and the K loop runs without counted
+// waits or barriers.  Same pieces in the same slots, same k order: bit-identical to the shallow form.
+template <int BM, int BK, int WK, bool BKF, int EPI, bool XB, bool DEEP, typename Hook>
 __device__ __forceinline__ void cg_tile(const CgArgs& a, const int bid, float* smem, Hook hook) {
+    static_assert(DEEP || !XB, "the cross-block form is built on the deep pipeline");
     constexpr int BN = CG_BN;
     constexpr int WM = BM / 32, W = WM * WK, T = 64 * W;
     constexpr int A_FL = BM * BK, B_FL = BN * BK, SLOT_FL = A_FL + B_FL;
@@ -191,7 +197,7 @@ __device__ __forceinline__ void cg_tile(const CgArgs& a, const int bid, float* s
             }
         }
     };
-    if constexpr (!XB) setup();
+    if constexpr (!DEEP) setup();
     auto issue = [&](int slot) {
         float* st = smem + slot * SLOT_FL;
 #pragma unroll
@@ -215,8 +221,8 @@ __device__ __forceinline__ void cg_tile(const CgArgs& a, const int bid, float* s
 
     // ---- XB: separate cursors for the two operands (the weights run ahead of the barrier) ------------------------------------
     constexpr int NA = PA / W, NB = PB / W;
-    static_assert(!XB || (PA % W == 0 && PB % W == 0), "XB: whole pieces per wave and operand");
-    uint32_t offA[XB ? NA : 1], offB[XB ? NB : 1];
+    static_assert(!DEEP || (PA % W == 0 && PB % W == 0), "DEEP: whole pieces per wave and operand");
+    uint32_t offA[DEEP ? NA : 1], offB[DEEP ? NB : 1];
     const char* curA = nullptr;
     const char* curB = nullptr;
     long curStepB = 0;
@@ -258,11 +264,15 @@ __device__ __forceinline__ void cg_tile(const CgArgs& a, const int bid, float* s
             }
         }
     };
-    auto issueA = [&](int slot) {   // the activations may be another block's output of this very launch: sc1
+    auto issueA = [&](int slot) {   // XB: the activations may be another block's output of this very launch: sc1
         float* st = smem + slot * SLOT_FL;
 #pragma unroll
-        for (int j = 0; j < NA; ++j)
-            __builtin_amdgcn_global_load_lds((cg_gbl_void*)(curA + offA[j]), (cg_lds_void*)(st + (wave + W * j) * 256), 16, 0, 16);
+        for (int j = 0; j < NA; ++j) {
+            if constexpr (XB)
+                __builtin_amdgcn_global_load_lds((cg_gbl_void*)(curA + offA[j]), (cg_lds_void*)(st + (wave + W * j) * 256), 16, 0, 16);
+            else
+                __builtin_amdgcn_global_load_lds((cg_gbl_void*)(curA + offA[j]), (cg_lds_void*)(st + (wave + W * j) * 256), 16, 0, 0);
+        }
         curA += BK * 4;
         kA += BK;
         if (kA >= segKA) {
@@ -284,12 +294,12 @@ __device__ __forceinline__ void cg_tile(const CgArgs& a, const int bid, float* s
             setupB();
         }
     };
-    const int SLx = XB ? xb_uni(a.slots) : 0;
+    const int SLx = DEEP ? xb_uni(a.slots) : 0;
     // K steps whose operands are requested up front: all of them when the ring holds the whole K range (every slot is then
     // used once and the K loop needs neither counted waits nor barriers), else what the ring has in flight
-    const bool ALLIN = XB && total_iters <= SLx;
-    const int PRE = XB ? (ALLIN ? total_iters : SLx - 1) : 0;
-    if constexpr (XB) {
+    const bool ALLIN = DEEP && total_iters <= SLx;
+    const int PRE = DEEP ? (ALLIN ? total_iters : SLx - 1) : 0;
+    if constexpr (DEEP) {
         setupA();
         setupB();
         for (int s = 0; s < PRE; ++s) issueB(s);
@@ -371,9 +381,9 @@ __device__ __forceinline__ void cg_tile(const CgArgs& a, const int bid, float* s
 
     // Ring of SL slots, SL - 1 K steps in flight: a step is a few hundred matrix-pipe cycles but a microsecond of L2 / fabric
     // latency under load, so the ring is as deep as the LDS of the blocks sharing a CU allows (host: cg_dispatch).
-    const int SL = XB ? SLx : a.slots;
+    const int SL = DEEP ? SLx : a.slots;
     int issued = 0;
-    if constexpr (XB) {
+    if constexpr (DEEP) {
         for (int s = 0; s < PRE; ++s) issueA(s);
         issued = PRE;
     } else {
@@ -406,14 +416,14 @@ __device__ __forceinline__ void cg_tile(const CgArgs& a, const int bid, float* s
         }
     };
     int cur = 0, fill = SL - 1;
-    if (ALLIN) {   // XB, whole K range resident: one wait, one barrier, then a loop the compiler can pipeline (same k order)
+    if (ALLIN) {   // DEEP, whole K range resident: one wait, one barrier, then a loop the compiler can pipeline (same k order)
         cg_wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         for (int it = 0; it < total_iters; ++it) k_step(smem + it * SLOT_FL);
     } else
     for (int it = 0; it < total_iters; ++it) {
         // this wave's pieces of step `it` have landed; the `younger` steps issued after it stay in flight
-        if constexpr (XB) {
+        if constexpr (DEEP) {
             // issue order: B of the PRE up-front steps | A of those steps | then whole steps (A, B) from inside the loop
             const int inloop = issued - PRE;                                   // whole steps issued from inside the loop
             const int younger = it < PRE ? (PRE - 1 - it) * NA + inloop * (NA + NB) : (issued - 1 - it) * (NA + NB);
@@ -430,7 +440,7 @@ __device__ __forceinline__ void cg_tile(const CgArgs& a, const int bid, float* s
         }
         __builtin_amdgcn_s_barrier();                     // ... everyone's have, and slot (it - 1) % SL is free
         if (issued < total_iters) {
-            if constexpr (XB) {
+            if constexpr (DEEP) {
                 issueA(fill);
                 issueB(fill);
             } else {

@@ -10,6 +10,7 @@ struct CgPrepared {      // rfn_cell_gemm's launch, not launched (rfn_cellgemm.h
     int blocks;          // tiles of the launch
     int epi;             // CG_EPI_*
     bool bkf;            // B operands are [n][k] (forward products)
+    bool deep;           // RFN_CELL_VARIANT_DEEP: take the deep-ring kernel when the tiles do not outnumber the CUs
 };
 int rfn_cg_prepare(int M, int nout, const rfn_cell_out* outs, int R, float drop_p, uint64_t seed, int variant, CgPrepared* pz);
 int rfn_cg_launch(const CgPrepared& pz, void* stream);

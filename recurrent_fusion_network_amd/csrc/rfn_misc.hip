@@ -802,6 +802,104 @@ extern "C" int rfn_xe_loss(const float* logp, int B, int T, int V1, const int64_
                           accumulate_loss, dlogp, stream);
 }
 
+// ---- XE language loss straight from the logits (misc/utils.py:163-184 + F.log_softmax of :276) --------------
+// The unfused pass writes log_prob (B, T, V+1), the criterion reads it back for the loss, writes d log_prob (B, T, V+1), and the
+// log-softmax backward reads both to write d logits: four passes over a 165 MB tensor at C3 that exist only because
+// `forward` has to hand `log_prob` to a caller-owned criterion (train.py:154-159).  When the caller asks for the LOSS
+// (RecurrentFusionModel.forward_loss) neither tensor is needed:
+//   forward : one pass over the time-major logits rows r = t * B + b -- the row's logsumexp (log_softmax_row: the same bits
+//             rfn_log_softmax_fwd would subtract) -> lse[r], and the row's loss term
+//             -mask * ((1 - eps) * (x[tg] - lse) + eps / V1 * (sum_v x[v] - V1 * lse)) -> row_loss[b * T + t]
+//   backward: d logits[v] = mask * g / B * (exp(x[v] - lse) - (1 - eps) * [v == tg] - eps / V1), written over the logits.
+// (sum_v d logp = -mask * g / B whatever eps is, which is what the log-softmax backward multiplies the probabilities with.)
+template <bool VEC>
+__global__ __launch_bounds__(256) void xe_logits_fwd_k(const float* __restrict__ logits, long ldl, int B, int T, int V1,
+                                                       const int64_t* __restrict__ target, long ld_t,
+                                                       const float* __restrict__ mask, long ld_m, float eps,
+                                                       float* __restrict__ lse_out, float* __restrict__ row_loss) {
+    __shared__ float red[4];
+    const int r = blockIdx.x, t = r / B, b = r - t * B;      // time-major rows
+    const float* x = logits + r * ldl;
+    lsm_f32x4 xr[LSM_R4];
+    const float lse = log_softmax_row<VEC>(x, V1, xr, red);
+    long tg = target[b * ld_t + t];
+    if (tg < 0 || tg >= V1) tg = 0;
+    const float mk = mask[b * ld_m + t];
+    float term = x[tg] - lse;
+    if (eps > 0.f) {
+        float s = 0.f;
+        if constexpr (VEC) {
+            const int n4 = V1 >> 2;
+#pragma unroll
+            for (int j = 0; j < LSM_R4; ++j)
+                if (threadIdx.x + 256 * j < n4) s += ((xr[j][0] - lse) + (xr[j][1] - lse)) + ((xr[j][2] - lse) + (xr[j][3] - lse));
+        } else {
+            for (int v = threadIdx.x; v < V1; v += 256) s += x[v] - lse;
+        }
+        s = block_sum_256(s, red);
+        term = (1.0f - eps) * term + (eps / (float)V1) * s;
+    }
+    if (threadIdx.x == 0) {
+        lse_out[r] = lse;
+        row_loss[b * T + t] = -mk * term;
+    }
+}
+template <bool VEC>
+__global__ __launch_bounds__(256) void xe_logits_bwd_k(float* __restrict__ logits, long ldl, int B, int T, int V1,
+                                                       const int64_t* __restrict__ target, long ld_t,
+                                                       const float* __restrict__ mask, long ld_m, float eps, float gcoef,
+                                                       const float* __restrict__ gdev, const float* __restrict__ lse_in) {
+    const int r = blockIdx.x, t = r / B, b = r - t * B;
+    float* x = logits + r * ldl;
+    long tg = target[b * ld_t + t];
+    if (tg < 0 || tg >= V1) tg = 0;
+    const float c = mask[b * ld_m + t] * (gdev ? gcoef * gdev[0] : gcoef);     // mask * d loss / B
+    const float lse = lse_in[r], uni = eps / (float)V1, hot = 1.0f - eps;
+    if constexpr (VEC) {
+        const int n4 = V1 >> 2;
+        for (int i = threadIdx.x; i < n4; i += 256) {
+            lsm_f32x4 v = *reinterpret_cast<const lsm_f32x4*>(x + 4 * i), o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = c * ((expf(v[e] - lse) - uni) - ((4 * i + e == tg) ? hot : 0.f));
+            *reinterpret_cast<lsm_f32x4*>(x + 4 * i) = o;
+        }
+    } else {
+        for (int v = threadIdx.x; v < V1; v += 256) x[v] = c * ((expf(x[v] - lse) - uni) - ((v == tg) ? hot : 0.f));
+    }
+}
+extern "C" int rfn_xe_logits_fwd(const float* logits, int64_t ldl, int B, int T, int V1, const int64_t* target,
+                                 int64_t ld_target, const float* mask, int64_t ld_mask, float eps, float* lse,
+                                 float* scratch, float* loss_out, int accumulate_loss, void* stream) {
+    if (B <= 0 || T <= 0 || V1 <= 0 || ldl < V1 || eps < 0.f || eps >= 1.f) return RFN_ERR_SHAPE;
+    if (!logits || !target || !mask || !lse || !scratch || !loss_out) return RFN_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (lsm_vec_ok(logits, ldl, V1, nullptr, 0, 0))
+        hipLaunchKernelGGL(xe_logits_fwd_k<true>, dim3(B * T), dim3(256), 0, st, logits, (long)ldl, B, T, V1, target,
+                           (long)ld_target, mask, (long)ld_mask, eps, lse, scratch);
+    else
+        hipLaunchKernelGGL(xe_logits_fwd_k<false>, dim3(B * T), dim3(256), 0, st, logits, (long)ldl, B, T, V1, target,
+                           (long)ld_target, mask, (long)ld_mask, eps, lse, scratch);
+    RFN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(sum_k, dim3(1), dim3(256), 0, st, scratch, B * T, 1.0f / (float)B, loss_out, accumulate_loss);
+    RFN_CHECK_LAUNCH();
+    return RFN_OK;
+}
+extern "C" int rfn_xe_logits_bwd(float* logits, int64_t ldl, int B, int T, int V1, const int64_t* target, int64_t ld_target,
+                                 const float* mask, int64_t ld_mask, float eps, const float* lse, float gscale,
+                                 const float* gscale_dev, void* stream) {
+    if (B <= 0 || T <= 0 || V1 <= 0 || ldl < V1 || eps < 0.f || eps >= 1.f) return RFN_ERR_SHAPE;
+    if (!logits || !target || !mask || !lse) return RFN_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (lsm_vec_ok(logits, ldl, V1, nullptr, 0, 0))
+        hipLaunchKernelGGL(xe_logits_bwd_k<true>, dim3(B * T), dim3(256), 0, st, logits, (long)ldl, B, T, V1, target,
+                           (long)ld_target, mask, (long)ld_mask, eps, gscale / (float)B, gscale_dev, lse);
+    else
+        hipLaunchKernelGGL(xe_logits_bwd_k<false>, dim3(B * T), dim3(256), 0, st, logits, (long)ldl, B, T, V1, target,
+                           (long)ld_target, mask, (long)ld_mask, eps, gscale / (float)B, gscale_dev, lse);
+    RFN_CHECK_LAUNCH();
+    return RFN_OK;
+}
+
 // ---- RL reward criterion, policy + entropy terms (misc/utils.py:50-72) ------------------------------------
 // One block per (b, t) row:  term = -pol(b,t) * mask(b,t) + entropy_reg * mask0(b,t) * sum_v lp*exp(lp),
 // mask0 = seq > 0, mask = [1, mask0[:, :-1]] (the step AFTER an END still counts), pol = input*reward or the

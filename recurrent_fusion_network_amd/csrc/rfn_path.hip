@@ -251,12 +251,14 @@ bool cell_ok(int B, int n, const rfn_cell_out* outs, int R) {
         if (outs[i].nseg > RFN_CELL_MAXSEG) return false;
     return n <= RFN_CELL_MAXOUT && rfn_cell_gemm_supported(B, n, outs, R) != 0;
 }
-int cell_run(int B, int n, const rfn_cell_out* outs, int R, float drop_p, uint64_t seed, void* st) {
-    return rfn_cell_gemm(B, n, outs, R, drop_p, seed, 0, st);
+// variant: 0, or RFN_CELL_VARIANT_DEEP from cell_variant(d) (A/B hook: few-tile launches on the deep-ring kernel)
+int cell_run(int B, int n, const rfn_cell_out* outs, int R, float drop_p, uint64_t seed, void* st, int variant) {
+    return rfn_cell_gemm(B, n, outs, R, drop_p, seed, variant, st);
 }
+inline int cell_variant(const rfn_dims* d) { return (d->path_flags & RFN_PATH_OPT_DEEP_CELLS) ? RFN_CELL_VARIANT_DEEP : 0; }
 // the same launch prepared instead of launched: one phase of a recurrence-chain step (rfn_chain.hip)
-int cell_prepare(int B, int n, const rfn_cell_out* outs, int R, float drop_p, uint64_t seed, CgPrepared* pz) {
-    return rfn_cg_prepare(B, n, outs, R, drop_p, seed, 0, pz);
+int cell_prepare(int B, int n, const rfn_cell_out* outs, int R, float drop_p, uint64_t seed, CgPrepared* pz, int variant) {
+    return rfn_cg_prepare(B, n, outs, R, drop_p, seed, variant, pz);
 }
 inline int chain_persist(const rfn_dims* d, uint32_t which) { return (d->path_flags & which) ? 1 : 0; }
 
@@ -643,7 +645,7 @@ static int prefix_fwd_impl(const rfn_dims* d, int B, const float* const* prm, co
             cell_lin(k0[i], fc[i], d->F[i], prm[P.fc_w(i)], d->F[i], d->F[i], prm[P.fc_b(i)]);
         }
         if (cell_ok(B, M, k0, R)) {   // the M fc2h products in one launch
-            RFN_TRY(cell_run(B, M, k0, R, 0.f, 0, st));
+            RFN_TRY(cell_run(B, M, k0, R, 0.f, 0, st, cell_variant(d)));
         } else {
             for (int i = 0; i < M; ++i)
                 RFN_TRY(gemm1(B, R, seg_lin(fc[i], d->F[i], prm[P.fc_w(i)], d->F[i], d->F[i], prm[P.fc_b(i)]), Hs + i * R,
@@ -701,7 +703,7 @@ static int prefix_fwd_impl(const rfn_dims* d, int B, const float* const* prm, co
                 cell_lin(k1[i], Hc + i * R, MR, prm[P.s1(t, i, 2)], R, R, prm[P.s1(t, i, 3)]);
             }
             if (cell_ok(B, M, k1, R)) {
-                RFN_TRY(cell_run(B, M, k1, R, 0.f, 0, st));
+                RFN_TRY(cell_run(B, M, k1, R, 0.f, 0, st, cell_variant(d)));
             } else {
                 for (int i = 0; i < M; ++i)
                     pr[i] = prob1(hp + (long)i * B * A, A,
@@ -843,10 +845,10 @@ static int prefix_fwd_impl(const rfn_dims* d, int B, const float* const* prm, co
             a_al[i] = al + (long)i * B * T1;
             a_z[i] = z + i * BR;
         }
-        return cell_prepare(B, M + 1, k1, R, 0.f, 0, &cs->g0) == RFN_OK &&
+        return cell_prepare(B, M + 1, k1, R, 0.f, 0, &cs->g0, cell_variant(d)) == RFN_OK &&
                rfn_attn_small_prepare_fwd(M, a_p, (long)T2 * A, (long)B * T2 * A, a_hp, a_w, a_b, a_x, MR, BMR, B, T1, A, R, a_al, a_z,
                                           R, &cs->at) == RFN_OK &&
-               cell_prepare(B, 1, &k3, R, d->drop_reason, seed, &cs->g2) == RFN_OK;
+               cell_prepare(B, 1, &k3, R, d->drop_reason, seed, &cs->g2, cell_variant(d)) == RFN_OK;
     };
     bool s2_chained = false;
     {
@@ -881,7 +883,7 @@ static int prefix_fwd_impl(const rfn_dims* d, int B, const float* const* prm, co
         cell_lstm(k3, cc, R, cn, R, hn, R, OFF_STAGE2 + (uint64_t)t);
         const bool fused = !d->review_maxout && cell_ok(B, M + 1, k1, R) && cell_ok(B, 1, &k3, R);
         if (fused) {
-            RFN_TRY(cell_run(B, M + 1, k1, R, 0.f, 0, st));
+            RFN_TRY(cell_run(B, M + 1, k1, R, 0.f, 0, st, cell_variant(d)));
         } else {
             for (int i = 0; i < M; ++i)
                 pr[i] = prob1(hp + (long)i * B * A, A, seg_lin(hc, R, prm[P.s2(t, i, 4)], R, R, prm[P.s2(t, i, 5)]));
@@ -905,7 +907,7 @@ static int prefix_fwd_impl(const rfn_dims* d, int B, const float* const* prm, co
                                        R, a_al, a_z, R, st));
         }
         if (fused) {
-            RFN_TRY(cell_run(B, 1, &k3, R, d->drop_reason, seed, st));
+            RFN_TRY(cell_run(B, 1, &k3, R, d->drop_reason, seed, st, cell_variant(d)));
         } else {
             RFN_TRY(gemm_segs(B, G2, M + 1, segs, g, G2, 0, gx));
             RFN_TRY(rfn_lstm_fwd(g, G2, cc, R, cn, R, hn, R, B, R, d->review_maxout, d->drop_reason, seed,
@@ -1045,10 +1047,10 @@ extern "C" int rfn_prefix_bwd(const rfn_dims* d, int B, const float* const* prm,
                 a_dw[i] = dwp + ((long)t * M + i) * BA;
                 a_dx[i] = dHs + BMR + i * R;
             }
-            ok = cell_prepare(B, M + 1, kb1, R, 0.f, 0, &cs.g0) == RFN_OK &&
+            ok = cell_prepare(B, M + 1, kb1, R, 0.f, 0, &cs.g0, cell_variant(d)) == RFN_OK &&
                  rfn_attn_small_prepare_bwd(M, a_p, (long)T2 * A, (long)B * T2 * A, a_hp, a_w, a_al, a_x, MR, BMR, a_dz, R, B, T1, A, R,
                                             a_dp, (long)T2 * A, (long)B * T2 * A, 0, a_dhp, a_dw, a_dx, &cs.at) == RFN_OK &&
-                 cell_prepare(B, 1, &kb2, R, d->drop_reason, seed, &cs.g2) == RFN_OK;
+                 cell_prepare(B, 1, &kb2, R, d->drop_reason, seed, &cs.g2, cell_variant(d)) == RFN_OK;
         }
         if (ok) {
             RFN_TRY(rfn_chain_run(steps.data(), T2 - 1, chain_persist(d, RFN_PATH_OPT_PERSIST_S2_BWD), (uint32_t*)(W + Lo.bar), st));
@@ -1077,7 +1079,7 @@ extern "C" int rfn_prefix_bwd(const rfn_dims* d, int B, const float* const* prm,
         } else {
             rfn_cell_out kb1[RFN_MAX_ENC + 1];
             s2_kb1(t, kb1);
-            RFN_TRY(cell_run(B, M + 1, kb1, R, 0.f, 0, st));
+            RFN_TRY(cell_run(B, M + 1, kb1, R, 0.f, 0, st, cell_variant(d)));
         }
         {   // whole attention backward of the M encoders in one fused launch (dP overwrites P in place)
             const float *a_p[RFN_MAX_ENC], *a_hp[RFN_MAX_ENC], *a_w[RFN_MAX_ENC], *a_al[RFN_MAX_ENC], *a_x[RFN_MAX_ENC],
@@ -1104,7 +1106,7 @@ extern "C" int rfn_prefix_bwd(const rfn_dims* d, int B, const float* const* prm,
         } else {
             rfn_cell_out kb2;
             s2_kb2(t, kb2);
-            RFN_TRY(cell_run(B, 1, &kb2, R, d->drop_reason, seed, st));
+            RFN_TRY(cell_run(B, 1, &kb2, R, d->drop_reason, seed, st, cell_variant(d)));
         }
     }
     // weight gradients of stage II, grouped over steps; every bias gradient rides on the GEMM that streams
@@ -1189,7 +1191,7 @@ extern "C" int rfn_prefix_bwd(const rfn_dims* d, int B, const float* const* prm,
                 cell_dx(kz[i], g + (long)i * B * 4 * R, 4 * R, prm[P.s1(t, i, 8)], d->D[i], 4 * R);
             }
             if (cell_ok(B, M, kz, R)) {
-                RFN_TRY(cell_run(B, M, kz, R, 0.f, 0, st));
+                RFN_TRY(cell_run(B, M, kz, R, 0.f, 0, st, cell_variant(d)));
                 dz_done = true;
             }
         }
@@ -1281,7 +1283,7 @@ extern "C" int rfn_prefix_bwd(const rfn_dims* d, int B, const float* const* prm,
                 kb[i] = cell_out(dHc + i * R, MR, R, 1);
                 cell_dx(kb[i], dhp + i * BA, A, prm[P.s1(t, i, 2)], R, A);
             }
-            if (cell_ok(B, M, kb, R)) RFN_TRY(cell_run(B, M, kb, R, 0.f, 0, st));
+            if (cell_ok(B, M, kb, R)) RFN_TRY(cell_run(B, M, kb, R, 0.f, 0, st, cell_variant(d)));
             else RFN_TRY(gemm_groups(B, R, M, pr, 1, gx));
         }
     }
@@ -1448,9 +1450,9 @@ static bool decoder_cell_prepare(const rfn_dims* d, int B, const float* const* p
     cell_lstm(k3, c, R, c_next, R, h_next, R, OFF_DECODER + (uint64_t)step);
     if (!cell_ok(B, 2, k1, R) || !cell_ok(B, 1, &k3, R)) return false;
     const float *w = prm[P.dec(10)], *bo = prm[P.dec(11)];
-    return cell_prepare(B, 2, k1, R, 0.f, 0, &cs->g0) == RFN_OK &&
+    return cell_prepare(B, 2, k1, R, 0.f, 0, &cs->g0, cell_variant(d)) == RFN_OK &&
            rfn_attn_small_prepare_fwd(1, &cproj, A, BA, &hp, &w, &bo, &comb, R, BR, B, T2, A, R, &al, &z, R, &cs->at) == RFN_OK &&
-           cell_prepare(B, 1, &k3, R, d->drop_lm, seed, &cs->g2) == RFN_OK;
+           cell_prepare(B, 1, &k3, R, d->drop_lm, seed, &cs->g2, cell_variant(d)) == RFN_OK;
 }
 
 static int decoder_cell_core(const rfn_dims* d, int B, const float* const* prm, const float* comb, const float* cproj,
@@ -1526,7 +1528,7 @@ extern "C" int rfn_decoder_fwd(const rfn_dims* d, int B, int S, const float* con
                                void* ws, size_t ws_bytes, int train, uint64_t seed, void* st) {
     RFN_TRY(check_dims(d));
     if (B < 1 || S < 1) return RFN_ERR_SHAPE;
-    if (!prm || !comb || !h0 || !c0 || !ids || !log_prob || !ws) return RFN_ERR_ARG;
+    if (!prm || !comb || !h0 || !c0 || !ids || !ws) return RFN_ERR_ARG;
     const DecoderLayout Lo = decoder_layout(d, B, S, train);
     if (ws_bytes < Lo.total * sizeof(float)) return RFN_ERR_WORKSPACE;
     const PIdx P(d);
@@ -1551,8 +1553,13 @@ extern "C" int rfn_decoder_fwd(const rfn_dims* d, int B, int S, const float* con
     }
     // logits of all steps, then log-softmax written in the reference's (B, S, V+1) layout
     RFN_TRY(gemm_logits(S * B, V1, W + Lo.hd + (long)B * R, R, prm[P.logit_w()], prm[P.logit_b()], W + Lo.logits, gx_whole));
-    RFN_TRY(rfn_log_softmax_fwd(W + Lo.logits, V1, S * B, V1, B, (long)S * V1, V1, log_prob, st));
-    return RFN_OK;
+    if (log_prob) RFN_TRY(rfn_log_softmax_fwd(W + Lo.logits, V1, S * B, V1, B, (long)S * V1, V1, log_prob, st));
+    return RFN_OK;      // log_prob == NULL: the logits stay in the workspace for rfn_xe_logits_fwd (rfn_decoder_logits)
+}
+
+extern "C" float* rfn_decoder_logits(const rfn_dims* d, int B, int S, int train, void* ws) {
+    if (check_dims(d) != RFN_OK || B < 1 || S < 1 || !ws) return nullptr;
+    return (float*)ws + decoder_layout(d, B, S, train).logits;
 }
 
 // Step-wise form of the same pass for scheduled sampling (misc/RecurrentFusionModel.py:260-270): the token fed at
@@ -1598,7 +1605,7 @@ extern "C" int rfn_decoder_bwd(const rfn_dims* d, int B, int S, const float* con
                                float* d_c0, float* const* grd, void* ws, size_t ws_bytes, uint64_t seed, void* st) {
     RFN_TRY(check_dims(d));
     if (B < 1 || S < 1) return RFN_ERR_SHAPE;
-    if (!prm || !comb || !ids || !log_prob || !d_log_prob || !d_comb || !d_h0 || !d_c0 || !grd || !ws)
+    if (!prm || !comb || !ids || (!log_prob != !d_log_prob) || !d_comb || !d_h0 || !d_c0 || !grd || !ws)
         return RFN_ERR_ARG;
     (void)h0; (void)c0;
     const DecoderLayout Lo = decoder_layout(d, B, S, 1);
@@ -1622,7 +1629,8 @@ extern "C" int rfn_decoder_bwd(const rfn_dims* d, int B, int S, const float* con
     float* dz = W + Lo.dz;
     float* dPd = W + Lo.dPd;
     // log-softmax backward into time-major rows, then the batched logit layer
-    RFN_TRY(rfn_log_softmax_bwd(d_log_prob, log_prob, S * B, V1, B, (long)S * V1, V1, dlg, V1, st));
+    // (no log_prob: rfn_xe_logits_bwd already turned the logits rows into d logits)
+    if (d_log_prob) RFN_TRY(rfn_log_softmax_bwd(d_log_prob, log_prob, S * B, V1, B, (long)S * V1, V1, dlg, V1, st));
     RFN_TRY(gemm_logits_dw(V1, R, grd[P.logit_w()], grd[P.logit_b()], dlg, hd + BR, S * B, gx));
     RFN_TRY(gemm_logits_dx(S * B, R, V1, dlg, prm[P.logit_w()], dhe, gx));
     RFN_TRY(mem_batch({{d_comb, nullptr, (long)T2 * BR}, {dPd, nullptr, (long)T2 * BA}}, st));
@@ -1669,10 +1677,10 @@ extern "C" int rfn_decoder_bwd(const rfn_dims* d, int B, int S, const float* con
             const float *proj = W + Lo.Pd, *hp = W + Lo.hpd + s * BA, *w = prm[P.dec(10)], *al = W + Lo.ald + (long)s * B * T2;
             const float* dzc = dz;
             float *dpr = dPd, *dhp = W + Lo.dhpd + s * BA, *dwp = W + Lo.dwp + s * BA, *dxc = d_comb;
-            ok = cell_prepare(B, 2, kb1, R, 0.f, 0, &cs.g0) == RFN_OK &&
+            ok = cell_prepare(B, 2, kb1, R, 0.f, 0, &cs.g0, cell_variant(d)) == RFN_OK &&
                  rfn_attn_small_prepare_bwd(1, &proj, A, BA, &hp, &w, &al, &comb, R, BR, &dzc, R, B, T2, A, R, &dpr, A, BA, 1, &dhp,
                                             &dwp, &dxc, &cs.at) == RFN_OK &&
-                 cell_prepare(B, 1, &kb2, R, d->drop_lm, seed, &cs.g2) == RFN_OK;
+                 cell_prepare(B, 1, &kb2, R, d->drop_lm, seed, &cs.g2, cell_variant(d)) == RFN_OK;
         }
         if (ok) {
             RFN_TRY(rfn_chain_run(steps.data(), S - 1, chain_persist(d, RFN_PATH_OPT_PERSIST_DEC_BWD), (uint32_t*)(W + Lo.bar), st));
@@ -1687,11 +1695,11 @@ extern "C" int rfn_decoder_bwd(const rfn_dims* d, int B, int S, const float* con
         if (fused) {
             rfn_cell_out kb1[2], kb2;
             dec_kb1(s, kb1);
-            RFN_TRY(cell_run(B, 2, kb1, R, 0.f, 0, st));
+            RFN_TRY(cell_run(B, 2, kb1, R, 0.f, 0, st, cell_variant(d)));
             RFN_TRY(attn1_bwd(W + Lo.Pd, A, BA, W + Lo.hpd + s * BA, prm[P.dec(10)], al, comb, R, BR, dz, R, B, T2, A, R,
                               dPd, A, BA, 1, dhp, W + Lo.dwp + s * BA, d_comb, st));
             dec_kb2(s, kb2);
-            RFN_TRY(cell_run(B, 1, &kb2, R, d->drop_lm, seed, st));
+            RFN_TRY(cell_run(B, 1, &kb2, R, d->drop_lm, seed, st, cell_variant(d)));
             continue;
         }
         if (s < S - 1) RFN_TRY(rfn_axpby_2d(1.f, dhrec, R, 1.f, dht, R, B, R, st));

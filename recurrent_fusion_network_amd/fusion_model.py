@@ -260,6 +260,73 @@ class _DecoderFn(torch.autograd.Function):
         return (None, None, None, None, None, d_comb, d_h0, d_c0, None, None) + (None,) * len(ctx.params)
 
 
+class _DecoderLossFn(torch.autograd.Function):
+    """Phase 2 + the language term of the XE criterion as ONE autograd node: rfn_decoder_fwd stops at the
+    logits (time-major rows in the workspace), rfn_xe_logits_fwd turns them into the masked (label-smoothed) NLL and the rows'
+    logsumexps; backward writes d logits over the logits (rfn_xe_logits_bwd, scaled by the upstream gradient read on the
+    device) and rfn_decoder_bwd runs from there.  Neither log_prob (B, S, V+1) nor its gradient is ever materialised
+    (misc/RecurrentFusionModel.py:276 + misc/utils.py:163-184)."""
+
+    @staticmethod
+    def forward(ctx, model, save_bwd, drop, seed, ids, target, mask, eps, comb, h0, c0, *params):
+        d = model._dims_for(drop)
+        B, S = ids.shape
+        dev = comb.device
+        comb, h0, c0, ids = comb.contiguous(), h0.contiguous(), c0.contiguous(), ids.contiguous()
+        table = model._param_table(params, model._decoder_slots)
+        train = bool(save_bwd)
+        ws_bytes = N.lib.rfn_decoder_ws_bytes(C.byref(d), B, S, int(train))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        st = N.stream_ptr()
+        N.check(N.lib.rfn_decoder_fwd(C.byref(d), B, S, table, comb.data_ptr(), h0.data_ptr(), c0.data_ptr(), ids.data_ptr(),
+                                      ids.stride(0), None, ws.data_ptr(), ws_bytes, int(train), seed, st), 'rfn_decoder_fwd')
+        logits = N.lib.rfn_decoder_logits(C.byref(d), B, S, int(train), ws.data_ptr())
+        lse = torch.empty(S * B, device=dev)
+        scratch = torch.empty(B * S, device=dev)
+        loss = torch.zeros(1, device=dev)
+        N.check(N.lib.rfn_xe_logits_fwd(logits, d.V1, B, S, d.V1, target.data_ptr(), target.stride(0), mask.data_ptr(),
+                                        mask.stride(0), float(eps), lse.data_ptr(), scratch.data_ptr(), loss.data_ptr(), 0, st),
+                'rfn_xe_logits_fwd')
+        if train:
+            ctx.model, ctx.seed, ctx.B, ctx.S, ctx.drop, ctx.eps = model, seed, B, S, drop, float(eps)
+            ctx.ids, ctx.target, ctx.mask, ctx.params, ctx.consumed = ids, target, mask, params, False
+            ctx.save_for_backward(comb, h0, c0, lse, ws)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        model, B, S = ctx.model, ctx.B, ctx.S
+        comb, h0, c0, lse, ws = ctx.saved_tensors
+        d = model._dims_for(ctx.drop)
+        dev = comb.device
+        st = N.stream_ptr()
+        table = model._param_table(ctx.params, model._decoder_slots)
+        flats, by_slot, gtable = model._grad_buffers(['decoder'], dev)
+        if ctx.consumed:
+            # the first backward turned the logits into their gradient and the activations into theirs: a second backward over
+            # the same graph recomputes the pass first (same inputs, same dropout seed, the weights as they are now)
+            N.check(N.lib.rfn_decoder_fwd(C.byref(d), B, S, table, comb.data_ptr(), h0.data_ptr(), c0.data_ptr(),
+                                          ctx.ids.data_ptr(), ctx.ids.stride(0), None, ws.data_ptr(), ws.numel(), 1, ctx.seed, st),
+                    'rfn_decoder_fwd (recompute)')
+            lse = torch.empty_like(lse)
+            tmp, junk = torch.empty(B * S, device=dev), torch.zeros(1, device=dev)
+            N.check(N.lib.rfn_xe_logits_fwd(N.lib.rfn_decoder_logits(C.byref(d), B, S, 1, ws.data_ptr()), d.V1, B, S, d.V1,
+                                            ctx.target.data_ptr(), ctx.target.stride(0), ctx.mask.data_ptr(), ctx.mask.stride(0),
+                                            ctx.eps, lse.data_ptr(), tmp.data_ptr(), junk.data_ptr(), 0, st), 'rfn_xe_logits_fwd')
+        ctx.consumed = True
+        g = g.contiguous().float()
+        logits = N.lib.rfn_decoder_logits(C.byref(d), B, S, 1, ws.data_ptr())
+        N.check(N.lib.rfn_xe_logits_bwd(logits, d.V1, B, S, d.V1, ctx.target.data_ptr(), ctx.target.stride(0),
+                                        ctx.mask.data_ptr(), ctx.mask.stride(0), ctx.eps, lse.data_ptr(), 1.0, g.data_ptr(), st),
+                'rfn_xe_logits_bwd')
+        d_comb, d_h0, d_c0 = torch.empty_like(comb), torch.empty_like(h0), torch.empty_like(c0)
+        N.check(N.lib.rfn_decoder_bwd(C.byref(d), B, S, table, comb.data_ptr(), h0.data_ptr(), c0.data_ptr(),
+                                      ctx.ids.data_ptr(), ctx.ids.stride(0), None, None, d_comb.data_ptr(), d_h0.data_ptr(),
+                                      d_c0.data_ptr(), gtable, ws.data_ptr(), ws.numel(), ctx.seed, st), 'rfn_decoder_bwd')
+        model._bucket_done('decoder', flats['decoder'])
+        return (None,) * 8 + (d_comb, d_h0, d_c0) + (None,) * len(ctx.params)
+
+
 class RecurrentFusionModel(nn.Module):
     def __init__(self, opt):
         super().__init__()
@@ -551,6 +618,42 @@ class RecurrentFusionModel(nn.Module):
             comb, h, c, reason = self._prefix(fc_feats, att_feats, train, seed)
         log_prob = self._decode_teacher_forced(seq[:, :S], comb, h, c, train, seed, self.ss_prob)
         return log_prob, list(reason.unbind(0))
+
+    def forward_loss(self, fc_feats, att_feats, seq, masks, top_words, crit, reason_weight=1.0):
+        """The XE train step's forward AND criterion in one call (opt-in) ->
+        (loss, reason_pred): the value and the gradients of
+            log_prob, reason_pred = model(fc_feats, att_feats, seq)
+            loss = crit(log_prob, seq[:, 1:], masks[:, 1:], reason_pred, top_words, reason_weight)     (train.py:154-159)
+        with `crit` a ReviewNetEnsembleCriterion (its label-smoothing setting is honoured), without the (B, T, V+1) log_prob
+        tensor, its gradient and the four passes over them: the language term comes straight from the logits and its
+        backward writes d logits in place (rfn_xe_logits_fwd / _bwd).  Equal to the two-call form to rounding (the row
+        logsumexp is the same; the loss terms are summed in the same order).  Scheduled sampling needs the per-step
+        distributions and takes the two-call form."""
+        from .criteria import _MLMFn
+        if self.ss_prob > 0:
+            log_prob, reason = self.forward(fc_feats, att_feats, seq)
+            return crit(log_prob, seq[:, 1:], masks[:, 1:], reason, top_words, reason_weight), reason
+        train = bool(self.training)
+        seed = _fresh_seed() if train else 0
+        S = self._decoder_steps(seq)
+        if seq.size(1) < S + 1 or masks.size(1) < S + 1:
+            raise N.RfnError('labels / masks need %d columns for %d decoder steps' % (S + 1, S))
+        if int(self.dedup_seq_per_img) > 1:
+            raise N.RfnError('forward_loss does not combine with dedup_seq_per_img; use forward() + the criterion')
+        dev = fc_feats[0].device
+        comb, h, c, reason = self._prefix(fc_feats, att_feats, train, seed)
+        seq = seq.to(dev).long()
+        masks = masks.to(dev).float()
+        if seq.stride(1) != 1:
+            seq = seq.contiguous()
+        if masks.stride(1) != 1:
+            masks = masks.contiguous()
+        eps = float(crit.label_smoothing_epsilon) if crit.use_label_smoothing else 0.0
+        params = self._params_of(self._decoder_slots)
+        lang = _DecoderLossFn.apply(self, torch.is_grad_enabled(), train, seed, seq[:, :S], seq[:, 1:S + 1], masks[:, 1:S + 1], eps,
+                                    comb, h, c, *params)
+        heads = list(reason.unbind(0))
+        return lang + _MLMFn.apply(float(reason_weight) / len(heads), top_words, *heads), heads
 
     def _decoder_steps(self, seq):
         """Number of decoder steps: the reference breaks at the first all-zero column i >= 1 (:274).  The

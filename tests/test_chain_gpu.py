@@ -86,3 +86,26 @@ def test_persistent_chains_at_the_c2_shape_run_after_run(dev, B):
     model.path_flags = N.PATH_OPT_PERSIST_ALL
     for rnd in range(12):
         _assert_same(_step(model, crit, batch), want, 'B=%d run %d' % (B, rnd))
+
+
+@pytest.mark.parametrize('name', ['mid', 'c2', 'c3'])
+def test_deep_ring_cell_products_match_the_shallow_kernel_bit_for_bit(dev, name):
+    """RFN_PATH_OPT_DEEP_CELLS (A/B hook) puts per-step products whose tiles do not outnumber the CUs -- all of them at the
+    golden tiers' batch sizes -- on the deep-ring kernel (8 slots, the whole K range of K <= 512 in flight, barrier-free K
+    loop; csrc/rfn_cellgemm.hip cell_gemm_deep_k) instead of the 3-slot kernel: same pieces, same k order, so forward, loss,
+    every gradient and the greedy decode agree bit for bit."""
+    import recurrent_fusion_network_amd as R
+    N = R._native
+    cfg, spec, P, batch, gold = load_case(name)
+    batch = to_dev(batch, dev)
+    crit = R.ReviewNetEnsembleCriterion(cfg)
+    shallow = build(cfg, P, dev, train=True)
+    deep = build(cfg, P, dev, train=True)
+    deep.path_flags = N.PATH_OPT_DEEP_CELLS
+    _assert_same(_step(deep, crit, batch), _step(shallow, crit, batch), name)
+    shallow.eval()
+    deep.eval()
+    with torch.no_grad():
+        a = shallow.sample(batch[0], batch[1], {'sample_max': 1})
+        b = deep.sample(batch[0], batch[1], {'sample_max': 1})
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
