@@ -56,6 +56,7 @@ class FusedClampAdam:
             self.flat[name] = dict(p=buf, m=torch.zeros(hi - lo, device=buf.device), v=torch.zeros(hi - lo, device=buf.device),
                                    n=total, lo=lo, hi=hi)
         self._gathers = {'prefix': [], 'decoder': []}
+        self._updated_early = set()
         self.reduced_shards = {}        # bucket -> this rank's summed gradient shard (parallel.GradSync(shard_optimizer=True))
         if self.shard_world > 1:
             model.param_wait_hook = self.wait_params
@@ -212,9 +213,10 @@ class FusedClampAdam:
         self.step_count += 1
         self.model._weights_epoch = getattr(self.model, '_weights_epoch', 0) + 1   # invalidates reuse_prefix entries
         todo, names = [], []
+        early, self._updated_early = self._updated_early, set()
         for name, st in self.flat.items():
             g = self.model._last_flat_grads.get(name)
-            if g is None:
+            if g is None or name in early:          # early: update_bucket_early() already ran this step's update of it
                 continue
             if g.numel() != st['n']:
                 raise N.RfnError('flat gradient layout changed')
@@ -244,6 +246,22 @@ class FusedClampAdam:
                                                   N.stream_ptr()), 'rfn_adam_step_multi')
         if self.shard_world > 1:
             self._gather_params(names)
+
+    def update_bucket_early(self, name, grad_shard, grad_scale):
+        """Sharded update of ONE bucket the moment its summed gradient shard is there -- from inside backward, on the caller's
+        current (side) stream: clamp + Adam on this rank's shard with the scalars of the step that the coming step() will
+        count, then the all-gather of the bucket's parameters.  Nothing in the rest of backward reads a bucket's parameters
+        once its gradients are complete (backward hands the buckets over in that order), so the exchange of bucket k and its
+        update run under the weight-gradient GEMMs of the buckets after it; step() then only counts the step."""
+        g0, st = self.param_groups[0], self.flat[name]
+        part = dict(p=st['p'][st['lo']:st['hi']], m=st['m'], v=st['v'], n=st['hi'] - st['lo'])
+        sizes = (C.c_int64 * 1)(part['n'])
+        N.check(N.lib.rfn_adam_step_multi(1, N.ptr_array([part['p']]), N.ptr_array([grad_shard]), N.ptr_array([part['m']]),
+                                          N.ptr_array([part['v']]), sizes, g0['lr'], g0['betas'][0], g0['betas'][1], g0['eps'],
+                                          g0['weight_decay'], g0['grad_clip'], grad_scale, self.step_count + 1, N.stream_ptr()),
+                'rfn_adam_step_multi')
+        self._updated_early.add(name)
+        self._gather_params([name])
 
     # ---- sharded update: parameters back to every rank ---------------------------------------------------------------
     def _gather_params(self, names):

@@ -106,6 +106,12 @@ class GradSync:
         self.sharded = shard_optimizer
         if shard_optimizer is not None and shard_optimizer.shard_world != max(1, world):
             raise ValueError('the optimizer shards over %d ranks, the exchange runs over %d' % (shard_optimizer.shard_world, world))
+        # sharded update, pipelined: bucket k's reduce-scatter, its 1/world update and the all-gather of its parameters run
+        # on a side stream under the rest of backward (FusedClampAdam.update_bucket_early); the compute stream meets them
+        # again where the next forward first reads parameters (model.param_wait_hook)
+        self.side = None
+        if shard_optimizer is not None and shard_optimizer.shard_world > 1 and torch.cuda.is_available():
+            self.side = torch.cuda.Stream()
         self.works = []
         self.buckets = []
         # exposed-wait bookkeeping (bench.py `exposed_ms`): off unless `record` is set.  On the nccl backend a wait() only
@@ -125,11 +131,19 @@ class GradSync:
         self.buckets.append(name)
         if self.world > 1 or (dist.is_available() and dist.is_initialized()):
             opt = self.sharded
-            if opt is not None and opt.shard_world > 1 and dist.get_backend(opt.group) == 'nccl':
+            if opt is not None and opt.shard_world > 1 and flat.is_cuda:
                 st = opt.flat[name]
-                out = torch.empty(st['hi'] - st['lo'], device=flat.device, dtype=flat.dtype)
-                self.works.append(dist.reduce_scatter_tensor(out, flat, op=dist.ReduceOp.SUM, group=opt.group, async_op=True))
-                opt.reduced_shards[name] = out
+                main = torch.cuda.current_stream(flat.device)
+                self.side.wait_stream(main)               # the kernels that finish this bucket are queued on `main`
+                flat.record_stream(self.side)
+                with torch.cuda.stream(self.side):
+                    if dist.get_backend(opt.group) == 'nccl':
+                        shard = torch.empty(st['hi'] - st['lo'], device=flat.device, dtype=flat.dtype)
+                        dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.SUM, group=opt.group)
+                    else:                                 # no reduce-scatter on this backend (gloo): all-reduce, read the slice
+                        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=opt.group)
+                        shard = flat[st['lo']:st['hi']]
+                    opt.update_bucket_early(name, shard, 1.0 / self.world)
             else:
                 self.works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True))
 

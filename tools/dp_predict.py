@@ -11,6 +11,12 @@ the step, decoder bucket at 53 %, core at 60 %, the encoders' big buckets (a) at
 because every phase scales with the batch except Adam.  BW: 153 GB/s = one xGMI link (a single ring, the pessimistic
 end), 7 x 153 GB/s = all links of the fully connected node (the optimistic end).
 
+Sharded update (round 5: FusedClampAdam(shard=...), bench.py --shard-optimizer): bucket k is reduce-scattered ((N-1)/N of its
+bytes), the rank updates its 1/N of it (the measured 10.9 GB launch, ADAM_MS, becomes ADAM_MS / N spread over the buckets) and
+the bucket's parameters are all-gathered ((N-1)/N of the bytes again) -- all three on a side stream under the rest of backward,
+bucket after bucket in the order backward finishes them; what is still running when backward ends is exposed.  Printed as a
+second table beside the all-reduce path.
+
     python tools/dp_predict.py [profiles/r03_shards.jsonl]
 """
 import json
@@ -64,3 +70,38 @@ for n in (1, 2, 4, 8):
         fmt = lambda r: '%.1f / %.1f (exposed %.1f / %.1f)' % (r[0][0], r[1][0], r[0][1], r[1][1])  # noqa: E731
         print('| %d | %s | %d | %.1f / %.1f | %s | %s | %s | %.0f / %.0f |' % (
             n, kind, b, ex, x3, fmt(lo), fmt(mid), fmt(hi), n * b / mid[0][0] * 1e3, n * b / hi[0][0] * 1e3))
+
+
+# ---- sharded update -----------------------------------------------------------------------------------------------------------
+ADAM_MS = 2.3            # the clamp+Adam launch over all 390 M parameters (2.0-2.45 ms by box, profiles/r05_pmc_step.md)
+PREFIX_BYTES = sum(sz for name, sz, _ in BUCKETS if name != 'decoder')
+
+
+def step_ms_sharded(compute_ms, n, bw):
+    """(step, exposed) in ms with the update sharded over n ranks and pipelined under backward."""
+    if n == 1:
+        return compute_ms, 0.0
+    body = compute_ms - ADAM_MS                       # the shard's step without the update launch
+    t_done = 0.0
+    for _, size, frac in BUCKETS:
+        ready = frac * compute_ms
+        wire = (n - 1) / n * size / bw * 1e3          # reduce-scatter, and again the all-gather
+        t_done = max(t_done, ready) + wire + ADAM_MS / n * size / TOTAL + wire
+    exposed = max(0.0, t_done - body)
+    return body + exposed, exposed
+
+
+print()
+print('sharded update (reduce-scatter + 1/N update + all-gather per bucket, under backward), exact f32, predicted step in ms (all-reduce path beside it):')
+print('| N | scaling | captions / rank | at 153 GB/s: all-reduce / sharded | at 350 GB/s | at 1071 GB/s |')
+print('|---|---|---|---|---|---|')
+for n in (2, 4, 8):
+    for kind in ('weak', 'strong'):
+        b = 256 if kind == 'weak' else 256 // n
+        if b not in meas:
+            continue
+        ex = meas[b][0]
+        cells = []
+        for bw in (153e9, MID, 7 * 153e9):
+            cells.append('%.1f / %.1f' % (step_ms(ex, n, bw)[0], step_ms_sharded(ex, n, bw)[0]))
+        print('| %d | %s | %d | %s |' % (n, kind, b, ' | '.join(cells)))
