@@ -75,6 +75,8 @@ typedef struct rfn_dims {
 #define RFN_PATH_OPT_PERSIST_DEC_BWD 4u   /* decoder backward sweep, steps S-1 ... 1 (rfn_decoder_bwd)        */
 #define RFN_PATH_OPT_PERSIST_S2_BWD 8u    /* stage-II backward sweep, steps T2-1 ... 1 (rfn_prefix_bwd)       */
 #define RFN_PATH_OPT_PERSIST_ALL 15u
+#define RFN_PATH_OPT_NO_SMALL_TILES 32u   /* A/B hook: per-step products keep 32-row tiles even when the launch has so few of them
+                                           * that the library would take 16-row tiles (rfn_cell_gemm variant 4; same results)  */
 #define RFN_PATH_OPT_DEEP_CELLS 16u       /* A/B hook: per-step products with no more tiles than CUs on the deep-ring kernel
                                            * (rfn_cell_gemm, RFN_CELL_VARIANT_DEEP) instead of the 3-slot one; not faster      */
 

@@ -32,7 +32,7 @@
 
 
 template <int BM, int BK, int WK, bool BKF, int EPI>
-__global__ __launch_bounds__(64 * (BM / 32) * WK) void cell_gemm_k(const CgArgs a) {
+__global__ __launch_bounds__(64 * (BM >= 32 ? BM / 32 : 1) * WK) void cell_gemm_k(const CgArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     cg_tile<BM, BK, WK, BKF, EPI, false, false>(a, blockIdx.x, smem, [] {});
 }
@@ -65,12 +65,22 @@ static int cg_launch(const CgArgs& a, int blocks, hipStream_t st) {
             return RFN_ERR_LAUNCH;
         ds.set[dev & 15] = true;
     }
-    hipLaunchKernelGGL(k, dim3(blocks), dim3(64 * (BM / 32) * WK), a.slots * slot, st, a);
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(64 * (BM >= 32 ? BM / 32 : 1) * WK), a.slots * slot, st, a);
     RFN_CHECK_LAUNCH();
     return RFN_OK;
 }
 
-// Tile variants: 1 = 64 rows, K step 32, 2 K-waves; 2 = 64 rows, K step 64, 4 K-waves; 3 = 32 rows, K step 64, 4 K-waves.
+static int cg_device_cus() {   // CU count of the current device (cached per device index)
+    static int cus[16] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    int& c = cus[dev & 15];
+    if (c == 0 && hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) c = 0;
+    return c;
+}
+
+// Tile variants: 1 = 64 rows, K step 32, 2 K-waves; 2 = 64 rows, K step 64, 4 K-waves; 3 = 32 rows, K step 64, 4 K-waves;
+// 4 = 16 rows, K step 64, 4 K-waves on the 16x16x4 MFMA shape (bit-identical to 2 and 3).
 // variant 0: the K step / K-wave count -- which fix the k order of every output element -- are chosen FROM THE K COUNTS
 // ONLY, so a row's arithmetic never depends on the batch it sits in (variants 2 and 3 give bit-identical results).
 static int cg_plan(CgPrepared& pz, int variant) {
@@ -90,10 +100,19 @@ static int cg_plan(CgPrepared& pz, int variant) {
     }
     // 32-row tiles whenever the K step of 64 applies: measured fastest at every per-step shape of the path (B = 64 ... 640),
     // because they put two to three independent blocks on a CU (profiles/r03_cellgemm.md)
-    if (variant == 0) variant = k64 ? 3 : 1;
-    if ((variant == 2 || variant == 3) && !k64) return RFN_ERR_SHAPE;
-    if (variant < 1 || variant > 3) return RFN_ERR_SHAPE;
-    const int bm = (variant == 3) ? 32 : 64;
+    if (variant == 0) {
+        variant = k64 ? 3 : 1;
+        // few tiles: 16-row tiles put the launch on twice the CUs with half the MFMA chain per block (variant 4, bit-identical
+        // to variant 3: rfn_cellgemm_body.h) -- taken when even the 16-row tiles do not outnumber the CUs
+        if (k64) {
+            long cols = 0;
+            for (int o = 0; o < a.nout; ++o) cols += a.out[o].N / CG_BN;
+            if ((long)rfn_cdiv(a.M, 16) * cols <= cg_device_cus()) variant = 4;
+        }
+    }
+    if ((variant == 2 || variant == 3 || variant == 4) && !k64) return RFN_ERR_SHAPE;
+    if (variant < 1 || variant > 4) return RFN_ERR_SHAPE;
+    const int bm = (variant == 4) ? 16 : (variant == 3) ? 32 : 64;
     max_iters /= (variant == 1) ? 32 : 64;
     a.tiles_m = rfn_cdiv(a.M, bm);
     int t0 = 0;
@@ -146,6 +165,9 @@ static int cg_launch_deep(const CgPrepared& pz, hipStream_t st, bool* taken) {
     return RFN_OK;
 }
 
+// The same product on 32-row tiles (bit-identical): what the persistent recurrence kernels are built from.
+int rfn_cg_replan32(CgPrepared* pz) { return pz->variant == 3 ? RFN_OK : cg_plan(*pz, 3); }
+
 int rfn_cg_launch(const CgPrepared& pz, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (pz.variant == 3 && pz.deep) {
@@ -162,6 +184,7 @@ int rfn_cg_launch(const CgPrepared& pz, void* stream) {
         case 1: return cg_launch<64, 32, 2, BKF_, EPI_>(pz.a, pz.blocks, st);                \
         case 2: return cg_launch<64, 64, 4, BKF_, EPI_>(pz.a, pz.blocks, st);                \
         case 3: return cg_launch<32, 64, 4, BKF_, EPI_>(pz.a, pz.blocks, st);                \
+        case 4: return cg_launch<16, 64, 4, BKF_, EPI_>(pz.a, pz.blocks, st);                \
         default: return RFN_ERR_SHAPE;                                                      \
     }
     if (pz.epi == CG_EPI_LSTM) { CG_CASE(true, CG_EPI_LSTM) }

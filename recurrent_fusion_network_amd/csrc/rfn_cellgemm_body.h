@@ -109,7 +109,13 @@ template <int BM, int BK, int WK, bool BKF, int EPI, bool XB, bool DEEP, typenam
 __device__ __forceinline__ void cg_tile(const CgArgs& a, const int bid, float* smem, Hook hook) {
     static_assert(DEEP || !XB, "the cross-block form is built on the deep pipeline");
     constexpr int BN = CG_BN;
-    constexpr int WM = BM / 32, W = WM * WK, T = 64 * W;
+    // BM = 16 (round 5): a 16-row tile = two 16 x 16 MFMA tiles side by side per wave (v_mfma_f32_16x16x4_f32), for launches
+    // with so few 32-row tiles that most CUs would idle: twice the blocks, half the MFMA chain per block.  The 16x16x4 shape is
+    // bit for bit the k-ordered fma chain of the 32x32x2 shape (tools/mfma16_order_probe.hip) and the k's of a k-group are fed in
+    // the order the 32-row form feeds them (0 4 1 5 | 2 6 3 7), so a 16-row tile's outputs are the 32-row tile's bits.
+    constexpr bool SMALL = (BM == 16);
+    static_assert(!SMALL || (BK == 64 && !XB && !DEEP), "the 16-row form exists for the launch kernel, K step 64");
+    constexpr int WM = SMALL ? 1 : BM / 32, W = WM * WK, T = 64 * W;
     constexpr int A_FL = BM * BK, B_FL = BN * BK, SLOT_FL = A_FL + B_FL;
     constexpr int PA = A_FL / 256, PB = B_FL / 256, P = PA + PB;   // 1-KiB pieces per K step
     static_assert(P % W == 0, "pieces must divide evenly over the waves");
@@ -123,10 +129,12 @@ __device__ __forceinline__ void cg_tile(const CgArgs& a, const int bid, float* s
     static_assert((EPI == CG_EPI_LSTM) ? BKF : true, "the gate epilogue belongs to forward products");
     static_assert((EPI == CG_EPI_LSTM_BWD) ? !BKF : true, "the gate-gradient epilogue belongs to dX products");
     constexpr int U = BN / 4;                       // units per tile of the gate epilogue
-    constexpr int NV = BM * BN / 4 / T;             // float4 of the tile per thread       (store epilogue)
-    constexpr int NP = BM * U / T;                  // (row, unit) pairs per thread         (gate epilogue)
+    constexpr int NV = (BM * BN / 4 + T - 1) / T;   // float4 of the tile per thread       (store epilogue)
+    constexpr int NP = (BM * U + T - 1) / T;        // (row, unit) pairs per thread         (gate epilogue)
     constexpr int NE = BM * BN / T;                 // (row, unit) elements per thread      (gate-gradient epilogue)
-    static_assert(NV >= 1 && NP >= 1 && BM * BN % (4 * T) == 0 && BM * U % T == 0, "epilogue tiling");
+    // 32- / 64-row tiles give every thread whole shares; a 16-row tile has work for half the threads of the float4 / pair loops
+    constexpr bool PART = (BM * BN / 4) % T != 0;
+    static_assert(NE >= 1 && BM * BN % T == 0 && (PART ? SMALL : (BM * BN % (4 * T) == 0 && BM * U % T == 0)), "epilogue tiling");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wk = wave / WM, wm = wave - wk * WM;
@@ -150,6 +158,8 @@ __device__ __forceinline__ void cg_tile(const CgArgs& a, const int bid, float* s
     cg_f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    cg_f32x4 acc16[2] = {cg_f32x4{0.f, 0.f, 0.f, 0.f}, cg_f32x4{0.f, 0.f, 0.f, 0.f}};   // SMALL: the two column halves
+    const int l15 = lane & 15, kq = lane >> 4;
 
     int total_iters = 0;
     for (int s = 0; s < nseg; ++s) total_iters += a.seg[seg0 + s].K / BK;
@@ -397,6 +407,34 @@ __device__ __forceinline__ void cg_tile(const CgArgs& a, const int bid, float* s
     const int swa = swz(l31), swb = swz(l31);   // tile rows are l31 + multiples of 32
     auto k_step = [&](const float* a_l) {   // the MFMAs of one K step on the slot at a_l
         const float* b_l = a_l + A_FL;
+        if constexpr (SMALL) {
+#pragma unroll
+            for (int t = 0; t < KG / WK; ++t) {
+                const int q = wk + WK * t;
+                // lane (row l15, k-quarter kq) feeds k = 8q + {0 4 1 5}[kq] to the first MFMA of the k-group and
+                // 8q + {2 6 3 7}[kq] to the second: 16-B chunk 2q + (kq & 1) of its row, elements kq >> 1 and (kq >> 1) + 2
+                const int ch = 2 * q + (kq & 1);
+                const cg_f32x4 af = *reinterpret_cast<const cg_f32x4*>(a_l + l15 * BK + 4 * (ch ^ swz(l15)));
+                const float a0 = (kq < 2) ? af[0] : af[1], a1 = (kq < 2) ? af[2] : af[3];
+#pragma unroll
+                for (int nh = 0; nh < 2; ++nh) {
+                    const int n = 16 * nh + l15;
+                    float b0, b1;
+                    if constexpr (BKF) {
+                        const cg_f32x4 bf = *reinterpret_cast<const cg_f32x4*>(b_l + n * BK + 4 * (ch ^ swz(n)));
+                        b0 = (kq < 2) ? bf[0] : bf[1];
+                        b1 = (kq < 2) ? bf[2] : bf[3];
+                    } else {
+                        const int k0 = 8 * q + 4 * (kq & 1) + (kq >> 1);
+                        b0 = b_l[k0 * BN + n];
+                        b1 = b_l[(k0 + 2) * BN + n];
+                    }
+                    acc16[nh] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc16[nh], 0, 0, 0);
+                    acc16[nh] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc16[nh], 0, 0, 0);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int t = 0; t < KG / WK; ++t) {
             const int q = wk + WK * t;
@@ -457,10 +495,17 @@ __device__ __forceinline__ void cg_tile(const CgArgs& a, const int bid, float* s
     CG_STAMP(2);
     __syncthreads();
     float* slab = smem;   // [WK][BM][BN]
+    if constexpr (SMALL) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int row = wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-        slab[(wk * BM + row) * BN + l31] = acc[i];
+        for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) slab[(wk * BM + 4 * kq + i) * BN + 16 * nh + l15] = acc16[nh][i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            slab[(wk * BM + row) * BN + l31] = acc[i];
+        }
     }
     __syncthreads();
 
@@ -470,7 +515,7 @@ __device__ __forceinline__ void cg_tile(const CgArgs& a, const int bid, float* s
         for (int v = 0; v < NV; ++v) {
             const int idx = tid + v * T;
             const int row = idx / C4, c4 = idx - row * C4, grow = row0 + row;
-            if (grow >= M) continue;
+            if (grow >= M || (PART && row >= BM)) continue;
             cg_f32x4 x = *reinterpret_cast<const cg_f32x4*>(slab + row * BN + 4 * c4);
 #pragma unroll
             for (int w = 1; w < WK; ++w) x += *reinterpret_cast<const cg_f32x4*>(slab + (w * BM + row) * BN + 4 * c4);
@@ -485,7 +530,7 @@ __device__ __forceinline__ void cg_tile(const CgArgs& a, const int bid, float* s
         for (int p = 0; p < NP; ++p) {
             const int idx = tid + p * T;
             const int row = idx / U, u = idx - row * U, grow = row0 + row;
-            if (grow >= M) continue;
+            if (grow >= M || (PART && row >= BM)) continue;
             const int unit = tn * U + u;
             float* G = O.C + (long)grow * O.ldc;
             float pre[4];

@@ -14,6 +14,7 @@ struct CgPrepared {      // rfn_cell_gemm's launch, not launched (rfn_cellgemm.h
 };
 int rfn_cg_prepare(int M, int nout, const rfn_cell_out* outs, int R, float drop_p, uint64_t seed, int variant, CgPrepared* pz);
 int rfn_cg_launch(const CgPrepared& pz, void* stream);
+int rfn_cg_replan32(CgPrepared* pz);      // re-tile a prepared launch on the 32-row variant (same results)
 
 struct AttnSmallPrepared {   // rfn_attn_small_fwd / _bwd's launch, not launched (rfn_attn.hip)
     AttnSmallArgs a;

@@ -109,3 +109,25 @@ def test_deep_ring_cell_products_match_the_shallow_kernel_bit_for_bit(dev, name)
         a = shallow.sample(batch[0], batch[1], {'sample_max': 1})
         b = deep.sample(batch[0], batch[1], {'sample_max': 1})
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+
+
+@pytest.mark.parametrize('name', ['mid', 'c2', 'c3'])
+def test_sixteen_row_tiles_in_the_path_match_the_32_row_tiles(dev, name):
+    """At the golden tiers' batch sizes every per-step product has fewer 16-row tiles than the chip has CUs, so the library
+    takes variant 4 (16-row tiles on the 16x16x4 MFMA shape); RFN_PATH_OPT_NO_SMALL_TILES keeps 32-row tiles.  Same fma chains:
+    forward, loss, every gradient and the greedy decode agree bit for bit."""
+    import recurrent_fusion_network_amd as R
+    N = R._native
+    cfg, spec, P, batch, gold = load_case(name)
+    batch = to_dev(batch, dev)
+    crit = R.ReviewNetEnsembleCriterion(cfg)
+    big = build(cfg, P, dev, train=True)
+    big.path_flags = N.PATH_OPT_NO_SMALL_TILES
+    small = build(cfg, P, dev, train=True)
+    _assert_same(_step(small, crit, batch), _step(big, crit, batch), name)
+    big.eval()
+    small.eval()
+    with torch.no_grad():
+        a = big.sample(batch[0], batch[1], {'sample_max': 1})
+        b = small.sample(batch[0], batch[1], {'sample_max': 1})
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
