@@ -360,15 +360,36 @@ static int x3_row_pad(int rows) { return (rows + 255) / 256 * 256; }   // row pi
 // encoder) needs enough blocks to stream at the chip's rate: the GROUPED launch of all M encoders counts M * B of them, a
 // per-encoder launch B.  Below that the split d-alpha kernel's (L/64, B) grid fills the chip better -- unless the map is so
 // small that launches, not bytes, are the cost.
-static bool attn_bwd_grouped(const rfn_dims* d, int B) {
-    if (d->M < 2) return false;
-    for (int i = 1; i < d->M; ++i)
-        if (d->D[i] != d->D[0] || d->L[i] != d->L[0]) return false;
-    return (long)B * d->M >= FUSED_ATTN_BWD_MIN_B || (!x3_takes(d, B, 0) && (long)d->L[0] * d->D[0] <= FUSED_ATTN_BWD_SMALL_MAP);
+// ONE definition, used by the backward sweep (which launches it) and by the weight-gradient pass (which has to know whether
+// encoder i's dP1 already sits in its plane image) -- ADVICE r04: the two used to restate each other's conditions.
+//   GROUPED(_KS)  all M encoders of a step in one launch (they share (L, D)); _KS: dP1 written as bf16 planes
+//   HET           all M encoders in one launch, maps of different (L, D), exact f32 only
+//   FUSED(_KS)    one launch per encoder, d alpha kept in LDS
+//   SPLIT         d alpha kernel + score-backward kernel per encoder
+// A launch needs enough blocks to stream at the chip's rate: it has (encoders in the launch) x B of them.
+enum AttnBwdForm { AB_GROUPED_KS, AB_GROUPED, AB_HET, AB_FUSED_KS, AB_FUSED, AB_SPLIT };
+static bool attn_bwd_small_map(const rfn_dims* d, int B, int i) {
+    return !x3_takes(d, B, i) && (long)d->L[i] * d->D[i] <= FUSED_ATTN_BWD_SMALL_MAP;
+}
+static AttnBwdForm attn_bwd_form(const rfn_dims* d, int B, int i, bool dz_in_one_launch) {
+    const int M = d->M;
+    bool same_ld = M > 1;
+    for (int j = 1; j < M; ++j) same_ld = same_ld && d->D[j] == d->D[0] && d->L[j] == d->L[0];
+    if (same_ld && ((long)B * M >= FUSED_ATTN_BWD_MIN_B || attn_bwd_small_map(d, B, 0)))
+        return x3_takes(d, B, 0) ? AB_GROUPED_KS : AB_GROUPED;
+    if (!same_ld && M > 1 && dz_in_one_launch) {   // every encoder must qualify for the exact-f32 fused form in the shared launch
+        bool het = true;
+        for (int j = 0; j < M && het; ++j)
+            het = !x3_takes(d, B, j) && ((long)B * M >= FUSED_ATTN_BWD_MIN_B || attn_bwd_small_map(d, B, j));
+        if (het) return AB_HET;
+    }
+    if (B >= FUSED_ATTN_BWD_MIN_B && x3_takes(d, B, i)) return AB_FUSED_KS;
+    if (B >= FUSED_ATTN_BWD_MIN_B || attn_bwd_small_map(d, B, i)) return AB_FUSED;
+    return AB_SPLIT;
 }
 static bool x3_dp_emitted(const rfn_dims* d, int B, int i) {   // dP1 of encoder i reaches its k-slow plane image from the attention launches
-    if (!x3_takes(d, B, i)) return false;
-    return attn_bwd_grouped(d, B) || B >= FUSED_ATTN_BWD_MIN_B;
+    const AttnBwdForm f = attn_bwd_form(d, B, i, false);       // (the HET form never takes plane products)
+    return f == AB_GROUPED_KS || f == AB_FUSED_KS;
 }
 static size_t x3_scratch_floats(const rfn_dims* d, int B, int train) {
     size_t most = 0;
@@ -1197,9 +1218,8 @@ extern "C" int rfn_prefix_bwd(const rfn_dims* d, int B, const float* const* prm,
                 dz_done = true;
             }
         }
-        bool same_ld = same_d && M > 1;
-        for (int i = 1; i < M; ++i) same_ld = same_ld && d->L[i] == d->L[0];
-        const bool grouped_bwd = attn_bwd_grouped(d, B);
+        const AttnBwdForm form0 = attn_bwd_form(d, B, 0, dz_done);
+        const bool grouped_bwd = form0 == AB_GROUPED || form0 == AB_GROUPED_KS;
         if (grouped_bwd) {   // all encoders' attention backward of this step: one launch
             const long L0 = d->L[0], D0 = d->D[0];
             const float *a_p[RFN_MAX_ENC], *a_hp[RFN_MAX_ENC], *a_w[RFN_MAX_ENC], *a_al[RFN_MAX_ENC], *a_dz[RFN_MAX_ENC];
@@ -1214,7 +1234,7 @@ extern "C" int rfn_prefix_bwd(const rfn_dims* d, int B, const float* const* prm,
                 a_dhp[i] = dhp + i * BA;
                 a_dw[i] = dwp + ((long)t * M + i) * BA;
             }
-            if (x3_takes(d, B, 0)) {   // dP1 of this step straight into the encoders' k-slow plane images
+            if (form0 == AB_GROUPED_KS) {   // dP1 of this step straight into the encoders' k-slow plane images
                 void* a_img[RFN_MAX_ENC];
                 for (int i = 0; i < M; ++i) a_img[i] = W + Lo.x3p[i];
                 RFN_TRY(rfn_attn_bwd_grouped_ks(M, a_p, L0 * A, (long)A, a_hp, a_w, a_al, att, L0 * D0, D0, a_dz, D0, B,
@@ -1224,10 +1244,7 @@ extern "C" int rfn_prefix_bwd(const rfn_dims* d, int B, const float* const* prm,
                                              B, (int)L0, A, (int)D0, a_dp, L0 * A, (long)A, 0, a_dhp, a_dw, st));
             }
         }
-        bool het_bwd = !grouped_bwd && !same_ld && M > 1 && dz_done;
-        for (int i = 0; i < M && het_bwd; ++i)     // every encoder would take the fused exact-f32 launch on its own
-            het_bwd = !x3_takes(d, B, i) &&
-                      (B >= FUSED_ATTN_BWD_MIN_B || (long)d->L[i] * d->D[i] <= FUSED_ATTN_BWD_SMALL_MAP);
+        const bool het_bwd = form0 == AB_HET;
         if (het_bwd) {   // maps of different (L, D): the M attention backwards of this step in one launch
             const float *a_p[RFN_MAX_ENC], *a_hp[RFN_MAX_ENC], *a_w[RFN_MAX_ENC], *a_al[RFN_MAX_ENC], *a_dz[RFN_MAX_ENC];
             float *a_dp[RFN_MAX_ENC], *a_dhp[RFN_MAX_ENC], *a_dw[RFN_MAX_ENC];
@@ -1253,9 +1270,10 @@ extern "C" int rfn_prefix_bwd(const rfn_dims* d, int B, const float* const* prm,
                 RFN_TRY(gemm1(B, (int)Di, seg_dx(g + (long)i * B * 4 * R, 4 * R, prm[P.s1(t, i, 8)], Di, 4 * R), dz, Di, 0, gx));
             float* dali = dal + (long)i * B * Li;
             float* p1 = W + Lo.P1[i] + (long)t * B * Li * A;
+            const AttnBwdForm form = attn_bwd_form(d, B, i, dz_done);
             if (grouped_bwd || het_bwd) {
                 // done above
-            } else if (B >= FUSED_ATTN_BWD_MIN_B && x3_takes(d, B, i)) {   // ... with dP1 as bf16 planes
+            } else if (form == AB_FUSED_KS) {   // ... with dP1 as bf16 planes
                 const float* p1c = p1;
                 const float* hpc = hp + i * BA;
                 const float* wc = prm[P.s1(t, i, 4)];
@@ -1266,7 +1284,7 @@ extern "C" int rfn_prefix_bwd(const rfn_dims* d, int B, const float* const* prm,
                 float* dwo = dwp + ((long)t * M + i) * BA;
                 RFN_TRY(rfn_attn_bwd_grouped_ks(1, &p1c, Li * A, (long)A, &hpc, &wc, &alc, &att[i], Li * Di, Di, &dzc, Di, B,
                                                 (int)Li, A, (int)Di, &img, x3_row_pad(T1 * A), t * A, &dhpo, &dwo, st));
-            } else if (B >= FUSED_ATTN_BWD_MIN_B || (!x3_takes(d, B, i) && Li * Di <= FUSED_ATTN_BWD_SMALL_MAP)) {   // dalpha stays in LDS, one launch
+            } else if (form == AB_FUSED) {   // dalpha stays in LDS, one launch
                 RFN_TRY(rfn_attn_bwd(p1, Li * A, (long)A, hp + i * BA, prm[P.s1(t, i, 4)],
                                      W + Lo.al1[i] + (long)t * B * Li, att[i], Li * Di, Di, dz, Di, B, (int)Li, A,
                                      (int)Di, p1, Li * A, (long)A, 0, dhp + i * BA,
