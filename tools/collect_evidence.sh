@@ -26,7 +26,7 @@ for args in "--workload c2" "--workload c3het" "--recipe" "--label-smoothing" "-
   python bench.py --no-cpu-baseline $args 2>/dev/null | tail -1 >> $O/secondary.jsonl
 done
 python bench.py --no-cpu-baseline --workload c5 --gemm bf16x3 2>/dev/null | tail -1 >> $O/secondary.jsonl
-bash tools/run_gemm_pmc.sh r04 "" all > $O/pmc_gemm.txt 2>&1
+bash tools/run_gemm_pmc.sh r05 "" all > $O/pmc_gemm.txt 2>&1
 : > $O/shards.jsonl      # single-GPU steps of data-parallel shards (tools/dp_predict.py)
 for b in 256 128 64 32; do
   python bench.py --no-cpu-baseline --batch $b 2>/dev/null | tail -1 >> $O/shards.jsonl
