@@ -80,7 +80,7 @@ static int cg_device_cus() {   // CU count of the current device (cached per dev
 }
 
 // Tile variants: 1 = 64 rows, K step 32, 2 K-waves; 2 = 64 rows, K step 64, 4 K-waves; 3 = 32 rows, K step 64, 4 K-waves;
-// 4 = 16 rows, K step 64, 4 K-waves on the 16x16x4 MFMA shape (bit-identical to 2 and 3).
+// 4 = 16 rows, K step 64, 4 K-waves on the 16x16x4 MFMA shape; 5 = the same on K steps of 128 (both bit-identical to 2 and 3).
 // variant 0: the K step / K-wave count -- which fix the k order of every output element -- are chosen FROM THE K COUNTS
 // ONLY, so a row's arithmetic never depends on the batch it sits in (variants 2 and 3 give bit-identical results).
 static int cg_plan(CgPrepared& pz, int variant) {
@@ -88,12 +88,13 @@ static int cg_plan(CgPrepared& pz, int variant) {
     const int force_slots = (variant >> 4) & 15;   // tools: bits 4-7 of `variant` force the ring depth
     const bool deep = (variant & RFN_CELL_VARIANT_DEEP) != 0;
     variant &= 15;
-    bool k64 = true;
+    bool k64 = true, k128 = true;
     int max_iters = 0;
     for (int o = 0; o < a.nout; ++o) {
         int it = 0;
         for (int s = 0; s < a.out[o].nseg; ++s) {
             k64 = k64 && (a.seg[a.out[o].seg0 + s].K % 64 == 0);
+            k128 = k128 && (a.seg[a.out[o].seg0 + s].K % 128 == 0);
             it += a.seg[a.out[o].seg0 + s].K;
         }
         max_iters = it > max_iters ? it : max_iters;
@@ -107,13 +108,16 @@ static int cg_plan(CgPrepared& pz, int variant) {
         if (k64) {
             long cols = 0;
             for (int o = 0; o < a.nout; ++o) cols += a.out[o].N / CG_BN;
-            if ((long)rfn_cdiv(a.M, 16) * cols <= cg_device_cus()) variant = 4;
+            // 5: the same on K steps of 128, for long reductions only (K = 2048: 13.7 against 15.6 us; at K = 512 the four
+            // fat K steps lose to eight lean ones: 7.4 against 6.4 us -- tools/bench_cellgemm.py --small --variants 3,4,5)
+            if ((long)rfn_cdiv(a.M, 16) * cols <= cg_device_cus()) variant = (k128 && max_iters >= 1024) ? 5 : 4;
         }
     }
     if ((variant == 2 || variant == 3 || variant == 4) && !k64) return RFN_ERR_SHAPE;
-    if (variant < 1 || variant > 4) return RFN_ERR_SHAPE;
-    const int bm = (variant == 4) ? 16 : (variant == 3) ? 32 : 64;
-    max_iters /= (variant == 1) ? 32 : 64;
+    if (variant == 5 && !k128) return RFN_ERR_SHAPE;
+    if (variant < 1 || variant > 5) return RFN_ERR_SHAPE;
+    const int bm = (variant >= 4) ? 16 : (variant == 3) ? 32 : 64;
+    max_iters /= (variant == 1) ? 32 : (variant == 5) ? 128 : 64;
     a.tiles_m = rfn_cdiv(a.M, bm);
     int t0 = 0;
     for (int o = 0; o < a.nout; ++o) {
@@ -185,6 +189,7 @@ int rfn_cg_launch(const CgPrepared& pz, void* stream) {
         case 2: return cg_launch<64, 64, 4, BKF_, EPI_>(pz.a, pz.blocks, st);                \
         case 3: return cg_launch<32, 64, 4, BKF_, EPI_>(pz.a, pz.blocks, st);                \
         case 4: return cg_launch<16, 64, 4, BKF_, EPI_>(pz.a, pz.blocks, st);                \
+        case 5: return cg_launch<16, 128, 4, BKF_, EPI_>(pz.a, pz.blocks, st);               \
         default: return RFN_ERR_SHAPE;                                                      \
     }
     if (pz.epi == CG_EPI_LSTM) { CG_CASE(true, CG_EPI_LSTM) }

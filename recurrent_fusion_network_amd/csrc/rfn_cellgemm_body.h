@@ -114,7 +114,7 @@ __device__ __forceinline__ void cg_tile(const CgArgs& a, const int bid, float* s
     // bit for bit the k-ordered fma chain of the 32x32x2 shape (tools/mfma16_order_probe.hip) and the k's of a k-group are fed in
     // the order the 32-row form feeds them (0 4 1 5 | 2 6 3 7), so a 16-row tile's outputs are the 32-row tile's bits.
     constexpr bool SMALL = (BM == 16);
-    static_assert(!SMALL || (BK == 64 && !XB && !DEEP), "the 16-row form exists for the launch kernel, K step 64");
+    static_assert(!SMALL || ((BK == 64 || BK == 128) && !XB && !DEEP), "the 16-row form exists for the launch kernel, K step 64 / 128");
     constexpr int WM = SMALL ? 1 : BM / 32, W = WM * WK, T = 64 * W;
     constexpr int A_FL = BM * BK, B_FL = BN * BK, SLOT_FL = A_FL + B_FL;
     constexpr int PA = A_FL / 256, PB = B_FL / 256, P = PA + PB;   // 1-KiB pieces per K step
@@ -123,7 +123,10 @@ __device__ __forceinline__ void cg_tile(const CgArgs& a, const int bid, float* s
     constexpr int CPR = BK / 4;      // 16-B chunks per [row][k] row
     constexpr int RPP = 64 / CPR;    // rows per piece
     constexpr int KG = BK / 8;       // k-groups per K step
-    static_assert(KG % WK == 0 && (BK == 32 || BK == 64), "unsupported K step");
+    // BK = 128 (round 5, few-tile launches): half the K steps of BK = 64 -- a K step costs ~0.45 us of waits, barrier and request
+    // issue whatever it computes -- and the SAME k order: wave wk takes the k-groups g with g % WK == wk in ascending order
+    // whatever the K step is, as long as it holds a multiple of WK groups.
+    static_assert(KG % WK == 0 && (BK == 32 || BK == 64 || BK == 128), "unsupported K step");
     static_assert(WK * BM * BN <= 2 * SLOT_FL, "the partial tiles reuse the ring (at least two slots)");
     static_assert(NIW * (CG_MAX_SLOTS - 1) <= 63, "vmcnt is a 6-bit counter");
     static_assert((EPI == CG_EPI_LSTM) ? BKF : true, "the gate epilogue belongs to forward products");
@@ -153,7 +156,7 @@ __device__ __forceinline__ void cg_tile(const CgArgs& a, const int bid, float* s
     const int M = XB ? xb_uni(a.M) : a.M, R = XB ? xb_uni(a.R) : a.R;
     const int nseg = XB ? xb_uni(O.nseg) : O.nseg, seg0 = XB ? xb_uni(O.seg0) : O.seg0;
 
-    auto swz = [](int row) -> int { return BK == 32 ? ((row >> 1) & 7) : (row & 15); };
+    auto swz = [](int row) -> int { return BK == 32 ? ((row >> 1) & 7) : (BK == 64 ? (row & 15) : (row & 31)); };
 
     cg_f32x16 acc;
 #pragma unroll

@@ -276,8 +276,8 @@ static bool chain_plan(const ChainStep* steps, int nsteps, ChainArgs& ca, bool& 
         ChainStep st = steps[s];
         // the bodies the kernel is built from: 32-row tiles, K step 64, 4 K-waves; vectorised attention backward.  A launch the
         // host would put on 16-row tiles (few tiles) computes the same bits on 32-row ones.
-        if (st.g0.variant == 4 && rfn_cg_replan32(&st.g0) != RFN_OK) return false;
-        if (st.g2.variant == 4 && rfn_cg_replan32(&st.g2) != RFN_OK) return false;
+        if (st.g0.variant >= 4 && rfn_cg_replan32(&st.g0) != RFN_OK) return false;
+        if (st.g2.variant >= 4 && rfn_cg_replan32(&st.g2) != RFN_OK) return false;
         if (st.g0.variant != 3 || st.g2.variant != 3) return false;
         if (st.g0.epi != CG_EPI_STORE || st.g0.bkf != fwd || st.g2.bkf != fwd) return false;
         if (st.g2.epi != (fwd ? CG_EPI_LSTM : CG_EPI_LSTM_BWD)) return false;
