@@ -56,6 +56,19 @@ struct CgArgs {
 };
 
 
+#ifndef CG_ISSUE_AFTER
+#define CG_ISSUE_AFTER 0    /* A/B: request the next K step after (1) or before (0) this step's MFMAs are issued */
+#endif
+// -DCG_LOOP_STAMPS (tools/cg_loop_probe.hip only): block 0, lane 0 of wave 0 stamps the shader clock inside every K step of
+// the launch kernel's shallow loop: [it][0] top, [1] own pieces landed, [2] block barrier passed, [3] next step requested,
+// [4] fragments read + MFMAs issued
+#ifdef CG_LOOP_STAMPS
+__device__ unsigned long long g_cg_loop_stamps[64 * 8];
+#define CG_LSTAMP(it_, k_) do { if (!XB && !DEEP && blockIdx.x == 0 && threadIdx.x == 0 && (it_) < 64) g_cg_loop_stamps[(it_) * 8 + (k_)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define CG_LSTAMP(it_, k_)
+#endif
+
 // RFN_CHAIN_TIMING builds (tools/chain_timing.py): lane 0 of a block stamps the 100 MHz clock inside the XB tile
 #ifdef RFN_CHAIN_TIMING
 #define CG_STAMP(i) do { if (XB && g_cg_stamp_local && threadIdx.x == 0) g_cg_stamp_local[i] = wall_clock64(); } while (0)
@@ -463,6 +476,7 @@ __device__ __forceinline__ void cg_tile(const CgArgs& a, const int bid, float* s
         for (int it = 0; it < total_iters; ++it) k_step(smem + it * SLOT_FL);
     } else
     for (int it = 0; it < total_iters; ++it) {
+        CG_LSTAMP(it, 0);
         // this wave's pieces of step `it` have landed; the `younger` steps issued after it stay in flight
         if constexpr (DEEP) {
             // issue order: B of the PRE up-front steps | A of those steps | then whole steps (A, B) from inside the loop
@@ -479,7 +493,16 @@ __device__ __forceinline__ void cg_tile(const CgArgs& a, const int bid, float* s
                 default: cg_wait_vmcnt<5 * NIW>(); break;
             }
         }
+        CG_LSTAMP(it, 1);
         __builtin_amdgcn_s_barrier();                     // ... everyone's have, and slot (it - 1) % SL is free
+        CG_LSTAMP(it, 2);
+#if CG_ISSUE_AFTER
+        // this step's fragment reads and MFMAs go out first: the matrix pipe then works while the wave does the address
+        // arithmetic and the issue of the next step's requests (a K step is one serial chain on a wave that has its SIMD to
+        // itself; tools/cg_loop_probe.hip)
+        k_step(smem + cur * SLOT_FL);
+        CG_LSTAMP(it, 3);
+#endif
         if (issued < total_iters) {
             if constexpr (DEEP) {
                 issueA(fill);
@@ -489,7 +512,11 @@ __device__ __forceinline__ void cg_tile(const CgArgs& a, const int bid, float* s
             }
             ++issued;
         }
+#if !CG_ISSUE_AFTER
+        CG_LSTAMP(it, 3);
         k_step(smem + cur * SLOT_FL);
+#endif
+        CG_LSTAMP(it, 4);
         cur = (cur + 1 == SL) ? 0 : cur + 1;
         fill = (fill + 1 == SL) ? 0 : fill + 1;
     }
