@@ -246,6 +246,7 @@ def parse_args(argv=None):
                          'those recurrences inside ONE persistent launch each (csrc/rfn_chain.hip) instead of three launches per step; '
                          '16 = RFN_PATH_OPT_DEEP_CELLS: few-tile per-step products on the deep-ring kernel instead of the 3-slot one; '
                          '32 = RFN_PATH_OPT_NO_SMALL_TILES: keep 32-row tiles where the library would take 16-row ones; '
+                         '64 = RFN_PATH_OPT_SHARED_SMALL_TILES: those 16-row tiles on block-shared ring slots (variants 4 / 5); '
                          'bit-identical either way (profiles/r05_chain.md)')
     ap.add_argument('--fused-loss', action='store_true',
                     help='forward + criterion through RecurrentFusionModel.forward_loss (the language term straight from the '
@@ -669,7 +670,8 @@ def run_train(args, rank, world, dev, R, DP, guard):
         model.gemm_flags |= N.GEMM_OPT_BF16X3
     if args.lds_lean:
         model.gemm_flags |= N.GEMM_OPT_LDS_LEAN
-    model.path_flags |= int(args.persist) & (N.PATH_OPT_PERSIST_ALL | N.PATH_OPT_DEEP_CELLS | N.PATH_OPT_NO_SMALL_TILES)
+    model.path_flags |= int(args.persist) & (N.PATH_OPT_PERSIST_ALL | N.PATH_OPT_DEEP_CELLS | N.PATH_OPT_NO_SMALL_TILES |
+                                              N.PATH_OPT_SHARED_SMALL_TILES)
     if args.micro_batches >= 0 and hasattr(model, 'micro_batches'):
         model.micro_batches = args.micro_batches
     crit = R.ReviewNetEnsembleCriterion(cfg)

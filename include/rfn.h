@@ -76,7 +76,9 @@ typedef struct rfn_dims {
 #define RFN_PATH_OPT_PERSIST_S2_BWD 8u    /* stage-II backward sweep, steps T2-1 ... 1 (rfn_prefix_bwd)       */
 #define RFN_PATH_OPT_PERSIST_ALL 15u
 #define RFN_PATH_OPT_NO_SMALL_TILES 32u   /* A/B hook: per-step products keep 32-row tiles even when the launch has so few of them
-                                           * that the library would take 16-row tiles (rfn_cell_gemm variant 4; same results)  */
+                                           * that the library would take 16-row tiles (rfn_cell_gemm variant 6; same results)  */
+#define RFN_PATH_OPT_SHARED_SMALL_TILES 64u /* A/B hook: those 16-row tiles on ring slots shared by the block (rfn_cell_gemm variants
+                                           * 4 / 5) instead of wave-private ones (variant 6, the default); same results        */
 #define RFN_PATH_OPT_DEEP_CELLS 16u       /* A/B hook: per-step products with no more tiles than CUs on the deep-ring kernel
                                            * (rfn_cell_gemm, RFN_CELL_VARIANT_DEEP) instead of the 3-slot one; not faster      */
 

@@ -21,6 +21,7 @@ PATH_OPT_PERSIST_DEC_FWD, PATH_OPT_PERSIST_S2_FWD, PATH_OPT_PERSIST_DEC_BWD, PAT
 PATH_OPT_PERSIST_ALL = 15
 PATH_OPT_DEEP_CELLS = 16          # rfn.h RFN_PATH_OPT_DEEP_CELLS (A/B hook)
 PATH_OPT_NO_SMALL_TILES = 32      # rfn.h RFN_PATH_OPT_NO_SMALL_TILES (A/B hook)
+PATH_OPT_SHARED_SMALL_TILES = 64  # rfn.h RFN_PATH_OPT_SHARED_SMALL_TILES (A/B hook)
 CELL_VARIANT_DEEP = 256
 GEMM_OPT_LDS_LEAN = 1
 GEMM_OPT_NO_DMA = 2

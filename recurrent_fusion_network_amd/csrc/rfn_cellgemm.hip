@@ -31,10 +31,10 @@
 #include "rfn_internal.h"
 
 
-template <int BM, int BK, int WK, bool BKF, int EPI>
+template <int BM, int BK, int WK, bool BKF, int EPI, bool WP = false>
 __global__ __launch_bounds__(64 * (BM >= 32 ? BM / 32 : 1) * WK) void cell_gemm_k(const CgArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    cg_tile<BM, BK, WK, BKF, EPI, false, false>(a, blockIdx.x, smem, [] {});
+    cg_tile<BM, BK, WK, BKF, EPI, false, false, WP>(a, blockIdx.x, smem, [] {});
 }
 // The deep-ring form of the 32-row variant (rfn_cellgemm_body.h, DEEP; opt-in, RFN_CELL_VARIANT_DEEP): for launches whose tiles
 // do not outnumber the CUs -- every per-step product of the recurrences at B <= 64, the backward ones up to B = 256.
@@ -45,16 +45,16 @@ __global__ __launch_bounds__(64 * (BM >= 32 ? BM / 32 : 1) * WK) void cell_gemm_
 template <bool BKF, int EPI>
 __global__ __launch_bounds__(256) void cell_gemm_deep_k(const CgArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    cg_tile<32, 64, 4, BKF, EPI, false, true>(a, blockIdx.x, smem, [] {});
+    cg_tile<32, 64, 4, BKF, EPI, false, true, false>(a, blockIdx.x, smem, [] {});
 }
 
 // ---- host side -----------------------------------------------------------------------------------------------------------
 struct CgDevState {
     bool set[16] = {};
 };
-template <int BM, int BK, int WK, bool BKF, int EPI>
+template <int BM, int BK, int WK, bool BKF, int EPI, bool WP = false>
 static int cg_launch(const CgArgs& a, int blocks, hipStream_t st) {
-    auto k = cell_gemm_k<BM, BK, WK, BKF, EPI>;
+    auto k = cell_gemm_k<BM, BK, WK, BKF, EPI, WP>;
     constexpr size_t slot = (size_t)(BM + CG_BN) * BK * sizeof(float);
     static CgDevState ds;
     int dev = 0;
@@ -80,7 +80,8 @@ static int cg_device_cus() {   // CU count of the current device (cached per dev
 }
 
 // Tile variants: 1 = 64 rows, K step 32, 2 K-waves; 2 = 64 rows, K step 64, 4 K-waves; 3 = 32 rows, K step 64, 4 K-waves;
-// 4 = 16 rows, K step 64, 4 K-waves on the 16x16x4 MFMA shape; 5 = the same on K steps of 128 (both bit-identical to 2 and 3).
+// 4 = 16 rows, K step 64, 4 K-waves on the 16x16x4 MFMA shape; 5 = the same on K steps of 128; 6 = 4 with wave-private ring
+// slots (all three bit-identical to 2 and 3).
 // variant 0: the K step / K-wave count -- which fix the k order of every output element -- are chosen FROM THE K COUNTS
 // ONLY, so a row's arithmetic never depends on the batch it sits in (variants 2 and 3 give bit-identical results).
 static int cg_plan(CgPrepared& pz, int variant) {
@@ -101,21 +102,23 @@ static int cg_plan(CgPrepared& pz, int variant) {
     }
     // 32-row tiles whenever the K step of 64 applies: measured fastest at every per-step shape of the path (B = 64 ... 640),
     // because they put two to three independent blocks on a CU (profiles/r03_cellgemm.md)
-    if (variant == 0) {
+    if (variant == 0 || variant == 7) {   // 7 (A/B hook): the library's choice with the shared-slot 16-row forms of round 5's first half
+        const bool shared16 = variant == 7;
         variant = k64 ? 3 : 1;
         // few tiles: 16-row tiles put the launch on twice the CUs with half the MFMA chain per block (variant 4, bit-identical
         // to variant 3: rfn_cellgemm_body.h) -- taken when even the 16-row tiles do not outnumber the CUs
         if (k64) {
             long cols = 0;
             for (int o = 0; o < a.nout; ++o) cols += a.out[o].N / CG_BN;
-            // 5: the same on K steps of 128, for long reductions only (K = 2048: 13.7 against 15.6 us; at K = 512 the four
-            // fat K steps lose to eight lean ones: 7.4 against 6.4 us -- tools/bench_cellgemm.py --small --variants 3,4,5)
-            if ((long)rfn_cdiv(a.M, 16) * cols <= cg_device_cus()) variant = (k128 && max_iters >= 1024) ? 5 : 4;
+            // 6: those tiles with wave-private ring slots -- no block barrier in the K loop, fragments read one step ahead
+            // (tools/bench_cellgemm.py --small --variants 3,4,5,6, B = 64: Kb1 17.4 / 15.7 / 13.7 / 10.1 us, stage-II K3 + LSTM
+            // 21.0 / 20.8 / 19.8 / 16.6, Kb2 6.9 / 6.5 / 6.2 / 5.4); 4 and 5 (shared slots, K steps of 64 / 128) stay as A/B forms
+            if ((long)rfn_cdiv(a.M, 16) * cols <= cg_device_cus()) variant = !shared16 ? 6 : (k128 && max_iters >= 1024) ? 5 : 4;
         }
     }
-    if ((variant == 2 || variant == 3 || variant == 4) && !k64) return RFN_ERR_SHAPE;
+    if ((variant == 2 || variant == 3 || variant == 4 || variant == 6) && !k64) return RFN_ERR_SHAPE;
     if (variant == 5 && !k128) return RFN_ERR_SHAPE;
-    if (variant < 1 || variant > 5) return RFN_ERR_SHAPE;
+    if (variant < 1 || variant > 6) return RFN_ERR_SHAPE;
     const int bm = (variant >= 4) ? 16 : (variant == 3) ? 32 : 64;
     max_iters /= (variant == 1) ? 32 : (variant == 5) ? 128 : 64;
     a.tiles_m = rfn_cdiv(a.M, bm);
@@ -133,6 +136,7 @@ static int cg_plan(CgPrepared& pz, int variant) {
     if (slots > CG_MAX_SLOTS) slots = CG_MAX_SLOTS;
     if (slots > max_iters + 1) slots = max_iters + 1;
     if (slots < 2) slots = 2;
+    if (variant == 6) slots = CG_WP_SLOTS;   // the wave-private form's ring depth is a compile-time constant
     a.slots = slots;
     pz.variant = variant;
     pz.blocks = t0;
@@ -190,6 +194,7 @@ int rfn_cg_launch(const CgPrepared& pz, void* stream) {
         case 3: return cg_launch<32, 64, 4, BKF_, EPI_>(pz.a, pz.blocks, st);                \
         case 4: return cg_launch<16, 64, 4, BKF_, EPI_>(pz.a, pz.blocks, st);                \
         case 5: return cg_launch<16, 128, 4, BKF_, EPI_>(pz.a, pz.blocks, st);               \
+        case 6: return cg_launch<16, 64, 4, BKF_, EPI_, true>(pz.a, pz.blocks, st);          \
         default: return RFN_ERR_SHAPE;                                                      \
     }
     if (pz.epi == CG_EPI_LSTM) { CG_CASE(true, CG_EPI_LSTM) }

@@ -20,6 +20,7 @@ typedef __attribute__((address_space(3))) void cg_lds_void;
 typedef const __attribute__((address_space(1))) void cg_gbl_void;
 
 #define CG_MAXSEG 24
+#define CG_WP_SLOTS 4             /* ring depth of the wave-private form (cg_tile WP): compile-time, the K loop counts on it */
 #define CG_MAX_SLOTS 6            /* ring slots are a launch parameter: as many as LDS allows for the blocks a CU hosts */
 #define CG_BN 32                   /* tile width: 8 units x 4 gates in the gate epilogue */
 enum { CG_EPI_STORE = 0, CG_EPI_LSTM = 1, CG_EPI_LSTM_BWD = 2 };
@@ -118,9 +119,15 @@ __device__ __forceinline__ void cg_wait_vmcnt_dyn(int n) {
 // to itself anyway): the ring is as deep as the launch's LDS allows (a.slots, up to 8), the two operands have cursors of their
 // own, and when the ring holds the whole K range every K step is requested up front and the K loop runs without counted
 // waits or barriers.  Same pieces in the same slots, same k order: bit-identical to the shallow form.
-template <int BM, int BK, int WK, bool BKF, int EPI, bool XB, bool DEEP, typename Hook>
+//
+// WP (round 5; 16-row tiles, the launch kernel of few-tile products): every wave requests exactly the k-groups IT consumes
+// into a region of the slot that is its own, so the K loop has no block barrier and no wave waits for another one's requests;
+// the fragments of step it + 1 are read from LDS while the MFMAs of step it run, and the slot they came from is requested
+// again right away.  Same k-groups per wave in the same order on the same MFMA shape: bit-identical to the shared-slot forms.
+template <int BM, int BK, int WK, bool BKF, int EPI, bool XB, bool DEEP, bool WP, typename Hook>
 __device__ __forceinline__ void cg_tile(const CgArgs& a, const int bid, float* smem, Hook hook) {
     static_assert(DEEP || !XB, "the cross-block form is built on the deep pipeline");
+    static_assert(!WP || (BM == 16 && BK == 64 && WK == 4 && !XB && !DEEP), "wave-private slots: 16-row tiles, K step 64");
     constexpr int BN = CG_BN;
     // BM = 16 (round 5): a 16-row tile = two 16 x 16 MFMA tiles side by side per wave (v_mfma_f32_16x16x4_f32), for launches
     // with so few 32-row tiles that most CUs would idle: twice the blocks, half the MFMA chain per block.  The 16x16x4 shape is
@@ -223,7 +230,7 @@ __device__ __forceinline__ void cg_tile(const CgArgs& a, const int bid, float* s
             }
         }
     };
-    if constexpr (!DEEP) setup();
+    if constexpr (!DEEP && !WP) setup();
     auto issue = [&](int slot) {
         float* st = smem + slot * SLOT_FL;
 #pragma unroll
@@ -320,6 +327,62 @@ __device__ __forceinline__ void cg_tile(const CgArgs& a, const int bid, float* s
             setupB();
         }
     };
+    // ---- WP: this wave's own three pieces of a K step: A rows x its 16 k's | B, two pieces -------------------------------------
+    // LDS image of a [16 rows][4 chunks] piece: chunk slot j of row r holds the wave's chunk j ^ wp_g(r) (chunks 0 1 = its first
+    // k-group of the step, 2 3 = its second), which makes every ds_read_b128 lane group of the fragment reads cover the 64
+    // banks once.  [k][n] weights: 8 k-rows x 8 column chunks per piece, rows 4-7 with the column halves swapped (the two
+    // 16-lane halves of a ds_read_b32 group read k-rows 4 apart).
+    auto wp_g = [](int r) -> int { return ((r >> 3) & 1) * 3; };
+    uint32_t offW[3] = {0u, 0u, 0u};
+    const char* wpA = nullptr;
+    const char* wpB = nullptr;
+    long wpStepB = 0;
+    int wpSeg = 0, wpK = 0, wpSegK = 0;
+    auto setupW = [&]() {
+        if (wpSeg >= nseg) return;
+        const CgSeg& sg = a.seg[seg0 + wpSeg];
+        wpSegK = sg.K;
+        wpA = (const char*)sg.A;
+        wpB = (const char*)sg.B;
+        wpStepB = BKF ? (long)BK * 4 : (long)BK * sg.ldb * 4;
+        const int rr = lane >> 2, j = (lane & 3) ^ wp_g(rr);
+        const int ck = 2 * (wk + WK * (j >> 1)) + (j & 1);     // 16-B chunk of the K step's 64 k's
+        {
+            int gr = row0 + rr;
+            gr = gr < M ? gr : M - 1;
+            offW[0] = (uint32_t)(((long)gr * sg.lda + 4 * ck) * 4);
+        }
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc) {
+            if constexpr (BKF) {
+                const int rt = 16 * pc + rr;     // tile column = row of the [n][k] weight
+                long n;
+                if constexpr (EPI == CG_EPI_LSTM) n = (long)(rt / U) * R + tn * U + rt % U;
+                else n = col0 + rt;
+                offW[1 + pc] = (uint32_t)((n * sg.ldb + 4 * ck) * 4);
+            } else {
+                const int kr = lane >> 3, cq = (lane & 7) ^ (4 * ((kr >> 2) & 1));
+                offW[1 + pc] = (uint32_t)(((long)(8 * (wk + WK * pc) + kr) * sg.ldb + col0 + 4 * cq) * 4);
+            }
+        }
+    };
+    auto wp_dma = [&](int slot) {     // request this wave's pieces of its next K step; wp_seg() must follow before the next one
+        float* st = smem + slot * SLOT_FL + wk * 768;
+        __builtin_amdgcn_global_load_lds((cg_gbl_void*)(wpA + offW[0]), (cg_lds_void*)(st), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((cg_gbl_void*)(wpB + offW[1]), (cg_lds_void*)(st + 256), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((cg_gbl_void*)(wpB + offW[2]), (cg_lds_void*)(st + 512), 16, 0, 0);
+        wpA += BK * 4;
+        wpB += wpStepB;
+        wpK += BK;
+    };
+    auto wp_seg = [&]() {             // kept out of wp_dma so that the K loop's body is one basic block
+        if (wpK >= wpSegK) {
+            wpK = 0;
+            ++wpSeg;
+            setupW();
+        }
+    };
+    if constexpr (WP) setupW();
     const int SLx = DEEP ? xb_uni(a.slots) : 0;
     // K steps whose operands are requested up front: all of them when the ring holds the whole K range (every slot is then
     // used once and the K loop needs neither counted waits nor barriers), else what the ring has in flight
@@ -412,6 +475,12 @@ __device__ __forceinline__ void cg_tile(const CgArgs& a, const int bid, float* s
     if constexpr (DEEP) {
         for (int s = 0; s < PRE; ++s) issueA(s);
         issued = PRE;
+    } else if constexpr (WP) {
+        for (int s = 0; s < CG_WP_SLOTS && s < total_iters; ++s) {   // every slot: a step's slot is requested again as soon as
+            wp_dma(s);                                                // its fragments are in registers
+            wp_seg();
+            ++issued;
+        }
     } else {
         for (int s = 0; s < SL - 1 && s < total_iters; ++s) {
             issue(s);
@@ -469,6 +538,105 @@ __device__ __forceinline__ void cg_tile(const CgArgs& a, const int bid, float* s
             for (int c = 0; c < 4; ++c) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c], bf[c], acc, 0, 0, 0);
         }
     };
+    if constexpr (WP) {
+        struct WpFrag {
+            cg_f32x4 af[2];
+            cg_f32x4 bf[BKF ? 4 : 1];
+            float bs[BKF ? 1 : 8];
+        };
+        auto wp_wait = [&](int younger_steps) {   // this wave's requests of all but the `younger_steps` newest steps have landed
+            switch (younger_steps) {
+                case 0: cg_wait_vmcnt<0>(); break;
+                case 1: cg_wait_vmcnt<3>(); break;
+                case 2: cg_wait_vmcnt<6>(); break;
+                case 3: cg_wait_vmcnt<9>(); break;
+                case 4: cg_wait_vmcnt<12>(); break;
+                case 5: cg_wait_vmcnt<15>(); break;
+                case 6: cg_wait_vmcnt<18>(); break;
+                default: cg_wait_vmcnt<21>(); break;
+            }
+        };
+        auto wp_read = [&](int slot, WpFrag& f) {
+            const float* w_l = smem + slot * SLOT_FL + wk * 768;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int js = (2 * t + (kq & 1)) ^ wp_g(l15);
+                f.af[t] = *reinterpret_cast<const cg_f32x4*>(w_l + (l15 * 4 + js) * 4);
+                if constexpr (BKF) {
+                    f.bf[2 * t] = *reinterpret_cast<const cg_f32x4*>(w_l + 256 + (l15 * 4 + js) * 4);
+                    f.bf[2 * t + 1] = *reinterpret_cast<const cg_f32x4*>(w_l + 512 + (l15 * 4 + js) * 4);
+                } else {
+                    const int kr = 4 * (kq & 1) + (kq >> 1);      // k-row of the first MFMA's k inside the k-group; + 2: the second's
+                    const float* pb = w_l + 256 + 256 * t + kr * 32;
+                    const int nx = 16 * (kq & 1);
+#pragma unroll
+                    for (int nh = 0; nh < 2; ++nh) {
+                        f.bs[4 * t + 2 * nh] = pb[(16 * nh + l15) ^ nx];
+                        f.bs[4 * t + 2 * nh + 1] = pb[64 + ((16 * nh + l15) ^ nx)];
+                    }
+                }
+            }
+        };
+        // one v_cndmask per operand (written as `lo ? v[0] : v[1]` the compiler makes it a dynamic element extract: three)
+        const bool wp_lo = kq < 2;
+        auto wp_sel = [&](float x, float y) -> float {
+            asm("" : "+v"(x), "+v"(y));
+            return wp_lo ? x : y;
+        };
+        auto wp_mfma = [&](const WpFrag& f) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const float a0 = wp_sel(f.af[t][0], f.af[t][1]), a1 = wp_sel(f.af[t][2], f.af[t][3]);
+#pragma unroll
+                for (int nh = 0; nh < 2; ++nh) {
+                    float b0, b1;
+                    if constexpr (BKF) {
+                        b0 = wp_sel(f.bf[2 * t + nh][0], f.bf[2 * t + nh][1]);
+                        b1 = wp_sel(f.bf[2 * t + nh][2], f.bf[2 * t + nh][3]);
+                    } else {
+                        b0 = f.bs[4 * t + 2 * nh];
+                        b1 = f.bs[4 * t + 2 * nh + 1];
+                    }
+                    acc16[nh] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc16[nh], 0, 0, 0);
+                    acc16[nh] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc16[nh], 0, 0, 0);
+                }
+            }
+        };
+        constexpr int WSL = CG_WP_SLOTS;
+        WpFrag fc, fn;
+        if (total_iters >= WSL) {
+            // steady state: step it's fragments are in registers, steps it + 1 ... it + WSL - 1 are in flight or landed
+            wp_wait(WSL - 1);
+            wp_read(0, fc);
+            int rd = 1, fl = 0;     // slot of step it + 1; slot of step it (free: its fragments are in registers)
+            for (int it = total_iters - WSL; it > 0; --it) {
+                cg_wait_vmcnt<(WSL - 2) * 3>();
+                wp_read(rd, fn);
+                wp_mfma(fc);
+                wp_dma(fl);
+                fc = fn;
+                rd = (rd + 1 == WSL) ? 0 : rd + 1;
+                fl = (fl + 1 == WSL) ? 0 : fl + 1;
+                wp_seg();
+            }
+#pragma unroll
+            for (int j = 0; j < WSL; ++j) {   // the last WSL steps: nothing left to request
+                if (j < WSL - 1) {
+                    wp_wait(WSL - 2 - j);
+                    wp_read(rd, fn);
+                }
+                wp_mfma(fc);
+                fc = fn;
+                rd = (rd + 1 == WSL) ? 0 : rd + 1;
+            }
+        } else {   // fewer K steps than slots: all requested above
+            for (int it = 0; it < total_iters; ++it) {
+                wp_wait(total_iters - it - 1);
+                wp_read(it, fc);
+                wp_mfma(fc);
+            }
+        }
+    } else {
     int cur = 0, fill = SL - 1;
     if (ALLIN) {   // DEEP, whole K range resident: one wait, one barrier, then a loop the compiler can pipeline (same k order)
         cg_wait_vmcnt<0>();
@@ -519,6 +687,7 @@ __device__ __forceinline__ void cg_tile(const CgArgs& a, const int bid, float* s
         CG_LSTAMP(it, 4);
         cur = (cur + 1 == SL) ? 0 : cur + 1;
         fill = (fill + 1 == SL) ? 0 : fill + 1;
+    }
     }
 
     // ---- the WK partial tiles meet in LDS (the ring is free: every DMA has been waited for) ----------------------------

@@ -193,7 +193,7 @@ __global__ __launch_bounds__(CH_THREADS) void chain_k(const ChainArgs ca) {
         // ---- phase 0: the products of the recurrent state ---------------------------------------------------------------
         for (int vb = blockIdx.x; vb < n0; vb += G) {
             if (vb != (int)blockIdx.x) __syncthreads();   // the ring of this block's previous tile is free (arrive did it for the first)
-            cg_tile<32, 64, 4, FWD, CG_EPI_STORE, true, true>(D.g0, vb, smem, wait_prev);
+            cg_tile<32, 64, 4, FWD, CG_EPI_STORE, true, true, false>(D.g0, vb, smem, wait_prev);
         }
         wait_prev();
 #ifdef RFN_CHAIN_TIMING
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(CH_THREADS) void chain_k(const ChainArgs ca) {
         // ---- phase 2: the products of the contexts + the LSTM update (forward) / of d hproj + the LSTM backward below ----------
         for (int vb = blockIdx.x; vb < n2; vb += G) {
             if (vb != (int)blockIdx.x) __syncthreads();
-            cg_tile<32, 64, 4, FWD, FWD ? CG_EPI_LSTM : CG_EPI_LSTM_BWD, true, true>(D.g2, vb, smem, wait_prev);
+            cg_tile<32, 64, 4, FWD, FWD ? CG_EPI_LSTM : CG_EPI_LSTM_BWD, true, true, false>(D.g2, vb, smem, wait_prev);
         }
         wait_prev();
 #ifdef RFN_CHAIN_TIMING
