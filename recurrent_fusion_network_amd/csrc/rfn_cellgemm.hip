@@ -113,7 +113,11 @@ static int cg_plan(CgPrepared& pz, int variant) {
             // 6: those tiles with wave-private ring slots -- no block barrier in the K loop, fragments read one step ahead
             // (tools/bench_cellgemm.py --small --variants 3,4,5,6, B = 64: Kb1 17.4 / 15.7 / 13.7 / 10.1 us, stage-II K3 + LSTM
             // 21.0 / 20.8 / 19.8 / 16.6, Kb2 6.9 / 6.5 / 6.2 / 5.4); 4 and 5 (shared slots, K steps of 64 / 128) stay as A/B forms
-            if ((long)rfn_cdiv(a.M, 16) * cols <= cg_device_cus()) variant = !shared16 ? 6 : (k128 && max_iters >= 1024) ? 5 : 4;
+            const long t16 = (long)rfn_cdiv(a.M, 16) * cols, cus = cg_device_cus();
+            if (t16 <= cus) variant = !shared16 ? 6 : (k128 && max_iters >= 1024) ? 5 : 4;
+            // [k][n] weights (the backward products, K = 4R): still ahead with two 16-row tiles per CU (B = 256 Kb1: 15.3 against
+            // 17.6 us; the forward products at that size are not: 13.7 against 11.2)
+            else if (!shared16 && !pz.bkf && t16 <= 2 * cus) variant = 6;
         }
     }
     if ((variant == 2 || variant == 3 || variant == 4 || variant == 6) && !k64) return RFN_ERR_SHAPE;

@@ -20,7 +20,9 @@ typedef __attribute__((address_space(3))) void cg_lds_void;
 typedef const __attribute__((address_space(1))) void cg_gbl_void;
 
 #define CG_MAXSEG 24
-#define CG_WP_SLOTS 4             /* ring depth of the wave-private form (cg_tile WP): compile-time, the K loop counts on it */
+#ifndef CG_WP_SLOTS
+#define CG_WP_SLOTS 3             /* ring depth of the wave-private form (cg_tile WP): compile-time, the K loop counts on it */
+#endif
 #define CG_MAX_SLOTS 6            /* ring slots are a launch parameter: as many as LDS allows for the blocks a CU hosts */
 #define CG_BN 32                   /* tile width: 8 units x 4 gates in the gate epilogue */
 enum { CG_EPI_STORE = 0, CG_EPI_LSTM = 1, CG_EPI_LSTM_BWD = 2 };
