@@ -81,7 +81,7 @@ static int cg_device_cus() {   // CU count of the current device (cached per dev
 
 // Tile variants: 1 = 64 rows, K step 32, 2 K-waves; 2 = 64 rows, K step 64, 4 K-waves; 3 = 32 rows, K step 64, 4 K-waves;
 // 4 = 16 rows, K step 64, 4 K-waves on the 16x16x4 MFMA shape; 5 = the same on K steps of 128; 6 = 4 with wave-private ring
-// slots (all three bit-identical to 2 and 3).
+// slots; 8 = 3 with wave-private ring slots (all bit-identical to 2 and 3); 7 = the library's choice among 1-5 (A/B hook).
 // variant 0: the K step / K-wave count -- which fix the k order of every output element -- are chosen FROM THE K COUNTS
 // ONLY, so a row's arithmetic never depends on the batch it sits in (variants 2 and 3 give bit-identical results).
 static int cg_plan(CgPrepared& pz, int variant) {
@@ -113,17 +113,18 @@ static int cg_plan(CgPrepared& pz, int variant) {
             // 6: those tiles with wave-private ring slots -- no block barrier in the K loop, fragments read one step ahead
             // (tools/bench_cellgemm.py --small --variants 3,4,5,6, B = 64: Kb1 17.4 / 15.7 / 13.7 / 10.1 us, stage-II K3 + LSTM
             // 21.0 / 20.8 / 19.8 / 16.6, Kb2 6.9 / 6.5 / 6.2 / 5.4); 4 and 5 (shared slots, K steps of 64 / 128) stay as A/B forms
-            const long t16 = (long)rfn_cdiv(a.M, 16) * cols, cus = cg_device_cus();
+            const long t16 = (long)rfn_cdiv(a.M, 16) * cols, t32 = (long)rfn_cdiv(a.M, 32) * cols, cus = cg_device_cus();
             if (t16 <= cus) variant = !shared16 ? 6 : (k128 && max_iters >= 1024) ? 5 : 4;
-            // [k][n] weights (the backward products, K = 4R): still ahead with two 16-row tiles per CU (B = 256 Kb1: 15.3 against
-            // 17.6 us; the forward products at that size are not: 13.7 against 11.2)
-            else if (!shared16 && !pz.bkf && t16 <= 2 * cus) variant = 6;
+            // 8: 32-row tiles on wave-private slots while a CU gets at most one of them (B = 64: decoder K1 6.0 against 6.9 us,
+            // stage-II backward 14.6 against 17.8; B = 256 Kb1 14.3 against 17.6); with several blocks per CU the shared-slot
+            // form's waits are covered by the other blocks' waves and it stays ahead (B = 256 stage-II K3: 28.8 against 31.2)
+            else if (!shared16 && t32 <= cus) variant = 8;
         }
     }
-    if ((variant == 2 || variant == 3 || variant == 4 || variant == 6) && !k64) return RFN_ERR_SHAPE;
+    if ((variant == 2 || variant == 3 || variant == 4 || variant == 6 || variant == 8) && !k64) return RFN_ERR_SHAPE;
     if (variant == 5 && !k128) return RFN_ERR_SHAPE;
-    if (variant < 1 || variant > 6) return RFN_ERR_SHAPE;
-    const int bm = (variant >= 4) ? 16 : (variant == 3) ? 32 : 64;
+    if (variant < 1 || variant > 8 || variant == 7) return RFN_ERR_SHAPE;
+    const int bm = (variant == 3 || variant == 8) ? 32 : (variant >= 4) ? 16 : 64;
     max_iters /= (variant == 1) ? 32 : (variant == 5) ? 128 : 64;
     a.tiles_m = rfn_cdiv(a.M, bm);
     int t0 = 0;
@@ -140,7 +141,7 @@ static int cg_plan(CgPrepared& pz, int variant) {
     if (slots > CG_MAX_SLOTS) slots = CG_MAX_SLOTS;
     if (slots > max_iters + 1) slots = max_iters + 1;
     if (slots < 2) slots = 2;
-    if (variant == 6) slots = CG_WP_SLOTS;   // the wave-private form's ring depth is a compile-time constant
+    if (variant == 6 || variant == 8) slots = CG_WP_SLOTS;   // the wave-private form's ring depth is a compile-time constant
     a.slots = slots;
     pz.variant = variant;
     pz.blocks = t0;
@@ -199,6 +200,7 @@ int rfn_cg_launch(const CgPrepared& pz, void* stream) {
         case 4: return cg_launch<16, 64, 4, BKF_, EPI_>(pz.a, pz.blocks, st);                \
         case 5: return cg_launch<16, 128, 4, BKF_, EPI_>(pz.a, pz.blocks, st);               \
         case 6: return cg_launch<16, 64, 4, BKF_, EPI_, true>(pz.a, pz.blocks, st);          \
+        case 8: return cg_launch<32, 64, 4, BKF_, EPI_, true>(pz.a, pz.blocks, st);          \
         default: return RFN_ERR_SHAPE;                                                      \
     }
     if (pz.epi == CG_EPI_LSTM) { CG_CASE(true, CG_EPI_LSTM) }

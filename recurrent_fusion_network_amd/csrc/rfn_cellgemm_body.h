@@ -129,7 +129,7 @@ __device__ __forceinline__ void cg_wait_vmcnt_dyn(int n) {
 template <int BM, int BK, int WK, bool BKF, int EPI, bool XB, bool DEEP, bool WP, typename Hook>
 __device__ __forceinline__ void cg_tile(const CgArgs& a, const int bid, float* smem, Hook hook) {
     static_assert(DEEP || !XB, "the cross-block form is built on the deep pipeline");
-    static_assert(!WP || (BM == 16 && BK == 64 && WK == 4 && !XB && !DEEP), "wave-private slots: 16-row tiles, K step 64");
+    static_assert(!WP || ((BM == 16 || BM == 32) && BK == 64 && WK == 4 && !XB && !DEEP), "wave-private slots: 16- / 32-row tiles, K step 64");
     constexpr int BN = CG_BN;
     // BM = 16 (round 5): a 16-row tile = two 16 x 16 MFMA tiles side by side per wave (v_mfma_f32_16x16x4_f32), for launches
     // with so few 32-row tiles that most CUs would idle: twice the blocks, half the MFMA chain per block.  The 16x16x4 shape is
@@ -329,13 +329,16 @@ __device__ __forceinline__ void cg_tile(const CgArgs& a, const int bid, float* s
             setupB();
         }
     };
-    // ---- WP: this wave's own three pieces of a K step: A rows x its 16 k's | B, two pieces -------------------------------------
+    // ---- WP: this wave's own pieces of a K step: A rows x its 16 k's (one piece per 16 rows) | B, two pieces -----------------
     // LDS image of a [16 rows][4 chunks] piece: chunk slot j of row r holds the wave's chunk j ^ wp_g(r) (chunks 0 1 = its first
     // k-group of the step, 2 3 = its second), which makes every ds_read_b128 lane group of the fragment reads cover the 64
-    // banks once.  [k][n] weights: 8 k-rows x 8 column chunks per piece, rows 4-7 with the column halves swapped (the two
-    // 16-lane halves of a ds_read_b32 group read k-rows 4 apart).
-    auto wp_g = [](int r) -> int { return ((r >> 3) & 1) * 3; };
-    uint32_t offW[3] = {0u, 0u, 0u};
+    // banks once (16-row tiles: the lanes of a group ask for two different chunks; 32-row tiles: for one).  [k][n] weights:
+    // 8 k-rows x 8 column chunks per piece, rows 4-7 with the column halves swapped (the two 16-lane halves of a ds_read_b32
+    // group of the 16-row form read k-rows 4 apart).
+    constexpr int WPA = BM / 16, WPN = WPA + 2, WP_FL = WPN * 256;     // pieces (1 KiB) per wave and K step; floats
+    static_assert(!WP || WK * WP_FL == SLOT_FL, "the waves' regions tile the slot");
+    auto wp_g = [](int r) -> int { return SMALL ? ((r >> 3) & 1) * 3 : (r >> 2) & 3; };
+    uint32_t offW[WPN] = {};
     const char* wpA = nullptr;
     const char* wpB = nullptr;
     long wpStepB = 0;
@@ -349,10 +352,11 @@ __device__ __forceinline__ void cg_tile(const CgArgs& a, const int bid, float* s
         wpStepB = BKF ? (long)BK * 4 : (long)BK * sg.ldb * 4;
         const int rr = lane >> 2, j = (lane & 3) ^ wp_g(rr);
         const int ck = 2 * (wk + WK * (j >> 1)) + (j & 1);     // 16-B chunk of the K step's 64 k's
-        {
-            int gr = row0 + rr;
+#pragma unroll
+        for (int pa = 0; pa < WPA; ++pa) {
+            int gr = row0 + 16 * pa + rr;
             gr = gr < M ? gr : M - 1;
-            offW[0] = (uint32_t)(((long)gr * sg.lda + 4 * ck) * 4);
+            offW[pa] = (uint32_t)(((long)gr * sg.lda + 4 * ck) * 4);
         }
 #pragma unroll
         for (int pc = 0; pc < 2; ++pc) {
@@ -361,18 +365,20 @@ __device__ __forceinline__ void cg_tile(const CgArgs& a, const int bid, float* s
                 long n;
                 if constexpr (EPI == CG_EPI_LSTM) n = (long)(rt / U) * R + tn * U + rt % U;
                 else n = col0 + rt;
-                offW[1 + pc] = (uint32_t)((n * sg.ldb + 4 * ck) * 4);
+                offW[WPA + pc] = (uint32_t)((n * sg.ldb + 4 * ck) * 4);
             } else {
                 const int kr = lane >> 3, cq = (lane & 7) ^ (4 * ((kr >> 2) & 1));
-                offW[1 + pc] = (uint32_t)(((long)(8 * (wk + WK * pc) + kr) * sg.ldb + col0 + 4 * cq) * 4);
+                offW[WPA + pc] = (uint32_t)(((long)(8 * (wk + WK * pc) + kr) * sg.ldb + col0 + 4 * cq) * 4);
             }
         }
     };
     auto wp_dma = [&](int slot) {     // request this wave's pieces of its next K step; wp_seg() must follow before the next one
-        float* st = smem + slot * SLOT_FL + wk * 768;
-        __builtin_amdgcn_global_load_lds((cg_gbl_void*)(wpA + offW[0]), (cg_lds_void*)(st), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((cg_gbl_void*)(wpB + offW[1]), (cg_lds_void*)(st + 256), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((cg_gbl_void*)(wpB + offW[2]), (cg_lds_void*)(st + 512), 16, 0, 0);
+        float* st = smem + slot * SLOT_FL + wk * WP_FL;
+#pragma unroll
+        for (int pa = 0; pa < WPA; ++pa)
+            __builtin_amdgcn_global_load_lds((cg_gbl_void*)(wpA + offW[pa]), (cg_lds_void*)(st + 256 * pa), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((cg_gbl_void*)(wpB + offW[WPA]), (cg_lds_void*)(st + 256 * WPA), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((cg_gbl_void*)(wpB + offW[WPA + 1]), (cg_lds_void*)(st + 256 * WPA + 256), 16, 0, 0);
         wpA += BK * 4;
         wpB += wpStepB;
         wpK += BK;
@@ -543,38 +549,50 @@ __device__ __forceinline__ void cg_tile(const CgArgs& a, const int bid, float* s
     if constexpr (WP) {
         struct WpFrag {
             cg_f32x4 af[2];
-            cg_f32x4 bf[BKF ? 4 : 1];
+            cg_f32x4 bf[BKF ? (SMALL ? 4 : 2) : 1];
             float bs[BKF ? 1 : 8];
         };
         auto wp_wait = [&](int younger_steps) {   // this wave's requests of all but the `younger_steps` newest steps have landed
             switch (younger_steps) {
                 case 0: cg_wait_vmcnt<0>(); break;
-                case 1: cg_wait_vmcnt<3>(); break;
-                case 2: cg_wait_vmcnt<6>(); break;
-                case 3: cg_wait_vmcnt<9>(); break;
-                case 4: cg_wait_vmcnt<12>(); break;
-                case 5: cg_wait_vmcnt<15>(); break;
-                case 6: cg_wait_vmcnt<18>(); break;
-                default: cg_wait_vmcnt<21>(); break;
+                case 1: cg_wait_vmcnt<WPN>(); break;
+                case 2: cg_wait_vmcnt<2 * WPN>(); break;
+                case 3: cg_wait_vmcnt<3 * WPN>(); break;
+                case 4: cg_wait_vmcnt<4 * WPN>(); break;
+                case 5: cg_wait_vmcnt<5 * WPN>(); break;
+                default: cg_wait_vmcnt<6 * WPN>(); break;
             }
         };
         auto wp_read = [&](int slot, WpFrag& f) {
-            const float* w_l = smem + slot * SLOT_FL + wk * 768;
+            const float* w_l = smem + slot * SLOT_FL + wk * WP_FL;
+            const float* wb_l = w_l + 256 * WPA;
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                const int js = (2 * t + (kq & 1)) ^ wp_g(l15);
-                f.af[t] = *reinterpret_cast<const cg_f32x4*>(w_l + (l15 * 4 + js) * 4);
-                if constexpr (BKF) {
-                    f.bf[2 * t] = *reinterpret_cast<const cg_f32x4*>(w_l + 256 + (l15 * 4 + js) * 4);
-                    f.bf[2 * t + 1] = *reinterpret_cast<const cg_f32x4*>(w_l + 512 + (l15 * 4 + js) * 4);
-                } else {
-                    const int kr = 4 * (kq & 1) + (kq >> 1);      // k-row of the first MFMA's k inside the k-group; + 2: the second's
-                    const float* pb = w_l + 256 + 256 * t + kr * 32;
-                    const int nx = 16 * (kq & 1);
+                if constexpr (SMALL) {
+                    const int js = (2 * t + (kq & 1)) ^ wp_g(l15);
+                    f.af[t] = *reinterpret_cast<const cg_f32x4*>(w_l + (l15 * 4 + js) * 4);
+                    if constexpr (BKF) {
+                        f.bf[2 * t] = *reinterpret_cast<const cg_f32x4*>(wb_l + (l15 * 4 + js) * 4);
+                        f.bf[2 * t + 1] = *reinterpret_cast<const cg_f32x4*>(wb_l + 256 + (l15 * 4 + js) * 4);
+                    } else {
+                        const int kr = 4 * (kq & 1) + (kq >> 1);      // k-row of the first MFMA's k inside the k-group; + 2: the second's
+                        const float* pb = wb_l + 256 * t + kr * 32;
+                        const int nx = 16 * (kq & 1);
 #pragma unroll
-                    for (int nh = 0; nh < 2; ++nh) {
-                        f.bs[4 * t + 2 * nh] = pb[(16 * nh + l15) ^ nx];
-                        f.bs[4 * t + 2 * nh + 1] = pb[64 + ((16 * nh + l15) ^ nx)];
+                        for (int nh = 0; nh < 2; ++nh) {
+                            f.bs[4 * t + 2 * nh] = pb[(16 * nh + l15) ^ nx];
+                            f.bs[4 * t + 2 * nh + 1] = pb[64 + ((16 * nh + l15) ^ nx)];
+                        }
+                    }
+                } else {   // 32 rows: lane (row l31, k-half h) feeds k = 8q + 4h + c to the c-th MFMA of k-group q = wk + 4t
+                    const int rp = l31 & 15, js = (2 * t + h) ^ wp_g(rp), o = (l31 >> 4) * 256 + (rp * 4 + js) * 4;
+                    f.af[t] = *reinterpret_cast<const cg_f32x4*>(w_l + o);
+                    if constexpr (BKF) {
+                        f.bf[t] = *reinterpret_cast<const cg_f32x4*>(wb_l + o);
+                    } else {
+                        const float* pb = wb_l + 256 * t + (4 * h) * 32 + (l31 ^ (16 * h));
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) f.bs[4 * t + c] = pb[c * 32];
                     }
                 }
             }
@@ -588,19 +606,25 @@ __device__ __forceinline__ void cg_tile(const CgArgs& a, const int bid, float* s
         auto wp_mfma = [&](const WpFrag& f) {
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                const float a0 = wp_sel(f.af[t][0], f.af[t][1]), a1 = wp_sel(f.af[t][2], f.af[t][3]);
+                if constexpr (SMALL) {
+                    const float a0 = wp_sel(f.af[t][0], f.af[t][1]), a1 = wp_sel(f.af[t][2], f.af[t][3]);
 #pragma unroll
-                for (int nh = 0; nh < 2; ++nh) {
-                    float b0, b1;
-                    if constexpr (BKF) {
-                        b0 = wp_sel(f.bf[2 * t + nh][0], f.bf[2 * t + nh][1]);
-                        b1 = wp_sel(f.bf[2 * t + nh][2], f.bf[2 * t + nh][3]);
-                    } else {
-                        b0 = f.bs[4 * t + 2 * nh];
-                        b1 = f.bs[4 * t + 2 * nh + 1];
+                    for (int nh = 0; nh < 2; ++nh) {
+                        float b0, b1;
+                        if constexpr (BKF) {
+                            b0 = wp_sel(f.bf[2 * t + nh][0], f.bf[2 * t + nh][1]);
+                            b1 = wp_sel(f.bf[2 * t + nh][2], f.bf[2 * t + nh][3]);
+                        } else {
+                            b0 = f.bs[4 * t + 2 * nh];
+                            b1 = f.bs[4 * t + 2 * nh + 1];
+                        }
+                        acc16[nh] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc16[nh], 0, 0, 0);
+                        acc16[nh] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc16[nh], 0, 0, 0);
                     }
-                    acc16[nh] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc16[nh], 0, 0, 0);
-                    acc16[nh] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc16[nh], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f.af[t][c], BKF ? f.bf[BKF ? t : 0][c] : f.bs[BKF ? 0 : 4 * t + c], acc, 0, 0, 0);
                 }
             }
         };
@@ -612,7 +636,7 @@ __device__ __forceinline__ void cg_tile(const CgArgs& a, const int bid, float* s
             wp_read(0, fc);
             int rd = 1, fl = 0;     // slot of step it + 1; slot of step it (free: its fragments are in registers)
             for (int it = total_iters - WSL; it > 0; --it) {
-                cg_wait_vmcnt<(WSL - 2) * 3>();
+                cg_wait_vmcnt<(WSL - 2) * WPN>();
                 wp_read(rd, fn);
                 wp_mfma(fc);
                 wp_dma(fl);
