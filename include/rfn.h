@@ -354,8 +354,9 @@ int rfn_attn_small_bwd(int ngroups, const float* const* proj, int64_t proj_sb, i
  * of 8 for the gate epilogue; any M.  `variant` 0 lets the library pick: the K step and K-wave count -- which fix the k order
  * of every output element -- from the K counts alone, never from M, so a row's arithmetic does not depend on the batch it
  * sits in; the tile height may follow M (16-row tiles on wave-private ring slots, variant 6, for launches with few tiles:
- * the same fma chains, identical bits).  1..6 force a variant, 7 = the choice with the shared-slot 16-row forms 4 / 5 (tests,
- * tools, A/B); bits 4-7 force the ring depth of variants 1..5 (tools).  RFN_CELL_VARIANT_DEEP in `variant` (A/B hook): a launch of the 32-row variant whose tiles do not
+ * the same fma chains, identical bits).  1..6 and 8 force a variant; 7 / 9 = the library's choice restricted to the
+ * shared-slot forms 1..5 / to the 64- and 32-row shared-slot forms 1..3 (tests, tools, A/B); bits 4-7 force the ring depth
+ * of variants 1..5 (tools).  RFN_CELL_VARIANT_DEEP in `variant` (A/B hook): a launch of the 32-row variant whose tiles do not
  * outnumber the device's CUs runs on the deep-ring kernel (8 ring slots, the whole K range of K <= 512 in flight, a K loop
  * without barriers) -- bit-identical results, measured slower inside the step (profiles/r05_chain.md). */
 #define RFN_CELL_VARIANT_DEEP 256

@@ -81,7 +81,7 @@ static int cg_device_cus() {   // CU count of the current device (cached per dev
 
 // Tile variants: 1 = 64 rows, K step 32, 2 K-waves; 2 = 64 rows, K step 64, 4 K-waves; 3 = 32 rows, K step 64, 4 K-waves;
 // 4 = 16 rows, K step 64, 4 K-waves on the 16x16x4 MFMA shape; 5 = the same on K steps of 128; 6 = 4 with wave-private ring
-// slots; 8 = 3 with wave-private ring slots (all bit-identical to 2 and 3); 7 = the library's choice among 1-5 (A/B hook).
+// slots; 8 = 3 with wave-private ring slots (all bit-identical to 2 and 3); 7 / 9 = the library's choice among 1-5 / 1-3 (A/B hooks).
 // variant 0: the K step / K-wave count -- which fix the k order of every output element -- are chosen FROM THE K COUNTS
 // ONLY, so a row's arithmetic never depends on the batch it sits in (variants 2 and 3 give bit-identical results).
 static int cg_plan(CgPrepared& pz, int variant) {
@@ -102,12 +102,13 @@ static int cg_plan(CgPrepared& pz, int variant) {
     }
     // 32-row tiles whenever the K step of 64 applies: measured fastest at every per-step shape of the path (B = 64 ... 640),
     // because they put two to three independent blocks on a CU (profiles/r03_cellgemm.md)
-    if (variant == 0 || variant == 7) {   // 7 (A/B hook): the library's choice with the shared-slot 16-row forms of round 5's first half
-        const bool shared16 = variant == 7;
+    if (variant == 0 || variant == 7 || variant == 9) {   // A/B hooks: 7 = the choice with the shared-slot 16-row forms of round 5's
+        const bool shared16 = variant == 7;               // first half; 9 = the choice among the 64- / 32-row shared-slot forms only
+        const bool tall_only = variant == 9;
         variant = k64 ? 3 : 1;
         // few tiles: 16-row tiles put the launch on twice the CUs with half the MFMA chain per block (variant 4, bit-identical
         // to variant 3: rfn_cellgemm_body.h) -- taken when even the 16-row tiles do not outnumber the CUs
-        if (k64) {
+        if (k64 && !tall_only) {
             long cols = 0;
             for (int o = 0; o < a.nout; ++o) cols += a.out[o].N / CG_BN;
             // 6: those tiles with wave-private ring slots -- no block barrier in the K loop, fragments read one step ahead

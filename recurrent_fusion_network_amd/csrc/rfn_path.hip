@@ -256,7 +256,7 @@ int cell_run(int B, int n, const rfn_cell_out* outs, int R, float drop_p, uint64
     return rfn_cell_gemm(B, n, outs, R, drop_p, seed, variant, st);
 }
 inline int cell_variant(const rfn_dims* d) {
-    const int tiles = (d->path_flags & RFN_PATH_OPT_NO_SMALL_TILES) ? 3 : (d->path_flags & RFN_PATH_OPT_SHARED_SMALL_TILES) ? 7 : 0;
+    const int tiles = (d->path_flags & RFN_PATH_OPT_NO_SMALL_TILES) ? 9 : (d->path_flags & RFN_PATH_OPT_SHARED_SMALL_TILES) ? 7 : 0;
     return ((d->path_flags & RFN_PATH_OPT_DEEP_CELLS) ? RFN_CELL_VARIANT_DEEP : 0) | tiles;
 }
 // the same launch prepared instead of launched: one phase of a recurrence-chain step (rfn_chain.hip)
