@@ -595,7 +595,7 @@ int rfn_multinomial_pick(const float* logp, int64_t ldl, int B, int V1, float in
  *   order[r]    source row whose recurrent state row r continues (feed rfn_gather_rows),
  *   next_ids[r] token row r feeds to the next decoder step,
  * updating beam_seq / beam_lp (S, NB, W), beam_sum (NB, W), the done-beam arrays (NB, max_done, ...) and
- * active[k] (0 once image k has no candidate left, :480).  W <= 16, S <= 32. */
+ * active[k] (0 once image k has no candidate left, :480).  W <= 16 (rfn_beam_step_topk: W <= 32), S <= 64. */
 int rfn_beam_step(const float* logp, int64_t ldl, int V1, int W, int S, int t, int NB, int max_done,
                   int64_t* beam_seq, float* beam_lp, float* beam_sum, int32_t* order, int64_t* next_ids,
                   int64_t* done_seq, float* done_lp, float* done_p, int32_t* done_n, int32_t* active,
@@ -605,7 +605,7 @@ int rfn_beam_step(const float* logp, int64_t ldl, int V1, int W, int S, int t, i
 int rfn_beam_step_topk(const float* topv, const int32_t* topi, int V1, int W, int S, int t, int NB, int max_done,
                        int64_t* beam_seq, float* beam_lp, float* beam_sum, int32_t* order, int64_t* next_ids,
                        int64_t* done_seq, float* done_lp, float* done_p, int32_t* done_n, int32_t* active, void* stream);
-/* log-softmax of every row + its W <= 16 best entries, ordered (value descending, token ascending) as a descending
+/* log-softmax of every row + its W <= 32 best entries, ordered (value descending, token ascending) as a descending
  * sort lists them; the log-prob bits are those rfn_log_softmax_fwd writes, which are not materialised here. */
 int rfn_log_softmax_topk(const float* logits, int64_t ldl, int rows, int V1, int W, float* topv, int32_t* topi,
                          void* stream);

@@ -13,7 +13,8 @@
 // Nothing is read back per step; the host sorts the (few) done beams once at the end.
 #include "rfn_common.h"
 
-#define BEAM_MAX_W 16
+#define BEAM_MAX_W 32     /* beams per image; the full-row form (rfn_beam_step: phase 1 below) serves up to BEAM_WAVES of them */
+#define BEAM_MAX_S 64     /* decode steps a block keeps the beams' histories for (seq_length) */
 #define BEAM_THREADS 1024
 #define BEAM_WAVES 16
 
@@ -36,8 +37,8 @@ __global__ __launch_bounds__(BEAM_THREADS) void beam_step_k(
     __shared__ int ix[BEAM_MAX_W][BEAM_MAX_W];
     __shared__ float wys[BEAM_WAVES][BEAM_MAX_W];
     __shared__ int wix[BEAM_WAVES][BEAM_MAX_W];
-    __shared__ int prev_seq[32][BEAM_MAX_W];
-    __shared__ float prev_lp[32][BEAM_MAX_W];
+    __shared__ int prev_seq[BEAM_MAX_S][BEAM_MAX_W];
+    __shared__ float prev_lp[BEAM_MAX_S][BEAM_MAX_W];
     __shared__ float cand_p[BEAM_MAX_W * BEAM_MAX_W], cand_r[BEAM_MAX_W * BEAM_MAX_W];
     __shared__ int cand_c[BEAM_MAX_W * BEAM_MAX_W], cand_q[BEAM_MAX_W * BEAM_MAX_W], cand_ord[BEAM_MAX_W * BEAM_MAX_W];
     __shared__ int sel_ci[BEAM_MAX_W], slot_s[BEAM_MAX_W];
@@ -53,7 +54,7 @@ __global__ __launch_bounds__(BEAM_THREADS) void beam_step_k(
     }
     // ---- phase 1: top `cols` of every live beam row (descending, lowest index first on ties) -----------------
     const int live_rows = (t == 1) ? 1 : W;
-    const int wpr = BEAM_WAVES / live_rows;          // waves per row (>= 1: W <= 16)
+    const int wpr = topv ? 1 : BEAM_WAVES / live_rows;   // waves per row (full-row form: >= 1, the host checks W <= BEAM_WAVES)
     const int q = wave / wpr, part = wave - q * wpr;
     if (topv) {
         // the rows' top-W lists were produced with their log-softmax (rfn_log_softmax_topk): same values, same order
@@ -119,8 +120,8 @@ __global__ __launch_bounds__(BEAM_THREADS) void beam_step_k(
     }
     __syncthreads();
     if (topv) {
-        if (tid < live_rows * cols) {
-            const int qq = tid / cols, c = tid - qq * cols;
+        for (int i = tid; i < live_rows * cols; i += (int)blockDim.x) {
+            const int qq = i / cols, c = i - qq * cols;
             ys[qq][c] = topv[(long)(k * W + qq) * W + c];
             ix[qq][c] = topi[(long)(k * W + qq) * W + c];
         }
@@ -237,8 +238,9 @@ static int beam_step_launch(const float* logp, int64_t ldl, const float* topv, c
                             int NB, int max_done, int64_t* beam_seq, float* beam_lp, float* beam_sum, int32_t* order,
                             int64_t* next_ids, int64_t* done_seq, float* done_lp, float* done_p, int32_t* done_n,
                             int32_t* active, void* stream) {
-    if (W < 1 || W > BEAM_MAX_W || S < 1 || S > 32 || t < 1 || t > S || NB < 1 || V1 < 1 || max_done < 1)
+    if (W < 1 || W > BEAM_MAX_W || S < 1 || S > BEAM_MAX_S || t < 1 || t > S || NB < 1 || V1 < 1 || max_done < 1)
         return RFN_ERR_SHAPE;
+    if (!topv && W > BEAM_WAVES) return RFN_ERR_SHAPE;   // the full-row form cuts a row over 16 / W waves
     if ((!logp && !(topv && topi)) || !beam_seq || !beam_lp || !beam_sum || !order || !next_ids || !done_seq || !done_lp ||
         !done_p || !done_n || !active)
         return RFN_ERR_ARG;

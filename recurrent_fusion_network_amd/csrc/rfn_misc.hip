@@ -359,8 +359,8 @@ extern "C" int rfn_log_softmax_fwd(const float* logits, int64_t ldl, int rows, i
 // sample_beam only ever looks at the W best log-probs of a beam row (misc/RecurrentFusionModel.py:463-466: a full sort, of
 // which columns 0 .. beam_size-1 are read).  topv[r, c] / topi[r, c], c < W: the c-th largest log-prob of row r and its
 // token, ordered (value descending, token ascending) -- the order the reference's descending sort lists them -- computed
-// from the same log-prob bits rfn_log_softmax_fwd writes.  W <= 16.
-#define LSM_TOPW 16
+// from the same log-prob bits rfn_log_softmax_fwd writes.  W <= 32.
+#define LSM_TOPW 32
 __device__ __forceinline__ bool lsm_before(float x, int i, float y, int j) { return x > y || (x == y && i < j); }
 template <bool VEC, int LW>
 __global__ __launch_bounds__(256) void log_softmax_topk_k(const float* __restrict__ logits, long ldl, int V1, int W,
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(256) void log_softmax_topk_k(const float* __restric
     {
         int pos[4] = {0, 0, 0, 0};
         thr = -INFINITY;
-        for (int c = 0; c < cols; ++c) {         // every thread merges the four sorted lists redundantly (cols <= 16)
+        for (int c = 0; c < cols; ++c) {         // every thread merges the four sorted lists redundantly (cols <= 32)
             int bp = 0;
             float bv = -INFINITY;
             for (int p = 0; p < 4; ++p)
@@ -510,7 +510,8 @@ extern "C" int rfn_log_softmax_topk(const float* logits, int64_t ldl, int rows, 
     hipLaunchKernelGGL((log_softmax_topk_k<VECV, LWV>), dim3(rows), dim3(256), 0, st, logits, (long)ldl, V1, W, topv, topi)
     if (W <= 4) { if (vec) LSM_LAUNCH(true, 4); else LSM_LAUNCH(false, 4); }
     else if (W <= 8) { if (vec) LSM_LAUNCH(true, 8); else LSM_LAUNCH(false, 8); }
-    else { if (vec) LSM_LAUNCH(true, 16); else LSM_LAUNCH(false, 16); }
+    else if (W <= 16) { if (vec) LSM_LAUNCH(true, 16); else LSM_LAUNCH(false, 16); }
+    else { if (vec) LSM_LAUNCH(true, 32); else LSM_LAUNCH(false, 32); }
 #undef LSM_LAUNCH
     RFN_CHECK_LAUNCH();
     return RFN_OK;

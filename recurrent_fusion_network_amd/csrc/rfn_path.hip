@@ -1902,7 +1902,7 @@ extern "C" int rfn_beam_loop(const rfn_dims* d, int NB, int W, int S, const floa
     if (NB < 1 || W < 1 || S < 1) return RFN_ERR_SHAPE;
     if (!prm || !comb || !cproj || !h || !c || !h_alt || !c_alt || !logp || !ids || !order || !ws) return RFN_ERR_ARG;
     const int rows = NB * W, V1 = d->V1, R = d->R;
-    if (W > 16) return RFN_ERR_SHAPE;
+    if (W > 32) return RFN_ERR_SHAPE;
     float* topv = logp;
     int32_t* topi = (int32_t*)(logp + (size_t)rows * W);
     float *hc = h, *cc = c, *ha = h_alt, *ca = c_alt;

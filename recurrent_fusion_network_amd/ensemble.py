@@ -87,8 +87,8 @@ class EnsembleDecoder:
         W = opt.get('beam_size', 10)
         m0 = self.models[0]
         B, S, V1 = fc_feats[0].size(0), m0.seq_length, m0.vocab_size + 1
-        if W > 16 or S > 32 or W > V1:
-            raise N.RfnError('beam search supports beam_size <= 16 (and <= V+1) and seq_length <= 32')
+        if W > 32 or S > 64 or W > V1:
+            raise N.RfnError('beam search supports beam_size <= 32 (and <= V+1) and seq_length <= 64')
         steppers = []
         for m in self.models:
             comb, h, c, _ = m._prefix(fc_feats, att_feats, False, 0)

@@ -808,8 +808,8 @@ class RecurrentFusionModel(nn.Module):
         beam_size = opt.get('beam_size', 10)
         B, S, V1 = fc_feats[0].size(0), self.seq_length, self.vocab_size + 1
         assert beam_size <= V1, 'lets assume this for now'
-        if beam_size > 16 or S > 32:
-            raise N.RfnError('beam search supports beam_size <= 16 and seq_length <= 32')
+        if beam_size > 32 or S > 64:
+            raise N.RfnError('beam search supports beam_size <= 32 and seq_length <= 64')
         W = beam_size
         with torch.no_grad():
             drop = bool(self.training)

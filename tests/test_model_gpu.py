@@ -601,3 +601,42 @@ def test_cpu_inputs_fail_loudly():
     model = R.RecurrentFusionModel(cfg)
     with pytest.raises(R._native.RfnError):
         model(batch[0], batch[1], batch[2])
+
+
+def test_beam_search_on_long_captions(dev):
+    """seq_length = 40 (the beam kernel keeps up to 64 steps of history per image): against the oracle's per-image search."""
+    from oracle import rfn_oracle as O
+    info = [dict(att_num=L, att_feat_size=D, fc_feat_size=F) for (L, D, F) in [(5, 24, 24), (7, 40, 32)]]
+    cfg = O.make_cfg(info, vocab_size=50, rnn_size=16, input_encoding_size=16, att_hid_size=16, num_review_steps_0=3,
+                     num_review_steps=3, top_words_count=20, seq_length=40)
+    P = O.seeded_params(cfg, 21, scale=0.3)
+    fc, att, labels, masks, top = O.synthetic_batch(cfg, 3, seed=77)
+    want_seq, want_lp, want_top_seq, want_top_prob, _, _ = O.sample_beam(cfg, P, fc, att, 3)
+    model = build(cfg, P, dev)
+    seq, seq_lp, top_seq, top_prob, reason = model.sample([f.to(dev) for f in fc], [a.to(dev) for a in att], {'beam_size': 3})
+    assert seq.shape == (3, 40)
+    assert torch.equal(seq.cpu(), want_seq)
+    assert maxerr(seq_lp, want_lp) < LOGP_TOL
+    assert int((want_seq != 0).sum(1).max()) > 32          # the case does run past the old 32-step limit
+    for k in range(3):
+        assert torch.equal(top_seq[k], want_top_seq[k])
+        assert np.allclose(np.array(top_prob[k]), np.array(want_top_prob[k]), atol=1e-3)
+
+
+@pytest.mark.parametrize('beam', [20, 32])
+def test_beam_search_with_wide_beams(dev, beam):
+    """beam_size above 16 (the device bookkeeping serves up to 32 beams per image): against the oracle's per-image search."""
+    from oracle import rfn_oracle as O
+    info = [dict(att_num=L, att_feat_size=D, fc_feat_size=F) for (L, D, F) in [(5, 24, 24), (7, 40, 32)]]
+    cfg = O.make_cfg(info, vocab_size=50, rnn_size=16, input_encoding_size=16, att_hid_size=16, num_review_steps_0=3,
+                     num_review_steps=3, top_words_count=20, seq_length=6)
+    P = O.seeded_params(cfg, 5, scale=0.4)
+    fc, att, labels, masks, top = O.synthetic_batch(cfg, 2, seed=78)
+    want_seq, want_lp, want_top_seq, want_top_prob, _, _ = O.sample_beam(cfg, P, fc, att, beam)
+    model = build(cfg, P, dev)
+    seq, seq_lp, top_seq, top_prob, reason = model.sample([f.to(dev) for f in fc], [a.to(dev) for a in att], {'beam_size': beam})
+    assert torch.equal(seq.cpu(), want_seq)
+    assert maxerr(seq_lp, want_lp) < LOGP_TOL
+    for k in range(2):
+        assert torch.equal(top_seq[k], want_top_seq[k])
+        assert np.allclose(np.array(top_prob[k]), np.array(want_top_prob[k]), atol=1e-3)
