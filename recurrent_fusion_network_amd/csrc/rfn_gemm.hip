@@ -23,7 +23,7 @@
 //         staged [k][row] and read with conflict-free ds_read_b32 -- no transposition pass anywhere.
 //   * 1-D grid with a bijective XCD remap + 8-row bands so the blocks sharing an A row-panel and a
 //     B column-panel run on one XCD's L2 at the same time; the last, partly filled round of a big launch runs as
-//     half-height tiles.
+//     half-height tiles (as quarter tiles when it is at most a quarter full: the projections of B <= 128 shards).
 //   * options travel with the call (rfn_gemm_f32_opt flags); no environment variable is read.
 #include <string.h>
 
@@ -94,6 +94,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef GEMM_TAIL_HALF
 #define GEMM_TAIL_HALF 1   /* half-height tiles for the last, partly filled round of a big NT launch */
 #endif
+#ifndef GEMM_TAIL_QUARTER
+#define GEMM_TAIL_QUARTER 1 /* quarter tiles when four per tail tile still fit one round (round 5) */
+#endif
 #ifndef GEMM_TAIL_MIN_ROUNDS
 #define GEMM_TAIL_MIN_ROUNDS 2 /* full rounds in front of a tail round (4 until round 4: a B = 32 shard's projection is 3.06 rounds) */
 #endif
@@ -134,6 +137,7 @@ struct GemmArgs {
     unsigned flags;        // host side only: RFN_GEMM_OPT_* bits of the call
     int tail_main_blocks;   // > 0: blocks past this id process HALF-height tiles (see rfn_gemm_kernel)
     int tail_idx_main;      // first per-XCD tile index of the tail round
+    int tail_parts;         // 2: half-height tiles (BM/2 x BN); 4: quarter tiles (BM/2 x BN/2), when four per tile still fit one round
     float* part;  // [ngroups][splitk][M][N]
     int* tickets; // non-NULL: one zeroed counter per output tile; the last K range to arrive finishes the tile in-kernel
     int n_tickets;
@@ -913,7 +917,9 @@ __device__ __forceinline__ void gemm_tile_dma(const GemmArgs& args, const int gr
 
 // ---- block -> (group, tile_m, tile_n): bijective XCD remap, then 8-row bands --------------------------------------
 // TAIL (big NT launches whose tile count is not a multiple of the resident slots): the blocks of the last, partly
-// filled round each take HALF a tile (BM/2 rows), so that round lasts half as long on twice as many CUs.  Consecutive
+// filled round each take HALF a tile (BM/2 rows), so that round lasts half as long on twice as many CUs -- a QUARTER
+// (BM/2 x BN/2) when four blocks per tile still fit the round (args.tail_parts; B = 32 shard: 0.81 against 0.84 ms per
+// projection launch).  A tile's shape does not enter the k order of an output element: same bits.  Consecutive
 // block ids land on consecutive XCDs, so the tail round is "the last tile indices of every XCD", two blocks per tile.
 template <int BM, int BN, bool AK, bool BKF, bool VEC, int STAGES, int BK, bool FAST, int THREADS = GEMM_THREADS,
           bool TAIL = false, int DMA = 0>
@@ -930,8 +936,13 @@ __global__ __launch_bounds__(THREADS, (THREADS == 64) ? 1 : (DMA ? GEMM_DMA_MIN_
         const int q = nblk >> 3, r = nblk & 7;
         if (TAIL && bid >= args.tail_main_blocks) {   // r == 0, splitk == 1 (host-checked)
             const int j = bid - args.tail_main_blocks, jdx = j >> 3;
-            lid = (j & 7) * q + args.tail_idx_main + (jdx >> 1);
-            half = jdx & 1;
+            if (args.tail_parts == 4) {
+                lid = (j & 7) * q + args.tail_idx_main + (jdx >> 2);
+                half = 2 + (jdx & 3);     // 2 ... 5: quarter (row half, column half) = ((half - 2) >> 1, (half - 2) & 1)
+            } else {
+                lid = (j & 7) * q + args.tail_idx_main + (jdx >> 1);
+                half = jdx & 1;
+            }
         } else {
             const int xcd = bid & 7, idx = bid >> 3;
             lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
@@ -951,6 +962,15 @@ __global__ __launch_bounds__(THREADS, (THREADS == 64) ? 1 : (DMA ? GEMM_DMA_MIN_
     const int grp = vcol / args.tiles_n;
     const int tn = vcol - grp * args.tiles_n;
     if constexpr (TAIL) {
+        if (half >= 2) {   // quarter tiles: the same fma chain per output element (a tile's shape does not enter the k order)
+            const int qr = (half - 2) >> 1, qc = (half - 2) & 1;
+            if constexpr (DMA > 0)
+                gemm_tile_dma<BM / 2, BN / 2, AK, BKF, BK, DMA>(args, grp, ks, tm * BM + qr * (BM / 2), tn * BN + qc * (BN / 2));
+            else
+                gemm_tile<BM / 2, BN / 2, AK, BKF, VEC, STAGES, BK, FAST, THREADS>(args, grp, tn, ks, tm * BM + qr * (BM / 2),
+                                                                                  tn * BN + qc * (BN / 2));
+            return;
+        }
         if (half >= 0) {
             if constexpr (DMA > 0)
                 gemm_tile_dma<BM / 2, BN, AK, BKF, BK, DMA>(args, grp, ks, tm * BM + half * (BM / 2), tn * BN);
@@ -1132,7 +1152,10 @@ static int launch_cfg(const GemmArgs& a_in, hipStream_t st) {
         GemmArgs t = a;
         t.tail_idx_main = has_tail ? q - tail : 0;
         t.tail_main_blocks = has_tail ? 8 * t.tail_idx_main : 0x7fffffff;
-        hipLaunchKernelGGL(kt, dim3(has_tail ? t.tail_main_blocks + 16 * tail : nblk), dim3(THREADS), lds, st, t);
+        // a tail of at most a quarter of a round (the projections of the B <= 128 shards): quarter tiles, a round of a
+        // quarter of the work on four times the CUs
+        t.tail_parts = (GEMM_TAIL_QUARTER && has_tail && 4 * tail <= slots_per_xcd) ? 4 : 2;
+        hipLaunchKernelGGL(kt, dim3(has_tail ? t.tail_main_blocks + 8 * t.tail_parts * tail : nblk), dim3(THREADS), lds, st, t);
         RFN_CHECK_LAUNCH();
         launched = true;
     }
@@ -1350,6 +1373,7 @@ static int gemm_entry(int M, int N, int ngroups, const rfn_gemm_problem* problem
     a.splitk = 1;
     a.tail_main_blocks = 0;
     a.tail_idx_main = 0;
+    a.tail_parts = 2;
     a.flags = flags;
     a.tickets = (tickets && n_tickets > 0) ? (int*)tickets : nullptr;
     a.n_tickets = a.tickets ? n_tickets : 0;

@@ -241,8 +241,9 @@ def test_gemm_split_k_finished_in_kernel_keeps_the_bias_rider(dev, rows, Nn, K, 
 
 def test_gemm_half_height_tail_round(dev):
     """Big NT launches whose tile count leaves the last round at most half full process that round as half-height
-    tiles inside the same launch (rfn_gemm.hip, TAIL): 3200 tiles = 400 per XCD = 4 full rounds of 96 + 16, a ragged
-    last band, grouped problems -- every output element against fp64, and bit-identical from call to call."""
+    tiles inside the same launch -- as quarter tiles when it is at most a quarter full -- (rfn_gemm.hip, TAIL): 3200 tiles =
+    400 per XCD = 6 full rounds of 64 + 16 on the LDS-DMA kernel (quarter tiles), other splits on the kernels below, a
+    ragged last band, grouped problems -- every output element against fp64, and bit-identical from call to call."""
     n = N()
     M, Nn, K, G = 12800, 2048, 64, 2          # 100 x 16 tiles x 2 groups = 3200
     A = rnd(M, K, seed=1)
