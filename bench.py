@@ -256,6 +256,9 @@ def parse_args(argv=None):
                     help='data parallel only: every rank updates 1/N of each flat bucket (FusedClampAdam(shard=...): '
                          'reduce-scatter of the gradients, Adam on the shard, all-gather of the parameters under the next '
                          'forward) instead of all-reduce + the full update on every rank; bit-identical parameters')
+    ap.add_argument('--overlap-update', action='store_true',
+                    help='single GPU, opt-in A/B: each bucket\'s clamp + Adam on a side stream as soon as backward has finished the '
+                         'bucket (parallel.OverlappedUpdate) instead of one launch after backward; bit-identical parameters')
     ap.add_argument('--selftest-launch', action='store_true',
                     help='launcher / rendezvous check without a GPU: ranks meet, reduce a timing, rank 0 prints the line')
     args = ap.parse_args(argv)
@@ -686,6 +689,10 @@ def run_train(args, rank, world, dev, R, DP, guard):
     sync = DP.GradSync(model, world, shard_optimizer=opt if shard else None)     # per-bucket async exchange, overlapped with the rest of backward
     if args.graph:
         model.grad_ready_hook = None     # no exchange to overlap on one GPU
+    if args.overlap_update:
+        if in_group or args.graph:
+            raise SystemExit('--overlap-update: single GPU, eager steps')
+        sync = DP.OverlappedUpdate(model, opt)
     start = opt.snapshot() if (not x3 and not args.no_alt_line) else None     # the bf16x3 leg restarts from here
 
     trace = [] if args.trace_steps else None
@@ -865,7 +872,8 @@ def run_train(args, rank, world, dev, R, DP, guard):
                        'parallelism': 'dp%d (batch sharded, RCCL all-reduce of grads)' % world if world > 1 else 'single GPU',
                        'micro_batches': int(getattr(model, 'micro_batches', 1) or 1),
                        'final_loss': round(final_loss, 4), 'updates': head['settle_n'] + args.warmup + args.steps,
-                       'hip_graph': bool(args.graph), 'shard_optimizer': bool(shard), 'fused_loss': bool(args.fused_loss),
+                       'hip_graph': bool(args.graph), 'shard_optimizer': bool(shard), 'overlap_update': bool(args.overlap_update),
+                       'fused_loss': bool(args.fused_loss),
                        'gemm_flags': int(model.gemm_flags), 'digest': digest},
         }
         if in_group:

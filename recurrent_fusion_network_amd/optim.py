@@ -261,7 +261,8 @@ class FusedClampAdam:
                                           g0['weight_decay'], g0['grad_clip'], grad_scale, self.step_count + 1, N.stream_ptr()),
                 'rfn_adam_step_multi')
         self._updated_early.add(name)
-        self._gather_params([name])
+        if self.shard_world > 1:
+            self._gather_params([name])
 
     # ---- sharded update: parameters back to every rank ---------------------------------------------------------------
     def _gather_params(self, names):

@@ -90,6 +90,46 @@ def allreduce_flat(buffers, world, async_op=False):
     return works
 
 
+class OverlappedUpdate:
+    """One process, opt-in: the clamp + Adam of a bucket is launched on a side stream the moment backward has queued the
+    kernels that finish the bucket's gradients (the model's `grad_ready_hook`: decoder first, then the fusion core, then the
+    encoders) instead of in one launch after backward -- the update of bucket k streams its 28 bytes per parameter under the
+    matrix-bound weight-gradient products of the buckets after it.  Nothing in the rest of backward reads a bucket's parameters
+    once its gradients are complete, and the next forward waits for the side stream where it first hands parameters to a
+    kernel (`param_wait_hook`).  Same element arithmetic as the single launch (FusedClampAdam.update_bucket_early): parameters
+    and moments bit-identical.  `optimizer.step()` afterwards only counts the step (and updates what no hook delivered)."""
+
+    def __init__(self, model, optimizer):
+        if optimizer.shard_world != 1:
+            raise ValueError('the sharded optimizer already pipelines its update (GradSync(shard_optimizer=...))')
+        self.opt = optimizer
+        self.side = torch.cuda.Stream()
+        model.grad_ready_hook = self.on_bucket
+        model.param_wait_hook = self.wait
+
+    def on_bucket(self, name, flat):
+        main = torch.cuda.current_stream(flat.device)
+        self.side.wait_stream(main)
+        flat.record_stream(self.side)
+        with torch.cuda.stream(self.side):
+            self.opt.update_bucket_early(name, flat, 1.0)
+
+    def wait(self, which=None):
+        torch.cuda.current_stream().wait_stream(self.side)
+
+    def finish(self):
+        return 1.0
+
+    # the part of GradSync's interface bench.py drives (nothing is exchanged here)
+    record = False
+
+    def exposed_ms(self):
+        return None, {}, None
+
+    def abandon(self):
+        pass
+
+
 class GradSync:
     """Overlapped gradient exchange: registers as the model's `grad_ready_hook`, launches one asynchronous SUM
     all-reduce per gradient bucket the moment backward has queued the kernels that finish it (decoder first,

@@ -340,3 +340,43 @@ def test_graphed_train_step_serves_batches_of_any_caption_length_and_refuses_wha
     model.train()
     opt.set_lr(1e-3)            # the one thing a replay re-reads
     g(*short)
+
+
+def test_overlapped_update_is_bit_identical_to_the_single_launch(dev):
+    """parallel.OverlappedUpdate (opt-in, one process): every bucket's clamp + Adam on a side stream as soon as backward has
+    finished the bucket, the next forward waiting for it where it first reads parameters -- three steps give the same loss,
+    parameters and moments as the one launch after backward, bit for bit (measured slower on MI355X: profiles/r05_notes.md;
+    it stays an A/B hook)."""
+    import recurrent_fusion_network_amd as R
+    from recurrent_fusion_network_amd import parallel as DP
+    cfg, spec, P, batch, gold = load_case('mid')
+    fc, att, labels, masks, top = to_dev(batch, dev)
+    kw = dict(lr=5e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5, grad_clip=0.01)
+    crit = R.ReviewNetEnsembleCriterion(cfg)
+    runs = []
+    for overlapped in (False, True):
+        model = build(cfg, P, dev, train=True)
+        opt = R.FusedClampAdam(model, **kw)
+        if overlapped:
+            DP.OverlappedUpdate(model, opt)
+        losses = []
+        for _ in range(3):
+            opt.zero_grad()
+            lp, reason = model(fc, att, labels)
+            loss = crit(lp, labels[:, 1:], masks[:, 1:], reason, top, 1.0)
+            loss.backward()
+            opt.step()
+            losses.append(loss.detach().clone())
+        torch.cuda.synchronize()
+        assert opt.step_count == 3
+        runs.append((model, opt, losses))
+    (m0, o0, l0), (m1, o1, l1) = runs
+    for a, b in zip(l0, l1):
+        assert torch.equal(a, b)
+    for (k, p), (_, q) in zip(m0.named_parameters(), m1.named_parameters()):
+        assert torch.equal(p, q), k
+    for name in o0.flat:            # the moments of every parameter (the 16-B padding between parameters holds no state)
+        params, offs, _ = m0.bucket_layout(name)
+        for p_, o in zip(params, offs):
+            for k in ('m', 'v'):
+                assert torch.equal(o0.flat[name][k][o:o + p_.numel()], o1.flat[name][k][o:o + p_.numel()]), (name, k)
