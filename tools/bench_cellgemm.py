@@ -66,6 +66,7 @@ def main():
                 ('B=%d stage II bwd: dhrec, 4 dz' % Ms, Ms, [(512, [2048])] * 5, False, 0),
                 ('B=%d stage I gates 4 enc K=4096 -> lstm' % Ms, Ms, [(2048, [2048, 2048])], True, 1),
                 ('B=%d stage I dz 4 enc N=2048 K=2048' % Ms, Ms, [(2048, [2048])] * 4, False, 0),
+                ('B=%d stage I gates 2 enc K=1024+512 -> lstm (C2)' % Ms, Ms, [(2048, [1024, 512])] * 2, True, 1),
             ]
     if a.floor:      # fixed cost vs K slope: one output N = 2048 at M = 256, both epilogues
         cases = [('K=%d %s' % (k, 'lstm' if l else 'store'), 256, [(2048, [k])], l, 1) for l in (False, True)
