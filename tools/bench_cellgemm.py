@@ -32,6 +32,7 @@ def main():
     ap.add_argument('--reps', type=int, default=200)
     ap.add_argument('--floor', action='store_true')
     ap.add_argument('--small', action='store_true')
+    ap.add_argument('--batch', type=int, default=0, help='run the B = 256 cases at this batch size instead')
     ap.add_argument('--slots', type=lambda x: [int(v) for v in x.split(',')], default=[2, 3, 4, 6])
     ap.add_argument('--variants', type=lambda x: [int(v) for v in x.split(',')], default=[1, 2, 3])
     a = ap.parse_args()
@@ -53,6 +54,8 @@ def main():
         ('decoder bwd: dhrec += dhp . W', 256, [(512, [512])], False, 0),
         ('stage II bwd: dhrec, 4 dz', 256, [(512, [2048])] * 5, False, 0),
     ]
+    if a.batch:
+        cases = [('B=%d %s' % (a.batch, nm), a.batch, o, l, k) for nm, m, o, l, k in cases if m == 256]
     if a.small:      # the small-shard regime (B = 32 / 64 per GPU; BASELINE config 2): grids far below 256 CUs
         cases = []
         for Ms in (32, 64):
