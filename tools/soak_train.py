@@ -15,10 +15,12 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--steps', type=int, default=300)
 ap.add_argument('--recipe', action='store_true')
 ap.add_argument('--gemm', default='exact', choices=['exact', 'bf16x3'])
+ap.add_argument('--workload', default='c3', choices=sorted(HB.WORKLOADS))
+ap.add_argument('--batch', type=int, default=0, help='captions (default: the workload value)')
 a = ap.parse_args()
 dev = torch.device('cuda:0')
-w = dict(HB.WORKLOADS['c3'])
-B = 256
+w = dict(HB.WORKLOADS[a.workload])
+B = a.batch or w.get('B', 256)
 cfg = HB.make_cfg(w)
 if a.recipe:
     cfg.drop_prob_lm, cfg.use_label_smoothing = 0.3, 1
