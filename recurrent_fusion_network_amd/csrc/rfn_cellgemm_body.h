@@ -635,8 +635,12 @@ __device__ __forceinline__ void cg_tile(const CgArgs& a, const int bid, float* s
             wp_wait(WSL - 1);
             wp_read(0, fc);
             int rd = 1, fl = 0;     // slot of step it + 1; slot of step it (free: its fragments are in registers)
+            [[maybe_unused]] int wp_it = 0;   // probe builds only (CG_LOOP_STAMPS)
             for (int it = total_iters - WSL; it > 0; --it) {
+                CG_LSTAMP(wp_it, 0);
                 cg_wait_vmcnt<(WSL - 2) * WPN>();
+                CG_LSTAMP(wp_it, 1);
+                ++wp_it;
                 wp_read(rd, fn);
                 wp_mfma(fc);
                 wp_dma(fl);

@@ -37,6 +37,23 @@ int main() {
             outs[0].seg[0].A = z; outs[0].seg[0].lda = R; outs[0].seg[0].a_kfast = 1;
             outs[0].seg[0].B = Wz; outs[0].seg[0].ldb = R; outs[0].seg[0].b_kfast = 1; outs[0].seg[0].K = R;
         }
+        for (int variant : {6, 8}) {     // wave-private slots: the steady-state loop stamps its top and the end of its counted wait
+            for (int rep = 0; rep < 3; ++rep) {
+                if (rfn_cell_gemm(M, nout, outs, R, 0.f, 0, variant, 0) != 0) { printf("variant %d refused\n", variant); break; }
+                hipDeviceSynchronize();
+            }
+            unsigned long long st[64 * 8];
+            hipMemcpyFromSymbol(st, HIP_SYMBOL(g_cg_loop_stamps), sizeof(st));
+            const int T = (shape == 0 ? 2048 : 512) / 64 - CG_WP_SLOTS;     // steady-state steps
+            double wait = 0, total = 0;
+            for (int it = 0; it < T && it < 64; ++it) {
+                wait += (double)(st[it * 8 + 1] - st[it * 8]);
+                if (it + 1 < T) total += (double)(st[(it + 1) * 8] - st[it * 8]);
+            }
+            printf("%s variant %d: %2d steady K steps, cycles per step: counted wait %6.0f | step total %6.0f\n",
+                   shape == 0 ? "Kb1 (K = 2048, [k][n] weights)" : "forward store (K = 512, [n][k] weights)", variant, T, wait / T,
+                   total / (T - 1));
+        }
         for (int variant : {3, 4, 5}) {
             for (int rep = 0; rep < 3; ++rep) {
                 if (rfn_cell_gemm(M, nout, outs, R, 0.f, 0, variant, 0) != 0) { printf("variant %d refused\n", variant); break; }
