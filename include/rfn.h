@@ -36,7 +36,7 @@ extern "C" {
 #define RFN_ERR_ARG (-5)         /* null / misaligned pointer */
 
 #define RFN_MAX_ENC 8
-#define RFN_ABI_VERSION 6
+#define RFN_ABI_VERSION 7
 
 /* Model dimensions: the fields RecurrentFusionModel.__init__ reads from `opt`
  * (misc/RecurrentFusionModel.py:118-151).  Limits (RFN_ERR_SHAPE otherwise): M <= RFN_MAX_ENC,
@@ -79,6 +79,10 @@ typedef struct rfn_dims {
                                            * that the library would take 16-row tiles (rfn_cell_gemm variant 6; same results)  */
 #define RFN_PATH_OPT_SHARED_SMALL_TILES 64u /* A/B hook: those 16-row tiles on ring slots shared by the block (rfn_cell_gemm variants
                                            * 4 / 5) instead of wave-private ones (variant 6, the default); same results        */
+#define RFN_PATH_OPT_DEC_UNHOISTED 128u   /* A/B hook: the decoder cell of rounds 3-5 (z2h(z) as a per-step product: three
+                                           * dependent launches per step each way) instead of the hoisted form (two).  Same
+                                           * mathematics, different rounding.  Implied by the PERSIST_DEC_* bits; the beam loop,
+                                           * whose rows share their image's thought vectors, has no unhoisted form          */
 #define RFN_PATH_OPT_DEEP_CELLS 16u       /* A/B hook: per-step products with no more tiles than CUs on the deep-ring kernel
                                            * (rfn_cell_gemm, RFN_CELL_VARIANT_DEEP) instead of the 3-slot one; not faster      */
 
@@ -329,6 +333,29 @@ int rfn_attn_small_bwd(int ngroups, const float* const* proj, int64_t proj_sb, i
                        int64_t lddz, int B, int L, int A, int D, float* const* dproj, int64_t dproj_sb,
                        int64_t dproj_sl, int accumulate_dproj, float* const* dhproj, float* const* dw_part,
                        float* const* datt_seq, void* stream);
+
+/* ---- decoder cell with z2h hoisted through the attention (csrc/rfn_deccell.hip, round 6) -------------------------------
+ * misc/LSTMSoftAttentionCore.py:64-81 applies z2h to z = sum_l alpha_l v_l over the SAME thought vectors v with the SAME
+ * weights on every step; z2h is linear, so z2h(z) = b_z + sum_l alpha_l U_l with U = v . W_z^T computed once per call.
+ * rfn_dec_cell_fwd: one launch = scores (:64-75), softmax (:76), gates = (sum_l alpha_l U_l + b_z) + gates_in (:81; gates_in =
+ *   i2h(x) + h2h(h) already in `gates`), LSTM update (:83-101) with the dropout mask of (seed, drop_offset); the gate
+ *   activations overwrite `gates` (4R wide, 5R with maxout) as rfn_lstm_fwd leaves them.  proj / U rows of batch row b are
+ *   those of row b / row_div (beam search: the rows of one image share its thought vectors).  alpha (B, L) out.
+ * rfn_dec_attn_bwd: the attention backward of one step from that step's gate gradients: d alpha_l = <dgates, U_l>, softmax
+ *   and tanh backward; dproj (accumulated when `accumulate`), dhproj, dw_part as rfn_attn_small_bwd.  GD = 4R or 5R.
+ * rfn_dec_du: after the loop, dU[b, l, :] = sum_s alpha[s, b, l] * dgates[s, b, :] (alpha (S, B, L), dgates (S, B, GD)
+ *   contiguous; dU strides as U). */
+int rfn_dec_cell_fwd(const float* proj, int64_t psb, int64_t psl, const float* hproj, const float* w_out,
+                     const float* b_out, const float* U, int64_t usb, int64_t usl, const float* bz, float* gates,
+                     int64_t ldg, const float* c_prev, int64_t ldcp, float* c_next, int64_t ldcn, float* h_next,
+                     int64_t ldh, float* alpha, int B, int L, int A, int R, int maxout, int row_div, float drop_p,
+                     uint64_t seed, uint64_t drop_offset, void* stream);
+int rfn_dec_attn_bwd(const float* proj, int64_t psb, int64_t psl, const float* hproj, const float* w_out,
+                     const float* alpha, const float* U, int64_t usb, int64_t usl, const float* dgates, int64_t ldg,
+                     int B, int L, int A, int GD, float* dproj, int64_t dpsb, int64_t dpsl, int accumulate,
+                     float* dhproj, float* dw_part, void* stream);
+int rfn_dec_du(const float* alpha, const float* dgates, int S, int B, int L, int GD, float* dU, int64_t usb,
+               int64_t usl, void* stream);
 
 /* ---- row-panel GEMM of the recurrences (csrc/rfn_cellgemm.hip) ------------------------------------------------------
  * One launch computes up to RFN_CELL_MAXOUT outputs over the same M (= batch) rows, each with its own destination,
@@ -687,13 +714,17 @@ int rfn_decoder_bwd(const rfn_dims* d, int B, int S, const float* const* params,
 /* One free-running decoder step for sample()/sample_beam()/one_time_step
  * (misc/RecurrentFusionModel.py:345-350, 616-653, 526-527): state (h,c) is updated in place,
  * logits (B,V1) pre-softmax and/or logp (B,V1) are written when non-NULL.
- * cproj = att_2_att_h(comb) (T2*B, A) must have been filled by rfn_decoder_prepare.
+ * cproj (rfn_decoder_cproj_floats(d, B) floats) must have been filled by rfn_decoder_prepare: the loop-invariant products of
+ * the thought vectors, [att_2_att_h(comb) (T2*B, A) | U = comb . z2h.weight^T (T2*B, 4R or 5R), 256-B aligned] -- the
+ * reference recomputes the first every step (misc/LSTMSoftAttentionCore.py:64-66) and applies z2h to the context every step
+ * (:81); z2h(sum_l alpha_l v_l) = z2h.bias + sum_l alpha_l U_l (csrc/rfn_deccell.hip).
  * The step is computed with the operation sequence of step `step` of rfn_decoder_fwd: with d->drop_lm > 0 it applies
  * the dropout mask of (seed, step) that rfn_decoder_fwd(train, seed) applies at that step, and its log-probs are
  * bit-identical to the teacher-forced pass fed the same tokens -- the reference samples (scheduled sampling :260-270,
  * multinomial sample :623-631) from the very distribution it differentiates.  Hosts pass drop_lm = 0 outside
  * training mode. */
 size_t rfn_decoder_step_ws_bytes(const rfn_dims* d, int B);
+size_t rfn_decoder_cproj_floats(const rfn_dims* d, int B);
 int rfn_decoder_prepare(const rfn_dims* d, int B, const float* const* params, const float* comb,
                         float* cproj, void* stream);
 int rfn_decoder_step(const rfn_dims* d, int B, const float* const* params, const float* comb,
@@ -736,7 +767,9 @@ int rfn_decoder_fwd_sampled(const rfn_dims* d, int B, int S, const float* const*
                             float inv_temperature, const float* u_draw, const float* u_coin, float* log_prob, void* ws,
                             size_t ws_bytes, int train, uint64_t seed, void* stream);
 /* rfn_beam_loop: sample_beam's search (:451-531) for NB images x W beams: S x (rfn_beam_step, two rfn_gather_rows,
- *   rfn_decoder_step on the NB * W rows, ending in rfn_log_softmax_topk instead of the full log-softmax).  h / c
+ *   rfn_decoder_step on the NB * W rows, ending in rfn_log_softmax_topk instead of the full log-softmax).  comb (T2, NB, R)
+ *   and cproj = rfn_decoder_prepare(d, NB, ...) are per IMAGE: the W beam rows of image k read row k (the reference feeds
+ *   beam_size copies of the image's thought vectors, :417-420).  h / c
  *   (NB * W, R) in / out, h_alt / c_alt same-size scratch, logp: 2 * NB * W * W floats of scratch (the rows' top-W lists);
  *   the beam / done arrays as rfn_beam_step (zero-initialised by the caller; active = 1). */
 int rfn_beam_loop(const rfn_dims* d, int NB, int W, int S, const float* const* params, const float* comb,

@@ -16,12 +16,13 @@ LIB_PATH = os.path.join(_HERE, 'librfn_hip.so')
 RFN_MAX_ENC = 8
 RFN_GEMM_MAXSEG = 8
 RFN_GEMM_MAXGROUP = 8
-ABI_VERSION = 6
+ABI_VERSION = 7
 PATH_OPT_PERSIST_DEC_FWD, PATH_OPT_PERSIST_S2_FWD, PATH_OPT_PERSIST_DEC_BWD, PATH_OPT_PERSIST_S2_BWD = 1, 2, 4, 8   # rfn.h
 PATH_OPT_PERSIST_ALL = 15
 PATH_OPT_DEEP_CELLS = 16          # rfn.h RFN_PATH_OPT_DEEP_CELLS (A/B hook)
 PATH_OPT_NO_SMALL_TILES = 32      # rfn.h RFN_PATH_OPT_NO_SMALL_TILES (A/B hook)
 PATH_OPT_SHARED_SMALL_TILES = 64  # rfn.h RFN_PATH_OPT_SHARED_SMALL_TILES (A/B hook)
+PATH_OPT_DEC_UNHOISTED = 128      # rfn.h RFN_PATH_OPT_DEC_UNHOISTED (A/B hook: the three-launch decoder cell of rounds 3-5)
 CELL_VARIANT_DEEP = 256
 GEMM_OPT_LDS_LEAN = 1
 GEMM_OPT_NO_DMA = 2
@@ -174,6 +175,10 @@ def _load():
         'rfn_beam_loop': (C.c_int, [DP, I, I, I] + [P] * 18 + [I, P, SZ, U64, P]),
         'rfn_decoder_step_ws_bytes': (SZ, [DP, I]),
         'rfn_decoder_prepare': (C.c_int, [DP, I, P, P, P, P]),
+        'rfn_decoder_cproj_floats': (SZ, [DP, I]),
+        'rfn_dec_cell_fwd': (C.c_int, [P, L, L, P, P, P, P, L, L, P, P, L, P, L, P, L, P, L, P, I, I, I, I, I, I, C.c_float, U64, U64, P]),
+        'rfn_dec_attn_bwd': (C.c_int, [P, L, L, P, P, P, P, L, L, P, L, I, I, I, I, P, L, L, I, P, P, P]),
+        'rfn_dec_du': (C.c_int, [P, P, I, I, I, I, P, L, L, P]),
         'rfn_decoder_step': (C.c_int, [DP, I, P, P, P, P, P, P, P, P, L, P, SZ, U64, I, P]),
         'rfn_decoder_step_embedded': (C.c_int, [DP, I, P, P, P, P, L, P, P, P, P, L, P, SZ, U64, I, P]),
     }

@@ -456,8 +456,8 @@ PrefixLayout prefix_layout(const rfn_dims* d, int B, int train) {
 }
 
 struct DecoderLayout {
-    size_t Pd, xs, gd, hd, cd, hpd, ald, zd, logits;
-    size_t dhe, dhrec, dc, dz, dal, dwp, dhpd, dPd, dxs;
+    size_t Pd, Ud, xs, gd, hd, cd, hpd, ald, zd, logits;
+    size_t dhe, dhrec, dc, dz, dal, dwp, dhpd, dPd, dUd, dxs;
     size_t gws, tk, bar;
     size_t total;
 };
@@ -468,6 +468,7 @@ DecoderLayout decoder_layout(const rfn_dims* d, int B, int S, int train) {
     Bump b;
     const size_t R = d->R, A = d->A, E = d->E, T2 = d->T2, V1 = d->V1, Bz = B, Sz = S;
     L.Pd = b.take(T2 * Bz * A);
+    L.Ud = b.take(T2 * Bz * GD);      // U = thought vectors . W_z^T (z2h hoisted through the attention, rfn_deccell.hip)
     L.xs = b.take(Sz * Bz * E);
     L.gd = b.take(Sz * Bz * GD);
     L.hd = b.take((Sz + 1) * Bz * R);
@@ -488,6 +489,7 @@ DecoderLayout decoder_layout(const rfn_dims* d, int B, int S, int train) {
         L.dwp = b.take(Sz * Bz * A);
         L.dhpd = b.take(Sz * Bz * A);
         L.dPd = b.take(T2 * Bz * A);
+        L.dUd = b.take(T2 * Bz * GD);
         L.dxs = b.take(Sz * Bz * E);
     }
     L.total = b.off;
@@ -495,6 +497,14 @@ DecoderLayout decoder_layout(const rfn_dims* d, int B, int S, int train) {
 }
 
 const uint64_t OFF_STAGE2 = RFN_DROP_OFFSET_STAGE2, OFF_DECODER = RFN_DROP_OFFSET_DECODER;   // rfn.h: rfn_dropout_mask
+
+// The decoder cell's form: z2h hoisted through the attention (rfn_deccell.hip: two dependent launches per step each way)
+// unless the caller asks for the three-launch form of rounds 3-5 (A/B hook; the persistent decoder chains are built from it).
+inline bool dec_hoisted(const rfn_dims* d) {
+    return !(d->path_flags & (RFN_PATH_OPT_DEC_UNHOISTED | RFN_PATH_OPT_PERSIST_DEC_FWD | RFN_PATH_OPT_PERSIST_DEC_BWD));
+}
+// rfn_decoder_prepare's buffer: [Pd = att_2_att_h(comb) (T2 * Bc, A) | U = comb . W_z^T (T2 * Bc, GD)], U 256-B aligned
+inline size_t cproj_u_off(const rfn_dims* d, int Bc) { return ((size_t)d->T2 * Bc * d->A + 63) & ~(size_t)63; }
 
 }  // namespace
 
@@ -1476,13 +1486,34 @@ static bool decoder_cell_prepare(const rfn_dims* d, int B, const float* const* p
            cell_prepare(B, 1, &k3, R, d->drop_lm, seed, &cs->g2, cell_variant(d)) == RFN_OK;
 }
 
+// Hoisted form (default, rfn_deccell.hip; 2 launches): K1 as above, then ONE per-row launch = scores, softmax,
+// gates += b_z + sum_l alpha_l U_l, LSTM update.  `U` = comb . W_z^T (Bc = B / row_div rows per thought vector; the rows
+// b of one beam-search image share row b / row_div of cproj / U).  z is not computed.
 static int decoder_cell_core(const rfn_dims* d, int B, const float* const* prm, const float* comb, const float* cproj,
-                             const float* h, const float* c, float* h_next, float* c_next, float* hp, float* al, float* z,
-                             float* g, const GemmCtx& gx, uint64_t seed, int step, void* st) {
+                             const float* U, int row_div, const float* h, const float* c, float* h_next, float* c_next,
+                             float* hp, float* al, float* z, float* g, const GemmCtx& gx, uint64_t seed, int step, void* st) {
     const PIdx P(d);
     const int R = d->R, A = d->A, T2 = d->T2;
     const int GD = gate_width(d->decoder_maxout, R);
     const long BR = (long)B * R, BA = (long)B * A;
+    if (dec_hoisted(d)) {
+        const int Bc = B / row_div;
+        rfn_cell_out k1[2];
+        k1[0] = cell_out(hp, A, A, 0);
+        cell_lin(k1[0], h, R, prm[P.dec(8)], R, R, prm[P.dec(9)]);
+        k1[1] = cell_out(g, GD, GD, 1);
+        cell_lin(k1[1], h, R, prm[P.dec(2)], R, R, prm[P.dec(3)]);
+        if (cell_ok(B, 2, k1, R)) {
+            RFN_TRY(cell_run(B, 2, k1, R, 0.f, 0, st, cell_variant(d)));
+        } else {
+            RFN_TRY(gemm1(B, A, seg_lin(h, R, prm[P.dec(8)], R, R, prm[P.dec(9)]), hp, A, 0, gx));
+            RFN_TRY(gemm1(B, GD, seg_lin(h, R, prm[P.dec(2)], R, R, prm[P.dec(3)]), g, GD, 1, gx));
+        }
+        return rfn_dec_cell_fwd(cproj, A, (long)Bc * A, hp, prm[P.dec(10)], prm[P.dec(11)], U, GD, (long)Bc * GD, prm[P.dec(5)], g,
+                                GD, c, R, c_next, R, h_next, R, al, B, T2, A, R, d->decoder_maxout, row_div, d->drop_lm, seed,
+                                OFF_DECODER + (uint64_t)step, st);
+    }
+    if (row_div != 1) return RFN_ERR_UNSUPPORTED;   // the three-launch form reads comb per row
     {
         ChainStep cs;
         if (decoder_cell_prepare(d, B, prm, comb, cproj, h, c, h_next, c_next, hp, al, z, g, seed, step, &cs))
@@ -1513,8 +1544,8 @@ static int decoder_fwd_cell(const rfn_dims* d, int B, int s, const float* const*
     float* al = W + Lo.ald + (long)s * B * T2;
     float* z = W + Lo.zd + s * BR;
     float* g = W + Lo.gd + (long)s * B * GD;
-    return decoder_cell_core(d, B, prm, comb, W + Lo.Pd, hc, cd + s * BR, hd + (s + 1) * BR, cd + (s + 1) * BR, hp, al, z, g,
-                             gx, seed, s, st);
+    return decoder_cell_core(d, B, prm, comb, W + Lo.Pd, W + Lo.Ud, 1, hc, cd + s * BR, hd + (s + 1) * BR, cd + (s + 1) * BR, hp,
+                             al, z, g, gx, seed, s, st);
 }
 
 static bool decoder_fwd_cell_prepare(const rfn_dims* d, int B, int s, const float* const* prm, const float* comb, float* W,
@@ -1541,6 +1572,10 @@ static int decoder_fwd_begin(const rfn_dims* d, int B, const float* const* prm, 
     const int R = d->R, A = d->A, T2 = d->T2;
     const GemmCtx gx_whole{st, nullptr, 0, d->gemm_flags};
     RFN_TRY(gemm1(T2 * B, A, seg_lin(comb, R, prm[P.dec(6)], R, R, prm[P.dec(7)]), W + Lo.Pd, A, 0, gx_whole));
+    if (dec_hoisted(d)) {   // U = comb . W_z^T, no bias: z2h of every thought vector, once (misc/LSTMSoftAttentionCore.py:78-81)
+        const int GD = gate_width(d->decoder_maxout, R);
+        RFN_TRY(gemm1(T2 * B, GD, seg_lin(comb, R, prm[P.dec(4)], R, R, nullptr), W + Lo.Ud, GD, 0, gx_whole));
+    }
     return mem_batch({{W + Lo.hd, h0, (long)B * R}, {W + Lo.cd, c0, (long)B * R}}, st);
 }
 
@@ -1562,7 +1597,9 @@ extern "C" int rfn_decoder_fwd(const rfn_dims* d, int B, int S, const float* con
     // all token embeddings and their i2h projections in one go (teacher forcing: ids are known)
     RFN_TRY(rfn_embed_fwd(prm[P.embed()], E, V1, ids, B, ld_ids, 1, S * B, W + Lo.xs, E, st));
     RFN_TRY(gemm1(S * B, GD, seg_lin(W + Lo.xs, E, prm[P.dec(0)], E, E, prm[P.dec(1)]), W + Lo.gd, GD, 0, gx_whole));
-    {   // the S cell steps: one persistent launch (rfn_chain.hip) when every step takes the fused form, else step by step
+    if (dec_hoisted(d)) {   // the S cell steps, two launches each (rfn_deccell.hip)
+        for (int s = 0; s < S; ++s) RFN_TRY(decoder_fwd_cell(d, B, s, prm, comb, W, Lo, gx, seed, st));
+    } else {   // three-launch form: one persistent launch (rfn_chain.hip) when every step takes the fused form, else step by step
         std::vector<ChainStep> steps((size_t)S);
         bool fused = true;
         for (int s = 0; s < S && fused; ++s) fused = decoder_fwd_cell_prepare(d, B, s, prm, comb, W, Lo, seed, &steps[s]);
@@ -1654,6 +1691,70 @@ extern "C" int rfn_decoder_bwd(const rfn_dims* d, int B, int S, const float* con
     if (d_log_prob) RFN_TRY(rfn_log_softmax_bwd(d_log_prob, log_prob, S * B, V1, B, (long)S * V1, V1, dlg, V1, st));
     RFN_TRY(gemm_logits_dw(V1, R, grd[P.logit_w()], grd[P.logit_b()], dlg, hd + BR, S * B, gx));
     RFN_TRY(gemm_logits_dx(S * B, R, V1, dlg, prm[P.logit_w()], dhe, gx));
+    if (dec_hoisted(d)) {
+        // ---- z2h hoisted (rfn_deccell.hip): per step the attention backward from that step's gate gradients, then ONE product
+        // d h = [d gates_s | d hproj_s] . [W_hh ; W_h] whose epilogue finishes d h of step s-1 (+ the logit layer's share) and
+        // runs that step's LSTM backward.  d thoughts / d W_z / d att_2_att_h follow after the loop from dU and dPd.
+        const float* Ud = W + Lo.Ud;
+        float* dUd = W + Lo.dUd;
+        RFN_TRY(mem_batch({{dPd, nullptr, (long)T2 * BA}}, st));
+        auto kb_of = [&](int s, rfn_cell_out& kb) {
+            kb = cell_out(dhrec, R, R, 0);
+            cell_dx(kb, gd + (long)s * B * GD, GD, prm[P.dec(2)], R, GD);
+            cell_dx(kb, W + Lo.dhpd + s * BA, A, prm[P.dec(8)], R, A);
+            if (s > 0)
+                cell_lstm_bwd(kb, gd + (long)(s - 1) * B * GD, GD, cd + (s - 1) * BR, R, cd + s * BR, R, dhe + (s - 1) * BR, R,
+                              dc, R, dc, R, OFF_DECODER + (uint64_t)(s - 1));
+        };
+        bool fusedh = !d->decoder_maxout;
+        for (int s = 0; s < S && fusedh; ++s) {
+            rfn_cell_out t;
+            kb_of(s, t);
+            fusedh = cell_ok(B, 1, &t, R);
+        }
+        if (fusedh)   // LSTM backward of the last step: nothing recurrent flows into it
+            RFN_TRY(rfn_lstm_bwd(gd + (long)(S - 1) * B * GD, GD, cd + (S - 1) * BR, R, cd + S * BR, R, dhe + (S - 1) * BR, R, nullptr,
+                                 R, dc, R, B, R, 0, d->drop_lm, seed, OFF_DECODER + (uint64_t)(S - 1), st));
+        for (int s = S - 1; s >= 0; --s) {
+            float* g = gd + (long)s * B * GD;
+            float* dhp = W + Lo.dhpd + s * BA;
+            if (!fusedh) {
+                float* dht = dhe + s * BR;
+                if (s < S - 1) RFN_TRY(rfn_axpby_2d(1.f, dhrec, R, 1.f, dht, R, B, R, st));
+                RFN_TRY(rfn_lstm_bwd(g, GD, cd + s * BR, R, cd + (s + 1) * BR, R, dht, R, (s < S - 1) ? dc : nullptr, R, dc, R, B, R,
+                                     d->decoder_maxout, d->drop_lm, seed, OFF_DECODER + (uint64_t)s, st));
+            }
+            RFN_TRY(rfn_dec_attn_bwd(W + Lo.Pd, A, BA, W + Lo.hpd + s * BA, prm[P.dec(10)], W + Lo.ald + (long)s * B * T2, Ud, GD,
+                                     (long)B * GD, g, GD, B, T2, A, GD, dPd, A, BA, 1, dhp, W + Lo.dwp + s * BA, st));
+            if (fusedh) {
+                rfn_cell_out kb;
+                kb_of(s, kb);
+                RFN_TRY(cell_run(B, 1, &kb, R, d->drop_lm, seed, st, cell_variant(d)));
+            } else {
+                rfn_gemm_seg sg[2] = {seg_dx(g, GD, prm[P.dec(2)], R, GD), seg_dx(dhp, A, prm[P.dec(8)], R, A)};
+                RFN_TRY(gemm_segs(B, R, 2, sg, dhrec, R, 0, gx));
+            }
+        }
+        RFN_TRY(mem_batch({{d_h0, dhrec, BR}, {d_c0, dc, BR}, {grd[P.dec(11)], nullptr, 1}}, st));
+        // d U = sum_s alpha_s (x) d gates_s; d thoughts = dPd . W_att + dU . W_z (one product, two K segments)
+        RFN_TRY(rfn_dec_du(W + Lo.ald, gd, S, B, T2, GD, dUd, GD, (long)B * GD, st));
+        {
+            rfn_gemm_seg sg[2] = {seg_dx(dPd, A, prm[P.dec(6)], R, A), seg_dx(dUd, GD, prm[P.dec(4)], R, GD)};
+            RFN_TRY(gemm_segs(T2 * B, R, 2, sg, d_comb, R, 0, gx));
+        }
+        RFN_TRY(gemm_dw(A, R, grd[P.dec(6)], R, grd[P.dec(7)], dPd, A, comb, R, T2 * B, gx));
+        RFN_TRY(gemm_dw(GD, R, grd[P.dec(4)], R, nullptr, dUd, GD, comb, R, T2 * B, gx));   // d z2h.weight = dU^T . thoughts
+        // weights shared across steps: one GEMM over (S*B) time-major rows each, bias gradients ride along
+        RFN_TRY(rfn_colsum_f32(W + Lo.dwp, A, S * B, A, grd[P.dec(10)], 0, st));
+        RFN_TRY(gemm_dw(A, R, grd[P.dec(8)], R, grd[P.dec(9)], W + Lo.dhpd, A, hd, R, S * B, gx));
+        RFN_TRY(gemm_dw(GD, R, grd[P.dec(2)], R, grd[P.dec(3)], gd, GD, hd, R, S * B, gx));
+        RFN_TRY(gemm_dw(GD, E, grd[P.dec(0)], E, grd[P.dec(1)], gd, GD, W + Lo.xs, E, S * B, gx));
+        // d z2h.bias = column sums of the gate gradients = d h2h.bias (b_z enters every step's gates as b_h2h does)
+        RFN_TRY(mem_batch({{grd[P.dec(5)], grd[P.dec(3)], (long)GD}}, st));
+        RFN_TRY(gemm1(S * B, E, seg_dx(gd, GD, prm[P.dec(0)], E, GD), W + Lo.dxs, E, 0, gx));
+        RFN_TRY(rfn_embed_bwd(W + Lo.dxs, E, ids, B, ld_ids, 1, S * B, E, V1, grd[P.embed()], st));
+        return RFN_OK;
+    }
     RFN_TRY(mem_batch({{d_comb, nullptr, (long)T2 * BR}, {dPd, nullptr, (long)T2 * BA}}, st));
     rfn_gemm_problem pr[2];
     // Fused form of a backward step (3 launches): Kb1 = [dh_rec | dz] = dgates . [W_hh | W_z] in one launch (they share the
@@ -1765,6 +1866,11 @@ extern "C" size_t rfn_decoder_step_ws_bytes(const rfn_dims* d, int B) {
     return b.off * sizeof(float);
 }
 
+extern "C" size_t rfn_decoder_cproj_floats(const rfn_dims* d, int B) {
+    if (check_dims(d) != RFN_OK || B < 1) return 0;
+    return cproj_u_off(d, B) + (size_t)d->T2 * B * gate_width(d->decoder_maxout, d->R);
+}
+
 extern "C" int rfn_decoder_prepare(const rfn_dims* d, int B, const float* const* prm, const float* comb, float* cproj,
                                    void* st) {
     RFN_TRY(check_dims(d));
@@ -1772,7 +1878,10 @@ extern "C" int rfn_decoder_prepare(const rfn_dims* d, int B, const float* const*
     if (!prm || !comb || !cproj) return RFN_ERR_ARG;
     const PIdx P(d);
     const GemmCtx gx{st, nullptr, 0, d->gemm_flags};
-    return gemm1(d->T2 * B, d->A, seg_lin(comb, d->R, prm[P.dec(6)], d->R, d->R, prm[P.dec(7)]), cproj, d->A, 0, gx);
+    RFN_TRY(gemm1(d->T2 * B, d->A, seg_lin(comb, d->R, prm[P.dec(6)], d->R, d->R, prm[P.dec(7)]), cproj, d->A, 0, gx));
+    if (!dec_hoisted(d)) return RFN_OK;
+    const int GD = gate_width(d->decoder_maxout, d->R);   // the same unsplit product as decoder_fwd_begin's
+    return gemm1(d->T2 * B, GD, seg_lin(comb, d->R, prm[P.dec(4)], d->R, d->R, nullptr), cproj + cproj_u_off(d, B), GD, 0, gx);
 }
 
 // One decoder step computed with exactly the operation sequence of one step of rfn_decoder_fwd (unsplit i2h, then
@@ -1782,9 +1891,9 @@ extern "C" int rfn_decoder_prepare(const rfn_dims* d, int B, const float* const*
 static int decoder_step_impl(const rfn_dims* d, int B, const float* const* prm, const float* comb, const float* cproj,
                              const int64_t* ids, const float* xt, int64_t ld_xt, float* h, float* c, float* logits,
                              float* logp, int64_t ld_logp, void* ws, size_t ws_bytes, uint64_t seed, int step,
-                             void* st, float* topv = nullptr, int32_t* topi = nullptr, int topw = 0) {
+                             void* st, float* topv = nullptr, int32_t* topi = nullptr, int topw = 0, int row_div = 1) {
     RFN_TRY(check_dims(d));
-    if (B < 1 || step < 0) return RFN_ERR_SHAPE;
+    if (B < 1 || step < 0 || row_div < 1 || B % row_div) return RFN_ERR_SHAPE;
     if (!prm || !comb || !cproj || (!ids && !xt) || !h || !c || !ws) return RFN_ERR_ARG;
     if (xt && ld_xt < d->E) return RFN_ERR_SHAPE;
     if (ws_bytes < rfn_decoder_step_ws_bytes(d, B)) return RFN_ERR_WORKSPACE;
@@ -1804,7 +1913,8 @@ static int decoder_step_impl(const rfn_dims* d, int B, const float* const* prm, 
     if (!xt) RFN_TRY(rfn_embed_fwd(prm[P.embed()], E, V1, ids, B, 1, 0, B, x, E, st));
     RFN_TRY(gemm1(B, GD, xt ? seg_lin(xt, ld_xt, prm[P.dec(0)], E, E, prm[P.dec(1)]) : seg_lin(x, E, prm[P.dec(0)], E, E, prm[P.dec(1)]),
                   g, GD, 0, gx_whole));
-    RFN_TRY(decoder_cell_core(d, B, prm, comb, cproj, h, c, h, c, hp, al, z, g, gx, seed, step, st));
+    RFN_TRY(decoder_cell_core(d, B, prm, comb, cproj, cproj + cproj_u_off(d, B / row_div), row_div, h, c, h, c, hp, al, z, g, gx,
+                              seed, step, st));
     if (logits || logp || topv) {
         RFN_TRY(gemm_logits(B, V1, h, R, prm[P.logit_w()], prm[P.logit_b()], lg, gx_whole));
         if (logp) {
@@ -1918,7 +2028,7 @@ extern "C" int rfn_beam_loop(const rfn_dims* d, int NB, int W, int S, const floa
             x = cc; cc = ca; ca = x;
         }
         RFN_TRY(decoder_step_impl(d, rows, prm, comb, cproj, ids, nullptr, 0, hc, cc, nullptr, nullptr, 0, ws, ws_bytes, seed, t, st,
-                                  topv, topi, W));
+                                  topv, topi, W, W));   // the W rows of an image share its thought vectors (comb / cproj: NB rows)
     }
     if (hc != h) {   // an odd number of swaps: bring the live state home
         RFN_TRY(mem_batch({{h, hc, (long)rows * R}, {c, cc, (long)rows * R}}, st));

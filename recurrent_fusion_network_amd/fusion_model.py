@@ -816,8 +816,8 @@ class RecurrentFusionModel(nn.Module):
             seed = _fresh_seed() if drop else 0
             comb_b, h_b, c_b, reason = self._prefix(fc_feats, att_feats, drop, seed)
             dev = comb_b.device
-            comb = comb_b.repeat_interleave(W, dim=1).contiguous()         # (T2, B*W, R): row k*W+q = image k
-            stepper = _Stepper(self, comb, h_b.repeat_interleave(W, dim=0).contiguous(),
+            # the W beam rows of image k (rows k*W .. k*W+W-1) read the image's thought vectors: comb stays (T2, B, R)
+            stepper = _Stepper(self, comb_b, h_b.repeat_interleave(W, dim=0).contiguous(),
                                c_b.repeat_interleave(W, dim=0).contiguous(), drop, seed)
             rows, max_done = B * W, W * S
             bs = torch.zeros(S, B, W, dtype=torch.long, device=dev)
@@ -995,8 +995,10 @@ class _Stepper:
         self.B = self.h.size(0)
         dev = self.h.device
         self.table = model._param_table(model._params_of(model._decoder_slots), model._decoder_slots)
-        self.cproj = torch.empty(self.d.T2 * self.B, self.d.A, device=dev)
-        N.check(N.lib.rfn_decoder_prepare(C.byref(self.d), self.B, self.table, self.comb.data_ptr(),
+        # the loop-invariant products of the thought vectors: att_2_att_h(comb) and U = comb . z2h.weight^T (rfn.h)
+        self.Bc = self.comb.size(1)          # rows per thought vector: B, or the images of a beam search (B = Bc * beam)
+        self.cproj = torch.empty(N.lib.rfn_decoder_cproj_floats(C.byref(self.d), self.Bc), device=dev)
+        N.check(N.lib.rfn_decoder_prepare(C.byref(self.d), self.Bc, self.table, self.comb.data_ptr(),
                                           self.cproj.data_ptr(), N.stream_ptr()), 'rfn_decoder_prepare')
         self.ws_bytes = N.lib.rfn_decoder_step_ws_bytes(C.byref(self.d), self.B)
         self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev)
@@ -1004,6 +1006,8 @@ class _Stepper:
     def step(self, ids, out=None, want='logp'):
         """ids: int64 token ids (B,) -- or an already embedded float input (B, E), as the reference's one_time_step."""
         V1 = self.d.V1
+        if self.Bc != self.B:
+            raise N.RfnError('a stepper whose rows share thought vectors (beam search) is driven by rfn_beam_loop only')
         if out is None:
             out = torch.empty(self.B, V1, device=self.h.device)
         logits_ptr = out.data_ptr() if want == 'logits' else None
