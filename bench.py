@@ -247,7 +247,9 @@ def parse_args(argv=None):
                          '16 = RFN_PATH_OPT_DEEP_CELLS: few-tile per-step products on the deep-ring kernel instead of the 3-slot one; '
                          '32 = RFN_PATH_OPT_NO_SMALL_TILES: keep 32-row tiles where the library would take 16-row ones; '
                          '64 = RFN_PATH_OPT_SHARED_SMALL_TILES: those 16-row tiles on block-shared ring slots (variants 4 / 5); '
-                         'bit-identical either way (profiles/r05_chain.md)')
+                         'bit-identical either way (profiles/r05_chain.md); '
+                         '128 = RFN_PATH_OPT_DEC_UNHOISTED: the three-launch decoder cell of rounds 3-5 (z2h(z) as a per-step product) '
+                         'instead of the hoisted two-launch form (csrc/rfn_deccell.hip); same mathematics, different rounding')
     ap.add_argument('--fused-loss', action='store_true',
                     help='forward + criterion through RecurrentFusionModel.forward_loss (the language term straight from the '
                          'logits, d logits written in place: no (B, T, V+1) log_prob / d log_prob round trip) instead of '
@@ -384,6 +386,10 @@ def run_decode(args, rank, world, dev):
     if args.gemm == 'bf16x3':
         import recurrent_fusion_network_amd._native as N
         model.gemm_flags |= N.GEMM_OPT_BF16X3
+    import recurrent_fusion_network_amd._native as N_
+    model.path_flags |= int(args.persist) & (N_.PATH_OPT_PERSIST_ALL | N_.PATH_OPT_DEEP_CELLS | N_.PATH_OPT_NO_SMALL_TILES |
+                                              N_.PATH_OPT_SHARED_SMALL_TILES | N_.PATH_OPT_DEC_UNHOISTED)
+    unhoisted = bool(model.path_flags & N_.PATH_OPT_DEC_UNHOISTED)    # A/B hook; the beam loop has no three-launch form
     fc, att, labels, masks, top = synthetic_inputs(cfg, B, 100 + rank, dev)
     rl_crit = R.ReviewNetRewardCriterion(cfg)
     opt = R.FusedClampAdam(model, lr=5e-5, weight_decay=0.0, grad_clip=1.0)
@@ -425,7 +431,7 @@ def run_decode(args, rank, world, dev):
         fence()
         return DP.max_over_ranks(time.perf_counter() - t0, world, dev) / args.steps
 
-    t_beam, t_greedy, t_rl = timed(beam), timed(greedy), timed(rl_step)
+    t_beam, t_greedy, t_rl = (timed(beam) if not unhoisted else float('nan')), timed(greedy), timed(rl_step)
     if rank != 0:
         return
     fwd_flops = (train_step_flops(cfg, B) / 7.667 * 3.680)    # forward-only share (3.680 of 7.667 TF at C3)
@@ -674,7 +680,7 @@ def run_train(args, rank, world, dev, R, DP, guard):
     if args.lds_lean:
         model.gemm_flags |= N.GEMM_OPT_LDS_LEAN
     model.path_flags |= int(args.persist) & (N.PATH_OPT_PERSIST_ALL | N.PATH_OPT_DEEP_CELLS | N.PATH_OPT_NO_SMALL_TILES |
-                                              N.PATH_OPT_SHARED_SMALL_TILES)
+                                              N.PATH_OPT_SHARED_SMALL_TILES | N.PATH_OPT_DEC_UNHOISTED)
     if args.micro_batches >= 0 and hasattr(model, 'micro_batches'):
         model.micro_batches = args.micro_batches
     crit = R.ReviewNetEnsembleCriterion(cfg)

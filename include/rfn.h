@@ -417,6 +417,11 @@ typedef struct rfn_cell_out {
     int64_t lddcn;
     float* dc_prev;
     int64_t lddcp;
+    /* RFN_CELL_EPI_STORE and _LSTM_BWD with accumulate: the sums start from C + C[acc_stride] + ... + C[(acc_parts - 1) *
+     * acc_stride] (slabs of C's shape, added in that order; 0 or 1 = C alone) -- the K-split partial products of an earlier
+     * launch (the decoder's d gates . W_hh, computed beside the attention backward; csrc/rfn_deccell.hip) */
+    int32_t acc_parts;
+    int64_t acc_stride;
 } rfn_cell_out;
 int rfn_cell_gemm_supported(int M, int nout, const rfn_cell_out* outs_host, int R);
 int rfn_cell_gemm(int M, int nout, const rfn_cell_out* outs_host, int R, float drop_p, uint64_t seed, int variant,

@@ -31,6 +31,10 @@
 #include "rfn_internal.h"
 
 
+struct CgDevStateRows {
+    bool set[16] = {};
+};
+
 template <int BM, int BK, int WK, bool BKF, int EPI, bool WP = false>
 __global__ __launch_bounds__(64 * (BM >= 32 ? BM / 32 : 1) * WK) void cell_gemm_k(const CgArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -46,6 +50,33 @@ template <bool BKF, int EPI>
 __global__ __launch_bounds__(256) void cell_gemm_deep_k(const CgArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     cg_tile<32, 64, 4, BKF, EPI, false, true, false>(a, blockIdx.x, smem, [] {});
+}
+
+// A store-epilogue dX product and the rows of the decoder's hoisted attention backward in ONE launch (round 6): the two are
+// independent -- both consume the step's gate gradients -- so they run beside each other instead of one after the other.
+// Blocks [0, rows) take the attention rows (the critical path: the product after this launch reads their d hproj), the rest
+// the GEMM tiles.  Same device bodies as the separate launches: identical bits.
+template <int BM, bool WP>
+__global__ __launch_bounds__(256) void cell_gemm_rows_k(const CgArgs a, const DecAttnBwdArgs d, const int rows) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    if ((int)blockIdx.x < rows) dec_attn_bwd_fast_body(d, blockIdx.x);
+    else cg_tile<BM, 64, 4, false, CG_EPI_STORE, false, false, WP>(a, blockIdx.x - rows, smem, [] {});
+}
+template <int BM, bool WP>
+static int cg_launch_rows(const CgArgs& a, int blocks, const DecAttnBwdArgs& d, int rows, hipStream_t st) {
+    auto k = cell_gemm_rows_k<BM, WP>;
+    constexpr size_t slot = (size_t)(BM + CG_BN) * 64 * sizeof(float);
+    static CgDevStateRows ds;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return RFN_ERR_LAUNCH;
+    if (!ds.set[dev & 15]) {
+        if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(CG_MAX_SLOTS * slot)) != hipSuccess)
+            return RFN_ERR_LAUNCH;
+        ds.set[dev & 15] = true;
+    }
+    hipLaunchKernelGGL(k, dim3(rows + blocks), dim3(256), a.slots * slot, st, a, d, rows);
+    RFN_CHECK_LAUNCH();
+    return RFN_OK;
 }
 
 // ---- host side -----------------------------------------------------------------------------------------------------------
@@ -211,6 +242,19 @@ int rfn_cg_launch(const CgPrepared& pz, void* stream) {
 #undef CG_CASE
 }
 
+// rfn_cg_launch(pz) with `rows` rows of the decoder's attention backward in the same launch.  RFN_ERR_UNSUPPORTED (nothing
+// launched) when the prepared product is not a 256-thread store-epilogue dX launch or the rows do not take the fast body.
+int rfn_cg_launch_with_rows(const CgPrepared& pz, const DecAttnBwdArgs& d, int rows, void* stream) {
+    if (pz.epi != CG_EPI_STORE || pz.bkf || pz.deep || rows < 1 || !rfn_dec_attn_bwd_fast_ok(d)) return RFN_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    switch (pz.variant) {
+        case 3: return cg_launch_rows<32, false>(pz.a, pz.blocks, d, rows, st);
+        case 6: return cg_launch_rows<16, true>(pz.a, pz.blocks, d, rows, st);
+        case 8: return cg_launch_rows<32, true>(pz.a, pz.blocks, d, rows, st);
+        default: return RFN_ERR_UNSUPPORTED;
+    }
+}
+
 extern "C" int rfn_cell_gemm_supported(int M, int nout, const rfn_cell_out* outs, int R) {
     if (M < 1 || nout < 1 || nout > RFN_CELL_MAXOUT || !outs) return 0;
     int nseg = 0;
@@ -222,6 +266,7 @@ extern "C" int rfn_cell_gemm_supported(int M, int nout, const rfn_cell_out* outs
         if (epi != RFN_CELL_EPI_LSTM_BWD || t.C) {
             if (!t.C || t.ldc % 4 || !rfn_aligned16(t.C)) return 0;
         }
+        if (t.acc_parts > 1 && (!t.accumulate || !t.C || epi == RFN_CELL_EPI_LSTM || t.acc_parts > 8 || t.acc_stride % 4)) return 0;
         if (epi == RFN_CELL_EPI_LSTM) {
             // gate-major tiles: 8 units x 4 gates per 32 columns
             if (R < 8 || R % 8 || t.N != 4 * R || !t.c_prev || !t.c_next || !t.h_next || !bkf) return 0;
@@ -266,6 +311,7 @@ int rfn_cg_prepare(int M, int nout, const rfn_cell_out* outs, int R, float drop_
         d.ldcp = t.ldcp; d.ldcn = t.ldcn; d.ldh = t.ldh; d.drop_offset = t.drop_offset;
         d.gates = t.gates; d.ldg = t.ldg; d.dh_ext = t.dh_ext; d.lddh = t.lddh;
         d.dc_next = t.dc_next; d.lddcn = t.lddcn; d.dc_prev = t.dc_prev; d.lddcp = t.lddcp;
+        d.acc_parts = t.acc_parts; d.acc_stride = t.acc_stride;
         for (int s = 0; s < t.nseg; ++s) {
             CgSeg& g = a.seg[ns++];
             g.A = t.seg[s].A; g.B = t.seg[s].B; g.bias = t.seg[s].bias;

@@ -48,6 +48,8 @@ struct CgOut {
     long ldcp, ldcn, ldh, ldg, lddh, lddcn, lddcp;
     unsigned long long drop_offset;
     int N, accumulate, seg0, nseg, tile0, tiles_n;
+    int acc_parts;       // accumulate: C + (acc_parts - 1) further slabs at C + p * acc_stride (store / gate-gradient epilogue)
+    long acc_stride;
 };
 struct CgArgs {
     int M, nout, R, tiles_m;
@@ -431,7 +433,11 @@ __device__ __forceinline__ void cg_tile(const CgArgs& a, const int bid, float* s
             if constexpr (XB) {
                 if (O.accumulate) e_prev[v] = xb_buf_ld4_sc1(xb_rsrc(xb_uni_ptr(O.C)), (uint32_t)(((long)grow * O.ldc + col) * 4));
             } else {
-                if (O.accumulate) e_prev[v] = *reinterpret_cast<const cg_f32x4*>(O.C + (long)grow * O.ldc + col);
+                if (O.accumulate) {
+                    e_prev[v] = *reinterpret_cast<const cg_f32x4*>(O.C + (long)grow * O.ldc + col);
+                    for (int pp = 1; pp < O.acc_parts; ++pp)   // K-split partial slabs of an earlier launch, in order
+                        e_prev[v] += *reinterpret_cast<const cg_f32x4*>(O.C + pp * O.acc_stride + (long)grow * O.ldc + col);
+                }
             }
         }
     } else if constexpr (EPI == CG_EPI_LSTM) {
@@ -465,6 +471,10 @@ __device__ __forceinline__ void cg_tile(const CgArgs& a, const int bid, float* s
             const int unit = col0 + cc;
             const float* G = O.gates + (long)grow * O.ldg;
             b_in[e][0] = O.accumulate ? xb_ld1<XB>(O.C + (long)grow * O.ldc + unit) : 0.f;
+            if constexpr (!XB) {
+                if (O.accumulate)
+                    for (int pp = 1; pp < O.acc_parts; ++pp) b_in[e][0] += O.C[pp * O.acc_stride + (long)grow * O.ldc + unit];
+            }
             b_in[e][1] = O.dh_ext ? xb_ld1<XB>(O.dh_ext + (long)grow * O.lddh + unit) : 0.f;
             b_in[e][2] = xb_ld1<XB>(G + unit);
             b_in[e][3] = xb_ld1<XB>(G + R + unit);

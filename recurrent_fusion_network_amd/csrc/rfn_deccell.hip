@@ -19,6 +19,7 @@
 // scores with the same lane partition (row_tanh_dot) and the same serial softmax, the gate sums run over l in order.
 #include "rfn_attn_small_body.h"
 #include "rfn_common.h"
+#include "rfn_deccell_body.h"
 
 struct DecCellArgs {
     const float* proj;     // att_2_att_h(v): (b', l, :) at proj + b' * psb + l * psl, b' = b / row_div
@@ -38,7 +39,6 @@ struct DecCellArgs {
     uint64_t seed, drop_offset;
 };
 
-#define DEC_LREG 8   /* thought vectors whose U values a thread keeps in registers across the score phase */
 
 template <int NG>
 __global__ __launch_bounds__(256) void dec_cell_fwd_k(const DecCellArgs a) {
@@ -133,6 +133,135 @@ __global__ __launch_bounds__(256) void dec_cell_fwd_k(const DecCellArgs a) {
     a.h_next[(long)b * a.ldh + unit] = hv;
 }
 
+// The same cell for the shapes the path runs at (A <= 512 in 16-B chunks, L <= 8, R a multiple of 256): 256 threads per block
+// whatever the block's share of the row (UB = 256 / TPU units, TPU threads per unit taking the gates g = k, k + TPU, ...), and
+// EVERYTHING the block reads -- its waves' projection rows, hproj and w_out in score-fragment order, the U values, the incoming
+// gate sums -- requested before the first dependent instruction: two barriers, one global-memory latency.  Same arithmetic as
+// dec_cell_fwd_k element for element (row_tanh_dot<true>'s lane partition and order, serial softmax, l-ordered gate sums), so a
+// row's bits depend neither on the kernel nor on TPU.
+template <int NG, int TPU>
+__global__ __launch_bounds__(256) void dec_cell_fwd_fast_k(const DecCellArgs a) {
+    constexpr int UB = 256 / TPU, NGT = (NG + TPU - 1) / TPU;
+    __shared__ float s_s[DEC_LREG];
+    __shared__ float pre_s[(TPU > 1) ? NG * UB : 1];
+    const int A = a.A, L = a.L, R = a.R;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.y, pb = b / a.row_div;
+    const int u_loc = tid % UB, k = tid / UB;
+    const int unit = blockIdx.x * UB + u_loc;
+    const float* Ub = a.U + (long)pb * a.usb;
+    float* G = a.gates + (long)b * a.ldg;
+    // ---- requests ---------------------------------------------------------------------------------------------------------
+    float uv[DEC_LREG][NGT], gin[NGT], bzv[NGT];
+#pragma unroll
+    for (int j = 0; j < NGT; ++j) {
+        const int g = k + j * TPU;
+        const bool ok = g < NG;
+#pragma unroll
+        for (int l = 0; l < DEC_LREG; ++l) uv[l][j] = (ok && l < L) ? Ub[l * a.usl + g * R + unit] : 0.f;
+        gin[j] = ok ? G[g * R + unit] : 0.f;
+        bzv[j] = ok ? a.bz[g * R + unit] : 0.f;
+    }
+    const float cprev = (k == 0) ? a.c_prev[(long)b * a.ldcp + unit] : 0.f;
+    const float* proj = a.proj + (long)pb * a.psb;
+    const float* hp = a.hproj + (long)b * A;
+    f32x4 hh[2], ww[2], pv[2][2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int c = lane * 4 + 256 * q;
+        const bool ok = c < A;
+        hh[q] = ok ? *reinterpret_cast<const f32x4*>(hp + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        ww[q] = ok ? *reinterpret_cast<const f32x4*>(a.w_out + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int l = wave + ATT_WAVES * j;
+            pv[j][q] = (ok && l < L) ? *reinterpret_cast<const f32x4*>(proj + l * a.psl + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    const float bo = a.b_out ? a.b_out[0] : 0.f;
+    // ---- scores: row_tanh_dot<true>'s elements in its order ----------------------------------------------------------------
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int l = wave + ATT_WAVES * j;
+        if (l < L) {
+            float part = 0.f;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                if (lane * 4 + 256 * q < A) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) part += rfn_tanh_fast(pv[j][q][e] + hh[q][e]) * ww[q][e];
+                }
+            }
+            const float sc = rfn_wave_sum(part) + bo;
+            if (lane == 0) s_s[l] = sc;
+        }
+    }
+    __syncthreads();
+    float m = -INFINITY, sum = 0.f;
+    for (int l = 0; l < L; ++l) m = fmaxf(m, s_s[l]);
+    for (int l = 0; l < L; ++l) sum += expf(s_s[l] - m);
+    const float inv = 1.0f / sum;
+    if (blockIdx.x == 0 && tid < L) a.alpha[(long)b * L + tid] = expf(s_s[tid] - m) * inv;
+    // ---- gates = (sum_l alpha_l U_l + b_z) + (i2h + h2h), l in order -----------------------------------------------------
+    float pre[NGT];
+#pragma unroll
+    for (int j = 0; j < NGT; ++j) pre[j] = 0.f;
+#pragma unroll
+    for (int l = 0; l < DEC_LREG; ++l) {
+        if (l < L) {
+            const float al = expf(s_s[l] - m) * inv;
+#pragma unroll
+            for (int j = 0; j < NGT; ++j) pre[j] += al * uv[l][j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NGT; ++j) pre[j] = (pre[j] + bzv[j]) + gin[j];
+    float pg[NG];
+    if constexpr (TPU > 1) {
+#pragma unroll
+        for (int j = 0; j < NGT; ++j) {
+            const int g = k + j * TPU;
+            if (g < NG) pre_s[g * UB + u_loc] = pre[j];
+        }
+        __syncthreads();
+        if (k != 0) return;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) pg[g] = pre_s[g * UB + u_loc];
+    } else {
+#pragma unroll
+        for (int g = 0; g < NG; ++g) pg[g] = pre[g];
+    }
+    // ---- LSTM update (rfn_cell.hip lstm_fwd_k, same formulas; :83-101) ----------------------------------------------------
+    const float ig = rfn_sigmoid(pg[0]), fg = rfn_sigmoid(pg[1]), og = rfn_sigmoid(pg[2]);
+    float gg;
+    if constexpr (NG == 5) {
+        const float x = pg[3], y = pg[4];
+        gg = fmaxf(x, y);
+        G[4 * R + unit] = (x > y) ? 1.f : ((x == y) ? 0.5f : 0.f);
+    } else {
+        gg = tanhf(pg[3]);
+    }
+    G[unit] = ig;
+    G[R + unit] = fg;
+    G[2 * R + unit] = og;
+    G[3 * R + unit] = gg;
+    const float c = fg * cprev + ig * gg;
+    a.c_next[(long)b * a.ldcn + unit] = c;
+    float hv = og * tanhf(c);
+    if (a.drop_p > 0.f) {
+        const float u = rfn_philox_uniform(a.seed, a.drop_offset, (uint64_t)((long)b * R + unit));
+        hv = (u >= a.drop_p) ? hv * (1.0f / (1.0f - a.drop_p)) : 0.f;
+    }
+    a.h_next[(long)b * a.ldh + unit] = hv;
+}
+template <int NG>
+static void dec_cell_fwd_fast_launch(const DecCellArgs& a, int tpu, hipStream_t st) {
+    const dim3 grid(a.R / (256 / tpu), a.B);
+    if (tpu == 4) hipLaunchKernelGGL((dec_cell_fwd_fast_k<NG, 4>), grid, dim3(256), 0, st, a);
+    else if (tpu == 2) hipLaunchKernelGGL((dec_cell_fwd_fast_k<NG, 2>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((dec_cell_fwd_fast_k<NG, 1>), grid, dim3(256), 0, st, a);
+}
+
 static int dec_device_cus() {
     static int cus[16] = {};
     int dev = 0;
@@ -156,6 +285,16 @@ extern "C" int rfn_dec_cell_fwd(const float* proj, int64_t psb, int64_t psl, con
     a.B = B; a.L = L; a.A = A; a.R = R; a.row_div = row_div; a.drop_p = drop_p; a.seed = seed; a.drop_offset = drop_offset;
     // units per block: the widest block that still gives every CU one (a row's result does not depend on the choice)
     const int cus = dec_device_cus();
+    const bool fast = A % 4 == 0 && A <= 512 && L <= DEC_LREG && R % 256 == 0 && (psb | psl) % 4 == 0 && rfn_aligned16(proj) &&
+                      rfn_aligned16(hproj) && rfn_aligned16(w_out);
+    if (fast) {
+        int tpu = 1;
+        while (tpu < 4 && (long)B * (R / (256 / tpu)) < cus) tpu <<= 1;
+        if (maxout) dec_cell_fwd_fast_launch<5>(a, tpu, (hipStream_t)stream);
+        else dec_cell_fwd_fast_launch<4>(a, tpu, (hipStream_t)stream);
+        RFN_CHECK_LAUNCH();
+        return RFN_OK;
+    }
     int ub = 256;
     while (ub > 64 && ((long)B * rfn_cdiv(R, ub) < cus || ub / 2 >= R)) ub >>= 1;
     const size_t lds = (size_t)(2 * ((A + 3) & ~3) + L) * sizeof(float);
@@ -172,19 +311,6 @@ extern "C" int rfn_dec_cell_fwd(const float* proj, int64_t psb, int64_t psl, con
 // the (L, A) slice -> d proj (accumulated across the steps: every step reads the same projection), d hproj, the per-row part
 // of d att_h_2_out.weight.  One block per batch row.
 // ---------------------------------------------------------------------------------------------------------------------------
-struct DecAttnBwdArgs {
-    const float* proj;     // (b, l, :) at proj + b * psb + l * psl
-    const float* hproj;    // (B, A)
-    const float* w_out;    // (A)
-    const float* alpha;    // (B, L)
-    const float* U;        // (b, l, :) at U + b * usb + l * usl, GD wide
-    const float* dgates;   // (B, GD) row stride ldg
-    float* dproj;          // same shape as proj, strides dpsb / dpsl
-    float* dhproj;         // (B, A)
-    float* dw_part;        // (B, A)
-    long psb, psl, usb, usl, ldg, dpsb, dpsl;
-    int L, A, GD, accumulate;
-};
 
 template <bool VEC, bool VECU>   // VEC: 16-B accesses on the (L, A) side; VECU: on the GD-wide rows of U / d gates
 __global__ __launch_bounds__(ATT_THREADS) void dec_attn_bwd_k(const DecAttnBwdArgs a) {
@@ -304,23 +430,42 @@ __global__ __launch_bounds__(ATT_THREADS) void dec_attn_bwd_k(const DecAttnBwdAr
     }
 }
 
-extern "C" int rfn_dec_attn_bwd(const float* proj, int64_t psb, int64_t psl, const float* hproj, const float* w_out,
-                                const float* alpha, const float* U, int64_t usb, int64_t usl, const float* dgates, int64_t ldg,
-                                int B, int L, int A, int GD, float* dproj, int64_t dpsb, int64_t dpsl, int accumulate,
-                                float* dhproj, float* dw_part, void* stream) {
+__global__ __launch_bounds__(ATT_THREADS) void dec_attn_bwd_fast_k(const DecAttnBwdArgs a) { dec_attn_bwd_fast_body(a, blockIdx.x); }
+
+// which kernel serves the call (the fast body's shapes): also asked by the fused launch of rfn_cellgemm.hip
+bool rfn_dec_attn_bwd_fast_ok(const DecAttnBwdArgs& a) {
+    return a.A % 4 == 0 && a.A <= 512 && a.L <= DEC_LREG && a.GD % 4 == 0 && (a.psb | a.psl | a.dpsb | a.dpsl | a.usb | a.usl | a.ldg) % 4 == 0 &&
+           rfn_aligned16(a.proj) && rfn_aligned16(a.dproj) && rfn_aligned16(a.dhproj) && rfn_aligned16(a.dw_part) && rfn_aligned16(a.U) &&
+           rfn_aligned16(a.dgates) && rfn_aligned16(a.hproj) && rfn_aligned16(a.w_out);
+}
+int rfn_dec_attn_bwd_args(const float* proj, int64_t psb, int64_t psl, const float* hproj, const float* w_out, const float* alpha,
+                          const float* U, int64_t usb, int64_t usl, const float* dgates, int64_t ldg, int B, int L, int A, int GD,
+                          float* dproj, int64_t dpsb, int64_t dpsl, int accumulate, float* dhproj, float* dw_part, DecAttnBwdArgs* out) {
     if (B <= 0 || L <= 0 || L > ATS_MAX_L || A <= 0 || GD <= 0) return RFN_ERR_SHAPE;
     if (!proj || !hproj || !w_out || !alpha || !U || !dgates || !dproj || !dhproj || !dw_part) return RFN_ERR_ARG;
-    const bool vecu = GD % 4 == 0 && rfn_aligned16(U) && rfn_aligned16(dgates) && (usb | usl | ldg) % 4 == 0;
-    DecAttnBwdArgs a;
+    DecAttnBwdArgs& a = *out;
     a.proj = proj; a.hproj = hproj; a.w_out = w_out; a.alpha = alpha; a.U = U; a.dgates = dgates;
     a.dproj = dproj; a.dhproj = dhproj; a.dw_part = dw_part;
     a.psb = psb; a.psl = psl; a.usb = usb; a.usl = usl; a.ldg = ldg; a.dpsb = dpsb; a.dpsl = dpsl;
     a.L = L; a.A = A; a.GD = GD; a.accumulate = accumulate;
+    return RFN_OK;
+}
+
+extern "C" int rfn_dec_attn_bwd(const float* proj, int64_t psb, int64_t psl, const float* hproj, const float* w_out,
+                                const float* alpha, const float* U, int64_t usb, int64_t usl, const float* dgates, int64_t ldg,
+                                int B, int L, int A, int GD, float* dproj, int64_t dpsb, int64_t dpsl, int accumulate,
+                                float* dhproj, float* dw_part, void* stream) {
+    DecAttnBwdArgs a;
+    RFN_TRY(rfn_dec_attn_bwd_args(proj, psb, psl, hproj, w_out, alpha, U, usb, usl, dgates, ldg, B, L, A, GD, dproj, dpsb, dpsl,
+                                  accumulate, dhproj, dw_part, &a));
+    const bool vecu = GD % 4 == 0 && rfn_aligned16(U) && rfn_aligned16(dgates) && (usb | usl | ldg) % 4 == 0;
     const size_t lds = (size_t)(2 * ((A + 3) & ~3) + 2 * ((L + 3) & ~3) + ATT_WAVES * DEC_LREG) * sizeof(float);
     if (lds > 64 * 1024) return RFN_ERR_SHAPE;
     const bool vec = (A % 4 == 0) && ((psb | psl | dpsb | dpsl) % 4 == 0) && rfn_aligned16(proj) && rfn_aligned16(dproj) &&
                      rfn_aligned16(dhproj) && rfn_aligned16(dw_part);
-    if (vec && vecu) hipLaunchKernelGGL((dec_attn_bwd_k<true, true>), dim3(B), dim3(ATT_THREADS), lds, (hipStream_t)stream, a);
+    if (rfn_dec_attn_bwd_fast_ok(a))
+        hipLaunchKernelGGL(dec_attn_bwd_fast_k, dim3(B), dim3(ATT_THREADS), 0, (hipStream_t)stream, a);
+    else if (vec && vecu) hipLaunchKernelGGL((dec_attn_bwd_k<true, true>), dim3(B), dim3(ATT_THREADS), lds, (hipStream_t)stream, a);
     else if (vecu) hipLaunchKernelGGL((dec_attn_bwd_k<false, true>), dim3(B), dim3(ATT_THREADS), lds, (hipStream_t)stream, a);
     else if (vec) hipLaunchKernelGGL((dec_attn_bwd_k<true, false>), dim3(B), dim3(ATT_THREADS), lds, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((dec_attn_bwd_k<false, false>), dim3(B), dim3(ATT_THREADS), lds, (hipStream_t)stream, a);

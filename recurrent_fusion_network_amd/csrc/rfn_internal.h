@@ -3,6 +3,7 @@
 #pragma once
 #include "rfn_attn_small_body.h"
 #include "rfn_cellgemm_body.h"
+#include "rfn_deccell_body.h"
 
 struct CgPrepared {      // rfn_cell_gemm's launch, not launched (rfn_cellgemm.hip)
     CgArgs a;
@@ -15,6 +16,14 @@ struct CgPrepared {      // rfn_cell_gemm's launch, not launched (rfn_cellgemm.h
 int rfn_cg_prepare(int M, int nout, const rfn_cell_out* outs, int R, float drop_p, uint64_t seed, int variant, CgPrepared* pz);
 int rfn_cg_launch(const CgPrepared& pz, void* stream);
 int rfn_cg_replan32(CgPrepared* pz);      // re-tile a prepared launch on the 32-row variant (same results)
+// The decoder's hoisted attention backward (rfn_deccell.hip): argument block without the launch, whether its rows take the fast
+// body, and a prepared store-epilogue dX product launched WITH those rows in one grid (rfn_cellgemm.hip; RFN_ERR_UNSUPPORTED =
+// nothing launched, the caller issues the two launches).
+int rfn_dec_attn_bwd_args(const float* proj, int64_t psb, int64_t psl, const float* hproj, const float* w_out, const float* alpha,
+                          const float* U, int64_t usb, int64_t usl, const float* dgates, int64_t ldg, int B, int L, int A, int GD,
+                          float* dproj, int64_t dpsb, int64_t dpsl, int accumulate, float* dhproj, float* dw_part, DecAttnBwdArgs* out);
+bool rfn_dec_attn_bwd_fast_ok(const DecAttnBwdArgs& a);
+int rfn_cg_launch_with_rows(const CgPrepared& pz, const DecAttnBwdArgs& rows_args, int rows, void* stream);
 
 struct AttnSmallPrepared {   // rfn_attn_small_fwd / _bwd's launch, not launched (rfn_attn.hip)
     AttnSmallArgs a;

@@ -455,6 +455,7 @@ PrefixLayout prefix_layout(const rfn_dims* d, int B, int train) {
     return L;
 }
 
+const int DEC_KSPLIT = 4;   // the decoder's d gates . W_hh (K = 4R) is computed as this many K-split partial products (rfn_decoder_bwd)
 struct DecoderLayout {
     size_t Pd, Ud, xs, gd, hd, cd, hpd, ald, zd, logits;
     size_t dhe, dhrec, dc, dz, dal, dwp, dhpd, dPd, dUd, dxs;
@@ -482,7 +483,7 @@ DecoderLayout decoder_layout(const rfn_dims* d, int B, int S, int train) {
     L.bar = b.take(RFN_CHAIN_BAR_WORDS);
     if (train) {
         L.dhe = b.take(Sz * Bz * R);
-        L.dhrec = b.take(Bz * R);
+        L.dhrec = b.take(DEC_KSPLIT * Bz * R);   // the recurrent d h; hoisted form: + the K-split partial slabs of d gates . W_hh
         L.dc = b.take(Bz * R);
         L.dz = b.take(Bz * R);
         L.dal = b.take(Bz * T2);
@@ -1698,19 +1699,31 @@ extern "C" int rfn_decoder_bwd(const rfn_dims* d, int B, int S, const float* con
         const float* Ud = W + Lo.Ud;
         float* dUd = W + Lo.dUd;
         RFN_TRY(mem_batch({{dPd, nullptr, (long)T2 * BA}}, st));
-        auto kb_of = [&](int s, rfn_cell_out& kb) {
-            kb = cell_out(dhrec, R, R, 0);
-            cell_dx(kb, gd + (long)s * B * GD, GD, prm[P.dec(2)], R, GD);
-            cell_dx(kb, W + Lo.dhpd + s * BA, A, prm[P.dec(8)], R, A);
+        // The fused form of a step, two launches: X = the step's attention-backward rows BESIDE the tiles of d gates_s . W_hh cut
+        // DEC_KSPLIT ways along K into partial slabs (neither depends on the other; one grid, rfn_cg_launch_with_rows), then
+        // Y = d hproj_s . W_h + the slabs, whose epilogue finishes d h of step s-1 and runs that step's LSTM backward.
+        auto kx_of = [&](int s, rfn_cell_out* kx) {
+            const int Kp = GD / DEC_KSPLIT;
+            for (int j = 0; j < DEC_KSPLIT; ++j) {
+                kx[j] = cell_out(dhrec + (long)j * BR, R, R, 0);
+                cell_dx(kx[j], gd + (long)s * B * GD + (long)j * Kp, GD, prm[P.dec(2)] + (long)j * Kp * R, R, Kp);
+            }
+        };
+        auto ky_of = [&](int s, rfn_cell_out& ky) {
+            ky = cell_out(dhrec, R, R, 1);
+            ky.acc_parts = DEC_KSPLIT;
+            ky.acc_stride = BR;
+            cell_dx(ky, W + Lo.dhpd + s * BA, A, prm[P.dec(8)], R, A);
             if (s > 0)
-                cell_lstm_bwd(kb, gd + (long)(s - 1) * B * GD, GD, cd + (s - 1) * BR, R, cd + s * BR, R, dhe + (s - 1) * BR, R,
+                cell_lstm_bwd(ky, gd + (long)(s - 1) * B * GD, GD, cd + (s - 1) * BR, R, cd + s * BR, R, dhe + (s - 1) * BR, R,
                               dc, R, dc, R, OFF_DECODER + (uint64_t)(s - 1));
         };
-        bool fusedh = !d->decoder_maxout;
+        bool fusedh = !d->decoder_maxout && GD % (DEC_KSPLIT * 32) == 0;
         for (int s = 0; s < S && fusedh; ++s) {
-            rfn_cell_out t;
-            kb_of(s, t);
-            fusedh = cell_ok(B, 1, &t, R);
+            rfn_cell_out tx[DEC_KSPLIT], ty;
+            kx_of(s, tx);
+            ky_of(s, ty);
+            fusedh = cell_ok(B, DEC_KSPLIT, tx, R) && cell_ok(B, 1, &ty, R);
         }
         if (fusedh)   // LSTM backward of the last step: nothing recurrent flows into it
             RFN_TRY(rfn_lstm_bwd(gd + (long)(S - 1) * B * GD, GD, cd + (S - 1) * BR, R, cd + S * BR, R, dhe + (S - 1) * BR, R, nullptr,
@@ -1723,17 +1736,29 @@ extern "C" int rfn_decoder_bwd(const rfn_dims* d, int B, int S, const float* con
                 if (s < S - 1) RFN_TRY(rfn_axpby_2d(1.f, dhrec, R, 1.f, dht, R, B, R, st));
                 RFN_TRY(rfn_lstm_bwd(g, GD, cd + s * BR, R, cd + (s + 1) * BR, R, dht, R, (s < S - 1) ? dc : nullptr, R, dc, R, B, R,
                                      d->decoder_maxout, d->drop_lm, seed, OFF_DECODER + (uint64_t)s, st));
-            }
-            RFN_TRY(rfn_dec_attn_bwd(W + Lo.Pd, A, BA, W + Lo.hpd + s * BA, prm[P.dec(10)], W + Lo.ald + (long)s * B * T2, Ud, GD,
-                                     (long)B * GD, g, GD, B, T2, A, GD, dPd, A, BA, 1, dhp, W + Lo.dwp + s * BA, st));
-            if (fusedh) {
-                rfn_cell_out kb;
-                kb_of(s, kb);
-                RFN_TRY(cell_run(B, 1, &kb, R, d->drop_lm, seed, st, cell_variant(d)));
-            } else {
+                RFN_TRY(rfn_dec_attn_bwd(W + Lo.Pd, A, BA, W + Lo.hpd + s * BA, prm[P.dec(10)], W + Lo.ald + (long)s * B * T2, Ud, GD,
+                                         (long)B * GD, g, GD, B, T2, A, GD, dPd, A, BA, 1, dhp, W + Lo.dwp + s * BA, st));
                 rfn_gemm_seg sg[2] = {seg_dx(g, GD, prm[P.dec(2)], R, GD), seg_dx(dhp, A, prm[P.dec(8)], R, A)};
                 RFN_TRY(gemm_segs(B, R, 2, sg, dhrec, R, 0, gx));
+                continue;
             }
+            rfn_cell_out kx[DEC_KSPLIT], ky;
+            kx_of(s, kx);
+            CgPrepared px;
+            DecAttnBwdArgs da;
+            RFN_TRY(cell_prepare(B, DEC_KSPLIT, kx, R, 0.f, 0, &px, cell_variant(d)));
+            RFN_TRY(rfn_dec_attn_bwd_args(W + Lo.Pd, A, BA, W + Lo.hpd + s * BA, prm[P.dec(10)], W + Lo.ald + (long)s * B * T2, Ud, GD,
+                                          (long)B * GD, g, GD, B, T2, A, GD, dPd, A, BA, 1, dhp, W + Lo.dwp + s * BA, &da));
+            const int rc = rfn_cg_launch_with_rows(px, da, B, st);
+            if (rc == RFN_ERR_UNSUPPORTED) {   // shapes the fused grid does not take: the same two bodies as two launches
+                RFN_TRY(rfn_dec_attn_bwd(W + Lo.Pd, A, BA, W + Lo.hpd + s * BA, prm[P.dec(10)], W + Lo.ald + (long)s * B * T2, Ud, GD,
+                                         (long)B * GD, g, GD, B, T2, A, GD, dPd, A, BA, 1, dhp, W + Lo.dwp + s * BA, st));
+                RFN_TRY(rfn_cg_launch(px, st));
+            } else {
+                RFN_TRY(rc);
+            }
+            ky_of(s, ky);
+            RFN_TRY(cell_run(B, 1, &ky, R, d->drop_lm, seed, st, cell_variant(d)));
         }
         RFN_TRY(mem_batch({{d_h0, dhrec, BR}, {d_c0, dc, BR}, {grd[P.dec(11)], nullptr, 1}}, st));
         // d U = sum_s alpha_s (x) d gates_s; d thoughts = dPd . W_att + dU . W_z (one product, two K segments)

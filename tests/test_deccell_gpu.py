@@ -38,7 +38,9 @@ def ref_cell(v, Wa, ba, hp, w, bo, Wz, bz, gin, c0, maxout):
 
 
 @pytest.mark.parametrize('B,L,A,R,maxout,row_div', [(6, 8, 512, 512, 0, 1), (5, 8, 64, 96, 1, 1), (4, 5, 30, 18, 0, 1),
-                                                    (12, 8, 128, 64, 0, 3), (3, 11, 17, 7, 1, 1), (300, 8, 64, 128, 0, 5)])
+                                                    (12, 8, 128, 64, 0, 3), (3, 11, 17, 7, 1, 1), (300, 8, 64, 128, 0, 5),
+                                                    (40, 8, 256, 256, 0, 5), (5, 8, 64, 256, 1, 1), (300, 7, 128, 256, 1, 1),
+                                                    (70, 3, 512, 768, 0, 1)])
 def test_hoisted_decoder_cell_matches_the_references_formulas_in_fp64(dev, B, L, A, R, maxout, row_div):
     n = N()
     NG = 5 if maxout else 4
