@@ -230,6 +230,8 @@ def parse_args(argv=None):
     ap.add_argument('--no-alt-line', action='store_true',
                     help="with --gemm exact (the default): do not append the same workload re-timed with --gemm bf16x3 "
                          "(the 'bf16x3' object of the JSON line; `value` is always the exact-f32 measurement)")
+    ap.add_argument('--no-secondary', action='store_true',
+                    help='skip the `secondary` object of the default single-GPU line (BASELINE configs 2 and 5 timed after the headline)')
     ap.add_argument('--cpu-sample', type=int, default=CPU_SAMPLE_B, help='captions in the CPU-baseline sample')
     ap.add_argument('--micro-batches', type=int, default=-1, help='override model.micro_batches (-1: model default)')
     ap.add_argument('--lds-lean', action='store_true',
@@ -394,44 +396,8 @@ def run_decode(args, rank, world, dev):
     rl_crit = R.ReviewNetRewardCriterion(cfg)
     opt = R.FusedClampAdam(model, lr=5e-5, weight_decay=0.0, grad_clip=1.0)
 
-    def beam():
-        model.eval()
-        with torch.no_grad():
-            return model.sample(fc, att, {'beam_size': 5})
-
-    def greedy():
-        model.eval()
-        with torch.no_grad():
-            return model.sample(fc, att, {'sample_max': 1})
-
-    def rl_step():
-        model.train()
-        opt.zero_grad()
-        seq, lp, lp_all, reason = model.sample(fc, att, {'sample_max': 0})
-        with torch.no_grad():
-            model.eval()
-            model.sample(fc, att, {'sample_max': 1})
-            model.train()
-        reward = torch.randn(B, 1, device=dev).expand(B, seq.size(1)).contiguous()   # CIDEr-D scoring is out of scope
-        rl_crit(lp, seq, reward, lp_all, 0.01, reason, top, 1.0, None, cfg).backward()
-        opt.step()
-
-    def fence():
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
-
-    def timed(fn):
-        for _ in range(args.warmup):
-            fn()
-        fence()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            fn()
-        fence()
-        return DP.max_over_ranks(time.perf_counter() - t0, world, dev) / args.steps
-
-    t_beam, t_greedy, t_rl = (timed(beam) if not unhoisted else float('nan')), timed(greedy), timed(rl_step)
+    t_beam, t_greedy, t_rl = decode_legs(model, opt, rl_crit, cfg, (fc, att, labels, masks, top), B, dev, world, args.steps,
+                                         args.warmup, beam=not unhoisted)
     if rank != 0:
         return
     fwd_flops = (train_step_flops(cfg, B) / 7.667 * 3.680)    # forward-only share (3.680 of 7.667 TF at C3)
@@ -460,6 +426,190 @@ def run_decode(args, rank, world, dev):
         out['cpu_baseline'] = cpu_baseline(cfg, min(args.cpu_sample, 16), 100, mode='greedy')
     flush_c_stdio()
     print(json.dumps(out), flush=True)
+
+
+def decode_legs(model, opt, rl_crit, cfg, inputs, B, dev, world, steps, warmup, beam=True):
+    """BASELINE configs[4] on `model`: seconds per call of beam = 5 sample_beam, greedy sample and the self-critical RL step
+    (train_rl.py:160-203: multinomial sample with grad, greedy baseline, reward criterion, backward, clamp + Adam)."""
+    import torch
+    from recurrent_fusion_network_amd import parallel as DP
+    fc, att, labels, masks, top = inputs
+
+    def beam5():
+        model.eval()
+        with torch.no_grad():
+            return model.sample(fc, att, {'beam_size': 5})
+
+    def greedy():
+        model.eval()
+        with torch.no_grad():
+            return model.sample(fc, att, {'sample_max': 1})
+
+    def rl_step():
+        model.train()
+        opt.zero_grad()
+        seq, lp, lp_all, reason = model.sample(fc, att, {'sample_max': 0})
+        with torch.no_grad():
+            model.eval()
+            model.sample(fc, att, {'sample_max': 1})
+            model.train()
+        reward = torch.randn(B, 1, device=dev).expand(B, seq.size(1)).contiguous()   # CIDEr-D scoring is out of scope
+        rl_crit(lp, seq, reward, lp_all, 0.01, reason, top, 1.0, None, cfg).backward()
+        opt.step()
+
+    def fence():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    def timed(fn):
+        for _ in range(warmup):
+            fn()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        fence()
+        return DP.max_over_ranks(time.perf_counter() - t0, world, dev) / steps
+
+    was_training = model.training
+    try:
+        return (timed(beam5) if beam else float('nan')), timed(greedy), timed(rl_step)
+    finally:
+        model.train(was_training)
+
+
+# SURVEY.md 8(d): forward-only algorithmic FLOP of a decode at the C3 shape = prefix (stages I/II) 3.59 TF per 256 images +
+# 5.3 GF per 256 decoder rows and decoded step; the XE train step is 7.667 TF per 256 captions, of which 3.680 forward.
+def decode_flops(images, rows, steps=17):
+    return 3.59e12 * images / 256.0 + 5.3e9 * rows / 256.0 * steps
+
+
+def secondary_legs(args, dev, model, opt, start, R, N):
+    """BASELINE configs 2 and 5 beside the headline, in the SAME process and JSON line (`secondary`), so that the driver's
+    run times them too: `--workload c2` (eager and replayed from a HIP graph) on a fresh C2 model, and config 5 (beam = 5
+    sample_beam, greedy sample, the self-critical RL step at B = 128) on the headline's own model restored to its initial
+    weights (C5 has the C3 architecture).  Each entry carries the roofline it is priced against; a failing entry reports its
+    error, the headline line stands.  ~10 s."""
+    import torch
+    out = {}
+
+    def guarded(name, fn):
+        try:
+            out[name] = fn()
+        except Exception as e:      # noqa: BLE001
+            out[name] = {'error': '%s: %s' % (type(e).__name__, e)}
+        torch.cuda.synchronize()
+
+    def c2():
+        w = WORKLOADS['c2']
+        B = w['B']
+        cfg = make_cfg(w)
+        m2 = R.RecurrentFusionModel(cfg).to(dev)
+        seeded_weights_(m2, 100)
+        m2.train()
+        crit = R.ReviewNetEnsembleCriterion(cfg)
+        o2 = R.FusedClampAdam(m2, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5, grad_clip=1.0)
+        fc, att, labels, masks, top = synthetic_inputs(cfg, B, 100, dev)
+
+        def eager():
+            o2.zero_grad()
+            log_prob, top_pred = m2(fc, att, labels)
+            loss = crit(log_prob, labels[:, 1:], masks[:, 1:], top_pred, top, 1.0)
+            loss.backward()
+            o2.step()
+            return loss
+
+        def timed(fn, n, settle_s):
+            ts = time.perf_counter()
+            while time.perf_counter() - ts < settle_s:
+                fn()
+                torch.cuda.synchronize()
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / n
+
+        n = 20
+        t_eager = timed(eager, n, 0.5)
+        launches = count_launches(eager)
+        m2.grad_ready_hook = None
+        from recurrent_fusion_network_amd.graphed import GraphedTrainStep
+        g = GraphedTrainStep(m2, crit, o2, fc, att, labels, masks, top)
+        t_graph = timed(g, n, 0.5)
+        flops = w['step_tflop'] * 1e12
+        return {'workload': 'C2: RecurrentFusionModel XE train step (zero_grad+fwd+criterion+bwd+clamp+Adam), M=2 encoders, '
+                            'L=49, D=512, B=%d, seq=16 (17 decoder steps)' % B,
+                'ms_per_step': round(t_eager * 1e3, 3), 'value': round(B / t_eager, 1), 'unit': 'captions/s', 'steps': n,
+                'graph_ms_per_step': round(t_graph * 1e3, 3), 'graph_value': round(B / t_graph, 1),
+                'launches': launches,
+                'step_frac': round(flops / t_eager / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                'graph_step_frac': round(flops / t_graph / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                'roofline': {'bound': 'mfma', 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'step_tflop': w['step_tflop'],
+                             'achieved': round(flops / t_graph / 1e12, 2), 'frac': round(flops / t_graph / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                             'note': 'whole step (SURVEY 8d: 0.1706 TF) against the f32-MFMA peak, graph-replayed; a latency-regime '
+                                     'workload: ~320 dependent launches of 5-15 us'}}
+
+    def c5():
+        B = WORKLOADS['c5']['B']
+        cfg = make_cfg(WORKLOADS['c5'])
+        if start is not None:
+            opt.restore(start)              # bench.py --workload c5's weights: the seeded initial ones
+        inputs = synthetic_inputs(cfg, B, 100, dev)
+        rl_crit = R.ReviewNetRewardCriterion(cfg)
+        t_beam, t_greedy, t_rl = decode_legs(model, opt, rl_crit, cfg, inputs, B, dev, 1, 5, 2)
+        S1 = cfg.seq_length + 1
+        f_greedy, f_beam = decode_flops(B, B, S1), decode_flops(B, 5 * B, S1)
+        # RL step: sampled pass with grad = the train step's forward and backward on B rows, + the greedy baseline decode
+        f_rl = 7.667e12 * B / 256.0 + f_greedy
+
+        def entry(t, flops, what):
+            return {'ms_per_step': round(t * 1e3, 3), 'value': round(B / t, 1), 'unit': 'images/s', 'steps': 5,
+                    'step_frac': round(flops / t / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                    'roofline': {'bound': 'mfma', 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'step_tflop': round(flops / 1e12, 4),
+                                 'achieved': round(flops / t / 1e12, 2), 'frac': round(flops / t / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                                 'flop_count': what}}
+        return {
+            'c5_beam5': entry(t_beam, f_beam, 'SURVEY 8d forward-only: prefix 3.59 TF x B/256 + 5.3 GF x (5B)/256 x %d decoder steps' % S1),
+            'c5_greedy': entry(t_greedy, f_greedy, 'SURVEY 8d forward-only: prefix 3.59 TF x B/256 + 5.3 GF x B/256 x %d decoder steps' % S1),
+            'c5_rl': entry(t_rl, f_rl, 'multinomial sample with grad + backward = the XE train step 7.667 TF x B/256, + the greedy '
+                                        'baseline decode (forward-only figure above); reward criterion and Adam are not FLOP-bound'),
+        }
+
+    guarded('c2', c2)
+    try:
+        out.update(c5())
+    except Exception as e:      # noqa: BLE001
+        out['c5'] = {'error': '%s: %s' % (type(e).__name__, e)}
+    torch.cuda.synchronize()
+    out['note'] = ('BASELINE configs 2 and 5 timed in this process after the headline (B = 64 / B = 128 images on this GPU); '
+                   'c5_* run on the headline model restored to its seeded initial weights; workload-level evidence: profiles/r06_secondary.jsonl')
+    return out
+
+
+def count_launches(fn):
+    """Kernel launches of one call of `fn`, counted by the profiler's device-activity records (None when unavailable)."""
+    try:
+        import torch
+        from torch.profiler import ProfilerActivity, profile
+        torch.cuda.synchronize()
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            fn()
+            torch.cuda.synchronize()
+        n = 0
+        for ev in prof.events():
+            if getattr(ev, 'device_type', None) is not None and 'cuda' in str(ev.device_type).lower():
+                name = ev.name.lower()
+                if 'memcpy' in name or 'memset' in name:
+                    continue
+                n += 1
+        return n or None
+    except Exception:      # noqa: BLE001
+        return None
 
 
 def flush_c_stdio():
@@ -684,7 +834,7 @@ def run_train(args, rank, world, dev, R, DP, guard):
     if args.micro_batches >= 0 and hasattr(model, 'micro_batches'):
         model.micro_batches = args.micro_batches
     crit = R.ReviewNetEnsembleCriterion(cfg)
-    shard = (rank, world) if (args.shard_optimizer and world > 1) else None
+    shard = (rank, world) if (args.shard_optimizer and (world > 1 or in_group)) else None     # a one-rank group (RFN_FORCE_DIST=1) runs the RCCL branches too
     opt = R.FusedClampAdam(model, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5, grad_clip=1.0, shard=shard)
     inputs = synthetic_inputs(cfg, B, 100 + rank, dev)
     if args.strong:
@@ -848,8 +998,16 @@ def run_train(args, rank, world, dev, R, DP, guard):
         import hashlib
         import struct
         hsh = hashlib.sha256(struct.pack('<f', final_loss))
+        opt.wait_params()               # a sharded / overlapped update may still be writing parameters on another stream
         # over the PARAMETERS, in name order (the flat buckets also hold the 16-B padding between them, which is no state)
         ps = [p_.detach().double() for _, p_ in sorted(model.named_parameters())]
+        # ... and the Adam moments, bucket by bucket (gathered from the ranks when the update is sharded: a collective)
+        # -- parameter by parameter: the 16-B alignment gaps between parameters in a flat bucket hold whatever the gradient
+        # buffer's allocation held, which is no state either
+        sd = opt.state_dict()['buckets']
+        for k in sorted(sd):
+            params_k, offs_k, _ = model.bucket_layout(k)
+            ps += [sd[k][mv][o:o + p_.numel()].double() for p_, o in zip(params_k, offs_k) for mv in ('m', 'v')]
         sums = torch.stack([q.sum() for q in ps] + [(q * q).sum() for q in ps]).cpu().tolist()
         hsh.update(struct.pack('<%dd' % len(sums), *sums))
         digest = hsh.hexdigest()[:16]
@@ -1029,6 +1187,11 @@ def run_train(args, rank, world, dev, R, DP, guard):
                     model.gemm_flags &= ~N.GEMM_OPT_BF16X3
         if rank == 0:
             out['bf16x3'] = alt
+    # (3) BASELINE configs 2 and 5 beside the headline (single GPU, the default run only)
+    if (world == 1 and args.workload == 'c3' and not args.batch and not args.no_alt_line and not args.no_secondary and not x3
+            and not args.graph and not args.persist):
+        err, sec = optional('secondary', lambda: secondary_legs(args, dev, model, opt, start, R, N))
+        out['secondary'] = {'error': err} if err else sec
     if rank != 0:
         return
     if world == 1 and not args.no_cpu_baseline:

@@ -402,6 +402,9 @@ class RecurrentFusionModel(nn.Module):
         # callable('prefix' | 'decoder'): called right before the parameters of that phase are handed to a kernel.  A
         # sharded optimizer (FusedClampAdam(shard=...)) waits there for the all-gather of the parameters it updated.
         self.param_wait_hook = None
+        # state_dict() (the reference's checkpoint pattern right after optimizer.step(), train.py:226-233) must not read
+        # parameters an asynchronous update is still writing: join first
+        self.register_state_dict_pre_hook(_join_before_state_dict)
         # flat buckets (gradients, and the optimizer's parameter / moment buffers) are padded to a multiple of this many
         # elements: 4 * world_size under a sharded optimizer, so every rank's shard is the same 16-B aligned length
         self.flat_pad = 1
@@ -470,10 +473,17 @@ class RecurrentFusionModel(nn.Module):
         return self._dims[key]
 
     def _params_of(self, slots):
-        # Parameter objects are stable under .cuda()/.to() (their .data is swapped in place), so the
-        # by-name lookup is done once per slot list
+        """The parameters of a phase, about to be handed to its kernels: the one place the compute stream meets an
+        asynchronous update of them again (`param_wait_hook`: a sharded optimizer's all-gathers, an overlapped update's side
+        stream).  Forward entry points only -- bookkeeping that merely needs the parameter OBJECTS (bucket layouts, gradient
+        views) uses `_params_lookup` and waits for nothing (the hook used to fire from inside backward)."""
         if self.param_wait_hook is not None:
             self.param_wait_hook('decoder' if slots is self._decoder_slots else 'prefix')
+        return self._params_lookup(slots)
+
+    def _params_lookup(self, slots):
+        # Parameter objects are stable under .cuda()/.to() (their .data is swapped in place), so the
+        # by-name lookup is done once per slot list
         key = id(slots)
         if key not in self._param_cache:
             named = dict(self.named_parameters())
@@ -493,7 +503,7 @@ class RecurrentFusionModel(nn.Module):
 
     def bucket_layout(self, name):
         """(params, offsets, total) of one bucket: parameters back to back, each start 16-B aligned."""
-        params = self._params_of(self._bucket_slots[name])
+        params = self._params_lookup(self._bucket_slots[name])
         offs, total = [], 0
         for p in params:
             offs.append(total)
@@ -979,6 +989,12 @@ class _LazyList(collections.abc.MutableSequence):
 
     def __reduce_ex__(self, protocol):
         return (list, (list(self.materialize()),))
+
+
+def _join_before_state_dict(module, prefix, keep_vars):
+    hook = getattr(module, 'param_wait_hook', None)
+    if hook is not None:
+        hook(None)
 
 
 class _Stepper:

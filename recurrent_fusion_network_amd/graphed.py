@@ -20,7 +20,9 @@ What a capture freezes, and how each is dealt with:
     (only `lr` is re-read per step, through `coef`).
   * addresses: inputs are copied into static device buffers; the workspaces, flat gradient buffers and the loss live in the
     graph's private memory pool; `.grad` of every parameter is a view of those buffers after each replay, as in eager mode.
-A captured step is bit-identical to the eager step (same kernels, same arguments; tests/test_trainer_contract_gpu.py).
+A captured step is bit-identical to the eager step that runs the SAME number of decoder steps (same kernels, same arguments;
+tests/test_trainer_contract_gpu.py).  A `full_length=True` capture replayed on a batch the eager path would cut short (the break
+at the first all-zero column) runs longer weight-gradient reductions than that eager step: equal to rounding, not to the bit.
 """
 import torch
 
@@ -84,6 +86,7 @@ class GraphedTrainStep:
         return dict(betas=tuple(g0['betas']), eps=g0['eps'], weight_decay=g0['weight_decay'], grad_clip=g0['grad_clip'],
                     reason_weight=self.reason_weight, training=m.training, ss_prob=m.ss_prob,
                     dropout=(m.drop_prob_lm, m.drop_prob_reason, m.drop_prob_fusion), gemm_flags=m.gemm_flags,
+                    path_flags=int(getattr(m, 'path_flags', 0)),
                     dedup=int(m.dedup_seq_per_img), micro_batches=getattr(m, 'micro_batches', None), crit=crit)
 
     def _fill_coef(self):

@@ -15,14 +15,22 @@ flat bucket is cut into `world` equal 16-B aligned shards; a rank keeps Adam mom
 gradient of its shard (parallel.GradSync(shard_optimizer=True): reduce-scatter instead of all-reduce, half the wire bytes),
 updates its shard of the parameters with the same element arithmetic, and the shards are all-gathered into every rank's full
 parameter buffer -- asynchronously, in the order the next forward uses them, the model waiting (``param_wait_hook``) right
-before the phase that reads them.  Same wire bytes as the all-reduce in total; element for element the same update, so the
-parameters are bit-identical to the unsharded step (tests/test_parallel_gloo.py, tests/test_parallel_gpu.py).
+before the phase that reads them.  Same wire bytes as the all-reduce in total; element for element the same update arithmetic.  The
+parameters are bit-identical to the unsharded step whenever the two exchanges sum in the same order: on gloo (an all-reduce
+followed by a slice) and for 2 ranks (a + b commutes) -- which is what tests/test_parallel_gloo.py and
+tests/test_parallel_gpu.py assert; RCCL's reduce-scatter and all-reduce at N > 2 may associate the N terms differently
+(last-bit differences, not checked on hardware yet).
 """
 import ctypes as C
 
 import torch
 
 from . import _native as N
+
+
+def _dist_ready():
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized()
 
 
 class FusedClampAdam:
@@ -33,7 +41,12 @@ class FusedClampAdam:
         self.group = process_group
         if not 0 <= self.shard_rank < self.shard_world:
             raise N.RfnError('shard = (rank, world) with 0 <= rank < world, got %r' % (shard,))
-        if self.shard_world > 1:
+        # the sharded code path (reduce-scatter, shard update, all-gather, padded buckets) is taken whenever a shard was asked
+        # for and there is a process group to run its collectives on -- also by a one-rank group (shard = (0, 1)), which is
+        # how the RCCL branches are exercised on a single GPU (RFN_FORCE_DIST=1, tests/test_parallel_gpu.py)
+        self.sharded = bool(shard) and (self.shard_world > 1 or _dist_ready())
+        self._joiners = []              # callables that order the current stream after pending asynchronous updates
+        if self.sharded:
             from . import parallel as DP
             model.flat_pad = DP.shard_pad(self.shard_world)       # before any flat buffer of this model is laid out
         # one group, torch.optim layout: utils.set_lr writes group['lr'], which step() reads
@@ -50,7 +63,7 @@ class FusedClampAdam:
                 buf[o:o + p.numel()].copy_(p.data.reshape(-1))
                 p.data = buf[o:o + p.numel()].view_as(p)
             lo, hi = 0, total                             # the whole bucket when the update is not sharded
-            if self.shard_world > 1:
+            if self.sharded:
                 from . import parallel as DP
                 lo, hi = DP.shard_bounds(total, self.shard_rank, self.shard_world)
             self.flat[name] = dict(p=buf, m=torch.zeros(hi - lo, device=buf.device), v=torch.zeros(hi - lo, device=buf.device),
@@ -58,7 +71,7 @@ class FusedClampAdam:
         self._gathers = {'prefix': [], 'decoder': []}
         self._updated_early = set()
         self.reduced_shards = {}        # bucket -> this rank's summed gradient shard (parallel.GradSync(shard_optimizer=True))
-        if self.shard_world > 1:
+        if self.sharded:
             model.param_wait_hook = self.wait_params
 
     # ---- torch.optim-style accessors ---------------------------------------------------------------
@@ -96,7 +109,7 @@ class FusedClampAdam:
 
     def _full_moment(self, st, key):
         """The whole bucket's moment (a collective when the update is sharded: every rank must call it)."""
-        if self.shard_world == 1:
+        if not self.sharded:
             return st[key].detach().clone()
         import torch.distributed as dist
         parts = [torch.empty_like(st[key]) for _ in range(self.shard_world)]
@@ -106,6 +119,7 @@ class FusedClampAdam:
     def state_dict(self):
         """Adam moments per bucket (flat, same layout as the parameters), the step count and the hyper-parameters.  With a
         sharded update this gathers every rank's moment shards: call it on every rank."""
+        self.wait_params()      # the moments may still be written by an overlapped / sharded update on another stream
         hyper = {k: v for k, v in self.param_groups[0].items() if k != 'params'}
         return {'step_count': self.step_count, 'hyper': hyper,
                 'buckets': {name: {'m': self._full_moment(st, 'm'), 'v': self._full_moment(st, 'v'), 'n': st['n']}
@@ -220,7 +234,7 @@ class FusedClampAdam:
                 continue
             if g.numel() != st['n']:
                 raise N.RfnError('flat gradient layout changed')
-            if self.shard_world > 1:
+            if self.sharded:
                 # this rank's shard: the reduce-scattered gradient when GradSync delivered one, else the slice of the
                 # (all-reduced or single-process) full buffer -- the same numbers either way
                 gs = self.reduced_shards.pop(name, None)
@@ -244,7 +258,7 @@ class FusedClampAdam:
                 N.check(N.lib.rfn_adam_step_multi(len(part), *ptrs, sizes, g0['lr'], g0['betas'][0], g0['betas'][1], g0['eps'],
                                                   g0['weight_decay'], g0['grad_clip'], grad_scale, self.step_count,
                                                   N.stream_ptr()), 'rfn_adam_step_multi')
-        if self.shard_world > 1:
+        if self.sharded:
             self._gather_params(names)
 
     def update_bucket_early(self, name, grad_shard, grad_scale):
@@ -261,7 +275,7 @@ class FusedClampAdam:
                                           g0['weight_decay'], g0['grad_clip'], grad_scale, self.step_count + 1, N.stream_ptr()),
                 'rfn_adam_step_multi')
         self._updated_early.add(name)
-        if self.shard_world > 1:
+        if self.sharded:
             self._gather_params([name])
 
     # ---- sharded update: parameters back to every rank ---------------------------------------------------------------
@@ -283,3 +297,12 @@ class FusedClampAdam:
             for w in works:
                 w.wait()
             works.clear()
+        if which is None:
+            for join in self._joiners:
+                join()
+
+    def add_joiner(self, fn):
+        """`fn()` orders the current stream after an asynchronous update of this optimizer's buffers that lives outside it
+        (parallel.OverlappedUpdate's side stream): called by wait_params(), i.e. before state_dict / snapshot / restore read
+        parameters or moments and by the model's state_dict pre-hook."""
+        self._joiners.append(fn)

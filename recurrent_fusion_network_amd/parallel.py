@@ -100,12 +100,13 @@ class OverlappedUpdate:
     and moments bit-identical.  `optimizer.step()` afterwards only counts the step (and updates what no hook delivered)."""
 
     def __init__(self, model, optimizer):
-        if optimizer.shard_world != 1:
+        if optimizer.sharded:
             raise ValueError('the sharded optimizer already pipelines its update (GradSync(shard_optimizer=...))')
         self.opt = optimizer
         self.side = torch.cuda.Stream()
         model.grad_ready_hook = self.on_bucket
         model.param_wait_hook = self.wait
+        optimizer.add_joiner(self.wait)     # state_dict() / snapshot() / restore() read what the side stream may still write
 
     def on_bucket(self, name, flat):
         main = torch.cuda.current_stream(flat.device)
@@ -150,8 +151,9 @@ class GradSync:
         # on a side stream under the rest of backward (FusedClampAdam.update_bucket_early); the compute stream meets them
         # again where the next forward first reads parameters (model.param_wait_hook)
         self.side = None
-        if shard_optimizer is not None and shard_optimizer.shard_world > 1 and torch.cuda.is_available():
+        if shard_optimizer is not None and shard_optimizer.sharded and torch.cuda.is_available():
             self.side = torch.cuda.Stream()
+        self._shard_bufs = {}            # bucket -> this rank's reduce-scatter output, allocated once (nothing in the step allocates)
         self.works = []
         self.buckets = []
         # exposed-wait bookkeeping (bench.py `exposed_ms`): off unless `record` is set.  On the nccl backend a wait() only
@@ -171,14 +173,17 @@ class GradSync:
         self.buckets.append(name)
         if self.world > 1 or (dist.is_available() and dist.is_initialized()):
             opt = self.sharded
-            if opt is not None and opt.shard_world > 1 and flat.is_cuda:
+            if opt is not None and opt.sharded and flat.is_cuda:
                 st = opt.flat[name]
                 main = torch.cuda.current_stream(flat.device)
                 self.side.wait_stream(main)               # the kernels that finish this bucket are queued on `main`
                 flat.record_stream(self.side)
                 with torch.cuda.stream(self.side):
                     if dist.get_backend(opt.group) == 'nccl':
-                        shard = torch.empty(st['hi'] - st['lo'], device=flat.device, dtype=flat.dtype)
+                        shard = self._shard_bufs.get(name)       # reused every step: its reader (this bucket's update of the
+                        if shard is None or shard.numel() != st['hi'] - st['lo'] or shard.device != flat.device:   # previous step)
+                            shard = torch.empty(st['hi'] - st['lo'], device=flat.device, dtype=flat.dtype)        # is ahead on
+                            self._shard_bufs[name] = shard                                                        # this stream
                         dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.SUM, group=opt.group)
                     else:                                 # no reduce-scatter on this backend (gloo): all-reduce, read the slice
                         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=opt.group)

@@ -135,6 +135,35 @@ def test_one_rank_rccl_group_with_lean_tiles_is_bit_equal_to_the_plain_step():
 
 
 @pytest.mark.gpu
+def test_one_rank_rccl_group_runs_the_sharded_updates_rccl_branches_bit_equal_and_without_allocating():
+    """the code the first multi-GPU `--shard-optimizer` run takes -- per bucket `reduce_scatter_tensor` on a
+    side stream, clamp + Adam on the shard (update_bucket_early), `all_gather_into_tensor` of the parameters, the padded flat
+    buckets, `param_wait_hook` before the next forward -- executed on RCCL by a ONE-rank process group (RFN_FORCE_DIST=1;
+    FusedClampAdam(shard=(0, 1)) takes the sharded path whenever a group exists).  After 1 warm-up + 2 timed steps the loss,
+    every parameter and both Adam moments (config.digest) equal the plain single-process optimizer's bit for bit, and the
+    timed region performed no device allocation (the reduce-scatter outputs are allocated once)."""
+    # 3 warm-up steps: a gradient bucket handed to the side stream (record_stream) is recycled one step later than on one
+    # stream, so the allocator reaches its steady state -- two generations of flat buffers -- after the second step
+    base = [sys.executable, os.path.join(ROOT, 'bench.py'), '--batch', '32', '--steps', '2', '--warmup', '3', '--settle', '0',
+            '--no-cpu-baseline', '--no-alt-line', '--digest']
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.pop('RFN_FORCE_DIST', None)
+    plain = subprocess.run(base, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert plain.returncode == 0, plain.stderr[-2000:]
+    a = json.loads([l for l in plain.stdout.splitlines() if l.startswith('{"metric"')][-1])
+    env_d = dict(env, RFN_FORCE_DIST='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(29500 + os.getpid() % 1000))
+    dist = subprocess.run(base + ['--shard-optimizer'], env=env_d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                          timeout=900)
+    assert dist.returncode == 0, dist.stderr[-2000:]
+    b = json.loads([l for l in dist.stdout.splitlines() if l.startswith('{"metric"')][-1])
+    assert a['config']['shard_optimizer'] is False and a['dist_backend'] is None
+    assert b['config']['shard_optimizer'] is True and b['dist_backend'] == 'nccl' and b['rccl_ranks'] == 1
+    assert a['config']['digest'] and a['config']['digest'] == b['config']['digest'], (a['config'], b['config'])
+    assert b['device_mallocs_frees_in_timed_region'] == 0, b['device_mallocs_frees_in_timed_region']
+    assert b['strong']['device_mallocs_frees_in_timed_region'] == 0
+
+
+@pytest.mark.gpu
 def test_failing_rank_inside_the_train_step_exits_fast():
     """rank 1 raises inside run_train after its first step while rank 0 is inside the bucket all-reduce of
     the next one.  The parent must return non-zero within 60 s of the failure (no finally-barrier, no watchdog wait)."""

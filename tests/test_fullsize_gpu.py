@@ -339,3 +339,88 @@ def test_bf16x3_at_the_benchmarked_shape(dev):
         assert err <= 1e-6 + rel * float(g0[name].abs().max()), (name, err)
     assert torch.equal(s0, s1), 'greedy ids differ between the exact and the bf16x3 path'
     assert float((slp0 - slp1).abs().max()) < X3_LOGP_BAR
+
+
+def test_c2_at_its_stated_batch_64_every_gradient_against_the_oracle(dev):
+    """BASELINE config 2 at the size it is stated at (M = 2, L = 49, D = 512, B = 64; the golden tier `c2` is B = 8): at B = 64
+    the per-step products take the tile variants and the decoder the block shapes the benchmark runs (rfn_cell_gemm picks
+    them from the tile count against the CU count, rfn_dec_cell_fwd its threads per unit from B * R), so this is the check
+    that THOSE launches are right, against the CPU oracle (~2 s): log-probs <= 1e-3, loss, EVERY gradient tensor (max error
+    relative to the tensor's max), greedy ids of all 64 captions exact.  """
+    import bench as HB
+    import recurrent_fusion_network_amd as R
+    from oracle import rfn_oracle as O
+    B = HB.WORKLOADS['c2']['B']
+    assert B == 64
+    cfg = HB.make_cfg(HB.WORKLOADS['c2'])
+    P = O.seeded_params(cfg, 61)
+    fc, att, labels, masks, top = O.synthetic_batch(cfg, B, seed=62)
+    model = R.RecurrentFusionModel(cfg)
+    model.load_state_dict(P)
+    model = model.to(dev).eval()
+    d = lambda ts: [t.to(dev) for t in ts]  # noqa: E731
+    lp, reason = model(d(fc), d(att), labels.to(dev))
+    crit = R.ReviewNetEnsembleCriterion(cfg)
+    loss = crit(lp, labels.to(dev)[:, 1:], masks.to(dev)[:, 1:], reason, top.to(dev), 1.0)
+    loss.backward()
+    o_lp = O.forward(cfg, P, fc, att, labels)[0]
+    o_loss, o_grads = O.train_step_loss_and_grads(cfg, P, fc, att, labels, masks, top, 1.0)
+    assert float((lp.detach().cpu() - o_lp).abs().max()) < 1e-3
+    assert abs(float(loss.detach()) - float(o_loss)) < 1e-4 * max(1.0, abs(float(o_loss)))
+    named = dict(model.named_parameters())
+    assert set(o_grads) == set(named)
+    for k, g in o_grads.items():
+        err = float((named[k].grad.cpu() - g).abs().max())
+        tol = 1e-5 + 1e-3 * float(g.abs().max())
+        assert err <= tol, (k, err, tol)
+    o_seq, o_slp, o_all, _ = O.sample_greedy(cfg, P, fc, att)
+    with torch.no_grad():
+        seq, slp, lp_all, _ = model.sample(d(fc), d(att), {'sample_max': 1})
+    top2 = o_all.topk(2, dim=2).values
+    assert torch.equal(seq.cpu(), o_seq), 'greedy ids differ (smallest oracle top1-top2 margin %.3g)' % float((top2[..., 0] - top2[..., 1]).min())
+    assert float((slp.cpu() - o_slp).abs().max()) < 1e-3
+    assert float((lp_all.cpu() - o_all).abs().max()) < 1e-3
+
+
+def test_config5_at_its_stated_batch_128_greedy_and_beam_against_the_oracle(dev):
+    """BASELINE config 5 at the size it is stated at (M = 4, L = 196, D = 2048, B = 128 images; the golden decode tier `c5` has
+    the shape but a handful of images): greedy `sample` ids and log-probs of ALL 128 images against the oracle's free-running
+    decode, and beam = 5 `sample_beam` -- run on the full 128-image batch, where the 640 beam rows share one decoder batch and
+    read their image's thought-vector products through row / beam -- for 8 of the images against the oracle's per-image search
+    on those 8 alone.  A greedy row is compared only if every decision of the oracle's decode has a top1-top2 margin >= 1e-5
+    (two f32-accurate paths may break a closer tie differently); the excluded rows are counted and bounded.  """
+    import bench as HB
+    import numpy as np
+    import recurrent_fusion_network_amd as R
+    from oracle import rfn_oracle as O
+    B = HB.WORKLOADS['c5']['B']
+    assert B == 128
+    cfg = HB.make_cfg(HB.WORKLOADS['c5'])
+    P = O.seeded_params(cfg, 71)
+    fc, att, labels, masks, top = O.synthetic_batch(cfg, B, seed=72)
+    model = R.RecurrentFusionModel(cfg)
+    model.load_state_dict(P)
+    model = model.to(dev).eval()
+    d = lambda ts: [t.to(dev) for t in ts]  # noqa: E731
+    fcd, attd = d(fc), d(att)
+    o_seq, o_slp, o_all, _ = O.sample_greedy(cfg, P, fc, att)
+    with torch.no_grad():
+        seq, slp, lp_all, _ = model.sample(fcd, attd, {'sample_max': 1})
+    assert tuple(lp_all.shape) == tuple(o_all.shape) and tuple(seq.shape) == tuple(o_seq.shape)
+    assert float((lp_all.cpu() - o_all).abs().max()) < 1e-3
+    top2 = o_all.topk(2, dim=2).values
+    margin = (top2[..., 0] - top2[..., 1]).min(1).values          # per image: its closest decision
+    safe = margin >= 1e-5
+    assert int((~safe).sum()) <= 4, 'too many near-tied rows for the case to mean anything: %d' % int((~safe).sum())
+    assert torch.equal(seq.cpu()[safe], o_seq[safe]), 'greedy ids differ on rows whose oracle margins are all >= 1e-5'
+    assert float((slp.cpu()[safe] - o_slp[safe]).abs().max()) < 1e-3
+    # beam search: the full batch on the device, 8 images on the CPU
+    pick = [0, 17, 34, 51, 68, 85, 102, 127]
+    with torch.no_grad():
+        bseq, bslp, top_seq, top_prob, _ = model.sample(fcd, attd, {'beam_size': 5})
+    w_seq, w_lp, w_top_seq, w_top_prob, _, _ = O.sample_beam(cfg, P, [f[pick] for f in fc], [a[pick] for a in att], 5)
+    assert torch.equal(bseq.cpu()[pick], w_seq)
+    assert float((bslp.cpu()[pick] - w_lp).abs().max()) < 1e-3
+    for j, k in enumerate(pick):
+        assert torch.equal(top_seq[k], w_top_seq[j]), k
+        assert np.allclose(np.array(top_prob[k]), np.array(w_top_prob[j]), atol=1e-3), k
