@@ -497,6 +497,15 @@ DecoderLayout decoder_layout(const rfn_dims* d, int B, int S, int train) {
     return L;
 }
 
+inline int stage1_cell_cus() {   // CU count of the current device (cached); 256 when it cannot be read
+    static int cus[16] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    int& c = cus[dev & 15];
+    if (c == 0 && hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) c = 256;
+    return c > 0 ? c : 256;
+}
+
 const uint64_t OFF_STAGE2 = RFN_DROP_OFFSET_STAGE2, OFF_DECODER = RFN_DROP_OFFSET_DECODER;   // rfn.h: rfn_dropout_mask
 
 // The decoder cell's form: z2h hoisted through the attention (rfn_deccell.hip: two dependent launches per step each way)
@@ -807,6 +816,22 @@ static int prefix_fwd_impl(const rfn_dims* d, int B, const float* const* prm, co
             p.nseg = 2;
             p.seg[0] = seg_lin(Hc, MR, prm[P.s1(t, i, 6)], MR, (int)MR, prm[P.s1(t, i, 7)]);
             p.seg[1] = seg_lin(z, Di, prm[P.s1(t, i, 8)], Di, (int)Di, prm[P.s1(t, i, 9)]);
+        }
+        // Small batches (BASELINE config 2, the shards of a strong-scaled batch): the M gate products in ONE cell-GEMM launch
+        // with the LSTM update as its epilogue (no split-K partials, no reduce launch) -- when the launch's 32-row tiles do not
+        // outnumber the CUs two to one; beyond that the 128 x 128 split-K kernel below is the faster one (17 GFLOP per step at C3).
+        if ((long)rfn_cdiv(B, 32) * M * (4 * R / 32) <= 2L * stage1_cell_cus()) {
+            rfn_cell_out kg[RFN_MAX_ENC];
+            for (int i = 0; i < M; ++i) {
+                kg[i] = cell_out(g + (long)i * B * 4 * R, 4 * R, 4 * R, 0);
+                cell_lin(kg[i], Hc, MR, prm[P.s1(t, i, 6)], MR, (int)MR, prm[P.s1(t, i, 7)]);
+                cell_lin(kg[i], W + Lo.z1[i] + (long)t * B * d->D[i], d->D[i], prm[P.s1(t, i, 8)], d->D[i], d->D[i], prm[P.s1(t, i, 9)]);
+                cell_lstm(kg[i], Cc + i * R, MR, Cn + i * R, MR, Hn + i * R, MR, (uint64_t)(t * M + i));
+            }
+            if (cell_ok(B, M, kg, R)) {
+                RFN_TRY(cell_run(B, M, kg, R, d->drop_fusion, seed, st, cell_variant(d)));
+                continue;
+            }
         }
         // gate GEMM of the M cells (grouped) with the LSTM update riding on its split-K reduce: encoder i's state is column
         // block i of the (B, M*R) rows

@@ -153,6 +153,7 @@ class GradSync:
         self.side = None
         if shard_optimizer is not None and shard_optimizer.sharded and torch.cuda.is_available():
             self.side = torch.cuda.Stream()
+        self._held, self._held_events = [], []   # gradient buffers the side stream may still read, and the events that say when not
         self._shard_bufs = {}            # bucket -> this rank's reduce-scatter output, allocated once (nothing in the step allocates)
         self.works = []
         self.buckets = []
@@ -176,8 +177,16 @@ class GradSync:
             if opt is not None and opt.sharded and flat.is_cuda:
                 st = opt.flat[name]
                 main = torch.cuda.current_stream(flat.device)
+                if len(self.buckets) == 1 and self._held:
+                    # first bucket of a step: the previous step's gradient buffers, kept alive for the side stream, go back
+                    # to the allocator -- behind the events that mark the side stream's last read of them (long past: a whole
+                    # forward lies in between).  Deterministic two-generation recycling instead of record_stream(), whose
+                    # deferred frees made the allocator miss now and then (device_mallocs_frees_in_timed_region).
+                    for ev in self._held_events:
+                        main.wait_event(ev)
+                    self._held.clear()
+                    self._held_events.clear()
                 self.side.wait_stream(main)               # the kernels that finish this bucket are queued on `main`
-                flat.record_stream(self.side)
                 with torch.cuda.stream(self.side):
                     if dist.get_backend(opt.group) == 'nccl':
                         shard = self._shard_bufs.get(name)       # reused every step: its reader (this bucket's update of the
@@ -189,6 +198,10 @@ class GradSync:
                         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=opt.group)
                         shard = flat[st['lo']:st['hi']]
                     opt.update_bucket_early(name, shard, 1.0 / self.world)
+                    ev = torch.cuda.Event()
+                    ev.record(self.side)                  # the side stream's last read of `flat` (gloo: the shard is a view of it)
+                self._held.append(flat)
+                self._held_events.append(ev)
             else:
                 self.works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True))
 
