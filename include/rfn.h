@@ -417,9 +417,11 @@ typedef struct rfn_cell_out {
     int64_t lddcn;
     float* dc_prev;
     int64_t lddcp;
-    /* RFN_CELL_EPI_STORE and _LSTM_BWD with accumulate: the sums start from C + C[acc_stride] + ... + C[(acc_parts - 1) *
-     * acc_stride] (slabs of C's shape, added in that order; 0 or 1 = C alone) -- the K-split partial products of an earlier
-     * launch (the decoder's d gates . W_hh, computed beside the attention backward; csrc/rfn_deccell.hip) */
+    /* RFN_CELL_EPI_STORE and _LSTM_BWD with accumulate: the sums start from C + S_0 + ... + S_{acc_parts-1}, added in that
+     * order, where slab S_p has C's shape and leading dimension and starts at acc_slabs + p * acc_stride (acc_parts = 0: C
+     * alone) -- the partial products of an earlier launch: the decoder's K-split d gates . W_hh computed beside the attention
+     * backward (csrc/rfn_deccell.hip), the stage-I cells' d gates_j . W_H_j of small batches */
+    const float* acc_slabs;
     int32_t acc_parts;
     int64_t acc_stride;
 } rfn_cell_out;

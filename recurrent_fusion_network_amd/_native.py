@@ -73,7 +73,7 @@ class CellOut(C.Structure):
                 ('c_next', C.c_void_p), ('ldcn', C.c_int64), ('h_next', C.c_void_p), ('ldh', C.c_int64),
                 ('drop_offset', C.c_uint64), ('gates', C.c_void_p), ('ldg', C.c_int64), ('dh_ext', C.c_void_p),
                 ('lddh', C.c_int64), ('dc_next', C.c_void_p), ('lddcn', C.c_int64), ('dc_prev', C.c_void_p),
-                ('lddcp', C.c_int64), ('acc_parts', C.c_int32), ('acc_stride', C.c_int64)]
+                ('lddcp', C.c_int64), ('acc_slabs', C.c_void_p), ('acc_parts', C.c_int32), ('acc_stride', C.c_int64)]
 
 
 def _load():

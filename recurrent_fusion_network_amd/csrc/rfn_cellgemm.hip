@@ -266,7 +266,9 @@ extern "C" int rfn_cell_gemm_supported(int M, int nout, const rfn_cell_out* outs
         if (epi != RFN_CELL_EPI_LSTM_BWD || t.C) {
             if (!t.C || t.ldc % 4 || !rfn_aligned16(t.C)) return 0;
         }
-        if (t.acc_parts > 1 && (!t.accumulate || !t.C || epi == RFN_CELL_EPI_LSTM || t.acc_parts > 8 || t.acc_stride % 4)) return 0;
+        if (t.acc_parts < 0 || (t.acc_parts > 0 && (!t.accumulate || !t.C || !t.acc_slabs || !rfn_aligned16(t.acc_slabs) ||
+                                                    epi == RFN_CELL_EPI_LSTM || t.acc_parts > 8 || t.acc_stride % 4)))
+            return 0;
         if (epi == RFN_CELL_EPI_LSTM) {
             // gate-major tiles: 8 units x 4 gates per 32 columns
             if (R < 8 || R % 8 || t.N != 4 * R || !t.c_prev || !t.c_next || !t.h_next || !bkf) return 0;
@@ -311,7 +313,7 @@ int rfn_cg_prepare(int M, int nout, const rfn_cell_out* outs, int R, float drop_
         d.ldcp = t.ldcp; d.ldcn = t.ldcn; d.ldh = t.ldh; d.drop_offset = t.drop_offset;
         d.gates = t.gates; d.ldg = t.ldg; d.dh_ext = t.dh_ext; d.lddh = t.lddh;
         d.dc_next = t.dc_next; d.lddcn = t.lddcn; d.dc_prev = t.dc_prev; d.lddcp = t.lddcp;
-        d.acc_parts = t.acc_parts; d.acc_stride = t.acc_stride;
+        d.acc_slabs = t.acc_slabs; d.acc_parts = t.acc_parts; d.acc_stride = t.acc_stride;
         for (int s = 0; s < t.nseg; ++s) {
             CgSeg& g = a.seg[ns++];
             g.A = t.seg[s].A; g.B = t.seg[s].B; g.bias = t.seg[s].bias;

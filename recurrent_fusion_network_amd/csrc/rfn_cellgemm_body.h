@@ -48,7 +48,8 @@ struct CgOut {
     long ldcp, ldcn, ldh, ldg, lddh, lddcn, lddcp;
     unsigned long long drop_offset;
     int N, accumulate, seg0, nseg, tile0, tiles_n;
-    int acc_parts;       // accumulate: C + (acc_parts - 1) further slabs at C + p * acc_stride (store / gate-gradient epilogue)
+    const float* acc_slabs;   // accumulate: C + acc_parts further slabs (C's shape and ld) at acc_slabs + p * acc_stride
+    int acc_parts;            // (store / gate-gradient epilogue)
     long acc_stride;
 };
 struct CgArgs {
@@ -435,8 +436,8 @@ __device__ __forceinline__ void cg_tile(const CgArgs& a, const int bid, float* s
             } else {
                 if (O.accumulate) {
                     e_prev[v] = *reinterpret_cast<const cg_f32x4*>(O.C + (long)grow * O.ldc + col);
-                    for (int pp = 1; pp < O.acc_parts; ++pp)   // K-split partial slabs of an earlier launch, in order
-                        e_prev[v] += *reinterpret_cast<const cg_f32x4*>(O.C + pp * O.acc_stride + (long)grow * O.ldc + col);
+                    for (int pp = 0; pp < O.acc_parts; ++pp)   // partial slabs of an earlier launch, in order
+                        e_prev[v] += *reinterpret_cast<const cg_f32x4*>(O.acc_slabs + pp * O.acc_stride + (long)grow * O.ldc + col);
                 }
             }
         }
@@ -473,7 +474,7 @@ __device__ __forceinline__ void cg_tile(const CgArgs& a, const int bid, float* s
             b_in[e][0] = O.accumulate ? xb_ld1<XB>(O.C + (long)grow * O.ldc + unit) : 0.f;
             if constexpr (!XB) {
                 if (O.accumulate)
-                    for (int pp = 1; pp < O.acc_parts; ++pp) b_in[e][0] += O.C[pp * O.acc_stride + (long)grow * O.ldc + unit];
+                    for (int pp = 0; pp < O.acc_parts; ++pp) b_in[e][0] += O.acc_slabs[pp * O.acc_stride + (long)grow * O.ldc + unit];
             }
             b_in[e][1] = O.dh_ext ? xb_ld1<XB>(O.dh_ext + (long)grow * O.lddh + unit) : 0.f;
             b_in[e][2] = xb_ld1<XB>(G + unit);

@@ -337,7 +337,7 @@ const size_t STEP_GEMM_WS_FLOATS = GEMM_WS_FLOATS;   // the free-running step ma
 struct PrefixLayout {
     size_t P1[RFN_MAX_ENC], al1[RFN_MAX_ENC], z1[RFN_MAX_ENC], P2[RFN_MAX_ENC], dz1[RFN_MAX_ENC];
     size_t Hs, Cs, hp1, g1, rmat, rarg, h2, c2, hp2, al2, z2, g2;
-    size_t dHs, dC, dal, dwp, dhp1, dh2e, dhrec, dc2, dz2, dhp2;
+    size_t dHs, dHpart, dC, dal, dwp, dhp1, dh2e, dhrec, dc2, dz2, dhp2;
     size_t gws;
     size_t bar;     // grid-barrier counters of the persistent recurrence kernels (RFN_CHAIN_BAR_WORDS uint32, rfn_chain.hip)
     size_t tk;      // split-K tile counters (GEMM_TICKETS int32), zeroed at the head of every entry point that splits
@@ -441,6 +441,7 @@ PrefixLayout prefix_layout(const rfn_dims* d, int B, int train) {
     if (train) {
         for (int i = 0; i < d->M; ++i) L.dz1[i] = b.take(Bz * d->D[i]);
         L.dHs = b.take((T1 + 1) * Bz * M * R);
+        L.dHpart = b.take(M * Bz * M * R);       // small batches: the M partial products d gates_j . W_H_j of a stage-I step
         L.dC = b.take(Bz * M * R);
         L.dal = b.take(M * Bz * maxL);
         L.dwp = b.take((T1 > T2 ? T1 : T2) * M * Bz * A);
@@ -1223,27 +1224,81 @@ extern "C" int rfn_prefix_bwd(const rfn_dims* d, int B, const float* const* prm,
     RFN_TRY(gemm_groups(K, R, M, pr, 0, gx));
 
     // ---- stage I backward --------------------------------------------------------------------------------
+    // Small batches (BASELINE config 2, the shards of a strong-scaled batch) take three launches per step instead of seven:
+    //   X  every product of the step's gate gradients in ONE cell-GEMM launch: the M partial slabs d gates_j . W_H[t,j] of
+    //      d H_t (each cell reads the whole concatenated H, :53) and the M d z_i = d gates_i . W_z[t,i];
+    //   the attention backward of the M encoders (unchanged);
+    //   Y  d H_t[:, i] = external + sum_j slab_j[:, i] + d hproj_i . W_h[t,i], whose epilogue runs the LSTM backward of cell
+    //      (t-1, i) -- the next thing the sweep needs (no split-K partials, no reduce / axpby / lstm launches).
+    // Taken while the X launch's 32-row tiles do not outnumber the CUs two to one and every product fits the cell GEMM.
+    auto s1x_of = [&](int t, rfn_cell_out* kx) {
+        float* g = W + Lo.g1 + (long)t * M * B * 4 * R;
+        for (int j = 0; j < M; ++j) {
+            kx[j] = cell_out(W + Lo.dHpart + (long)j * BMR, MR, (int)MR, 0);
+            cell_dx(kx[j], g + (long)j * B * 4 * R, 4 * R, prm[P.s1(t, j, 6)], MR, 4 * R);
+        }
+        for (int i = 0; i < M; ++i) {
+            kx[M + i] = cell_out(W + Lo.dz1[i], d->D[i], d->D[i], 0);
+            cell_dx(kx[M + i], g + (long)i * B * 4 * R, 4 * R, prm[P.s1(t, i, 8)], d->D[i], 4 * R);
+        }
+    };
+    auto s1y_of = [&](int t, rfn_cell_out* ky) {
+        float* dHc = dHs + t * BMR;
+        float* dhp = W + Lo.dhp1 + (long)t * M * BA;
+        for (int i = 0; i < M; ++i) {
+            ky[i] = cell_out(dHc + i * R, MR, R, 1);
+            ky[i].acc_slabs = W + Lo.dHpart + i * R;
+            ky[i].acc_parts = M;
+            ky[i].acc_stride = BMR;
+            cell_dx(ky[i], dhp + i * BA, A, prm[P.s1(t, i, 2)], R, A);
+            if (t > 0)
+                cell_lstm_bwd(ky[i], W + Lo.g1 + ((long)(t - 1) * M + i) * B * 4 * R, 4 * R, Cs + (t - 1) * BMR + i * R, MR,
+                              Cs + t * BMR + i * R, MR, nullptr, 0, dC + i * R, MR, dC + i * R, MR, (uint64_t)((t - 1) * M + i));
+        }
+    };
+    bool s1_small = 2 * M <= RFN_CELL_MAXOUT && M <= 8;
+    {
+        long cols = (long)M * (MR / 32);
+        for (int i = 0; i < M; ++i) cols += d->D[i] / 32;
+        s1_small = s1_small && (long)rfn_cdiv(B, 32) * cols <= 2L * stage1_cell_cus();
+        for (int t = 0; t < T1 && s1_small; ++t) {
+            rfn_cell_out tx[2 * RFN_MAX_ENC], ty[RFN_MAX_ENC];
+            s1x_of(t, tx);
+            s1y_of(t, ty);
+            // step 0's Y is a plain accumulate, the others carry the gate-gradient epilogue: one epilogue per launch
+            s1_small = cell_ok(B, 2 * M, tx, R) && cell_ok(B, M, ty, R);
+        }
+    }
     for (int t = T1 - 1; t >= 0; --t) {
         float* dHn = dHs + (t + 1) * BMR;  // total gradient of Hs[t+1]
         float* dHc = dHs + t * BMR;        // external gradient of Hs[t]; the recurrent part is added here
         float* g = W + Lo.g1 + (long)t * M * B * 4 * R;
         float* hp = W + Lo.hp1 + (long)t * M * BA;
         float* dhp = W + Lo.dhp1 + (long)t * M * BA;
-        RFN_TRY(rfn_lstm_bwd_grouped(g, 4 * R, Cs + t * BMR, MR, Cs + (t + 1) * BMR, MR, dHn, MR, dC, MR, dC, MR, B, R, 0,
-                                     d->drop_fusion, seed, (uint64_t)(t * M), M, (long)B * 4 * R, R, R, R, st));
+        if (!s1_small || t == T1 - 1)
+            RFN_TRY(rfn_lstm_bwd_grouped(g, 4 * R, Cs + t * BMR, MR, Cs + (t + 1) * BMR, MR, dHn, MR, dC, MR, dC, MR, B, R, 0,
+                                         d->drop_fusion, seed, (uint64_t)(t * M), M, (long)B * 4 * R, R, R, R, st));
+        if (s1_small) {
+            rfn_cell_out kx[2 * RFN_MAX_ENC];
+            s1x_of(t, kx);
+            RFN_TRY(cell_run(B, 2 * M, kx, R, 0.f, 0, st, cell_variant(d)));
+        } else {
         // dH_t += sum_i dgates_i . W_H[t,i]   (every cell reads the whole concatenated H, :53)
         for (int i = 0; i < M; ++i) segs[i] = seg_dx(g + (long)i * B * 4 * R, 4 * R, prm[P.s1(t, i, 6)], MR, 4 * R);
         RFN_TRY(gemm_segs(B, (int)MR, M, segs, dHc, MR, 1, gx));
+        }
         // dz_i = dgates_i . W_z[t,i]: one grouped launch when the encoders share a feature width
         bool same_d = true;
         for (int i = 1; i < M; ++i) same_d = same_d && d->D[i] == d->D[0];
-        if (same_d && M > 1) {
+        if (s1_small) {
+            // done by X
+        } else if (same_d && M > 1) {
             for (int i = 0; i < M; ++i)
                 pr[i] = prob1(W + Lo.dz1[i], d->D[0],
                               seg_dx(g + (long)i * B * 4 * R, 4 * R, prm[P.s1(t, i, 8)], d->D[0], 4 * R));
             RFN_TRY(gemm_groups(B, d->D[0], M, pr, 0, gx));
         }
-        bool dz_done = same_d && M > 1;
+        bool dz_done = (same_d && M > 1) || s1_small;
         if (!dz_done && M > 1) {   // heterogeneous feature widths: the M products still share one launch (an output each)
             rfn_cell_out kz[RFN_MAX_ENC];
             for (int i = 0; i < M; ++i) {
@@ -1334,7 +1389,11 @@ extern "C" int rfn_prefix_bwd(const rfn_dims* d, int B, const float* const* prm,
             }
             pr[i] = prob1(dHc + i * R, MR, seg_dx(dhp + i * BA, A, prm[P.s1(t, i, 2)], R, A));
         }
-        {
+        if (s1_small) {
+            rfn_cell_out ky[RFN_MAX_ENC];
+            s1y_of(t, ky);
+            RFN_TRY(cell_run(B, M, ky, R, d->drop_fusion, seed, st, cell_variant(d)));
+        } else {
             rfn_cell_out kb[RFN_MAX_ENC];
             for (int i = 0; i < M; ++i) {
                 kb[i] = cell_out(dHc + i * R, MR, R, 1);
@@ -1735,8 +1794,9 @@ extern "C" int rfn_decoder_bwd(const rfn_dims* d, int B, int S, const float* con
             }
         };
         auto ky_of = [&](int s, rfn_cell_out& ky) {
-            ky = cell_out(dhrec, R, R, 1);
-            ky.acc_parts = DEC_KSPLIT;
+            ky = cell_out(dhrec, R, R, 1);        // C = slab 0 (+ the other DEC_KSPLIT - 1 slabs behind it)
+            ky.acc_slabs = dhrec + BR;
+            ky.acc_parts = DEC_KSPLIT - 1;
             ky.acc_stride = BR;
             cell_dx(ky, W + Lo.dhpd + s * BA, A, prm[P.dec(8)], R, A);
             if (s > 0)
