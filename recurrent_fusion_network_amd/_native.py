@@ -11,7 +11,9 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'librfn_hip.so')
+# RFN_HIP_LIB: development hook (tools/ A/B builds of the same ABI, e.g. `make EXTRA=-D...` into another file); the product
+# loads the library next to this file
+LIB_PATH = os.environ.get('RFN_HIP_LIB') or os.path.join(_HERE, 'librfn_hip.so')
 
 RFN_MAX_ENC = 8
 RFN_GEMM_MAXSEG = 8
