@@ -47,6 +47,10 @@ WORKLOADS = {
     'c3het': dict(desc='shipped 5 heterogeneous encoders', B=256,
                   enc=[(196, 2048, 2048), (64, 1536, 1536), (64, 1280, 2048), (49, 2208, 2208), (64, 1536, 1536)],
                   step_tflop=None),
+    # the same five encoders with the 196 x 2048 one LAST (A/B of launch-order effects on its projection: profiles/r06_c3het.md)
+    'c3het_last': dict(desc='shipped 5 heterogeneous encoders, the 196 x 2048 map last', B=256,
+                       enc=[(64, 1536, 1536), (64, 1280, 2048), (49, 2208, 2208), (64, 1536, 1536), (196, 2048, 2048)],
+                       step_tflop=None),
     'c5': dict(desc='C5 decode', B=128, enc=[(196, 2048, 2048)] * 4, step_tflop=None),
 }
 for _w in WORKLOADS.values():       # uniform-encoder shorthands used by tools/

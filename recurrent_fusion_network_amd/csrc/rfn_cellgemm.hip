@@ -115,6 +115,9 @@ static int cg_device_cus() {   // CU count of the current device (cached per dev
 // slots; 8 = 3 with wave-private ring slots (all bit-identical to 2 and 3); 7 / 9 = the library's choice among 1-5 / 1-3 (A/B hooks).
 // variant 0: the K step / K-wave count -- which fix the k order of every output element -- are chosen FROM THE K COUNTS
 // ONLY, so a row's arithmetic never depends on the batch it sits in (variants 2 and 3 give bit-identical results).
+#ifndef CG_T16_PER_CU
+#define CG_T16_PER_CU 1     /* 16-row tiles are taken while a CU gets at most this many of them (A/B knob, tools/build_variant.sh) */
+#endif
 static int cg_plan(CgPrepared& pz, int variant) {
     CgArgs& a = pz.a;
     const int force_slots = (variant >> 4) & 15;   // tools: bits 4-7 of `variant` force the ring depth
@@ -146,7 +149,7 @@ static int cg_plan(CgPrepared& pz, int variant) {
             // (tools/bench_cellgemm.py --small --variants 3,4,5,6, B = 64: Kb1 17.4 / 15.7 / 13.7 / 10.1 us, stage-II K3 + LSTM
             // 21.0 / 20.8 / 19.8 / 16.6, Kb2 6.9 / 6.5 / 6.2 / 5.4); 4 and 5 (shared slots, K steps of 64 / 128) stay as A/B forms
             const long t16 = (long)rfn_cdiv(a.M, 16) * cols, t32 = (long)rfn_cdiv(a.M, 32) * cols, cus = cg_device_cus();
-            if (t16 <= cus) variant = !shared16 ? 6 : (k128 && max_iters >= 1024) ? 5 : 4;
+            if (t16 <= CG_T16_PER_CU * cus) variant = !shared16 ? 6 : (k128 && max_iters >= 1024) ? 5 : 4;
             // 8: 32-row tiles on wave-private slots while a CU gets at most one of them (B = 64: decoder K1 6.0 against 6.9 us,
             // stage-II backward 14.6 against 17.8; B = 256 Kb1 14.3 against 17.6); with several blocks per CU the shared-slot
             // form's waits are covered by the other blocks' waves and it stays ahead (B = 256 stage-II K3: 28.8 against 31.2)
