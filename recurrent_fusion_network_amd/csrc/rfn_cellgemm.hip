@@ -12,7 +12,7 @@
 //     h2h share the operand h; dz of every encoder and the recurrent dh share the gate gradients);
 //   * a per-step product has too few output tiles for 256 CUs and a K chain that is all latency (a wave's 32x32 tile
 //     takes 32 cycles per k on the f32 matrix pipe): the K range is cut across the WAVES OF ONE BLOCK (k-groups of 8
-//     dealt round-robin), partial tiles meet in LDS and are added in wave order -- no partial slabs in HBM, no second
+//     dealt to the waves in adjacent pairs, cg_kgroup()), partial tiles meet in LDS and are added in wave order -- no partial slabs in HBM, no second
 //     kernel, no atomics; the k order of an output element depends on nothing but the K step and the wave count of the
 //     tile variant, which the host picks from (N, K) only -- never from the batch size -- so the free-running, step-wise
 //     and batched decoder passes stay bit-identical to each other and rows stay independent of their batch;

@@ -82,6 +82,20 @@ __device__ unsigned long long g_cg_loop_stamps[64 * 8];
 #define CG_STAMP(i)
 #endif
 
+// Which k-group (8 consecutive k) of a K step is the t-th one wave `wk` of WK K-waves takes.  Round 6: with four K-waves a wave
+// owns PAIRS of adjacent k-groups -- groups {2 wk, 2 wk + 1} of every 64 k -- so that what it requests of an operand row in the
+// wave-private form is one 64-B run instead of two 32-B runs a quarter line apart (every 128-B line of a [row][k] operand used
+// to be asked for by all four waves).  The assignment depends on nothing but the absolute k index, so every tile variant and
+// K step (64 / 128) still adds the same k's in the same order per wave: the variants stay bit-identical to each other.
+// -DCG_KGROUP_INTERLEAVED=1: the round-3..5 assignment (group g to wave g % WK), A/B.
+#ifndef CG_KGROUP_INTERLEAVED
+#define CG_KGROUP_INTERLEAVED 0
+#endif
+template <int WK>
+__device__ __forceinline__ constexpr int cg_kgroup(int wk, int t) {
+    return (WK == 4 && !CG_KGROUP_INTERLEAVED) ? 2 * wk + (t & 1) + 8 * (t >> 1) : wk + WK * t;
+}
+
 template <int N>
 __device__ __forceinline__ void cg_wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -149,7 +163,7 @@ __device__ __forceinline__ void cg_tile(const CgArgs& a, const int bid, float* s
     constexpr int RPP = 64 / CPR;    // rows per piece
     constexpr int KG = BK / 8;       // k-groups per K step
     // BK = 128 (round 5, few-tile launches): half the K steps of BK = 64 -- a K step costs ~0.45 us of waits, barrier and request
-    // issue whatever it computes -- and the SAME k order: wave wk takes the k-groups g with g % WK == wk in ascending order
+    // issue whatever it computes -- and the SAME k order: wave wk takes the k-groups cg_kgroup() gives it, in ascending order,
     // whatever the K step is, as long as it holds a multiple of WK groups.
     static_assert(KG % WK == 0 && (BK == 32 || BK == 64 || BK == 128), "unsupported K step");
     static_assert(WK * BM * BN <= 2 * SLOT_FL, "the partial tiles reuse the ring (at least two slots)");
@@ -354,7 +368,7 @@ __device__ __forceinline__ void cg_tile(const CgArgs& a, const int bid, float* s
         wpB = (const char*)sg.B;
         wpStepB = BKF ? (long)BK * 4 : (long)BK * sg.ldb * 4;
         const int rr = lane >> 2, j = (lane & 3) ^ wp_g(rr);
-        const int ck = 2 * (wk + WK * (j >> 1)) + (j & 1);     // 16-B chunk of the K step's 64 k's
+        const int ck = 2 * cg_kgroup<WK>(wk, j >> 1) + (j & 1);     // 16-B chunk of the K step's 64 k's
 #pragma unroll
         for (int pa = 0; pa < WPA; ++pa) {
             int gr = row0 + 16 * pa + rr;
@@ -371,7 +385,7 @@ __device__ __forceinline__ void cg_tile(const CgArgs& a, const int bid, float* s
                 offW[WPA + pc] = (uint32_t)((n * sg.ldb + 4 * ck) * 4);
             } else {
                 const int kr = lane >> 3, cq = (lane & 7) ^ (4 * ((kr >> 2) & 1));
-                offW[WPA + pc] = (uint32_t)(((long)(8 * (wk + WK * pc) + kr) * sg.ldb + col0 + 4 * cq) * 4);
+                offW[WPA + pc] = (uint32_t)(((long)(8 * cg_kgroup<WK>(wk, pc) + kr) * sg.ldb + col0 + 4 * cq) * 4);
             }
         }
     };
@@ -514,7 +528,7 @@ __device__ __forceinline__ void cg_tile(const CgArgs& a, const int bid, float* s
         if constexpr (SMALL) {
 #pragma unroll
             for (int t = 0; t < KG / WK; ++t) {
-                const int q = wk + WK * t;
+                const int q = cg_kgroup<WK>(wk, t);
                 // lane (row l15, k-quarter kq) feeds k = 8q + {0 4 1 5}[kq] to the first MFMA of the k-group and
                 // 8q + {2 6 3 7}[kq] to the second: 16-B chunk 2q + (kq & 1) of its row, elements kq >> 1 and (kq >> 1) + 2
                 const int ch = 2 * q + (kq & 1);
@@ -541,7 +555,7 @@ __device__ __forceinline__ void cg_tile(const CgArgs& a, const int bid, float* s
         }
 #pragma unroll
         for (int t = 0; t < KG / WK; ++t) {
-            const int q = wk + WK * t;
+            const int q = cg_kgroup<WK>(wk, t);
             const cg_f32x4 af = *reinterpret_cast<const cg_f32x4*>(a_l + (wm * 32 + l31) * BK + 4 * ((2 * q + h) ^ swa));
             cg_f32x4 bf;
             if constexpr (BKF) {

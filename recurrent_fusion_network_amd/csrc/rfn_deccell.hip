@@ -262,6 +262,12 @@ static void dec_cell_fwd_fast_launch(const DecCellArgs& a, int tpu, hipStream_t 
     else hipLaunchKernelGGL((dec_cell_fwd_fast_k<NG, 1>), grid, dim3(256), 0, st, a);
 }
 
+#ifndef DEC_TPU_MIN
+#define DEC_TPU_MIN 1          /* A/B knobs (tools/build_variant.sh): least threads per unit, blocks wanted per CU */
+#endif
+#ifndef DEC_BLOCKS_PER_CU
+#define DEC_BLOCKS_PER_CU 1
+#endif
 static int dec_device_cus() {
     static int cus[16] = {};
     int dev = 0;
@@ -288,8 +294,8 @@ extern "C" int rfn_dec_cell_fwd(const float* proj, int64_t psb, int64_t psl, con
     const bool fast = A % 4 == 0 && A <= 512 && L <= DEC_LREG && R % 256 == 0 && (psb | psl) % 4 == 0 && rfn_aligned16(proj) &&
                       rfn_aligned16(hproj) && rfn_aligned16(w_out);
     if (fast) {
-        int tpu = 1;
-        while (tpu < 4 && (long)B * (R / (256 / tpu)) < cus) tpu <<= 1;
+        int tpu = DEC_TPU_MIN;
+        while (tpu < 4 && (long)B * (R / (256 / tpu)) < DEC_BLOCKS_PER_CU * cus) tpu <<= 1;
         if (maxout) dec_cell_fwd_fast_launch<5>(a, tpu, (hipStream_t)stream);
         else dec_cell_fwd_fast_launch<4>(a, tpu, (hipStream_t)stream);
         RFN_CHECK_LAUNCH();
