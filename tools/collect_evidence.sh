@@ -22,11 +22,11 @@ python tools/dominant_launches.py $O/x3/t_kernel_trace.csv > $O/dominant_x3.csv
 python tools/step_launches.py $O/exact/t_kernel_trace.csv > $O/step_launches_exact.txt
 python tools/step_launches.py $O/c2/t_kernel_trace.csv > $O/step_launches_c2.txt
 : > $O/secondary.jsonl
-for args in "--workload c2" "--workload c3het" "--recipe" "--label-smoothing" "--workload c5"; do
+for args in "--workload c2" "--workload c2 --graph --no-alt-line" "--workload c3het" "--recipe" "--label-smoothing" "--workload c5"; do
   python bench.py --no-cpu-baseline $args 2>/dev/null | tail -1 >> $O/secondary.jsonl
 done
 python bench.py --no-cpu-baseline --workload c5 --gemm bf16x3 2>/dev/null | tail -1 >> $O/secondary.jsonl
-bash tools/run_gemm_pmc.sh r05 "" all > $O/pmc_gemm.txt 2>&1
+bash tools/run_gemm_pmc.sh r06 "" all > $O/pmc_gemm.txt 2>&1
 : > $O/shards.jsonl      # single-GPU steps of data-parallel shards (tools/dp_predict.py)
 for b in 256 128 64 32; do
   python bench.py --no-cpu-baseline --batch $b 2>/dev/null | tail -1 >> $O/shards.jsonl
