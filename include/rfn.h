@@ -69,7 +69,11 @@ typedef struct rfn_dims {
 } rfn_dims;
 /* rfn_dims.path_flags: run the named recurrence -- all of its steps -- inside ONE persistent launch (csrc/rfn_chain.hip: the
  * per-step launches' device bodies, a grid barrier between dependent phases; bit-identical results) instead of three launches
- * per step.  Opt-in: measured on MI355X the in-launch hand-off costs what the launch boundary costs (profiles/r05_chain.md). */
+ * per step.  Opt-in: measured on MI355X the in-launch hand-off costs what the launch boundary costs (profiles/r05_chain.md).
+ * A/B hooks only: the persistent grid is launched non-cooperatively and relies on all of its blocks (<= CU count, 128 KB of LDS each)
+ * being resident at once -- do not set them beside other streams, processes or collectives on the same device (a block that cannot
+ * become resident makes its peers spin into a trap).  The decoder bits imply RFN_PATH_OPT_DEC_UNHOISTED (the chains are built
+ * from the three-launch decoder cell). */
 #define RFN_PATH_OPT_PERSIST_DEC_FWD 1u   /* teacher-forced decoder steps (rfn_decoder_fwd)                   */
 #define RFN_PATH_OPT_PERSIST_S2_FWD 2u    /* stage-II steps (rfn_prefix_fwd)                                  */
 #define RFN_PATH_OPT_PERSIST_DEC_BWD 4u   /* decoder backward sweep, steps S-1 ... 1 (rfn_decoder_bwd)        */
