@@ -286,7 +286,7 @@ def cell_gemm(M, outs, R=0, drop_p=0.0, seed=0, variant=0):
     """Row-panel GEMM of the recurrences (rfn_cell_gemm).  outs: list of dicts with C, ldc, N, accumulate, segs =
     [(A, lda, B, ldb, b_kfast, K, bias), ...] and, for the LSTM gate epilogue, lstm = (c_prev, ldcp, c_next, ldcn, h_next,
     ldh, drop_offset); for the gate-gradient epilogue lstm_bwd = (gates, ldg, c_prev, ldcp, c_next, ldcn, dh_ext, lddh,
-    dc_next, lddcn, dc_prev, lddcp, drop_offset) and C may be None."""
+    dc_next, lddcn, dc_prev, lddcp, drop_offset) and C may be None; acc = (slabs, parts, stride): partial slabs added to C."""
     check(lib.rfn_cell_gemm(M, len(outs), _cell_outs(outs), R, drop_p, seed, variant, stream_ptr()), 'rfn_cell_gemm')
 
 
@@ -302,6 +302,9 @@ def _cell_outs(outs):
             sg.A, sg.lda, sg.a_kfast = A.data_ptr(), lda, 1
             sg.B, sg.ldb, sg.b_kfast = B.data_ptr(), ldb, int(bk)
             sg.K, sg.bias = K, ptr(bias)
+        if 'acc' in spec:      # accumulate: C + `parts` slabs of C's shape at slabs + p * stride (rfn.h, rfn_cell_out)
+            slabs, parts, stride = spec['acc']
+            t.acc_slabs, t.acc_parts, t.acc_stride = slabs.data_ptr(), int(parts), int(stride)
         if 'lstm' in spec:
             cp, ldcp, cn, ldcn, hn, ldh, off = spec['lstm']
             t.c_prev, t.ldcp, t.c_next, t.ldcn, t.h_next, t.ldh, t.drop_offset = (cp.data_ptr(), ldcp, cn.data_ptr(), ldcn,
