@@ -10,10 +10,14 @@
 // and the per-step product K3 = z2h(z) -- one of the three dependent launches of a step -- disappears: a step is
 //     K1  [h_2_att_h(h) | gates += h2h(h)]                       (rfn_cell_gemm, as before)
 //     K2  scores, softmax, gates += b_z + sum_l alpha_l U_l, LSTM update          (dec_cell_fwd_k, this file)
-// Backward: with z gone, the attention backward needs only d gates of its own step (d alpha_l = <d gates, U_l>), so it runs
-// FIRST (dec_attn_bwd_k) and the two recurrent products merge into ONE, d h = [d gates | d hproj] . [W_hh ; W_h], whose
-// epilogue is the LSTM backward of the step below (rfn_cell_gemm).  After the loop d U = sum_s alpha_s (x) d gates_s
-// (dec_du_k), then d thoughts += d U . W_z and d W_z = d U^T . thoughts as one GEMM each over T2*B rows.
+// Backward: with z gone, the attention backward needs only d gates of its own step (d alpha_l = <d gates, U_l>), and
+// d h = d gates . W_hh + d hproj . W_h splits into a long part that does NOT depend on the attention backward and a short one
+// that does.  A step is two launches (rfn_path.hip, rfn_decoder_bwd):
+//     X   the attention-backward rows (dec_attn_bwd_fast_body) BESIDE the tiles of d gates . W_hh cut 4 ways along K into
+//         partial slabs, in one grid (cell_gemm_rows_k, rfn_cellgemm.hip)
+//     Y   d hproj . W_h + the slabs, with the LSTM backward of the step below as epilogue (rfn_cell_gemm, acc_slabs)
+// After the loop d U = sum_s alpha_s (x) d gates_s (dec_du_k), then d thoughts = d Pd . W_a + d U . W_z (one GEMM, two K
+// segments) and d W_z = d U^T . thoughts over T2*B rows.
 //
 // Rows are independent and a row's arithmetic does not depend on the launch shape: every block of a row recomputes the row's
 // scores with the same lane partition (row_tanh_dot) and the same serial softmax, the gate sums run over l in order.
