@@ -103,7 +103,7 @@ class FusedClampAdam:
         self.param_groups[0]['lr'] = lr
 
     def zero_grad(self):
-        for p in self.model.parameters():
+        for p in self.param_groups[0]['params']:      # the cached list: walking the module tree costs ~1 ms per call at 330 parameters
             p.grad = None
         self.model._last_flat_grads.clear()
 
