@@ -162,3 +162,45 @@ def test_bad_arguments_are_refused(dev):
     assert n.lib.rfn_dec_cell_fwd(p, 4, 4, p, p, p, None, 16, 16, p, p, 16, p, 4, p, 4, p, 4, p, 1, 1, 4, 4, 0, 1, 0.0, 0, 0, st) != 0
     assert n.lib.rfn_dec_attn_bwd(p, 4, 4, p, p, p, p, 16, 16, p, 16, 1, 1025, 4, 16, p, 4, 4, 0, p, p, st) != 0
     assert n.lib.rfn_dec_du(p, p, 1, 1, 0, 8, p, 8, 8, st) != 0
+
+
+@pytest.mark.parametrize('name', ['mid', 'c2', 'tinymax', 'odd'])
+@pytest.mark.parametrize('train', [False, True])
+def test_hoisted_and_three_launch_decoder_cells_are_the_same_mathematics(dev, name, train):
+    """RFN_PATH_OPT_DEC_UNHOISTED (the decoder cell of rounds 3-5: z2h(z) as a per-step product) against the default (z2h hoisted
+    through the attention) on reference-generated tiers -- `tinymax` has 5R-wide maxout gates, `odd` widths that are no multiple
+    of 4 (the scalar kernels), `train` adds dropout 0.3 on the decoder (the same Philox masks in both forms).  Same mathematics,
+    different association of the z2h sum: log-probs within 2e-5, loss within 1e-5 relative, every gradient within 1e-6 + 3e-4 of
+    its tensor's max, greedy ids identical.  (Each form is also checked against the oracle and the goldens on its own.)"""
+    import recurrent_fusion_network_amd as R
+    from conftest import load_case
+    from test_model_gpu import build, to_dev
+    N_ = R._native
+    cfg, spec, P, batch, gold = load_case(name)
+    if train:
+        cfg.drop_prob_lm = 0.3
+    batch = to_dev(batch, dev)
+    fc, att, labels, masks, top = batch
+    crit = R.ReviewNetEnsembleCriterion(cfg)
+    outs = []
+    for flags in (0, N_.PATH_OPT_DEC_UNHOISTED):
+        model = build(cfg, P, dev, train=train)
+        model.path_flags = flags
+        torch.manual_seed(9)                      # the dropout seed both forms draw
+        model.zero_grad()
+        lp, reason = model(fc, att, labels)
+        loss = crit(lp, labels[:, 1:], masks[:, 1:], reason, top, 1.0)
+        loss.backward()
+        grads = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+        model.eval()
+        with torch.no_grad():
+            seq = model.sample(fc, att, {'sample_max': 1})[0]
+        outs.append((lp.detach(), float(loss.detach()), grads, seq))
+    (lp0, l0, g0, s0), (lp1, l1, g1, s1) = outs
+    assert not torch.equal(lp0, lp1) or name == 'odd', 'the flag must change the arithmetic'
+    assert float((lp0 - lp1).abs().max()) < 2e-5
+    assert abs(l0 - l1) < 1e-5 * max(1.0, abs(l0))
+    for k in g0:
+        err = float((g0[k] - g1[k]).abs().max())
+        assert err <= 1e-6 + 3e-4 * float(g0[k].abs().max()), (k, err)
+    assert torch.equal(s0, s1)
