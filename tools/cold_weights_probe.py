@@ -23,6 +23,7 @@ def main():
     ap.add_argument('--reps', type=int, default=256)
     ap.add_argument('--sets', type=int, default=64)
     ap.add_argument('--batch', type=int, default=64)
+    ap.add_argument('--variants', type=lambda x: [int(v) for v in x.split(',')], default=[0], help='tile variants to force (0 = the library picks)')
     a = ap.parse_args()
     g = torch.Generator(device=dev).manual_seed(1)
     rnd = lambda *s: torch.randn(*s, device=dev, generator=g) * 0.1  # noqa: E731
@@ -54,7 +55,7 @@ def main():
                 outs.append(o)
             argsets.append((outs, N.cell_gemm_args(outs)))
 
-        def run(which):
+        def run(which, variant=0):
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             for warm in range(2):
@@ -62,14 +63,15 @@ def main():
                     e0.record()
                 for r in range(a.reps):
                     outs, arr = argsets[which(r)]
-                    N.check(N.lib.rfn_cell_gemm(M, len(outs), arr, R, 0.0, 0, 0, st))
+                    N.check(N.lib.rfn_cell_gemm(M, len(outs), arr, R, 0.0, 0, variant, st))
             e1.record()
             torch.cuda.synchronize()
             return e0.elapsed_time(e1) * 1e3 / a.reps
-        warm = run(lambda r: 0)
-        cold = run(lambda r: r % a.sets)
-        print('%-56s weights %5.1f MB | warm %6.2f us | cold %6.2f us (%.2f TB/s of weights)' % (
-            name, wbytes / 1e6, warm, cold, wbytes / cold / 1e6), flush=True)
+        for v in a.variants:
+            warm = run(lambda r: 0, v)
+            cold = run(lambda r: r % a.sets, v)
+            print('%-56s weights %5.1f MB | variant %d | warm %6.2f us | cold %6.2f us (%.2f TB/s of weights)' % (
+                name, wbytes / 1e6, v, warm, cold, wbytes / cold / 1e6), flush=True)
 
 
 if __name__ == '__main__':
