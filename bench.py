@@ -17,6 +17,10 @@ One step = the reference's timed region train.py:143-166: zero_grad -> forward -
 backward -> (N>1: one RCCL sum all-reduce per gradient bucket, overlapped with backward) -> clamp + Adam.  fp32
 throughout.  Rank 0 prints ONE JSON line; `value` is the whole-job aggregate over all N GPUs.
 
+The default single-GPU line also carries `"secondary": {"c2", "c5_beam5", "c5_greedy", "c5_rl"}`: BASELINE configs 2 (eager and
+replayed from a HIP graph) and 5 (beam = 5, greedy, the RL step at B = 128) timed in the same process after the headline and the
+bf16x3 leg, each with ms_per_step, value, step_frac and the roofline it is priced against (`--no-secondary` skips them).
+
 Other lines (same schema, not the headline): --workload c2 | c3het (the reference's shipped 5 heterogeneous encoders,
 feat_array.py:240-244) | c5 (BASELINE configs[4]: greedy / beam=5 decode and the self-critical RL step at B=128);
 --recipe (the published XE recipe train_recurrent_fusion_model.sh:17-27: drop_prob_lm 0.3, label smoothing, scheduled
